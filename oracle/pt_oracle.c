@@ -1,0 +1,1520 @@
+/*
+ * pt_oracle.c — CPU restatement of AdaPT's unidirectional path tracer (`--type pt`).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under adapt_amd/ may include, link or call
+ * this file; it is the checker that tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg compare the HIP path against.
+ *
+ * What it restates (citations are file:line under /root/reference):
+ *   renderer/vanilla_renderer.py:32-120   Renderer.render (one spp for all pixels)
+ *   tracer/tracer_base.py:136-278         pix2ray, aabb_test, ray_intersect, does_intersect
+ *   tracer/path_tracer.py:309-554         BVH traversal, BxDF dispatch, sample_light
+ *   tracer/ti_bvh.py:10-53                LinearBVH / LinearNode slab tests
+ *   tracer/bvh/bvh.cpp:19-212, bvh_helper.h:18-120   SAH BVH build + preorder linearise
+ *   bxdf/brdf.py:147-601, bxdf/bsdf.py:61-262        BRDF / BSDF models
+ *   emitters/abtract_source.py:35-232     TaichiSource.sample_hit / eval_le / solid_angle_pdf
+ *   sampler/general_sampling.py:16-123    direction / triangle samplers, balance heuristic
+ *   la/cam_transform.py:51-105, la/geo_optics.py:14-74   frames and optics
+ *
+ * Third-party arithmetic that is NOT in the reference tree: taichi==1.6.0
+ * (requirements.txt:1) supplies vector ops, the 3x3 inverse and the RNG.  Restated
+ * here from Taichi's published matrix code: normalized(v) = (1/sqrt(v.v)) * v,
+ * sum/dot accumulate left to right, 3x3 inverse = adjugate * (1/det) with
+ * det expanded along column 0.  The RNG (ti.random) is replaced by a counter-based
+ * Philox-4x32-10 stream — key (pixel, seed), counter (sample, draw/4) — the same
+ * stream the HIP path uses; draw ORDER follows the reference source.
+ *
+ * Pinning: the reference has no tests for this path.  The oracle is
+ * pinned by fixtures under tests/golden/ produced by running the reference's own
+ * Python source under a float32 stand-in for the absent `taichi` package
+ * (tests/golden/gen/), i.e. pinned at source level, unpinned at the real-Taichi
+ * boundary (RNG stream, fast-math rounding).
+ *
+ * All arithmetic is float32, compiled with -ffp-contract=off.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ vectors */
+typedef struct { float x, y, z; } v3;
+typedef struct { float m[3][3]; } m3;
+
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 vdiv(v3 a, v3 b) { return V(a.x / b.x, a.y / b.y, a.z / b.z); }
+static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 vdivs(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+static inline v3 vadds(v3 a, float s) { return V(a.x + s, a.y + s, a.z + s); }
+static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+static inline float vdot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float vnorm2(v3 a) { return vdot(a, a); }
+static inline float vnorm(v3 a) { return sqrtf(vnorm2(a)); }
+static inline v3 vnormalized(v3 a) { float inv = 1.0f / vnorm(a); return vscale(a, inv); }
+static inline v3 vcross(v3 a, v3 b) {
+    return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static inline float vmax(v3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+static inline float vmin(v3 a) { return fminf(fminf(a.x, a.y), a.z); }
+static inline v3 vabs(v3 a) { return V(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+static inline v3 vminv(v3 a, v3 b) { return V(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
+static inline v3 vmaxv(v3 a, v3 b) { return V(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
+static inline v3 vpow_sv(float b, v3 e) { return V(powf(b, e.x), powf(b, e.y), powf(b, e.z)); }
+static inline v3 m3mulv(const m3* M, v3 a) {
+    return V((M->m[0][0] * a.x + M->m[0][1] * a.y) + M->m[0][2] * a.z,
+             (M->m[1][0] * a.x + M->m[1][1] * a.y) + M->m[1][2] * a.z,
+             (M->m[2][0] * a.x + M->m[2][1] * a.y) + M->m[2][2] * a.z);
+}
+static inline float sq(float x) { return x * x; }   /* ti.pow(x, 2) / x ** 2: integer power -> x*x */
+static inline float signf_(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+static const v3 ZERO3 = {0.f, 0.f, 0.f};
+#define F_PI      ((float)3.14159265358979323846)
+#define F_INV_PI  ((float)(1.0 / 3.14159265358979323846))
+#define F_INV_2PI ((float)((1.0 / 3.14159265358979323846) * 0.5))
+#define F_PI2     ((float)(2.0 * 3.14159265358979323846))
+#define F_PI_DIV2 ((float)(3.14159265358979323846 / 2.0))
+#define BRDF_EPS  1e-7f
+
+/* taichi 3x3 inverse (adjugate / determinant), columns = (c0, c1, c2) */
+static inline void inverse_cols(v3 c0, v3 c1, v3 c2, m3* out) {
+    float a[3][3] = {{c0.x, c1.x, c2.x}, {c0.y, c1.y, c2.y}, {c0.z, c1.z, c2.z}};
+    float det = a[0][0] * (a[1][1] * a[2][2] - a[2][1] * a[1][2])
+              - a[1][0] * (a[0][1] * a[2][2] - a[2][1] * a[0][2])
+              + a[2][0] * (a[0][1] * a[1][2] - a[1][1] * a[0][2]);
+    float inv_det = 1.0f / det;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            out->m[j][i] = inv_det * (a[(i + 1) % 3][(j + 1) % 3] * a[(i + 2) % 3][(j + 2) % 3]
+                                    - a[(i + 2) % 3][(j + 1) % 3] * a[(i + 1) % 3][(j + 2) % 3]);
+}
+
+/* ---------------------------------------------------------------------- RNG */
+typedef struct {
+    int mode;                 /* 0 = Philox counter stream, 1 = scripted values */
+    uint32_t key0, key1, ctr0;
+    uint32_t draw;            /* draws consumed so far on this path */
+    uint32_t cache[4];
+    uint32_t cache_blk;       /* block index held in cache (0xffffffff = none) */
+    const double* script;
+    int script_n, script_pos;
+} rng_t;
+
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                          uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static void rng_seed(rng_t* r, uint32_t pixel, uint32_t seed, uint32_t sample) {
+    memset(r, 0, sizeof(*r));
+    r->key0 = pixel; r->key1 = seed; r->ctr0 = sample; r->cache_blk = 0xffffffffu;
+}
+static uint32_t rng_u32(rng_t* r) {
+    uint32_t d = r->draw++;
+    uint32_t blk = d >> 2;
+    if (blk != r->cache_blk) {
+        philox4x32_10(r->ctr0, blk, 0u, 0u, r->key0, r->key1, r->cache);
+        r->cache_blk = blk;
+    }
+    return r->cache[d & 3u];
+}
+/* ti.random(float): uniform in [0,1) — 24 high bits */
+static float rng_float(rng_t* r) {
+    if (r->mode == 1) {
+        double v = (r->script_pos < r->script_n) ? r->script[r->script_pos] : 0.5;
+        r->script_pos++; r->draw++;
+        return (float)v;
+    }
+    return (float)(rng_u32(r) >> 8) * (1.0f / 16777216.0f);
+}
+/* ti.random(int): full-range int32 */
+static int32_t rng_int(rng_t* r) {
+    if (r->mode == 1) {
+        double v = (r->script_pos < r->script_n) ? r->script[r->script_pos] : 0.0;
+        r->script_pos++; r->draw++;
+        return (int32_t)v;
+    }
+    return (int32_t)rng_u32(r);
+}
+/* Python-style modulo (Taichi integer % is floor-mod) */
+static inline int pymod(int a, int n) { int m = a % n; return (m < 0) ? m + n : m; }
+
+/* --------------------------------------------------------------- scene data */
+typedef struct {
+    int type, is_delta, is_bsdf;
+    v3 k_d, k_s, k_g, mean;
+    float ior;                /* attached medium ior (BSDF only) */
+} bxdf_t;
+
+typedef struct {
+    int type, bool_bits, obj_ref_id;
+    v3 intensity, dir, pos;
+    float inv_area, r;
+} src_t;
+
+typedef struct {              /* tracer/interaction.py:11-39 */
+    int obj_id, prim_id;
+    v3 n_s, n_g, tex;
+    float u, v, min_depth;
+} isect_t;
+
+typedef struct { v3 mini, maxi; int base, prim_cnt, all_offset; } lin_node_t;   /* ti_bvh.py:30-53 */
+typedef struct { v3 mini, maxi; int obj_idx, prim_idx; } lin_bvh_t;            /* ti_bvh.py:10-28 */
+
+/* flat description handed over by the test harness (ctypes) */
+typedef struct {
+    int n_prims, n_objects, n_sources, has_vertex_normal;
+    const float* prims;       /* n_prims*9 */
+    const float* normals;     /* n_prims*3 */
+    const float* v_normals;   /* n_prims*9 */
+    const int*   obj_info;    /* n_objects*3: start, count, is_sphere */
+    const float* obj_aabb;    /* n_objects*6 */
+    const int*   emitter_id;  /* n_objects */
+    const int*   bxdf_i;      /* n_objects*4: type, is_delta, is_bsdf, 0 */
+    const float* bxdf_f;      /* n_objects*13: k_d k_s k_g mean ior */
+    const int*   src_i;       /* n_sources*4: type, bool_bits, obj_ref_id, 0 */
+    const float* src_f;       /* n_sources*11: intensity dir pos inv_area r */
+    float world_ior;
+} orc_scene_desc;
+
+typedef struct {
+    int width, height;
+    int do_crop, start_x, end_x, start_y, end_y;
+    int max_bounce, num_shadow_ray;
+    int use_rr, use_mis, anti_alias, stratified, brdf_two_sides, use_bvh;
+    int rr_bounce_th;
+    float rr_threshold;
+    float cam_r[9], cam_t[3];
+    float inv_focal, half_w, half_h;
+    uint32_t seed;
+} orc_cfg;
+
+typedef struct {
+    long long n_samples, n_shade, n_shadow, n_lit, n_draws;
+} orc_stats;
+
+typedef struct {
+    int n_prims, n_objects, n_sources, has_vn;
+    v3 (*prims)[3];
+    v3 (*precom)[3];
+    v3 (*vnorm)[3];
+    v3* normals;
+    int (*obj_info)[3];
+    v3 (*aabbs)[2];
+    int* emitter_id;
+    bxdf_t* bxdf;
+    src_t* src;
+    float world_ior;
+    /* BVH (reference layout) */
+    int node_num, bvh_num;
+    lin_node_t* nodes;
+    lin_bvh_t* bvhs;
+} scene_t;
+
+typedef struct {
+    const scene_t* sc;
+    const orc_cfg* cfg;
+    float inv_num_shadow_ray;
+    m3 cam_r; v3 cam_t;
+} ctx_t;
+
+/* ------------------------------------------------ la/cam_transform.py:51-105 */
+static void rotation_between(v3 fixed, v3 target, m3* R) {
+    v3 axis = vcross(fixed, target);
+    float cos_theta = vdot(fixed, target);
+    if (fabsf(cos_theta) < 1.0f - 1e-5f) {
+        v3 n = vnormalized(axis);
+        float k = 1.0f - cos_theta;
+        float nn[3] = {n.x, n.y, n.z};
+        float skew[3][3] = {{0.f, -axis.z, axis.y}, {axis.z, 0.f, -axis.x}, {-axis.y, axis.x, 0.f}};
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                float d = (i == j) ? cos_theta : 0.0f;
+                R->m[i][j] = (d + (k * nn[i]) * nn[j]) + skew[i][j];
+            }
+    } else {
+        float s = signf_(cos_theta);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) R->m[i][j] = (i == j) ? s : 0.0f;
+    }
+}
+static v3 delocalize_rotate(v3 anchor, v3 local_dir, m3* R_out) {
+    m3 R; rotation_between(V(0.f, 1.f, 0.f), anchor, &R);
+    if (R_out) *R_out = R;
+    return m3mulv(&R, local_dir);
+}
+static v3 localize_rotate(v3 anchor, v3 global_dir) {
+    m3 R; rotation_between(anchor, V(0.f, 1.f, 0.f), &R);
+    return m3mulv(&R, global_dir);
+}
+/* convert_to_raw (cam_transform.py:71-88): (cos_theta, sin_theta, cos_phi, sin_phi) */
+static void convert_to_raw(v3 d_in, v3 normal, float raw[4]) {
+    v3 l = localize_rotate(normal, d_in);
+    float cos_theta = l.y;
+    float sin_theta = sqrtf(fmaxf(0.f, 1.f - cos_theta * cos_theta));
+    float cos_phi = 1.f, sin_phi = 0.f;
+    if (sin_theta > 1e-5f) { cos_phi = l.x / sin_theta; sin_phi = l.z / sin_theta; }
+    raw[0] = cos_theta; raw[1] = sin_theta; raw[2] = cos_phi; raw[3] = sin_phi;
+}
+
+/* ------------------------------------------------------ la/geo_optics.py:14-74 */
+static v3 inci_reflect_dir(v3 ray, v3 normal, float* dot_out) {
+    float d = vdot(normal, ray);
+    if (dot_out) *dot_out = d;
+    return vnormalized(vsub(ray, vscale(vscale(normal, 2.f), d)));
+}
+static v3 schlick_fresnel(v3 r_s, float dot_val) {
+    float p = powf(1.f - dot_val, 5.f);
+    return vadd(r_s, vscale(V(1.f - r_s.x, 1.f - r_s.y, 1.f - r_s.z), p));
+}
+static float fresnel_equation(float n_in, float n_out, float cos_inc, float cos_ref) {
+    float n1cos_i = n_in * cos_inc, n2cos_i = n_out * cos_inc;
+    float n1cos_r = n_in * cos_ref, n2cos_r = n_out * cos_ref;
+    float rs = (n1cos_i - n2cos_r) / (n1cos_i + n2cos_r);
+    float rp = (n1cos_r - n2cos_i) / (n1cos_r + n2cos_i);
+    return 0.5f * (rs * rs + rp * rp);
+}
+static int is_total_reflection(float dot_normal, float ni, float nr) {
+    return (1.f - sq(ni / nr) * (1.f - sq(dot_normal))) < 0.f;
+}
+static v3 snell_refraction(v3 incid, v3 normal, float dot_n, float ni, float nr, float* cos_r2_out) {
+    float exiting = signf_(dot_n);
+    float ratio = ni / nr;
+    float cos_r2 = 1.f - sq(ratio) * (1.f - sq(dot_n));
+    *cos_r2_out = cos_r2;
+    if (cos_r2 > 0.f) {
+        v3 a = vscale(incid, ratio);
+        v3 b = vscale(normal, ratio * dot_n);
+        v3 c = vscale(normal, exiting * sqrtf(cos_r2));
+        return vnormalized(vadd(vsub(a, b), c));
+    }
+    return ZERO3;
+}
+
+/* -------------------------------------- sampler/general_sampling.py:16-123 */
+static v3 cosine_hemisphere(rng_t* r, float* pdf) {
+    float eps = rng_float(r);
+    float cos_theta = sqrtf(eps);
+    float sin_theta = sqrtf(1.f - eps);
+    float phi = F_PI2 * rng_float(r);
+    *pdf = cos_theta * F_INV_PI;
+    return V(cosf(phi) * sin_theta, cos_theta, sinf(phi) * sin_theta);
+}
+static v3 mod_phong_hemisphere(rng_t* r, float alpha, float* pdf) {
+    float cos_theta = powf(rng_float(r), 1.f / (alpha + 1.f));
+    float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
+    float phi = F_PI2 * rng_float(r);
+    *pdf = 0.5f * (1.f + alpha) * powf(cos_theta, alpha) * F_INV_PI;
+    return V(cosf(phi) * sin_theta, cos_theta, sinf(phi) * sin_theta);
+}
+static v3 uniform_sphere(rng_t* r, float* pdf) {
+    float cos_theta = 2.f * rng_float(r) - 1.f;
+    float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
+    float phi = F_PI2 * rng_float(r);
+    *pdf = F_INV_2PI * 0.5f;
+    return V(cosf(phi) * sin_theta, cos_theta, sinf(phi) * sin_theta);
+}
+static v3 fresnel_hemisphere(rng_t* r, float nu, float nv, float* power_coeff) {
+    float eps1 = rng_float(r) * 4.f;
+    float inner_angle = eps1 - floorf(eps1);
+    float tan_phi = sqrtf((nu + 1.f) / (nv + 1.f)) * tanf(F_PI_DIV2 * inner_angle);
+    float cos_phi2 = 1.f / (1.f + tan_phi * tan_phi);
+    float sin_phi2 = 1.f - cos_phi2;
+    float cos_phi = sqrtf(cos_phi2);
+    if (eps1 > 1.f && eps1 <= 3.f) cos_phi *= -1.f;
+    float sin_phi = sqrtf(sin_phi2) * signf_(2.f - eps1);
+    float pc = nu * cos_phi2 + nv * sin_phi2;
+    float cos_theta = powf(1.f - rng_float(r), 1.f / (pc + 1.f));
+    float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
+    *power_coeff = pc;
+    return V(cos_phi * sin_theta, cos_theta, sin_phi * sin_theta);
+}
+static v3 sample_triangle(rng_t* r, v3 dv1, v3 dv2) {
+    float u1 = rng_float(r), u2 = rng_float(r);
+    v3 pt = vadd(vscale(dv1, u1), vscale(dv2, u2));
+    if (u1 + u2 > 1.0f) pt = vsub(vadd(dv1, dv2), pt);
+    return pt;
+}
+static float balance_heuristic(float a, float b) { return (a > 1e-7f) ? a / (a + b) : 0.f; }
+
+/* ------------------------------------------------------- bxdf/brdf.py:147-601 */
+static inline int tex_invalid(const isect_t* it) { return it->tex.x < 0.f; }
+static inline v3 diffuse_color(const bxdf_t* b, const isect_t* it) { return tex_invalid(it) ? b->k_d : it->tex; }
+
+static v3 eval_lambertian(const bxdf_t* b, const isect_t* it, v3 normal, v3 ray_out) {
+    float cosine = fmaxf(0.f, vdot(normal, ray_out));
+    return vscale(vscale(diffuse_color(b, it), F_INV_PI), cosine);
+}
+static v3 sample_lambertian(const bxdf_t* b, const isect_t* it, v3 normal, rng_t* r, v3* spec, float* pdf) {
+    v3 local = cosine_hemisphere(r, pdf);
+    v3 out = delocalize_rotate(normal, local, NULL);
+    *spec = eval_lambertian(b, it, normal, out);
+    return out;
+}
+static v3 eval_phong(const bxdf_t* b, const isect_t* it, v3 ray_in, v3 ray_out) {
+    v3 half = vsub(ray_out, ray_in);
+    if (vmax(vabs(half)) > BRDF_EPS) half = vnormalized(half); else half = ZERO3;
+    float dot_clamp = fmaxf(0.f, vdot(half, it->n_s));
+    v3 glossy = vpow_sv(dot_clamp, b->k_g);
+    float cosine = fmaxf(0.f, vdot(it->n_s, ray_out));
+    v3 spec_part = vmul(b->k_s, vmul(vscale(vadds(b->k_g, 2.0f), 0.5f), glossy));
+    return vscale(vscale(vadd(diffuse_color(b, it), spec_part), F_INV_PI), cosine);
+}
+static v3 eval_mod_phong(const bxdf_t* b, const isect_t* it, v3 ray_in, v3 ray_out) {
+    float dot_normal = vdot(it->n_s, ray_out);
+    v3 spec = ZERO3;
+    if (dot_normal > 0.f) {
+        v3 reflect_d = vnormalized(vsub(vscale(vscale(it->n_s, 2.f), dot_normal), ray_out));
+        float dot_view = fmaxf(0.f, -vdot(ray_in, reflect_d));
+        v3 glossy = vmul(vpow_sv(dot_view, b->k_g), b->k_s);
+        spec = vscale(vscale(vmul(vscale(vadds(b->k_g, 2.f), 0.5f), glossy), F_INV_PI), dot_normal);
+        spec = vadd(spec, eval_lambertian(b, it, it->n_s, ray_out));
+    }
+    return spec;
+}
+static v3 sample_mod_phong(const bxdf_t* b, const isect_t* it, v3 incid, rng_t* r, v3* spec_out, float* pdf_out) {
+    float eps = rng_float(r);
+    v3 out = V(0.f, 1.f, 0.f);
+    v3 spec = ZERO3;
+    float pdf = vmax(diffuse_color(b, it));
+    float ks_max = vmax(b->k_s);
+    if (eps < pdf) {
+        float lp;
+        out = sample_lambertian(b, it, it->n_s, r, &spec, &lp);
+        pdf *= lp;
+    } else if (eps < pdf + ks_max) {
+        v3 local = mod_phong_hemisphere(r, b->mean.z, &pdf);
+        v3 normal = delocalize_rotate(it->n_s, local, NULL);
+        out = vnormalized(vadd(vscale(vscale(normal, -2.f), vdot(incid, normal)), incid));
+        spec = eval_mod_phong(b, it, incid, out);
+        pdf *= ks_max;
+    } else {
+        pdf = 1.f - pdf - ks_max;
+    }
+    *spec_out = spec; *pdf_out = pdf;
+    return out;
+}
+/* Fresnel blend (Ashikhmin-Shirley), brdf.py:237-286 */
+static void fresnel_cos2_sin2(v3 half_vec, v3 normal, const m3* R, float dot_half, float* c2, float* s2) {
+    v3 tx = m3mulv(R, V(1.f, 0.f, 0.f));
+    float d = vdot(tx, vnormalized(vsub(half_vec, vscale(normal, dot_half))));
+    *c2 = d * d; *s2 = 1.f - *c2;
+}
+static v3 eval_fresnel_blend(const bxdf_t* b, const isect_t* it, v3 ray_in, v3 ray_out, const m3* R) {
+    v3 half_vec = vsub(ray_out, ray_in);
+    float dot_out = vdot(it->n_s, ray_out);
+    v3 spec = ZERO3;
+    if (dot_out > 0.f && vmax(vabs(half_vec)) > 1e-4f) {
+        half_vec = vnormalized(half_vec);
+        float dot_in = -vdot(it->n_s, ray_in);
+        float dot_half = fabsf(vdot(it->n_s, half_vec));
+        float dot_hk = fabsf(vdot(half_vec, ray_out));
+        v3 fresnel = schlick_fresnel(b->k_s, dot_hk);
+        float c2, s2; fresnel_cos2_sin2(half_vec, it->n_s, R, dot_half, &c2, &s2);
+        float denom = dot_hk * fmaxf(dot_in, dot_out);
+        float lobe = b->k_g.z * powf(dot_half, b->k_g.x * c2 + b->k_g.y * s2);
+        v3 specular = vdivs(vscale(fresnel, lobe), denom);
+        v3 kd = diffuse_color(b, it);
+        v3 diffuse = vmul(vscale(kd, (float)(28. / (23. * 3.14159265358979323846))),
+                          V(1.f - b->k_s.x, 1.f - b->k_s.y, 1.f - b->k_s.z));
+        float pow5_in = powf(1.f - dot_in / 2.f, 5.f);
+        float pow5_out = powf(1.f - dot_out / 2.f, 5.f);
+        diffuse = vscale(diffuse, (1.f - pow5_in) * (1.f - pow5_out));
+        spec = vscale(vadd(specular, diffuse), dot_out);
+    }
+    return spec;
+}
+static v3 sample_fresnel_blend(const bxdf_t* b, const isect_t* it, v3 incid, rng_t* r, v3* spec_out, float* pdf_out) {
+    float pc;
+    v3 local = fresnel_hemisphere(r, b->k_g.x, b->k_g.y, &pc);
+    m3 R;
+    v3 ray_half = delocalize_rotate(it->n_s, local, &R);
+    /* fresnel_blend_dir, brdf.py:237-244 */
+    float dot_incid;
+    v3 out = inci_reflect_dir(incid, ray_half, &dot_incid);
+    float half_pdf = b->k_g.z * powf(vdot(ray_half, it->n_s), pc);
+    float pdf = half_pdf / fmaxf(fabsf(dot_incid), BRDF_EPS);
+    int is_valid = vdot(it->n_s, out) > 0.f;
+    if (rng_float(r) > 0.5f) {
+        v3 s_; float p_;
+        out = sample_lambertian(b, it, it->n_s, r, &s_, &p_);
+    }
+    pdf = 0.5f * (pdf + fabsf(vdot(out, it->n_s)) * F_INV_PI);
+    *spec_out = is_valid ? eval_fresnel_blend(b, it, incid, out, &R) : ZERO3;
+    *pdf_out = pdf;
+    return out;
+}
+/* Oren-Nayar, brdf.py:312-342 */
+static v3 eval_oren_nayar(const bxdf_t* b, const isect_t* it, v3 ray_in, v3 ray_out) {
+    float wi[4], wo[4];
+    convert_to_raw(vneg(ray_in), it->n_s, wi);
+    convert_to_raw(ray_out, it->n_s, wo);
+    float sin_i = wi[1], sin_o = wo[1];
+    float max_cos = 0.f;
+    if (sin_i > 1e-5f && sin_o > 1e-5f) {
+        float d_cos = wi[2] * wo[2] + wi[3] * wo[3];
+        max_cos = fmaxf(0.f, d_cos);
+    }
+    float sin_alpha, tan_beta;
+    float aci = fabsf(wi[0]), aco = fabsf(wo[0]);
+    if (aci > aco) { sin_alpha = sin_o; tan_beta = sin_i / aci; }
+    else           { sin_alpha = sin_i; tan_beta = sin_o / aco; }
+    float f = b->k_g.x + b->k_g.y * max_cos * sin_alpha * tan_beta;
+    return vscale(vscale(vscale(diffuse_color(b, it), F_INV_PI), f), fabsf(wo[0]));
+}
+/* Thin coat, brdf.py:348-422 */
+static v3 sample_thin_coat(const bxdf_t* b, const isect_t* it, v3 incid, rng_t* r, v3* spec_out, float* pdf_out, int* is_specular) {
+    float pdf = 1.0f; v3 spec = ZERO3; v3 out = V(0.f, 1.f, 0.f);
+    float dot_normal = vdot(incid, it->n_s);
+    float cos_r2;
+    v3 refra_in = snell_refraction(incid, it->n_s, dot_normal, 1.0f, b->k_g.z, &cos_r2);
+    float in_ref_F = fresnel_equation(1.f, b->k_g.x, fabsf(dot_normal), sqrtf(cos_r2));
+    *is_specular = 0;
+    if (rng_float(r) > in_ref_F) {
+        v3 local = cosine_hemisphere(r, &pdf);
+        out = delocalize_rotate(it->n_s, local, NULL);
+        float dot_out = vdot(out, it->n_s);
+        if (!is_total_reflection(dot_out, b->k_g.z, 1.0f)) {
+            v3 refra_out = snell_refraction(out, it->n_s, dot_out, b->k_g.z, 1.0f, &cos_r2);
+            float out_ref_F = fresnel_equation(b->k_g.z, 1.f, fabsf(dot_out), sqrtf(cos_r2));
+            pdf *= (1.f - in_ref_F);
+            out = refra_out;
+            spec = eval_oren_nayar(b, it, refra_in, out);
+            spec = vscale(spec, (1.f - in_ref_F) * (1.f - out_ref_F));
+        }
+    } else {
+        spec = vscale(b->k_s, in_ref_F);
+        out = inci_reflect_dir(incid, it->n_s, NULL);
+        pdf = in_ref_F;
+        *is_specular = 1;
+    }
+    *spec_out = spec; *pdf_out = pdf;
+    return out;
+}
+static v3 eval_thin_coating(const bxdf_t* b, const isect_t* it, v3 ray_in, v3 ray_out) {
+    v3 ret;
+    v3 reflect = inci_reflect_dir(ray_in, it->n_s, NULL);
+    float dot_in = vdot(ray_in, it->n_s);
+    float cos_r2;
+    v3 refra_in = snell_refraction(ray_in, it->n_s, dot_in, 1.0f, b->k_g.z, &cos_r2);
+    float in_ref_F = fresnel_equation(1.f, b->k_g.z, fabsf(dot_in), sqrtf(cos_r2));
+    if (fabsf(vdot(ray_out, reflect)) > (1.f - 1e-4f)) {
+        ret = vscale(b->k_s, in_ref_F);
+    } else {
+        float dot_out = vdot(ray_out, it->n_s);
+        v3 refra_out = snell_refraction(ray_out, it->n_s, dot_out, 1.0f, b->k_g.z, &cos_r2);
+        float out_ref_F = fresnel_equation(1.0f, b->k_g.z, fabsf(dot_out), sqrtf(cos_r2));
+        ret = vscale(eval_oren_nayar(b, it, refra_in, refra_out), 1.f - fmaxf(in_ref_F, out_ref_F));
+    }
+    return ret;
+}
+static float thin_coat_fresnel(const bxdf_t* b, const isect_t* it, v3 ray_in) {
+    float dot_in = vdot(ray_in, it->n_s);
+    float ratio = 1.0f / b->k_g.z;
+    float cos_r2 = 1.f - sq(ratio) * (1.f - sq(dot_in));
+    return fresnel_equation(1.f, b->k_g.z, fabsf(dot_in), sqrtf(cos_r2));
+}
+
+/* BRDF.eval, brdf.py:503-526 */
+static v3 brdf_eval(const bxdf_t* b, const isect_t* it, v3 incid, v3 out) {
+    v3 ret = ZERO3;
+    if (vdot(incid, it->n_g) * vdot(out, it->n_g) < 0.f) {
+        switch (b->type) {
+        case 0: ret = eval_phong(b, it, incid, out); break;
+        case 1: ret = eval_lambertian(b, it, it->n_s, out); break;
+        case 4: ret = eval_mod_phong(b, it, incid, out); break;
+        case 5: { m3 R; rotation_between(V(0.f, 1.f, 0.f), it->n_s, &R); ret = eval_fresnel_blend(b, it, incid, out, &R); break; }
+        case 6: ret = eval_oren_nayar(b, it, incid, out); break;
+        case 7: ret = eval_thin_coating(b, it, incid, out); break;
+        default: break;            /* specular(2), microfacet(3, compiled out) -> 0 */
+        }
+    }
+    return ret;
+}
+/* BRDF.sample_new_rays, brdf.py:528-560 */
+static v3 brdf_sample(const bxdf_t* b, const isect_t* it, v3 incid, rng_t* r, v3* spec_out, float* pdf_out, int* is_specular) {
+    v3 dir = V(0.f, 1.f, 0.f); v3 spec = V(1.f, 1.f, 1.f); float pdf = 1.0f;
+    *is_specular = 0;
+    switch (b->type) {
+    case 0: {
+        v3 local = cosine_hemisphere(r, &pdf);
+        dir = delocalize_rotate(it->n_s, local, NULL);
+        spec = eval_phong(b, it, incid, dir);
+        break; }
+    case 1: case 6: dir = sample_lambertian(b, it, it->n_s, r, &spec, &pdf); break;
+    case 2: dir = inci_reflect_dir(incid, it->n_s, NULL); spec = diffuse_color(b, it); pdf = 1.0f; break;
+    case 7: dir = sample_thin_coat(b, it, incid, r, &spec, &pdf, is_specular); break;
+    case 4: dir = sample_mod_phong(b, it, incid, r, &spec, &pdf); break;
+    case 5: dir = sample_fresnel_blend(b, it, incid, r, &spec, &pdf); break;
+    case 3: dir = V(0.f, 1.f, 0.f); spec = ZERO3; pdf = 1.0f; break;
+    default: break;
+    }
+    if (!(vdot(dir, it->n_g) > 0.f)) spec = ZERO3;     /* brdf.py:558-559 */
+    *spec_out = spec; *pdf_out = pdf;
+    return dir;
+}
+/* BRDF.get_pdf, brdf.py:562-601 */
+static float brdf_pdf(const bxdf_t* b, const isect_t* it, v3 outdir, v3 incid) {
+    float pdf = 0.f;
+    float dot_outdir = vdot(it->n_s, outdir);
+    float dot_indir = vdot(it->n_s, incid);
+    if (dot_outdir * dot_indir < 0.f) {
+        switch (b->type) {
+        case 0: case 1: case 6: pdf = dot_outdir * F_INV_PI; break;
+        case 4: {
+            float gloss = b->mean.z;
+            v3 reflect_view = inci_reflect_dir(incid, it->n_s, NULL);
+            float dot_ref_out = fmaxf(0.f, vdot(reflect_view, outdir));
+            float diffuse_pdf = dot_outdir * F_INV_PI;
+            float specular_pdf = 0.5f * (gloss + 1.f) * F_INV_PI * powf(dot_ref_out, gloss);
+            pdf = vmax(diffuse_color(b, it)) * diffuse_pdf + vmax(b->k_s) * specular_pdf;
+            break; }
+        case 7: {
+            v3 reflect = inci_reflect_dir(incid, it->n_s, NULL);
+            float F = thin_coat_fresnel(b, it, incid);
+            pdf = (fabsf(vdot(outdir, reflect)) > (1.f - 1e-3f)) ? F : (1.f - F) * dot_outdir * F_INV_PI;
+            break; }
+        case 5: {
+            v3 half_vec = vnormalized(vsub(outdir, incid));
+            float dot_half = vdot(half_vec, it->n_s);
+            m3 R; rotation_between(V(0.f, 1.f, 0.f), it->n_s, &R);
+            float c2, s2; fresnel_cos2_sin2(half_vec, it->n_s, &R, dot_half, &c2, &s2);
+            pdf = b->k_g.z * powf(dot_half, b->k_g.x * c2 + b->k_g.y * s2) / fabsf(vdot(incid, half_vec));
+            pdf = 0.5f * (pdf + dot_outdir * F_INV_PI);
+            break; }
+        default: break;
+        }
+    }
+    return pdf;
+}
+
+/* ------------------------------------------------------- bxdf/bsdf.py:61-262 */
+static v3 sample_det_refraction(const bxdf_t* b, const isect_t* it, v3 incid, float world_ior, rng_t* r, v3* spec_out, float* pdf_out) {
+    float dot_normal = vdot(incid, it->n_s);
+    int entering = dot_normal < 0.f;
+    float ni = entering ? world_ior : b->ior;
+    float nr = entering ? b->ior : world_ior;
+    float ret_pdf = 1.0f;
+    v3 ret_dir;
+    v3 ret_int = diffuse_color(b, it);
+    if (is_total_reflection(dot_normal, ni, nr)) {
+        ret_dir = vnormalized(vsub(incid, vscale(vscale(it->n_s, 2.f), dot_normal)));
+    } else {
+        float cos_r2;
+        v3 refra = snell_refraction(incid, it->n_s, dot_normal, ni, nr, &cos_r2);
+        float reflect_ratio = fresnel_equation(ni, nr, fabsf(dot_normal), sqrtf(cos_r2));
+        if (rng_float(r) > reflect_ratio) {
+            ret_pdf = 1.f - reflect_ratio;
+            ret_dir = refra;              /* mode == TRANSPORT_UNI: no (ni/nr)^2 factor */
+        } else {
+            ret_dir = vnormalized(vsub(incid, vscale(vscale(it->n_s, 2.f), dot_normal)));
+            ret_pdf = reflect_ratio;
+        }
+    }
+    *spec_out = vscale(ret_int, ret_pdf); *pdf_out = ret_pdf;
+    return ret_dir;
+}
+static v3 eval_det_refraction(const bxdf_t* b, const isect_t* it, v3 ray_in, v3 ray_out, float world_ior) {
+    float dot_out = vdot(ray_out, it->n_s);
+    int entering = dot_out < 0.f;
+    float ni = entering ? world_ior : b->ior;
+    float nr = entering ? b->ior : world_ior;
+    v3 ret = ZERO3;
+    v3 kd = diffuse_color(b, it);
+    v3 ref_dir = vnormalized(vsub(ray_out, vscale(vscale(it->n_s, 2.f), dot_out)));
+    if (is_total_reflection(dot_out, ni, nr)) {
+        if (vdot(ref_dir, ray_in) > 1.f - 5e-5f) ret = kd;
+    } else {
+        float cos_r2;
+        v3 refra = snell_refraction(ray_out, it->n_s, dot_out, ni, nr, &cos_r2);
+        if (cos_r2 > 0.f) {
+            float rr = fresnel_equation(ni, nr, fabsf(dot_out), sqrtf(cos_r2));
+            if (vdot(refra, ray_in) > 1.f - 1e-4f) ret = vscale(kd, 1.f - rr);
+            else if (vdot(ref_dir, ray_in) > 1.f - 1e-4f) ret = vscale(kd, rr);
+        } else {
+            if (vdot(ref_dir, ray_in) > 1.f - 1e-4f) ret = kd;
+        }
+    }
+    return ret;
+}
+static v3 sample_lambertian_trans(const bxdf_t* b, const isect_t* it, v3 incid, float world_ior, rng_t* r, v3* spec_out, float* pdf_out, int* is_delta) {
+    float dot_normal = vdot(incid, it->n_s);
+    int entering = dot_normal < 0.f;
+    float ni = entering ? world_ior : b->ior;
+    float nr = entering ? b->ior : world_ior;
+    float ret_pdf = 1.0f, fresnel = 1.0f;
+    *is_delta = 1;
+    v3 ret_dir;
+    v3 ret_int = diffuse_color(b, it);
+    if (is_total_reflection(dot_normal, ni, nr)) {
+        ret_dir = vnormalized(vsub(incid, vscale(vscale(it->n_s, 2.f), dot_normal)));
+    } else {
+        float ratio = ni / nr;
+        float cos_r2 = 1.f - sq(ratio) * (1.f - sq(dot_normal));
+        float reflect_ratio = fresnel_equation(ni, nr, fabsf(dot_normal), sqrtf(cos_r2));
+        if (rng_float(r) > reflect_ratio) {
+            fresnel = 1.f - reflect_ratio;
+            v3 local = cosine_hemisphere(r, &ret_pdf);
+            ret_pdf *= fresnel;
+            v3 normal = vscale(it->n_s, signf_(dot_normal));
+            ret_dir = delocalize_rotate(normal, local, NULL);
+            float cosine = fmaxf(0.f, vdot(normal, ret_dir));
+            ret_int = vscale(ret_int, F_INV_PI * cosine);
+            *is_delta = 0;
+        } else {
+            ret_dir = vnormalized(vsub(incid, vscale(vscale(it->n_s, 2.f), dot_normal)));
+            fresnel = reflect_ratio;
+            ret_pdf = reflect_ratio;
+        }
+    }
+    *spec_out = vscale(ret_int, fresnel); *pdf_out = ret_pdf;
+    return ret_dir;
+}
+static v3 eval_lambertian_trans(const bxdf_t* b, const isect_t* it, v3 ray_in, v3 ray_out, float world_ior) {
+    float dot_out = vdot(ray_out, it->n_s);
+    int entering = dot_out < 0.f;
+    float ni = entering ? world_ior : b->ior;
+    float nr = entering ? b->ior : world_ior;
+    v3 ret = ZERO3;
+    v3 kd = diffuse_color(b, it);
+    v3 ref_dir = vnormalized(vsub(ray_out, vscale(vscale(it->n_s, 2.f), dot_out)));
+    if (is_total_reflection(dot_out, ni, nr)) {
+        if (vdot(ref_dir, ray_in) > 1.f - 1e-4f) ret = kd;
+    } else {
+        float ratio = ni / nr;
+        float cos_r2 = 1.f - sq(ratio) * (1.f - sq(dot_out));
+        float dot_in = vdot(ray_in, it->n_s);
+        if (cos_r2 > 0.f) {
+            float rr = fresnel_equation(ni, nr, fabsf(dot_out), sqrtf(cos_r2));
+            if (dot_in * dot_out < 0.f) {
+                if (vdot(ref_dir, ray_in) > 1.f - 1e-4f) ret = vscale(kd, rr);
+            } else {
+                ret = vscale(kd, (1.f - rr) * F_INV_PI * fabsf(dot_out));
+            }
+        } else {
+            if (vdot(ref_dir, ray_in) > 1.f - 1e-4f) ret = kd;
+        }
+    }
+    return ret;
+}
+/* BSDF.get_pdf, bsdf.py:211-236 */
+static float bsdf_pdf(const bxdf_t* b, const isect_t* it, v3 outdir, v3 incid, float world_ior) {
+    float pdf = 0.f;
+    if (b->type == -1) {
+        pdf = (vdot(incid, outdir) > 1.f - 1e-4f) ? 1.f : 0.f;
+    } else {
+        float dot_out = vdot(outdir, it->n_s);
+        int entering = dot_out < 0.f;
+        float ni = entering ? world_ior : b->ior;
+        float nr = entering ? b->ior : world_ior;
+        v3 ref_dir = vnormalized(vsub(outdir, vscale(vscale(it->n_s, 2.f), dot_out)));
+        float cos_r2;
+        v3 refra = snell_refraction(outdir, it->n_s, dot_out, ni, nr, &cos_r2);
+        if (cos_r2 > 0.0f) {
+            float rr = fresnel_equation(ni, nr, fabsf(dot_out), sqrtf(cos_r2));
+            if (vdot(ref_dir, incid) > 1.f - 1e-4f) pdf = rr;
+            else {
+                if (b->type == 0 && vdot(refra, incid) > 1.f - 1e-4f) pdf = 1.f - rr;
+                else if (b->type == 1 && (vdot(incid, it->n_s) * dot_out > 0.f)) pdf = (1.f - rr) * fabsf(dot_out) * F_INV_PI;
+            }
+        } else {
+            if (vdot(ref_dir, incid) > 1.f - 1e-4f) pdf = 1.f;
+        }
+    }
+    return pdf;
+}
+
+/* ---------------------------- PathTracer dispatch, path_tracer.py:424-526 */
+static v3 pt_sample_new_ray(const ctx_t* c, isect_t* it, v3 incid, rng_t* r, v3* spec, float* pdf, int* is_specular) {
+    const bxdf_t* b = &c->sc->bxdf[it->obj_id];
+    if (!b->is_bsdf) {
+        if (c->cfg->brdf_two_sides && vdot(incid, it->n_s) > 0.f) { it->n_s = vneg(it->n_s); it->n_g = vneg(it->n_g); }
+        return brdf_sample(b, it, incid, r, spec, pdf, is_specular);
+    }
+    v3 dir = ZERO3; *spec = ZERO3; *pdf = 0.f; *is_specular = 0;
+    if (b->type == 0) dir = sample_det_refraction(b, it, incid, c->sc->world_ior, r, spec, pdf);
+    else if (b->type == 1) dir = sample_lambertian_trans(b, it, incid, c->sc->world_ior, r, spec, pdf, is_specular);
+    return dir;
+}
+static v3 pt_eval(const ctx_t* c, isect_t* it, v3 incid, v3 out) {
+    const bxdf_t* b = &c->sc->bxdf[it->obj_id];
+    if (!b->is_bsdf) {
+        if (c->cfg->brdf_two_sides && vdot(incid, it->n_s) > 0.f) { it->n_s = vneg(it->n_s); it->n_g = vneg(it->n_g); }
+        return brdf_eval(b, it, incid, out);
+    }
+    if (b->type == 0) return eval_det_refraction(b, it, incid, out, c->sc->world_ior);
+    if (b->type == 1) return eval_lambertian_trans(b, it, incid, out, c->sc->world_ior);
+    return ZERO3;
+}
+static float pt_surface_pdf(const ctx_t* c, isect_t* it, v3 outdir, v3 incid) {
+    const bxdf_t* b = &c->sc->bxdf[it->obj_id];
+    if (!b->is_bsdf) {
+        if (c->cfg->brdf_two_sides && vdot(incid, it->n_s) > 0.f) { it->n_s = vneg(it->n_s); it->n_g = vneg(it->n_g); }
+        return brdf_pdf(b, it, outdir, incid);
+    }
+    return bsdf_pdf(b, it, outdir, incid, c->sc->world_ior);
+}
+static int pt_is_delta(const ctx_t* c, int idx) { return (idx >= 0) ? c->sc->bxdf[idx].is_delta : 0; }
+
+/* --------------------------------- emitters/abtract_source.py:35-232 */
+static float distance_attenuate(v3 x) { return fminf(1.0f / fmaxf(vnorm2(x), 1e-5f), 1.0f); }
+
+static v3 src_sample_hit(const ctx_t* c, const src_t* s, v3 hit_pos, rng_t* r, v3* ret_int_out, float* ret_pdf_out) {
+    const scene_t* sc = c->sc;
+    v3 ret_int = s->intensity, ret_pos = s->pos;
+    float ret_pdf = 1.0f;
+    v3 normal = ZERO3;
+    if (s->type == 0) {
+        ret_int = vscale(ret_int, distance_attenuate(vsub(hit_pos, ret_pos)));
+    } else if (s->type == 1) {
+        ret_pdf = s->inv_area;
+        int is_sphere = sc->obj_info[s->obj_ref_id][2];
+        if (is_sphere) {
+            int tri_id = sc->obj_info[s->obj_ref_id][0];
+            v3 center = sc->precom[tri_id][0];
+            float radius = sc->precom[tri_id][1].x;
+            v3 to_hit = vnormalized(vsub(hit_pos, center));
+            float pdf;
+            v3 local = uniform_sphere(r, &pdf);
+            normal = delocalize_rotate(to_hit, local, NULL);
+            ret_pos = vadd(center, vscale(normal, radius));
+            ret_pdf = pdf / (radius * radius);
+        } else {
+            int mesh_num = sc->obj_info[s->obj_ref_id][1];
+            int tri_id = pymod(rng_int(r), mesh_num) + sc->obj_info[s->obj_ref_id][0];
+            normal = sc->normals[tri_id];
+            v3 dv1 = sc->precom[tri_id][0], dv2 = sc->precom[tri_id][1];
+            ret_pos = vadd(sample_triangle(r, dv1, dv2), sc->precom[tri_id][2]);
+        }
+        v3 diff = vsub(hit_pos, ret_pos);
+        float dot_light = vdot(vnormalized(diff), normal);
+        if (dot_light <= 0.0f) {
+            ret_int = ZERO3; ret_pdf = 1.0f;
+        } else {
+            float diff_norm2 = vnorm2(diff);
+            ret_pdf *= diff_norm2 / dot_light;
+            ret_int = (ret_pdf > 0.0f) ? vdivs(ret_int, ret_pdf) : ZERO3;
+        }
+    } else if (s->type == 2) {
+        v3 to_hit = vsub(hit_pos, ret_pos);
+        float depth = fmaxf(vnorm(to_hit), 1e-5f);
+        to_hit = vdivs(to_hit, depth);
+        float cos_val = vdot(to_hit, s->dir);
+        if (cos_val > s->r) ret_int = vdivs(ret_int, depth * depth);
+        else ret_int = ZERO3;
+    } else if (s->type == 4) {
+        ret_pdf = 0.f;
+        if (s->r > 0.f) {
+            v3 to_hit = vsub(hit_pos, s->pos);
+            float proj_d = vdot(to_hit, s->dir);
+            if (proj_d > 0.0f) {
+                float dist = sqrtf(vnorm2(to_hit) - proj_d * proj_d);
+                if (dist < s->r) { ret_pos = vsub(hit_pos, vscale(s->dir, proj_d)); normal = s->dir; }
+                else ret_int = ZERO3;
+            }
+        } else ret_int = ZERO3;
+    }
+    (void)normal;
+    *ret_int_out = ret_int; *ret_pdf_out = ret_pdf;
+    return ret_pos;
+}
+static v3 src_eval_le(const src_t* s, v3 inci_dir, v3 normal) {
+    v3 ret = ZERO3;
+    if (s->type == 1) {
+        float dot_light = -vdot(vnormalized(inci_dir), normal);
+        if (dot_light > 0.f) ret = s->intensity;
+    }
+    return ret;
+}
+static float src_solid_angle_pdf(const src_t* s, const isect_t* it, v3 incid_dir) {
+    float dot_res = fabsf(vdot(incid_dir, it->n_s));
+    float area_pdf = (s->type == 1) ? s->inv_area : 0.f;
+    return (dot_res > 0.0f) ? area_pdf * sq(it->min_depth) / dot_res : 0.0f;
+}
+
+/* sample_light, path_tracer.py:537-554 */
+static const src_t* pt_sample_light(const ctx_t* c, int no_sample, rng_t* r, float* pdf, int* valid) {
+    int n = c->sc->n_sources;
+    int idx = pymod(rng_int(r), n);
+    *pdf = 1.f / (float)n;
+    *valid = 1;
+    if (no_sample >= 0) {
+        if (n <= 1) *valid = 0;
+        else {
+            idx = pymod(rng_int(r), n - 1);
+            if (idx >= no_sample) idx += 1;
+            *pdf = 1.f / (float)(n - 1);
+        }
+    }
+    return &c->sc->src[idx];
+}
+
+/* ----------------------------------------------------------- intersection */
+/* Interaction tail shared by both intersectors (tracer_base.py:209-237, path_tracer.py:375-394) */
+static void finish_isect(const scene_t* sc, isect_t* it, int sphere_flag, v3 ray, v3 start_p) {
+    it->n_g = V(1.f, 0.f, 0.f); it->n_s = V(1.f, 0.f, 0.f);
+    it->tex = V(-1.f, -1.f, -1.f);
+    if (it->obj_id >= 0) {
+        if (sphere_flag) {
+            v3 center = sc->prims[it->prim_id][0];
+            it->n_g = vnormalized(vsub(vadd(start_p, vscale(ray, it->min_depth)), center));
+            it->u = (atan2f(it->n_g.y, it->n_g.x) + F_PI) * F_INV_2PI;
+            it->v = acosf(it->n_g.z) * F_INV_PI;
+            it->n_s = it->n_g;
+        } else {
+            it->n_g = sc->normals[it->prim_id];
+            if (sc->has_vn) {
+                const v3* vn = sc->vnorm[it->prim_id];
+                it->n_s = vadd(vadd(vscale(vn[0], 1.f - it->u - it->v), vscale(vn[1], it->u)), vscale(vn[2], it->v));
+            } else it->n_s = it->n_g;
+        }
+    }
+}
+/* sphere test shared (tracer_base.py:184-199); returns ray_t or -1 */
+static float sphere_t(const scene_t* sc, int prim, v3 ray, v3 start_p) {
+    v3 center = sc->prims[prim][0];
+    float r = sc->prims[prim][1].x;
+    float radius2 = r * r;
+    v3 s2c = vsub(center, start_p);
+    float center_norm2 = vnorm2(s2c);
+    float proj = vdot(ray, s2c);
+    float c2ray = center_norm2 - proj * proj;
+    if (c2ray >= radius2) return -1.f;
+    float cut = sqrtf(radius2 - c2ray);
+    return proj + ((center_norm2 > radius2 + 1e-4f) ? -cut : cut);
+}
+static inline void tri_uvt(const scene_t* sc, int prim, v3 ray, v3 start_p, float* u, float* v, float* t) {
+    v3 p1 = sc->prims[prim][0];
+    v3 v1 = sc->precom[prim][0], v2 = sc->precom[prim][1];
+    m3 inv; inverse_cols(v1, v2, vneg(ray), &inv);
+    v3 s = vsub(start_p, p1);
+    v3 uvt = m3mulv(&inv, s);
+    *u = uvt.x; *v = uvt.y; *t = uvt.z;
+}
+/* TracerBase.aabb_test, tracer_base.py:159-166 (division by the ray, not inv_ray) */
+static int obj_aabb_test(const scene_t* sc, int idx, v3 ray, v3 ray_o, float* t_near) {
+    v3 tmin = vdiv(vsub(sc->aabbs[idx][0], ray_o), ray);
+    v3 tmax = vdiv(vsub(sc->aabbs[idx][1], ray_o), ray);
+    float tn = vmax(vminv(tmin, tmax));
+    float tf = vmin(vmaxv(tmin, tmax));
+    *t_near = tn;
+    return (tn < tf) && tf > 0.f;
+}
+/* TracerBase.ray_intersect, tracer_base.py:168-237 */
+static void ray_intersect_brute(const scene_t* sc, v3 ray, v3 start_p, float min_depth_in, isect_t* it) {
+    int obj_id = -1, prm_id = -1, sphere_flag = 0;
+    float cu = 0.f, cv = 0.f;
+    float min_depth = (min_depth_in > 0.0f) ? min_depth_in - 1e-4f : 1e7f;
+    for (int o = 0; o < sc->n_objects; o++) {
+        float t_near;
+        if (!obj_aabb_test(sc, o, ray, start_p, &t_near)) continue;
+        if (t_near > min_depth) continue;
+        int start_id = sc->obj_info[o][0];
+        if (sc->obj_info[o][2]) {
+            float rt = sphere_t(sc, start_id, ray, start_p);
+            /* `continue` on a miss: rt = -1 fails the > 1e-4 test */
+            if (rt > 1e-4f && rt < min_depth) { min_depth = rt; obj_id = o; prm_id = start_id; sphere_flag = 1; }
+        } else {
+            int tri_num = sc->obj_info[o][1];
+            for (int m = start_id; m < tri_num + start_id; m++) {
+                float u, v, t; tri_uvt(sc, m, ray, start_p, &u, &v, &t);
+                if (u >= 0.f && v >= 0.f && u + v <= 1.0f)
+                    if (t > 1e-4f && t < min_depth) { min_depth = t; obj_id = o; prm_id = m; cu = u; cv = v; sphere_flag = 0; }
+            }
+        }
+    }
+    it->obj_id = obj_id; it->prim_id = prm_id; it->u = cu; it->v = cv; it->min_depth = min_depth;
+    finish_isect(sc, it, sphere_flag, ray, start_p);
+}
+/* TracerBase.does_intersect, tracer_base.py:239-278 */
+static int does_intersect_brute(const scene_t* sc, v3 ray, v3 start_p, float min_depth_in) {
+    float min_depth = (min_depth_in > 0.0f) ? min_depth_in - 1e-4f : 1e7f;
+    for (int o = 0; o < sc->n_objects; o++) {
+        float t_near;
+        if (!obj_aabb_test(sc, o, ray, start_p, &t_near)) continue;
+        if (t_near > min_depth) continue;
+        int start_id = sc->obj_info[o][0];
+        if (sc->obj_info[o][2]) {
+            float rt = sphere_t(sc, start_id, ray, start_p);
+            if (rt > 1e-4f && rt < min_depth) return 1;
+        } else {
+            int tri_num = sc->obj_info[o][1];
+            for (int m = start_id; m < tri_num + start_id; m++) {
+                float u, v, t; tri_uvt(sc, m, ray, start_p, &u, &v, &t);
+                if (u >= 0.f && v >= 0.f && u + v <= 1.0f)
+                    if (t > 1e-4f && t < min_depth) return 1;
+            }
+        }
+    }
+    return 0;
+}
+/* LinearNode/LinearBVH.aabb_test, ti_bvh.py:17-24,38-45 */
+static int slab_test(v3 mini, v3 maxi, v3 inv_ray, v3 ray_o, float* t_near) {
+    v3 tmin = vmul(vsub(mini, ray_o), inv_ray);
+    v3 tmax = vmul(vsub(maxi, ray_o), inv_ray);
+    float tn = vmax(vminv(tmin, tmax));
+    float tf = vmin(vmaxv(tmin, tmax));
+    *t_near = tn;
+    return (tn < tf) && tf > 0.f;
+}
+/* PathTracer.bvh_intersect, path_tracer.py:309-336 */
+static float bvh_prim_t(const scene_t* sc, int bvh_id, v3 ray, v3 start_p, int* obj_idx, int* prim_idx, int* is_sphere, float* u, float* v) {
+    *obj_idx = sc->bvhs[bvh_id].obj_idx; *prim_idx = sc->bvhs[bvh_id].prim_idx;
+    *is_sphere = sc->obj_info[*obj_idx][2];
+    float ray_t = -1.f; *u = 0.f; *v = 0.f;
+    if (*is_sphere > 0) {
+        ray_t = sphere_t(sc, *prim_idx, ray, start_p);
+    } else {
+        float t; tri_uvt(sc, *prim_idx, ray, start_p, u, v, &t);
+        if (*u >= 0.f && *v >= 0.f && *u + *v <= 1.0f) ray_t = t;
+    }
+    return ray_t;
+}
+/* PathTracer.ray_intersect_bvh, path_tracer.py:338-394 */
+static void ray_intersect_bvh(const scene_t* sc, v3 ray, v3 start_p, float min_depth_in, isect_t* it) {
+    int obj_id = -1, prim_id = -1, sphere_flag = 0;
+    float min_depth = (min_depth_in > 0.0f) ? min_depth_in - 1e-4f : 1e7f;
+    int node_idx = 0;
+    v3 inv_ray = V(1.f / ray.x, 1.f / ray.y, 1.f / ray.z);
+    float cu = 0.f, cv = 0.f;
+    while (node_idx < sc->node_num) {
+        const lin_node_t* nd = &sc->nodes[node_idx];
+        float t_near;
+        int hit = slab_test(nd->mini, nd->maxi, inv_ray, start_p, &t_near);
+        if (!hit || t_near > min_depth) { node_idx += nd->all_offset; continue; }
+        if (nd->all_offset == 1) {
+            for (int bi = nd->base; bi < nd->base + nd->prim_cnt; bi++) {
+                const lin_bvh_t* lb = &sc->bvhs[bi];
+                hit = slab_test(lb->mini, lb->maxi, inv_ray, start_p, &t_near);
+                if (!hit || t_near > min_depth) continue;
+                int oi, pi, sph; float u, v;
+                float rt = bvh_prim_t(sc, bi, ray, start_p, &oi, &pi, &sph, &u, &v);
+                if (rt > 1e-4f && rt < min_depth) { min_depth = rt; obj_id = oi; prim_id = pi; sphere_flag = sph; cu = u; cv = v; }
+            }
+        }
+        node_idx += 1;
+    }
+    it->obj_id = obj_id; it->prim_id = prim_id; it->u = cu; it->v = cv; it->min_depth = min_depth;
+    finish_isect(sc, it, sphere_flag, ray, start_p);
+}
+/* PathTracer.does_intersect_bvh, path_tracer.py:396-422 */
+static int does_intersect_bvh(const scene_t* sc, v3 ray, v3 start_p, float min_depth_in) {
+    float min_depth = (min_depth_in > 0.0f) ? min_depth_in - 1e-4f : 1e7f;
+    int node_idx = 0;
+    v3 inv_ray = V(1.f / ray.x, 1.f / ray.y, 1.f / ray.z);
+    while (node_idx < sc->node_num) {
+        const lin_node_t* nd = &sc->nodes[node_idx];
+        float t_near;
+        int hit = slab_test(nd->mini, nd->maxi, inv_ray, start_p, &t_near);
+        if (!hit || t_near > min_depth) { node_idx += nd->all_offset; continue; }
+        if (nd->all_offset == 1) {
+            for (int bi = nd->base; bi < nd->base + nd->prim_cnt; bi++) {
+                const lin_bvh_t* lb = &sc->bvhs[bi];
+                hit = slab_test(lb->mini, lb->maxi, inv_ray, start_p, &t_near);
+                if (!hit || t_near > min_depth) continue;
+                int oi, pi, sph; float u, v;
+                float rt = bvh_prim_t(sc, bi, ray, start_p, &oi, &pi, &sph, &u, &v);
+                if (rt > 1e-4f && rt < min_depth) return 1;
+            }
+        }
+        node_idx += 1;
+    }
+    return 0;
+}
+static void pt_ray_intersect(const ctx_t* c, v3 ray, v3 o, isect_t* it) {
+    if (c->cfg->use_bvh && c->sc->node_num > 0) ray_intersect_bvh(c->sc, ray, o, -1.0f, it);
+    else ray_intersect_brute(c->sc, ray, o, -1.0f, it);
+}
+static int pt_does_intersect(const ctx_t* c, v3 ray, v3 o, float dist) {
+    if (c->cfg->use_bvh && c->sc->node_num > 0) return does_intersect_bvh(c->sc, ray, o, dist);
+    return does_intersect_brute(c->sc, ray, o, dist);
+}
+
+/* -------------------------------- SAH BVH build: tracer/bvh/bvh.cpp:19-212 */
+typedef struct { v3 mini, maxi; } aabb_t;
+typedef struct { aabb_t bound; v3 centroid; int prim_idx, obj_idx; } bvh_info_t;
+typedef struct bnode { int base, prim_num; aabb_t bound; struct bnode *l, *r; } bnode_t;
+#define NUM_BINS 12
+static const float TRAVERSE_COST = 0.1f;
+
+static void aabb_clear(aabb_t* a) { a->mini = V(1e4f, 1e4f, 1e4f); a->maxi = V(-1e4f, -1e4f, -1e4f); }
+static void aabb_grow(aabb_t* a, const aabb_t* b) { a->mini = vminv(b->mini, a->mini); a->maxi = vmaxv(b->maxi, a->maxi); }
+static float aabb_area(const aabb_t* a) {
+    v3 d = vsub(a->maxi, a->mini);
+    return (float)(2. * (double)(d.x * d.y + d.y * d.z + d.x * d.z));   /* bvh_helper.h:61-64: `2. *` is double */
+}
+static inline float comp(v3 a, int ax) { return ax == 0 ? a.x : (ax == 1 ? a.y : a.z); }
+
+static void prim_bound(const v3 p[3], int is_sphere, bvh_info_t* out) {     /* bvh_helper.h:30-45,75-85 */
+    if (is_sphere) {
+        out->bound.mini = vsub(p[0], p[1]); out->bound.maxi = vadd(p[0], p[1]);
+        out->centroid = p[0];
+    } else {
+        v3 lo = vminv(vminv(p[0], p[1]), p[2]), hi = vmaxv(vmaxv(p[0], p[1]), p[2]);
+        float* l = &lo.x; float* h = &hi.x;
+        for (int i = 0; i < 3; i++) if (h[i] - l[i] < 1e-4f) { l[i] -= 1e-4f; h[i] += 1e-4f; }
+        out->bound.mini = lo; out->bound.maxi = hi;
+        /* Eigen rowwise().mean(): (a+b+c)/3 */
+        out->centroid = V(((p[0].x + p[1].x) + p[2].x) / 3.f, ((p[0].y + p[1].y) + p[2].y) / 3.f, ((p[0].z + p[1].z) + p[2].z) / 3.f);
+    }
+}
+static int g_sort_axis;
+static int cmp_centroid(const void* a, const void* b) {
+    float ca = comp(((const bvh_info_t*)a)->centroid, g_sort_axis), cb = comp(((const bvh_info_t*)b)->centroid, g_sort_axis);
+    return (ca < cb) ? -1 : (ca > cb);
+}
+static int build_sah(bnode_t* cur, bvh_info_t* infos) {
+    aabb_t fwd, bwd; aabb_clear(&fwd); aabb_clear(&bwd);
+    int child_cnt = 0;
+    const int prim_num = cur->prim_num, base = cur->base, max_pos = base + prim_num;
+    float min_cost = 5e9f, node_prim_cnt = (float)prim_num;
+    float node_inv_area = (float)(1. / (double)aabb_area(&cur->bound));
+    /* max_extent_axis, bvh.cpp:19-41 */
+    v3 min_c = infos[base].centroid, max_c = infos[base].centroid;
+    for (int i = 1; i < prim_num; i++) { min_c = vminv(min_c, infos[base + i].centroid); max_c = vmaxv(max_c, infos[base + i].centroid); }
+    v3 diff = vsub(max_c, min_c);
+    float max_diff = diff.x; int axis = 0;
+    if (diff.y > max_diff) { max_diff = diff.y; axis = 1; }
+    if (diff.z > max_diff) { max_diff = diff.z; axis = 2; }
+    float bins[NUM_BINS];
+    float min_r = comp(min_c, axis) - 0.001f, interval = (max_diff + 0.002f) / (float)NUM_BINS;
+    for (int i = 0; i < NUM_BINS; i++) bins[i] = min_r + interval * (float)(i + 1);
+    if (prim_num > 4) {
+        aabb_t bin_bound[NUM_BINS]; int bin_cnt[NUM_BINS];
+        for (int i = 0; i < NUM_BINS; i++) { aabb_clear(&bin_bound[i]); bin_cnt[i] = 0; }
+        for (int i = base; i < max_pos; i++) {
+            float cv = comp(infos[i].centroid, axis);
+            int idx = 0; while (idx < NUM_BINS && bins[idx] < cv) idx++;      /* std::lower_bound */
+            if (idx >= NUM_BINS) idx = NUM_BINS - 1;                         /* cannot happen (bins padded) */
+            aabb_grow(&bin_bound[idx], &infos[i].bound); bin_cnt[idx]++;
+        }
+        int prim_cnts[NUM_BINS]; float fwd_areas[NUM_BINS], bwd_areas[NUM_BINS];
+        for (int i = 0; i < NUM_BINS; i++) {
+            aabb_grow(&fwd, &bin_bound[i]);
+            prim_cnts[i] = bin_cnt[i];
+            fwd_areas[i] = aabb_area(&fwd);
+            if (i > 0) { aabb_grow(&bwd, &bin_bound[NUM_BINS - i]); bwd_areas[NUM_BINS - 1 - i] = aabb_area(&bwd); }
+        }
+        for (int i = 1; i < NUM_BINS; i++) prim_cnts[i] += prim_cnts[i - 1];
+        int seg = 0;
+        for (int i = 0; i < NUM_BINS - 1; i++) {
+            float cost = TRAVERSE_COST + node_inv_area * ((float)prim_cnts[i] * fwd_areas[i] + (node_prim_cnt - (float)prim_cnts[i]) * bwd_areas[i]);
+            if (cost < min_cost) { min_cost = cost; seg = i; }
+        }
+        if (min_cost < node_prim_cnt) {
+            /* std::partition by centroid < pivot; a stable partition yields the same two sets */
+            float pivot = bins[seg];
+            bvh_info_t* tmp = (bvh_info_t*)malloc(sizeof(bvh_info_t) * (size_t)prim_num);
+            int k = 0;
+            for (int i = base; i < max_pos; i++) if (comp(infos[i].centroid, axis) < pivot) tmp[k++] = infos[i];
+            for (int i = base; i < max_pos; i++) if (!(comp(infos[i].centroid, axis) < pivot)) tmp[k++] = infos[i];
+            memcpy(infos + base, tmp, sizeof(bvh_info_t) * (size_t)prim_num);
+            free(tmp);
+            child_cnt = prim_cnts[seg];
+        }
+        aabb_clear(&fwd); aabb_clear(&bwd);
+        for (int i = 0; i <= seg; i++) aabb_grow(&fwd, &bin_bound[i]);
+        for (int i = NUM_BINS - 1; i > seg; i--) aabb_grow(&bwd, &bin_bound[i]);
+    } else {
+        int seg_idx = (base + max_pos) >> 1;
+        g_sort_axis = axis;                  /* nth_element -> full sort of <= 4 items: same split sets */
+        qsort(infos + base, (size_t)prim_num, sizeof(bvh_info_t), cmp_centroid);
+        for (int i = base; i < seg_idx; i++) aabb_grow(&fwd, &infos[i].bound);
+        for (int i = seg_idx; i < max_pos; i++) aabb_grow(&bwd, &infos[i].bound);
+        child_cnt = seg_idx - base;
+        float split_cost = TRAVERSE_COST + node_inv_area * (aabb_area(&fwd) * (float)child_cnt + aabb_area(&bwd) * (node_prim_cnt - (float)child_cnt));
+        if (split_cost >= node_prim_cnt) child_cnt = 0;
+    }
+    if (child_cnt > 0) {
+        cur->l = (bnode_t*)calloc(1, sizeof(bnode_t)); cur->r = (bnode_t*)calloc(1, sizeof(bnode_t));
+        cur->l->base = base; cur->l->prim_num = child_cnt; cur->l->bound = fwd;
+        cur->r->base = base + child_cnt; cur->r->prim_num = prim_num - child_cnt; cur->r->bound = bwd;
+        int n = 1;
+        n += (cur->l->prim_num > 1) ? build_sah(cur->l, infos) : 1;
+        n += (cur->r->prim_num > 1) ? build_sah(cur->r, infos) : 1;
+        return n;
+    }
+    return 1;
+}
+static int linearize(bnode_t* cur, lin_node_t* out, int* n) {       /* bvh.cpp:195-212 */
+    int me = (*n)++;
+    out[me].mini = cur->bound.mini; out[me].maxi = cur->bound.maxi;
+    out[me].base = cur->base; out[me].prim_cnt = cur->prim_num;
+    if (cur->l) {
+        int cnt = linearize(cur->l, out, n);
+        cnt += linearize(cur->r, out, n);
+        out[me].all_offset = cnt + 1;
+        return cnt + 1;
+    }
+    out[me].all_offset = 1;
+    return 1;
+}
+static void free_tree(bnode_t* n) { if (!n) return; free_tree(n->l); free_tree(n->r); free(n); }
+
+static void build_reference_bvh(scene_t* sc, v3 wmin, v3 wmax) {
+    int N = sc->n_prims;
+    bvh_info_t* infos = (bvh_info_t*)malloc(sizeof(bvh_info_t) * (size_t)N);
+    for (int o = 0; o < sc->n_objects; o++) {
+        int start = sc->obj_info[o][0], cnt = sc->obj_info[o][1], sph = sc->obj_info[o][2];
+        for (int p = start; p < start + cnt; p++) { prim_bound(sc->prims[p], sph > 0, &infos[p]); infos[p].prim_idx = p; infos[p].obj_idx = o; }
+    }
+    bnode_t* root = (bnode_t*)calloc(1, sizeof(bnode_t));
+    root->base = 0; root->prim_num = N; root->bound.mini = wmin; root->bound.maxi = wmax;
+    int node_num = build_sah(root, infos);
+    sc->nodes = (lin_node_t*)malloc(sizeof(lin_node_t) * (size_t)node_num);
+    int n = 0; linearize(root, sc->nodes, &n);
+    sc->node_num = n;
+    sc->bvhs = (lin_bvh_t*)malloc(sizeof(lin_bvh_t) * (size_t)N);
+    for (int i = 0; i < N; i++) { sc->bvhs[i].mini = infos[i].bound.mini; sc->bvhs[i].maxi = infos[i].bound.maxi; sc->bvhs[i].obj_idx = infos[i].obj_idx; sc->bvhs[i].prim_idx = infos[i].prim_idx; }
+    sc->bvh_num = N;
+    free(infos); free_tree(root);
+}
+
+/* ----------------------------------------------------- scene construction */
+static const v3* as_v3(const float* p) { return (const v3*)p; }
+
+ORC_API scene_t* orc_scene_create(const orc_scene_desc* d, const float cam_t[3], int build_bvh) {
+    scene_t* sc = (scene_t*)calloc(1, sizeof(scene_t));
+    int N = d->n_prims, O = d->n_objects, S = d->n_sources;
+    sc->n_prims = N; sc->n_objects = O; sc->n_sources = S; sc->has_vn = d->has_vertex_normal;
+    sc->world_ior = d->world_ior;
+    sc->prims = malloc(sizeof(v3) * 3 * (size_t)N); sc->precom = malloc(sizeof(v3) * 3 * (size_t)N);
+    sc->vnorm = malloc(sizeof(v3) * 3 * (size_t)N); sc->normals = malloc(sizeof(v3) * (size_t)N);
+    memcpy(sc->prims, d->prims, sizeof(v3) * 3 * (size_t)N);
+    memcpy(sc->normals, d->normals, sizeof(v3) * (size_t)N);
+    if (d->v_normals) memcpy(sc->vnorm, d->v_normals, sizeof(v3) * 3 * (size_t)N); else memset(sc->vnorm, 0, sizeof(v3) * 3 * (size_t)N);
+    sc->obj_info = malloc(sizeof(int) * 3 * (size_t)O); memcpy(sc->obj_info, d->obj_info, sizeof(int) * 3 * (size_t)O);
+    sc->aabbs = malloc(sizeof(v3) * 2 * (size_t)O); memcpy(sc->aabbs, d->obj_aabb, sizeof(v3) * 2 * (size_t)O);
+    sc->emitter_id = malloc(sizeof(int) * (size_t)O); memcpy(sc->emitter_id, d->emitter_id, sizeof(int) * (size_t)O);
+    /* load_primitives, tracer_base.py:117-134: precom = (v1-v0, v2-v0, v0); sphere rows keep (centre, rrr) */
+    for (int p = 0; p < N; p++) {
+        sc->precom[p][0] = vsub(sc->prims[p][1], sc->prims[p][0]);
+        sc->precom[p][1] = vsub(sc->prims[p][2], sc->prims[p][0]);
+        sc->precom[p][2] = sc->prims[p][0];
+    }
+    for (int o = 0; o < O; o++) if (sc->obj_info[o][2]) {
+        int p = sc->obj_info[o][0];
+        sc->precom[p][0] = sc->prims[p][0]; sc->precom[p][1] = sc->prims[p][1];
+    }
+    sc->bxdf = calloc((size_t)O, sizeof(bxdf_t));
+    for (int o = 0; o < O; o++) {
+        const int* bi = d->bxdf_i + 4 * o; const float* bf = d->bxdf_f + 13 * o;
+        bxdf_t* b = &sc->bxdf[o];
+        b->type = bi[0]; b->is_delta = bi[1]; b->is_bsdf = bi[2];
+        b->k_d = as_v3(bf)[0]; b->k_s = as_v3(bf)[1]; b->k_g = as_v3(bf)[2]; b->mean = as_v3(bf)[3]; b->ior = bf[12];
+    }
+    sc->src = calloc((size_t)(S > 0 ? S : 1), sizeof(src_t));
+    for (int s = 0; s < S; s++) {
+        const int* si = d->src_i + 4 * s; const float* sf = d->src_f + 11 * s;
+        src_t* e = &sc->src[s];
+        e->type = si[0]; e->bool_bits = si[1]; e->obj_ref_id = si[2];
+        e->intensity = as_v3(sf)[0]; e->dir = as_v3(sf)[1]; e->pos = as_v3(sf)[2]; e->inv_area = sf[9]; e->r = sf[10];
+    }
+    if (build_bvh) {
+        /* world AABB, path_tracer.py:130-138 */
+        v3 lo = V(1e3f, 1e3f, 1e3f), hi = V(-1e3f, -1e3f, -1e3f);
+        for (int o = 0; o < O; o++) { lo = vminv(lo, sc->aabbs[o][0]); hi = vmaxv(hi, sc->aabbs[o][1]); }
+        v3 ct = V(cam_t[0], cam_t[1], cam_t[2]);
+        build_reference_bvh(sc, vadds(vminv(ct, lo), -0.1f), vadds(vmaxv(ct, hi), 0.1f));
+    }
+    return sc;
+}
+ORC_API void orc_scene_destroy(scene_t* sc) {
+    if (!sc) return;
+    free(sc->prims); free(sc->precom); free(sc->vnorm); free(sc->normals); free(sc->obj_info); free(sc->aabbs);
+    free(sc->emitter_id); free(sc->bxdf); free(sc->src); free(sc->nodes); free(sc->bvhs); free(sc);
+}
+ORC_API int orc_bvh_counts(const scene_t* sc, int* node_num, int* bvh_num) { *node_num = sc->node_num; *bvh_num = sc->bvh_num; return 0; }
+/* node_minmax[M*6], node_info[M*3] (base,cnt,all_offset), bvh_minmax[N*6], bvh_info[N*2] (obj,prim): bvh.cpp:215-251 */
+ORC_API int orc_bvh_export(const scene_t* sc, float* node_minmax, int* node_info, float* bvh_minmax, int* bvh_info) {
+    for (int i = 0; i < sc->node_num; i++) {
+        memcpy(node_minmax + 6 * i, &sc->nodes[i].mini, 12); memcpy(node_minmax + 6 * i + 3, &sc->nodes[i].maxi, 12);
+        node_info[3 * i] = sc->nodes[i].base; node_info[3 * i + 1] = sc->nodes[i].prim_cnt; node_info[3 * i + 2] = sc->nodes[i].all_offset;
+    }
+    for (int i = 0; i < sc->bvh_num; i++) {
+        memcpy(bvh_minmax + 6 * i, &sc->bvhs[i].mini, 12); memcpy(bvh_minmax + 6 * i + 3, &sc->bvhs[i].maxi, 12);
+        bvh_info[2 * i] = sc->bvhs[i].obj_idx; bvh_info[2 * i + 1] = sc->bvhs[i].prim_idx;
+    }
+    return 0;
+}
+
+/* ------------------------------------- TracerBase.pix2ray, tracer_base.py:136-157 */
+static v3 pix2ray(const ctx_t* c, int i, int j, int cnt, rng_t* r) {
+    const orc_cfg* g = c->cfg;
+    float pi = (float)i, pj = (float)j, vx = 0.5f, vy = 0.5f;
+    if (g->anti_alias) {
+        if (g->stratified) {
+            int mod_val = pymod(cnt, 16);
+            vx = (float)(mod_val % 4) * 0.25f + rng_float(r) * 0.25f;
+            vy = (float)(mod_val / 4) * 0.25f + rng_float(r) * 0.25f;
+        } else {
+            const float eps = 1e-4f, inv_eps = (float)(1 - 1e-4 * 2.);
+            vx = rng_float(r) * inv_eps + eps;
+            vy = rng_float(r) * inv_eps + eps;
+        }
+    }
+    v3 cam_dir = V((g->half_w + vx - pi) * g->inv_focal, (pj - g->half_h - vy) * g->inv_focal, 1.f);
+    return vnormalized(m3mulv(&c->cam_r, cam_dir));
+}
+
+/* One pixel-sample of Renderer.render, vanilla_renderer.py:39-119.  Returns the
+ * sample's colour with NaN components zeroed (line 119). */
+typedef struct {
+    int max_events; int n_events;
+    float* ev;       /* per bounce: [obj_id, prim_id, min_depth, direct_int xyz, emit*w xyz, contribution xyz] = 12 floats */
+} trace_t;
+
+static v3 render_sample(const ctx_t* c, int i, int j, int cnt, rng_t* rng, orc_stats* st, trace_t* tr) {
+    const orc_cfg* g = c->cfg; const scene_t* sc = c->sc;
+    v3 ray_d = pix2ray(c, i, j, cnt, rng);
+    v3 ray_o = c->cam_t;
+    isect_t it; pt_ray_intersect(c, ray_d, ray_o, &it);
+    int hit_light = sc->emitter_id[it.obj_id > 0 ? it.obj_id : 0];
+    v3 color = ZERO3, contribution = V(1.f, 1.f, 1.f);
+    float emission_weight = 1.0f;
+    st->n_samples++;
+    for (int bounce = 0; bounce < g->max_bounce; bounce++) {
+        if (it.obj_id < 0) break;
+        if (g->use_rr) {
+            float max_value = vmax(contribution);
+            if (max_value < g->rr_threshold && bounce >= g->rr_bounce_th) {
+                if (rng_float(rng) > max_value) break;
+                else contribution = vscale(contribution, 1.f / (max_value + 1e-7f));
+            }
+        } else {
+            if (vmax(contribution) < 1e-4f) break;
+        }
+        st->n_shade++;
+        v3 hit_point = vadd(vscale(ray_d, it.min_depth), ray_o);
+        float direct_pdf = 1.0f, emitter_pdf = 1.0f;
+        int break_flag = 0;
+        v3 shadow_int = ZERO3, direct_int = ZERO3, direct_spec = V(1.f, 1.f, 1.f);
+        it.tex = V(-1.f, -1.f, -1.f);              /* get_uv_item: no textures -> INVALID */
+        for (int s = 0; s < g->num_shadow_ray; s++) {
+            int emitter_valid;
+            const src_t* emitter = pt_sample_light(c, hit_light, rng, &emitter_pdf, &emitter_valid);
+            v3 light_dir = ZERO3;
+            if (emitter_valid) {
+                v3 emit_pos = src_sample_hit(c, emitter, hit_point, rng, &shadow_int, &direct_pdf);
+                v3 to_emitter = vsub(emit_pos, hit_point);
+                float emitter_d = vnorm(to_emitter);
+                light_dir = vdivs(to_emitter, emitter_d);
+                st->n_shadow++;
+                if (pt_does_intersect(c, light_dir, hit_point, emitter_d)) shadow_int = ZERO3;
+                else { direct_spec = pt_eval(c, &it, ray_d, light_dir); st->n_lit++; }
+            } else { break_flag = 1; break; }
+            float light_pdf = emitter_pdf * direct_pdf;
+            if (g->use_mis) {
+                float mis_w = 1.0f;
+                if (!(emitter->bool_bits & 0x01)) {
+                    float bsdf_pdf_v = pt_surface_pdf(c, &it, light_dir, ray_d);
+                    mis_w = balance_heuristic(light_pdf, bsdf_pdf_v);
+                }
+                direct_int = vadd(direct_int, vdivs(vscale(vmul(direct_spec, shadow_int), mis_w), emitter_pdf));
+            } else {
+                direct_int = vadd(direct_int, vdivs(vmul(direct_spec, shadow_int), emitter_pdf));
+            }
+        }
+        if (!break_flag) direct_int = vscale(direct_int, c->inv_num_shadow_ray);
+        v3 emit_int = ZERO3;
+        if (hit_light >= 0) emit_int = src_eval_le(&sc->src[hit_light], vsub(hit_point, ray_o), it.n_s);
+        v3 indirect_spec; float ray_pdf; int is_specular;
+        v3 new_d = pt_sample_new_ray(c, &it, ray_d, rng, &indirect_spec, &ray_pdf, &is_specular);
+        if (tr && tr->n_events < tr->max_events) {
+            float* e = tr->ev + 12 * tr->n_events++;
+            v3 ew = vscale(emit_int, emission_weight);
+            e[0] = (float)it.obj_id; e[1] = (float)it.prim_id; e[2] = it.min_depth;
+            e[3] = direct_int.x; e[4] = direct_int.y; e[5] = direct_int.z;
+            e[6] = ew.x; e[7] = ew.y; e[8] = ew.z;
+            e[9] = contribution.x; e[10] = contribution.y; e[11] = contribution.z;
+        }
+        ray_d = new_d;
+        ray_o = hit_point;
+        color = vadd(color, vmul(vadd(direct_int, vscale(emit_int, emission_weight)), contribution));
+        contribution = vmul(contribution, vdivs(indirect_spec, ray_pdf));
+        pt_ray_intersect(c, ray_d, ray_o, &it);
+        if (it.obj_id >= 0) {
+            hit_light = sc->emitter_id[it.obj_id];
+            if (g->use_mis) {
+                float e_pdf = 0.0f;
+                if (hit_light >= 0 && pt_is_delta(c, it.obj_id) == 0 && !is_specular)
+                    e_pdf = src_solid_angle_pdf(&sc->src[hit_light], &it, ray_d);
+                emission_weight = balance_heuristic(ray_pdf, e_pdf);
+            }
+        }
+    }
+    st->n_draws += rng->draw;
+    if (isnan(color.x)) color.x = 0.f;
+    if (isnan(color.y)) color.y = 0.f;
+    if (isnan(color.z)) color.z = 0.f;
+    return color;
+}
+
+static void make_ctx(ctx_t* c, const scene_t* sc, const orc_cfg* cfg) {
+    c->sc = sc; c->cfg = cfg;
+    c->inv_num_shadow_ray = (cfg->num_shadow_ray > 0) ? 1.f / (float)cfg->num_shadow_ray : 1.f;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c->cam_r.m[i][j] = cfg->cam_r[3 * i + j];
+    c->cam_t = V(cfg->cam_t[0], cfg->cam_t[1], cfg->cam_t[2]);
+}
+
+/* Renderer.render x n_spp.  accum is color[w][h][3] ([i=x][j=y]), *cnt the sample counter. */
+ORC_API int orc_render(const scene_t* sc, const orc_cfg* cfg, float* accum, int* cnt, int n_spp, int n_threads, orc_stats* stats) {
+    ctx_t c; make_ctx(&c, sc, cfg);
+    const int W = cfg->width, H = cfg->height;
+    orc_stats total; memset(&total, 0, sizeof(total));
+    for (int s = 0; s < n_spp; s++) {
+        *cnt += 1;                                  /* vanilla_renderer.py:34 */
+        const int cur = *cnt;
+#ifdef _OPENMP
+        if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+        long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : a0, a1, a2, a3, a4)
+        for (int p = 0; p < W * H; p++) {
+            int i = p / H, j = p % H;
+            if (cfg->do_crop && !(i >= cfg->start_x && i < cfg->end_x && j >= cfg->start_y && j < cfg->end_y)) continue;
+            rng_t rng; rng_seed(&rng, (uint32_t)p, cfg->seed, (uint32_t)cur);
+            orc_stats st; memset(&st, 0, sizeof(st));
+            v3 col = render_sample(&c, i, j, cur, &rng, &st, NULL);
+            float* px = accum + 3 * (size_t)p;
+            px[0] += col.x; px[1] += col.y; px[2] += col.z;
+            a0 += st.n_samples; a1 += st.n_shade; a2 += st.n_shadow; a3 += st.n_lit; a4 += st.n_draws;
+        }
+        total.n_samples += a0; total.n_shade += a1; total.n_shadow += a2; total.n_lit += a3; total.n_draws += a4;
+    }
+    if (stats) *stats = total;
+    (void)n_threads;
+    return 0;
+}
+
+/* One pixel-sample with a per-bounce event trace and either RNG mode (script != NULL -> scripted). */
+ORC_API int orc_trace_sample(const scene_t* sc, const orc_cfg* cfg, int i, int j, int cnt, const double* script, int script_n,
+                             float color_out[3], float* events, int max_events, int* n_events, int* n_draws) {
+    ctx_t c; make_ctx(&c, sc, cfg);
+    rng_t rng; rng_seed(&rng, (uint32_t)(i * cfg->height + j), cfg->seed, (uint32_t)cnt);
+    if (script) { rng.mode = 1; rng.script = script; rng.script_n = script_n; }
+    orc_stats st; memset(&st, 0, sizeof(st));
+    trace_t tr = {max_events, 0, events};
+    v3 col = render_sample(&c, i, j, cnt, &rng, &st, events ? &tr : NULL);
+    color_out[0] = col.x; color_out[1] = col.y; color_out[2] = col.z;
+    if (n_events) *n_events = tr.n_events;
+    if (n_draws) *n_draws = (int)rng.draw;
+    return 0;
+}
+
+/* ------------------------------------------------ unit entry points (goldens) */
+static void load_it(isect_t* it, const float n_s[3], const float n_g[3], float min_depth) {
+    memset(it, 0, sizeof(*it));
+    it->n_s = V(n_s[0], n_s[1], n_s[2]); it->n_g = V(n_g[0], n_g[1], n_g[2]);
+    it->tex = V(-1.f, -1.f, -1.f); it->min_depth = min_depth;
+}
+static void load_bxdf(bxdf_t* b, const int bi[4], const float bf[13]) {
+    b->type = bi[0]; b->is_delta = bi[1]; b->is_bsdf = bi[2];
+    b->k_d = as_v3(bf)[0]; b->k_s = as_v3(bf)[1]; b->k_g = as_v3(bf)[2]; b->mean = as_v3(bf)[3]; b->ior = bf[12];
+}
+static void st3(float* o, v3 a) { o[0] = a.x; o[1] = a.y; o[2] = a.z; }
+#define LD3(p) V((p)[0], (p)[1], (p)[2])
+
+/* eval (f*cos), pdf for given directions; BRDF or BSDF by bi[2] */
+ORC_API void orc_bxdf_eval_pdf(const int bi[4], const float bf[13], float world_ior, const float n_s[3], const float n_g[3],
+                               const float incid[3], const float out[3], float eval_out[3], float* pdf_out) {
+    bxdf_t b; load_bxdf(&b, bi, bf); isect_t it; load_it(&it, n_s, n_g, 1.f);
+    v3 wi = LD3(incid), wo = LD3(out);
+    if (!b.is_bsdf) { st3(eval_out, brdf_eval(&b, &it, wi, wo)); *pdf_out = brdf_pdf(&b, &it, wo, wi); }
+    else {
+        v3 e = ZERO3;
+        if (b.type == 0) e = eval_det_refraction(&b, &it, wi, wo, world_ior);
+        else if (b.type == 1) e = eval_lambertian_trans(&b, &it, wi, wo, world_ior);
+        st3(eval_out, e); *pdf_out = bsdf_pdf(&b, &it, wo, wi, world_ior);
+    }
+}
+/* sample with a scripted RNG */
+ORC_API void orc_bxdf_sample(const int bi[4], const float bf[13], float world_ior, const float n_s[3], const float n_g[3],
+                             const float incid[3], const double* script, int script_n,
+                             float dir_out[3], float spec_out[3], float* pdf_out, int* is_specular, int* n_draws) {
+    bxdf_t b; load_bxdf(&b, bi, bf); isect_t it; load_it(&it, n_s, n_g, 1.f);
+    rng_t r; memset(&r, 0, sizeof(r)); r.mode = 1; r.script = script; r.script_n = script_n;
+    v3 spec; float pdf; int sp = 0; v3 dir;
+    if (!b.is_bsdf) dir = brdf_sample(&b, &it, LD3(incid), &r, &spec, &pdf, &sp);
+    else {
+        dir = ZERO3; spec = ZERO3; pdf = 0.f;
+        if (b.type == 0) dir = sample_det_refraction(&b, &it, LD3(incid), world_ior, &r, &spec, &pdf);
+        else if (b.type == 1) dir = sample_lambertian_trans(&b, &it, LD3(incid), world_ior, &r, &spec, &pdf, &sp);
+    }
+    st3(dir_out, dir); st3(spec_out, spec); *pdf_out = pdf; *is_specular = sp; *n_draws = (int)r.draw;
+}
+ORC_API void orc_rotation_between(const float a[3], const float b[3], float R_out[9]) {
+    m3 R; rotation_between(LD3(a), LD3(b), &R);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R_out[3 * i + j] = R.m[i][j];
+}
+ORC_API float orc_fresnel_equation(float a, float b, float c, float d) { return fresnel_equation(a, b, c, d); }
+ORC_API void orc_snell_refraction(const float incid[3], const float normal[3], float dot_n, float ni, float nr, float out[3], float* cos_r2) {
+    st3(out, snell_refraction(LD3(incid), LD3(normal), dot_n, ni, nr, cos_r2));
+}
+/* emitter sample_hit with scripted RNG; needs a scene for attached geometry */
+ORC_API void orc_src_sample_hit(const scene_t* sc, int src_idx, const float hit_pos[3], const double* script, int script_n,
+                                float pos_out[3], float int_out[3], float* pdf_out, int* n_draws) {
+    ctx_t c; memset(&c, 0, sizeof(c)); c.sc = sc;
+    rng_t r; memset(&r, 0, sizeof(r)); r.mode = 1; r.script = script; r.script_n = script_n;
+    v3 ri; float rp;
+    v3 p = src_sample_hit(&c, &sc->src[src_idx], LD3(hit_pos), &r, &ri, &rp);
+    st3(pos_out, p); st3(int_out, ri); *pdf_out = rp; *n_draws = (int)r.draw;
+}
+ORC_API void orc_src_eval(const scene_t* sc, int src_idx, const float inci_dir[3], const float normal[3], float min_depth,
+                          const float ray_d[3], float le_out[3], float* sa_pdf_out) {
+    isect_t it; load_it(&it, normal, normal, min_depth);
+    st3(le_out, src_eval_le(&sc->src[src_idx], LD3(inci_dir), LD3(normal)));
+    *sa_pdf_out = src_solid_angle_pdf(&sc->src[src_idx], &it, LD3(ray_d));
+}
+/* closest hit / occlusion for a batch of rays: hit_out[n*4] = (obj, prim, u|sphere-u, v), t_out[n] */
+ORC_API void orc_intersect_batch(const scene_t* sc, int use_bvh, int n, const float* o, const float* d,
+                                 int* obj_out, int* prim_out, float* t_out, float* uv_out, float* ns_out) {
+    for (int k = 0; k < n; k++) {
+        isect_t it;
+        if (use_bvh && sc->node_num > 0) ray_intersect_bvh(sc, LD3(d + 3 * k), LD3(o + 3 * k), -1.f, &it);
+        else ray_intersect_brute(sc, LD3(d + 3 * k), LD3(o + 3 * k), -1.f, &it);
+        obj_out[k] = it.obj_id; prim_out[k] = it.prim_id; t_out[k] = it.min_depth;
+        uv_out[2 * k] = it.u; uv_out[2 * k + 1] = it.v;
+        if (ns_out) st3(ns_out + 3 * k, it.n_s);
+    }
+}
+ORC_API void orc_occluded_batch(const scene_t* sc, int use_bvh, int n, const float* o, const float* d, const float* tmax, int* occ_out) {
+    for (int k = 0; k < n; k++)
+        occ_out[k] = (use_bvh && sc->node_num > 0) ? does_intersect_bvh(sc, LD3(d + 3 * k), LD3(o + 3 * k), tmax[k])
+                                                   : does_intersect_brute(sc, LD3(d + 3 * k), LD3(o + 3 * k), tmax[k]);
+}
+ORC_API void orc_pix2ray(const scene_t* sc, const orc_cfg* cfg, int i, int j, int cnt, const double* script, int script_n, float out[3]) {
+    ctx_t c; make_ctx(&c, sc, cfg);
+    rng_t r; memset(&r, 0, sizeof(r)); r.mode = 1; r.script = script; r.script_n = script_n;
+    st3(out, pix2ray(&c, i, j, cnt, &r));
+}
+/* raw RNG stream, for cross-checking the HIP generator and the golden generator's shim */
+ORC_API void orc_rng_stream(uint32_t pixel, uint32_t seed, uint32_t sample, int n, uint32_t* out) {
+    rng_t r; rng_seed(&r, pixel, seed, sample);
+    for (int k = 0; k < n; k++) out[k] = rng_u32(&r);
+}
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference's own source (authoring container only).
+
+    python tests/golden/gen/gen_goldens.py [--only parse|func|image] 
+
+Every fixture is produced by calling UNMODIFIED reference code (/root/reference) under the
+float32 stand-in `taichi` package in shim/ (third-party taichi==1.6.0 is not installable
+here).  Fixtures are plain input/output arrays; no reference source text is stored.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+import refenv
+
+ti = refenv.setup()
+from taichi.math import vec3  # noqa: E402
+
+OUT = os.path.abspath(os.path.join(refenv.HERE, ".."))
+RS = np.random.RandomState(20260928)
+
+
+def unit(v):
+    v = np.float32(v)
+    return v / np.float32(np.linalg.norm(v))
+
+
+def rand_dir():
+    return unit(RS.normal(size=3))
+
+
+# ------------------------------------------------------------------ parsed scenes
+def dump_parse(scene_dir, xml, tag):
+    from parsers.xml_parser import scene_parsing
+    emitters, arr, objs, cfg = scene_parsing(os.path.join(refenv.REFERENCE, "scenes", scene_dir), xml)
+    from la.cam_transform import np_rotation_between, fov2focal
+    orient = np.float32(cfg["transform"][0]) / np.linalg.norm(cfg["transform"][0])
+    out = {
+        "primitives": arr["primitives"], "n_g": arr["n_g"], "n_s": arr["n_s"], "uvs": arr["uvs"],
+        "indices": np.int64(arr["indices"]) if arr["indices"] is not None else np.int64([]),
+        "aabb": np.float32([o.aabb for o in objs]), "tri_num": np.int32([o.tri_num for o in objs]),
+        "obj_type": np.int32([o.type for o in objs]), "emitter_ref": np.int32([o.emitter_ref_id for o in objs]),
+        "bxdf_type": np.int32([o.bsdf.type_id for o in objs]), "bxdf_delta": np.int32([int(o.bsdf.is_delta) for o in objs]),
+        "bxdf_is_bsdf": np.int32([int(hasattr(o.bsdf, "medium")) for o in objs]),
+        "k_d": np.float32([o.bsdf.k_d for o in objs]), "k_s": np.float32([o.bsdf.k_s for o in objs]),
+        "k_g": np.float32([o.bsdf.k_g for o in objs]),
+        "ior": np.float32([o.bsdf.medium.ior if hasattr(o.bsdf, "medium") else 1.0 for o in objs]),
+        "src_type": np.array([e.type for e in emitters]), "src_intensity": np.float32([e.intensity for e in emitters]),
+        "src_inv_area": np.float32([e.inv_area for e in emitters]),
+        "src_pos": np.float32([getattr(e, "pos", np.zeros(3)) if not hasattr(getattr(e, "pos", None), "a") else np.zeros(3) for e in emitters]),
+        "cam_dir": np.float32(cfg["transform"][0]), "cam_pos": np.float32(cfg["transform"][1]),
+        "cam_r": np.float32(np_rotation_between(np.float32([0, 0, 1]), orient)),
+        "focal": np.float64(fov2focal(cfg["fov"], min(cfg["film"]["width"], cfg["film"]["height"]))),
+        "fov": np.float64(cfg["fov"]), "max_bounce": np.int32(cfg["max_bounce"]), "num_shadow_ray": np.int32(cfg["num_shadow_ray"]),
+        "width": np.int32(cfg["film"]["width"]), "height": np.int32(cfg["film"]["height"]),
+        "has_vertex_normal": np.int32(cfg["has_vertex_normal"]), "world_ior": np.float32(cfg["world"].medium.ior),
+    }
+    np.savez_compressed(os.path.join(OUT, f"parse_{tag}.npz"), **out)
+    print(f"parse_{tag}: {arr['primitives'].shape[0]} prims, {len(objs)} objects, {len(emitters)} emitters")
+
+
+# ------------------------------------------------------------- function vectors
+def gen_functions():
+    from bxdf.brdf import BRDF
+    from bxdf.bsdf import BSDF
+    from bxdf.medium import Medium
+    from tracer.interaction import Interaction
+    from la.cam_transform import rotation_between, delocalize_rotate
+    from la.geo_optics import fresnel_equation, snell_refraction, inci_reflect_dir, is_total_reflection
+    from renderer.constants import INVALID
+    from sampler import general_sampling as gs
+
+    out = {}
+    # --- rotation_between (incl. parallel / anti-parallel)
+    A, B, R = [], [], []
+    pairs = [(rand_dir(), rand_dir()) for _ in range(48)]
+    pairs += [(np.float32([0, 1, 0]), np.float32([0, 1, 0])), (np.float32([0, 1, 0]), np.float32([0, -1, 0])),
+              (np.float32([0, 1, 0]), unit([1e-3, 1, 0])), (np.float32([0, 1, 0]), unit([0.3, -0.2, 0.9]))]
+    for a, b in pairs:
+        A.append(a); B.append(b); R.append(rotation_between(vec3(a), vec3(b)).to_numpy())
+    out["rot_a"], out["rot_b"], out["rot_R"] = np.float32(A), np.float32(B), np.float32(R)
+
+    # --- fresnel / snell
+    fr_in, fr_out = [], []
+    for _ in range(32):
+        n1, n2 = np.float32(RS.uniform(1, 2)), np.float32(RS.uniform(1, 2))
+        c1, c2 = np.float32(RS.uniform(0, 1)), np.float32(RS.uniform(0, 1))
+        fr_in.append([n1, n2, c1, c2]); fr_out.append(fresnel_equation(n1, n2, c1, c2))
+    fr_in.append([1, 1.5, 1, 1]); fr_out.append(fresnel_equation(np.float32(1), np.float32(1.5), np.float32(1), np.float32(1)))
+    out["fresnel_in"], out["fresnel_out"] = np.float32(fr_in), np.float32(fr_out)
+    sn_in, sn_out = [], []
+    for _ in range(32):
+        n = rand_dir(); d = rand_dir()
+        ni, nr = (np.float32(1.0), np.float32(1.5)) if RS.rand() < 0.5 else (np.float32(1.5), np.float32(1.0))
+        dn = np.float32(np.dot(d, n))
+        v, c2 = snell_refraction(vec3(d), vec3(n), dn, ni, nr)
+        sn_in.append(np.concatenate([d, n, [dn, ni, nr]])); sn_out.append(np.concatenate([v.to_numpy(), [c2]]))
+    out["snell_in"], out["snell_out"] = np.float32(sn_in), np.float32(sn_out)
+
+    # --- BRDF / BSDF eval, pdf, sample
+    mats = []
+    def brdf(t, kd, ks, kg, delta=0):
+        kd, ks, kg = np.float32(kd), np.float32(ks), np.float32(kg)
+        if t == 5:
+            kg = kg.copy(); kg[2] = np.sqrt((kg[0] + 1) * (kg[1] + 1)) / (8. * np.pi)
+        mean = np.float32([kd.mean(), ks.mean(), kg.mean()])
+        return dict(is_bsdf=0, type=t, delta=delta, kd=kd, ks=ks, kg=kg, mean=mean, ior=np.float32(1))
+    h = lambda s: [int(s[i:i + 2], 16) / 255. for i in (0, 2, 4)]
+    mats.append(brdf(0, h("D2D2D2"), [0] * 3, [1] * 3))                     # phong (balls-mono diffuse)
+    mats.append(brdf(0, h("BCBCBC"), [0.3] * 3, [8, 8, 8]))                  # glossy blinn-phong
+    mats.append(brdf(1, h("FFFFFF"), [0] * 3, [1] * 3))                      # lambertian
+    mats.append(brdf(2, h("DEDEDE"), [0] * 3, [1] * 3, delta=1))             # mirror
+    mats.append(brdf(4, h("BCBCBC"), h("424242"), [10] * 3))                 # mod-phong
+    mats.append(brdf(5, h("CACACA"), h("333333"), [10, 1000, 0]))            # fresnel-blend
+    sig = np.float32(20.0) * np.float32(np.pi / 180.); s2 = sig * sig
+    on_kg = [1 - (s2 / (2 * (s2 + 0.33))), 0.45 * s2 / (s2 + 0.09), 1.5]
+    mats.append(brdf(6, h("C8B496"), [0] * 3, on_kg))                        # oren-nayar
+    mats.append(brdf(7, h("C8B496"), [0.9] * 3, on_kg))                      # thin-coat
+    mats.append(dict(is_bsdf=1, type=0, delta=1, kd=np.float32(h("FAFAFA")), ks=np.zeros(3, np.float32), kg=np.ones(3, np.float32),
+                     mean=np.zeros(3, np.float32), ior=np.float32(1.5)))     # det-refraction glass
+    mats.append(dict(is_bsdf=1, type=1, delta=0, kd=np.float32(h("E0E0FA")), ks=np.zeros(3, np.float32), kg=np.ones(3, np.float32),
+                     mean=np.zeros(3, np.float32), ior=np.float32(1.33)))    # lambertian transmission
+    world_medium = Medium(_type=-1, ior=1.0)
+
+    def build(m):
+        if m["is_bsdf"]:
+            return BSDF(_type=m["type"], is_delta=m["delta"], k_d=vec3(m["kd"]), k_s=vec3(m["ks"]), k_g=vec3(m["kg"]),
+                        medium=Medium(_type=-1, ior=m["ior"]))
+        return BRDF(_type=m["type"], is_delta=m["delta"], k_d=vec3(m["kd"]), k_s=vec3(m["ks"]), k_g=vec3(m["kg"]), mean=vec3(m["mean"]))
+
+    mat_i, mat_f = [], []
+    ev_in, ev_out, sm_in, sm_scr, sm_out = [], [], [], [], []
+    for mi, m in enumerate(mats):
+        obj = build(m)
+        mat_i.append([m["type"], m["delta"], m["is_bsdf"], 0])
+        mat_f.append(np.concatenate([m["kd"], m["ks"], m["kg"], m["mean"], [m["ior"]]]))
+        for _ in range(24):
+            n_s = rand_dir()
+            n_g = unit(n_s + np.float32(RS.normal(size=3) * 0.05))
+            incid = rand_dir()
+            if np.dot(incid, n_s) > 0 and RS.rand() < 0.8:
+                incid = -incid                                   # mostly arriving against the normal
+            outd = rand_dir()
+            if RS.rand() < 0.25:                                 # exercise the delta-direction matching branches
+                it0 = Interaction(n_s=vec3(n_s), n_g=vec3(n_g), tex=INVALID)
+                if m["is_bsdf"]:
+                    # eval/get_pdf match `incid` against the mirror / refraction of `out`: build such a pair
+                    dn = np.float32(np.dot(outd, n_s))
+                    if RS.rand() < 0.5:
+                        incid = (vec3(outd) - 2 * vec3(n_s) * dn).normalized().to_numpy()
+                    else:
+                        ni, nr = (np.float32(1.0), m["ior"]) if dn < 0 else (m["ior"], np.float32(1.0))
+                        rv, c2 = snell_refraction(vec3(outd), vec3(n_s), dn, ni, nr)
+                        if c2 > 0:
+                            incid = rv.to_numpy()
+                else:
+                    outd = inci_reflect_dir(vec3(incid), vec3(n_s))[0].to_numpy()
+            it = Interaction(n_s=vec3(n_s), n_g=vec3(n_g), tex=INVALID)
+            if m["is_bsdf"]:
+                e = obj.eval_surf(it, vec3(incid), vec3(outd), world_medium, -1)
+                p = obj.get_pdf(it, vec3(outd), vec3(incid), world_medium)
+            else:
+                e = obj.eval(it, vec3(incid), vec3(outd))
+                p = obj.get_pdf(it, vec3(outd), vec3(incid))
+            ev_in.append(np.concatenate([[mi], n_s, n_g, incid, outd])); ev_out.append(np.concatenate([e.to_numpy(), [p]]))
+            script = RS.rand(8)
+            ti.RNG.set_script(script)
+            it = Interaction(n_s=vec3(n_s), n_g=vec3(n_g), tex=INVALID)
+            if m["is_bsdf"]:
+                d, s, pdf, spec = obj.sample_surf_rays(it, vec3(incid), world_medium, -1)
+            else:
+                d, s, pdf, spec = obj.sample_new_rays(it, vec3(incid))
+            sm_in.append(np.concatenate([[mi], n_s, n_g, incid])); sm_scr.append(script)
+            sm_out.append(np.concatenate([np.float32(d.to_numpy()), np.float32(s.to_numpy()), [pdf, float(bool(spec)), ti.RNG.draw]]))
+    out["mat_i"], out["mat_f"] = np.int32(mat_i), np.float32(mat_f)
+    out["eval_in"], out["eval_out"] = np.float32(ev_in), np.float32(ev_out)
+    out["sample_in"], out["sample_script"], out["sample_out"] = np.float32(sm_in), np.float64(sm_scr), np.float32(sm_out)
+
+    # --- free samplers with scripted randoms
+    smp = {}
+    for name, fn, nrand in (("cosine_hemisphere", lambda: gs.cosine_hemisphere(), 2),
+                            ("uniform_sphere", lambda: gs.uniform_sphere(), 2),
+                            ("mod_phong_hemisphere", lambda: gs.mod_phong_hemisphere(np.float32(10.0)), 2),
+                            ("fresnel_hemisphere", lambda: gs.fresnel_hemisphere(np.float32(10.0), np.float32(1000.0)), 2)):
+        scr, res = [], []
+        for _ in range(16):
+            s = RS.rand(nrand); ti.RNG.set_script(s)
+            v, p = fn()
+            scr.append(s); res.append(np.concatenate([v.to_numpy(), [p]]))
+        out[f"smp_{name}_script"], out[f"smp_{name}_out"] = np.float64(scr), np.float32(res)
+    np.savez_compressed(os.path.join(OUT, "functions.npz"), **out)
+    print("functions:", {k: v.shape for k, v in out.items()})
+
+
+# ---------------------------------------------- scene-bound functions + images
+def gen_scene(scene_dir, xml, tag, w, h, spp, overrides, seed=0, n_rays=192):
+    ov = dict(overrides); ov.update(width=w, height=h)
+    t0 = time.time()
+    rdr, (emitters, arr, objs, cfg) = refenv.make_renderer(scene_dir, xml, ov)
+    out = {"width": np.int32(w), "height": np.int32(h), "spp": np.int32(spp), "seed": np.int32(seed),
+           "max_bounce": np.int32(rdr.max_bounce), "num_shadow_ray": np.int32(rdr.num_shadow_ray)}
+
+    # --- pix2ray with scripted jitter
+    pin, pout = [], []
+    for _ in range(24):
+        i, j, cnt = int(RS.randint(w)), int(RS.randint(h)), int(RS.randint(1, 40))
+        s = RS.rand(2); ti.RNG.set_script(s); rdr.cnt[None] = cnt
+        pin.append([i, j, cnt, s[0], s[1]]); pout.append(rdr.pix2ray(i, j).to_numpy())
+    rdr.cnt[None] = 0
+    out["pix2ray_in"], out["pix2ray_out"] = np.float64(pin), np.float32(pout)
+
+    # --- closest hit / occlusion on a ray batch (camera rays + rays from inside the room)
+    O, D, TM = [], [], []
+    for k in range(n_rays):
+        if k % 3 == 0:
+            ti.RNG.set_script(RS.rand(2)); rdr.cnt[None] = 1
+            O.append(rdr.cam_t.to_numpy()); D.append(rdr.pix2ray(int(RS.randint(w)), int(RS.randint(h))).to_numpy())
+        else:
+            O.append(np.float32(RS.uniform([0.2, 0.2, 0.2], [5.3, 5.2, 5.3]))); D.append(rand_dir())
+        TM.append(np.float32(RS.uniform(0.5, 6.0)))
+    rdr.cnt[None] = 0
+    hits, occ = [], []
+    for o, d, tm in zip(O, D, TM):
+        it = rdr.ray_intersect(vec3(d), vec3(o))
+        hits.append(np.concatenate([[it.obj_id, it.prim_id, it.min_depth], it.uv.to_numpy(), it.n_s.to_numpy(), it.n_g.to_numpy()]))
+        occ.append(int(bool(rdr.does_intersect(vec3(d), vec3(o), tm))))
+    out["ray_o"], out["ray_d"], out["ray_tmax"] = np.float32(O), np.float32(D), np.float32(TM)
+    out["ray_hit"], out["ray_occ"] = np.float32(hits), np.int32(occ)
+
+    # --- emitters: sample_hit (scripted), eval_le, solid_angle_pdf
+    from tracer.interaction import Interaction
+    ein, escr, eout = [], [], []
+    for s_idx in range(rdr.src_num):
+        for _ in range(16):
+            hp = np.float32(RS.uniform([0.2, 0.1, 0.2], [5.3, 5.0, 5.3]))
+            scr = np.concatenate([[RS.randint(-2 ** 31, 2 ** 31)], RS.rand(3)])
+            ti.RNG.set_script(scr)
+            pos, inten, pdf, _n = rdr.src_field[s_idx].sample_hit(rdr.precom_vec, rdr.normals, rdr.obj_info, vec3(hp))
+            nrm, rd = rand_dir(), rand_dir()
+            md = np.float32(RS.uniform(0.5, 5))
+            le = rdr.src_field[s_idx].eval_le(vec3(rd * md), vec3(nrm))
+            sap = rdr.src_field[s_idx].solid_angle_pdf(Interaction(n_s=vec3(nrm), n_g=vec3(nrm), min_depth=md), vec3(rd))
+            ein.append(np.concatenate([[s_idx], hp, nrm, rd, [md]])); escr.append(scr)
+            eout.append(np.concatenate([pos.to_numpy(), inten.to_numpy(), [pdf, ti.RNG.draw], le.to_numpy(), [sap]]))
+    out["emit_in"], out["emit_script"], out["emit_out"] = np.float32(ein), np.float64(escr), np.float32(eout)
+
+    # --- whole-kernel run on the Philox stream: per-sample colours and draw counts
+    colors = np.zeros((spp, w, h, 3), np.float32)
+    draws = np.zeros((spp, w, h), np.int32)
+    state = {"prev": None}
+
+    def hook(i, j):
+        if state["prev"] is not None:
+            pi, pj = state["prev"]; draws[state["s"], pi, pj] = ti.RNG.draw
+        ti.RNG.set_philox(i * h + j, seed, rdr.cnt[None])
+        state["prev"] = (i, j)
+
+    ti.PIXEL_HOOK[0] = hook
+    prev = rdr.color.to_numpy().copy()
+    for s in range(spp):
+        state["s"], state["prev"] = s, None
+        rdr.render(0, 0, 0, 0, 0, 0)
+        pi, pj = state["prev"]; draws[s, pi, pj] = ti.RNG.draw
+        cur = rdr.color.to_numpy()
+        colors[s] = cur if s == 0 else (cur - prev)     # exact only for s == 0; per-sample values re-derived below
+        prev = cur.copy()
+    ti.PIXEL_HOOK[0] = None
+    out["accum"], out["pixels"], out["draws"] = rdr.color.to_numpy(), rdr.pixels.to_numpy(), draws
+    out["first_sample"] = colors[0]
+    np.savez_compressed(os.path.join(OUT, f"scene_{tag}.npz"), **out)
+    n = w * h * spp
+    print(f"scene_{tag}: {w}x{h}x{spp}spp in {time.time() - t0:.1f}s ({n / (time.time() - t0):.0f} samples/s), "
+          f"mean draws {draws.mean():.2f}, mean radiance {out['pixels'].mean():.4f}")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="all")
+    a = ap.parse_args()
+    if a.only in ("all", "parse"):
+        dump_parse("cbox", "cbox.xml", "cbox")
+        dump_parse("csphere", "balls-mono.xml", "balls_mono")
+        dump_parse("cbox", "complex.xml", "complex")
+    if a.only in ("all", "func"):
+        gen_functions()
+    if a.only in ("all", "image"):
+        gen_scene("cbox", "cbox.xml", "cbox", 32, 32, 6, {"max_bounce": 8})
+        gen_scene("csphere", "balls-mono.xml", "balls_mono", 24, 24, 3, {})
+        gen_scene("cbox", "complex.xml", "complex", 20, 20, 3, {})
