@@ -1,0 +1,49 @@
+// rng.hpp — counter-based RNG for the path tracer: Philox-4x32-10 (Salmon et al., SC'11).
+//
+// Replaces the reference's stateful `ti.random` (third-party Taichi; call sites listed in
+// SURVEY.md A.4).  Stream definition (shared with oracle/ and the golden generator):
+//   key     = (global pixel index x*H + y, seed)
+//   counter = (sample counter `cnt` of that pixel-sample, draw_index / 4, 0, 0)
+//   draw d  = word (d & 3) of that block; floats use the top 24 bits -> [0,1); ints are the raw word
+// A path carries only its draw index; the last generated block is cached in registers.
+#pragma once
+#include "vec.hpp"
+#include <stdint.h>
+
+struct Philox {
+    uint32_t key0, key1, ctr0;
+    uint32_t draw;
+    uint32_t blk;        // block index held in c[] (0xffffffff = none)
+    uint32_t c[4];
+};
+
+APT_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+APT_HD void rng_init(Philox& r, uint32_t pixel, uint32_t seed, uint32_t sample, uint32_t draw) {
+    r.key0 = pixel; r.key1 = seed; r.ctr0 = sample; r.draw = draw; r.blk = 0xffffffffu;
+    r.c[0] = r.c[1] = r.c[2] = r.c[3] = 0u;
+}
+APT_HD uint32_t rng_u32(Philox& r) {
+    uint32_t d = r.draw++;
+    uint32_t b = d >> 2;
+    if (b != r.blk) { philox4x32_10(r.ctr0, b, 0u, 0u, r.key0, r.key1, r.c); r.blk = b; }
+    uint32_t w = d & 3u;     // select without dynamic register indexing
+    return (w == 0u) ? r.c[0] : ((w == 1u) ? r.c[1] : ((w == 2u) ? r.c[2] : r.c[3]));
+}
+APT_HD float rng_float(Philox& r) { return (float)(rng_u32(r) >> 8) * (1.0f / 16777216.0f); }
+APT_HD int32_t rng_int(Philox& r) { return (int32_t)rng_u32(r); }
+// Python-style modulo: the reference's `ti.random(int) % n` is non-negative
+APT_HD int pymod(int a, int n) { int m = a % n; return (m < 0) ? m + n : m; }

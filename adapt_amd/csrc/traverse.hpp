@@ -1,0 +1,126 @@
+// traverse.hpp — software BVH traversal for gfx950 (no RT hardware on CDNA4).
+//
+// Replaces the reference's intersectors: brute force `TracerBase.ray_intersect/does_intersect`
+// (tracer/tracer_base.py:168-278) and the stackless preorder walk
+// `PathTracer.ray_intersect_bvh/does_intersect_bvh` (tracer/path_tracer.py:338-422).
+// The per-primitive tests are the reference's, operation for operation (triangle: solve
+// [e1 e2 -d] (u v t)^T = o - p0 with the adjugate inverse; sphere: tracer_base.py:184-199),
+// so the closest hit is the same hit; the tree around them is ours (bvh_build.cpp):
+//   * ordered traversal (near child first) with a per-lane stack kept in LDS, laid out
+//     [depth][lane] so a wave's pushes/pops are bank-conflict free,
+//   * the top `n_staged` nodes and (for small scenes) every primitive record are staged into
+//     LDS once per workgroup; deeper nodes come from global memory through L1/L2.
+#pragma once
+#include "vec.hpp"
+
+struct DevBvh {
+    const float4* nodes;     // 4 float4 per node (bvh_build.cpp layout)
+    const float4* prims;     // 3 float4 per primitive, BVH order
+    int n_nodes, n_prims;
+};
+// primitive record: triangle q0=(p0, e1.x) q1=(e1.yz, e2.xy) q2=(e2.z, prim_id, 0, -)
+//                   sphere   q0=(centre, r)                  q2=(-, prim_id, 1, -)
+
+struct StagedBvh {           // LDS view; falls through to global beyond the staged prefix
+    const float4* g_nodes; const float4* g_prims;
+    const float4* s_nodes; const float4* s_prims;
+    int n_staged_nodes, n_staged_prims;
+    APT_D float4 node(int i, int q) const { return (i < n_staged_nodes) ? s_nodes[4 * i + q] : g_nodes[4 * i + q]; }
+    APT_D float4 prim(int i, int q) const { return (i < n_staged_prims) ? s_prims[3 * i + q] : g_prims[3 * i + q]; }
+};
+
+// cooperative copy of the staged prefix; call from every thread of the block, then __syncthreads()
+APT_D void stage_bvh(const DevBvh& b, float4* s_nodes, int cap_nodes, float4* s_prims, int cap_prims, StagedBvh& out) {
+    int nn = min(b.n_nodes, cap_nodes), np = (b.n_prims <= cap_prims) ? b.n_prims : 0;
+    for (int i = threadIdx.x; i < 4 * nn; i += blockDim.x) s_nodes[i] = b.nodes[i];
+    for (int i = threadIdx.x; i < 3 * np; i += blockDim.x) s_prims[i] = b.prims[i];
+    out.g_nodes = b.nodes; out.g_prims = b.prims; out.s_nodes = s_nodes; out.s_prims = s_prims;
+    out.n_staged_nodes = nn; out.n_staged_prims = np;
+}
+
+struct HitRec { float t; int prim; float u, v; };
+
+// entry distance of the slab test, or -1 when the box is missed / behind / beyond tmax
+APT_D float box_entry(f3 lo, f3 hi, f3 o, f3 inv_d, float tmax) {
+    f3 t0 = (lo - o) * inv_d, t1 = (hi - o) * inv_d;
+    float tn = max3(min3v(t0, t1));
+    float tf = min3(max3v(t0, t1));
+    return (tn <= tf && tf > 0.f && tn <= tmax) ? fmaxf(tn, 0.f) : -1.f;
+}
+
+// One primitive against the ray.  Returns the reference's ray_t (or -1) and barycentrics.
+APT_D float prim_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float& u, float& v) {
+    u = 0.f; v = 0.f;
+    if (__float_as_int(q2.z) != 0) {          // sphere: tracer_base.py:184-199
+        f3 c = mk3(q0.x, q0.y, q0.z);
+        float r2 = q0.w * q0.w;
+        f3 s2c = c - o;
+        float cn2 = norm2(s2c);
+        float proj = dot(d, s2c);
+        float c2ray = cn2 - proj * proj;
+        if (c2ray >= r2) return -1.f;
+        float cut = sqrtf(r2 - c2ray);
+        return proj + ((cn2 > r2 + 1e-4f) ? -cut : cut);
+    }
+    // triangle: columns (e1, e2, -d); inverse = adjugate * (1/det), Taichi's 3x3 formula
+    float a00 = q0.w, a10 = q1.x, a20 = q1.y;      // e1
+    float a01 = q1.z, a11 = q1.w, a21 = q2.x;      // e2
+    float a02 = -d.x, a12 = -d.y, a22 = -d.z;
+    float c00 = a11 * a22 - a21 * a12, c01 = a21 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
+    float det = (a00 * c00 + a10 * c01) + a20 * c02;
+    float inv_det = 1.0f / det;
+    f3 s = o - mk3(q0.x, q0.y, q0.z);
+    float c10 = a12 * a20 - a22 * a10, c11 = a22 * a00 - a02 * a20, c12 = a02 * a10 - a12 * a00;
+    float c20 = a10 * a21 - a20 * a11, c21 = a20 * a01 - a00 * a21, c22 = a00 * a11 - a10 * a01;
+    u = ((inv_det * c00) * s.x + (inv_det * c01) * s.y) + (inv_det * c02) * s.z;
+    v = ((inv_det * c10) * s.x + (inv_det * c11) * s.y) + (inv_det * c12) * s.z;
+    float t = ((inv_det * c20) * s.x + (inv_det * c21) * s.y) + (inv_det * c22) * s.z;
+    return (u >= 0.f && v >= 0.f && u + v <= 1.0f) ? t : -1.f;
+}
+
+// ANY = false: closest hit, rec.t starts at the search limit and ends at min_depth.
+// ANY = true : returns true on the first hit with 1e-4 < t < rec.t.
+// `stack` points at this lane's column of an LDS array [depth][stride].
+template <bool ANY>
+APT_D bool traverse(const StagedBvh& bvh, int* stack, int stride, f3 o, f3 d, HitRec& rec) {
+    f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int sp = 0;
+    int cur = 0;
+    bool running = true;
+    while (running) {
+        bool pop = false;
+        if (cur >= 0) {
+            float4 q0 = bvh.node(cur, 0), q1 = bvh.node(cur, 1), q2 = bvh.node(cur, 2), q3 = bvh.node(cur, 3);
+            float tl = box_entry(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, inv_d, rec.t);
+            float tr = box_entry(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, inv_d, rec.t);
+            int l = __float_as_int(q3.x), r = __float_as_int(q3.y);
+            bool hl = tl >= 0.f, hr = tr >= 0.f;
+            if (hl && hr) {
+                bool swap = tr < tl;
+                int near_ = swap ? r : l, far_ = swap ? l : r;
+                stack[sp * stride] = far_; sp++;
+                cur = near_;
+            } else if (hl) cur = l;
+            else if (hr) cur = r;
+            else pop = true;
+        } else {
+            int code = ~cur;
+            int first = code >> 4, count = code & 15;
+            for (int k = 0; k < count; k++) {
+                float4 p0 = bvh.prim(first + k, 0), p1 = bvh.prim(first + k, 1), p2 = bvh.prim(first + k, 2);
+                float u, v;
+                float t = prim_test(p0, p1, p2, o, d, u, v);
+                if (t > 1e-4f && t < rec.t) {
+                    if (ANY) return true;
+                    rec.t = t; rec.prim = __float_as_int(p2.y); rec.u = u; rec.v = v;
+                }
+            }
+            pop = true;
+        }
+        if (pop) {
+            if (sp > 0) { sp--; cur = stack[sp * stride]; }
+            else running = false;
+        }
+    }
+    return false;
+}

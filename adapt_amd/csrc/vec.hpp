@@ -1,0 +1,77 @@
+// vec.hpp — float3 algebra for the gfx950 path tracer.
+//
+// Operation ORDER is part of the contract: sums/dots accumulate left to right and
+// normalize() multiplies by a reciprocal length, which is what the reference's Taichi
+// vector ops do (see DESIGN.md "float parity").  Compiled with -ffp-contract=off, so what is
+// written here is what the VALU executes; do not "simplify" expressions.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define APT_HD __host__ __device__ __forceinline__
+#define APT_D __device__ __forceinline__
+
+struct f3 {
+    float x, y, z;
+};
+
+APT_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+APT_HD f3 splat3(float s) { return mk3(s, s, s); }
+APT_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+APT_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+APT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+APT_HD f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+APT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+APT_HD f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+APT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+APT_HD f3 operator+(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
+APT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+APT_HD float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+APT_HD float norm2(f3 a) { return dot(a, a); }
+APT_HD float norm(f3 a) { return sqrtf(norm2(a)); }
+APT_HD f3 normalize(f3 a) { float inv = 1.0f / norm(a); return a * inv; }
+APT_HD f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+APT_HD float max3(f3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+APT_HD float min3(f3 a) { return fminf(fminf(a.x, a.y), a.z); }
+APT_HD f3 abs3(f3 a) { return mk3(fabsf(a.x), fabsf(a.y), fabsf(a.z)); }
+APT_HD f3 min3v(f3 a, f3 b) { return mk3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
+APT_HD f3 max3v(f3 a, f3 b) { return mk3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
+APT_HD float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+APT_HD float sqr(float x) { return x * x; }
+
+struct m33 {
+    float m[3][3];
+};
+APT_HD f3 mul(const m33& M, f3 a) {
+    return mk3((M.m[0][0] * a.x + M.m[0][1] * a.y) + M.m[0][2] * a.z,
+               (M.m[1][0] * a.x + M.m[1][1] * a.y) + M.m[1][2] * a.z,
+               (M.m[2][0] * a.x + M.m[2][1] * a.y) + M.m[2][2] * a.z);
+}
+
+// ---- transcendental functions.
+// APT_EXACT_MATH=1 (default): evaluate in double and round once.  That reproduces what a
+// correctly rounded float libm returns, so the HIP path and the CPU oracle (glibc) agree
+// bit-for-bit on essentially every call; the cost is a handful of FP64 ops per bounce.
+// APT_EXACT_MATH=0: OCML's native float versions (1-2 ulp), faster, parity only statistical.
+#ifndef APT_EXACT_MATH
+#define APT_EXACT_MATH 1
+#endif
+#if APT_EXACT_MATH
+APT_D float apt_cos(float x) { return (float)cos((double)x); }
+APT_D float apt_sin(float x) { return (float)sin((double)x); }
+APT_D void apt_sincos(float x, float* s, float* c) { double ds, dc; sincos((double)x, &ds, &dc); *s = (float)ds; *c = (float)dc; }
+APT_D float apt_tan(float x) { return (float)tan((double)x); }
+APT_D float apt_pow(float x, float y) { return (float)pow((double)x, (double)y); }
+#else
+APT_D float apt_cos(float x) { return cosf(x); }
+APT_D float apt_sin(float x) { return sinf(x); }
+APT_D void apt_sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+APT_D float apt_tan(float x) { return tanf(x); }
+APT_D float apt_pow(float x, float y) { return powf(x, y); }
+#endif
+APT_D f3 pow_sv(float b, f3 e) { return mk3(apt_pow(b, e.x), apt_pow(b, e.y), apt_pow(b, e.z)); }
+
+#define APT_PI      ((float)3.14159265358979323846)
+#define APT_INV_PI  ((float)(1.0 / 3.14159265358979323846))
+#define APT_INV_2PI ((float)((1.0 / 3.14159265358979323846) * 0.5))
+#define APT_2PI     ((float)(2.0 * 3.14159265358979323846))
+#define APT_PI_2    ((float)(3.14159265358979323846 / 2.0))

@@ -1,0 +1,103 @@
+"""Image-tile sharding across GPUs and the framebuffer gather.
+
+The reference is single-device (no communication layer at all).  Pixels are
+independent, so the N-GPU path shards the film and exchanges data exactly once per
+readback:
+
+  * partition: columns x are grouped in bands of `band_width`; band b belongs to rank
+    b % world_size (interleaved for load balance: cost varies across the image).  Every rank
+    holds the whole scene; the RNG is keyed by the GLOBAL pixel index, so the assembled
+    image is identical to the single-GPU image bit for bit, whatever the partition.
+  * gather: one `all_gather` of the per-rank (n_cols, H, 3) float32 tiles over
+    torch.distributed (backend "nccl" == RCCL over xGMI on ROCm; "gloo" in the CPU tests),
+    ~1-2 MB per rank — latency-bound, not link-bound.  There is no other collective on the path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+__all__ = ["TilePlan", "gather_tiles", "gather_image", "assemble"]
+
+
+class TilePlan:
+    """Pure index arithmetic; mirrored on the device side by `local_to_global` in csrc/kernels.hip."""
+
+    def __init__(self, width: int, height: int, band_width: int, world_size: int):
+        if width <= 0 or height <= 0 or band_width <= 0 or world_size <= 0:
+            raise ValueError("TilePlan: all arguments must be positive")
+        self.width, self.height, self.band_width, self.world_size = int(width), int(height), int(band_width), int(world_size)
+
+    def owner(self, x: int) -> int:
+        return (x // self.band_width) % self.world_size
+
+    def columns(self, rank: int) -> np.ndarray:
+        """Global column index of every local column of `rank`, in local order."""
+        x = np.arange(self.width)
+        return x[(x // self.band_width) % self.world_size == rank]
+
+    def n_cols(self, rank: int) -> int:
+        return int(len(self.columns(rank)))
+
+    def max_cols(self) -> int:
+        return max(self.n_cols(r) for r in range(self.world_size))
+
+    def local_to_global(self, rank: int, lc: int) -> int:
+        lb, w = divmod(lc, self.band_width)
+        return (lb * self.world_size + rank) * self.band_width + w
+
+
+def assemble(plan: TilePlan, tiles) -> np.ndarray:
+    """tiles[r] = (>= n_cols(r), H, 3) array of rank r  ->  (W, H, 3) image."""
+    img = np.zeros((plan.width, plan.height, 3), np.float32)
+    for r in range(plan.world_size):
+        cols = plan.columns(r)
+        img[cols] = np.asarray(tiles[r])[:len(cols)]
+    return img
+
+
+class _DevView:
+    """Zero-copy torch view of a raw device pointer through __cuda_array_interface__."""
+
+    def __init__(self, ptr: int, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def gather_tiles(tile, plan: TilePlan, rank: int, world_size: int, group=None) -> np.ndarray:
+    """All-gather the per-rank tiles and assemble the full image (returned on every rank).
+
+    `tile` is this rank's (n_cols, H, 3) float32 data: a numpy array (CPU / gloo) or a torch
+    tensor already on the GPU (nccl)."""
+    if world_size == 1:
+        return assemble(plan, [np.asarray(tile)])
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        raise RuntimeError("gather_tiles: torch.distributed is not initialised")
+    t = tile if isinstance(tile, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(tile, np.float32))
+    mc = plan.max_cols()
+    padded = torch.zeros((mc, plan.height, 3), dtype=torch.float32, device=t.device)
+    padded[:t.shape[0]] = t
+    out = torch.empty((world_size, mc, plan.height, 3), dtype=torch.float32, device=t.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return assemble(plan, out.cpu().numpy())
+
+
+def gather_image(rdr, normalised: bool = True, group=None) -> np.ndarray:
+    """Full (W, H, 3) image from a sharded `Renderer` (every rank must call)."""
+    rdr.synchronize()
+    tile: Optional[object] = None
+    try:
+        import torch
+        if torch.cuda.is_available() and rdr.world_size > 1:
+            view = _DevView(rdr.device_accum_ptr(), (rdr.n_cols, rdr.h, 3))
+            tile = torch.as_tensor(view, device=f"cuda:{rdr.device}").clone()
+    except ImportError:
+        tile = None
+    if tile is None:
+        tile = rdr.tile_accum()
+    img = gather_tiles(tile, rdr.plan, rdr.rank, rdr.world_size, group)
+    if normalised and rdr._cnt > 0:
+        img = img / np.float32(rdr._cnt)
+    return img

@@ -1,0 +1,132 @@
+/*
+ * adapt_mi.h — C-ABI of libadapt_mi.so: the MI355X (gfx950) wavefront path tracer that
+ * stands in for AdaPT's Taichi `pt` renderer.
+ *
+ * What each entry point replaces in the reference (paths under /root/reference):
+ *   apt_bvh_build / apt_bvh_*      tracer/bvh/bvh.cpp:274-296  bvh_cpp.bvh_build(...) (pybind11 module),
+ *                                   called from tracer/path_tracer.py:143-179 (bvh_process)
+ *   apt_scene_create               tracer/tracer_base.py:117-134 (load_primitives) +
+ *                                   tracer/path_tracer.py:245-274 (initialze): numpy -> device fields
+ *   apt_renderer_create            renderer/vanilla_renderer.py:26-30 / tracer_base.py:36-102 (film, crop, camera,
+ *                                   sampling flags) — the constructor half that is not scene data
+ *   apt_render                     renderer/vanilla_renderer.py:32-120  Renderer.render (one launch == one spp
+ *                                   there; here `n_spp` samples per call, cnt += n_spp)
+ *   apt_read_pixels                `rdr.pixels.to_numpy()` (utils/watermark.py:23): color / cnt, layout [x][y][rgb]
+ *   apt_get_accum / apt_set_accum  tracer/path_tracer.py:181-211  get_check_point / load_check_point
+ *   apt_get_stats                  (none; the reference only has ti.profiler, render.py:154-160)
+ *   apt_device_ptr                 (none; hands the tile framebuffer to RCCL for the multi-GPU gather)
+ *
+ * Conventions: every function returns 0 on success, a negative APT_E_* code on failure, and
+ * apt_last_error() then returns a thread-local message.  Input pointers are borrowed for the
+ * duration of the call and copied; outputs are caller-allocated; handles are opaque; one host
+ * thread per handle.  All floats are IEEE binary32, ints are 32-bit.  There is no CPU fallback:
+ * without a HIP device apt_scene_create / apt_renderer_create fail with APT_E_NO_DEVICE.
+ */
+#ifndef ADAPT_MI_H
+#define ADAPT_MI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APT_OK            0
+#define APT_E_INVALID    -1   /* bad argument */
+#define APT_E_NO_DEVICE  -2   /* no usable HIP device */
+#define APT_E_HIP        -3   /* HIP runtime error (message has the hipError string) */
+#define APT_E_NOMEM      -4
+#define APT_E_STATE      -5   /* call not valid in this state */
+
+typedef struct apt_bvh apt_bvh;
+typedef struct apt_scene apt_scene;
+typedef struct apt_renderer apt_renderer;
+
+/* Flat scene description — the arrays of SURVEY.md §A.2 (what the reference keeps in Taichi fields). */
+typedef struct apt_scene_desc {
+    int32_t n_prims, n_objects, n_sources, has_vertex_normal;
+    const float*   prims;       /* n_prims*9   triangle (v0,v1,v2) | sphere (centre, r r r, 0 0 0) */
+    const float*   normals;     /* n_prims*3   geometric normals */
+    const float*   v_normals;   /* n_prims*9   per-vertex shading normals (zeros when a mesh has none) */
+    const int32_t* obj_info;    /* n_objects*3 first prim, prim count, 0 = mesh | 1 = sphere */
+    const float*   obj_aabb;    /* n_objects*6 min xyz, max xyz */
+    const int32_t* emitter_id;  /* n_objects   attached emitter index or -1 */
+    const int32_t* bxdf_i;      /* n_objects*4 type, is_delta, is_bsdf, 0     (bxdf/brdf.py:152-158, bsdf.py:68-73) */
+    const float*   bxdf_f;      /* n_objects*13 k_d k_s k_g mean, medium ior */
+    const int32_t* src_i;       /* n_sources*4 type, bool_bits, obj_ref_id, 0 (emitters/abtract_source.py:44-54) */
+    const float*   src_f;       /* n_sources*11 intensity dir pos inv_area r */
+    float          world_ior;   /* free-space medium ior */
+} apt_scene_desc;
+
+/* Per-renderer configuration: film, camera, sampling flags, tile ownership, batching. */
+typedef struct apt_render_cfg {
+    int32_t width, height;                        /* full film size */
+    int32_t do_crop, start_x, end_x, start_y, end_y;
+    int32_t max_bounce, num_shadow_ray;
+    int32_t use_rr, use_mis, anti_alias, stratified, brdf_two_sides;
+    int32_t rr_bounce_th;
+    float   rr_threshold;
+    float   cam_r[9];                             /* row-major camera rotation */
+    float   cam_t[3];
+    float   inv_focal, half_w, half_h;
+    uint32_t seed;                                /* Philox key word 1 (key word 0 = global pixel index x*H+y) */
+    /* tile ownership: columns x with (x / band_width) % world_size == rank belong to this renderer */
+    int32_t band_width, rank, world_size;
+    int32_t spp_per_batch;                        /* samples per pixel in flight per wavefront batch (0 = auto) */
+    int32_t device;                               /* HIP device ordinal */
+    int32_t profile;                              /* 1 = time every kernel launch with HIP events */
+} apt_render_cfg;
+
+#define APT_N_KERNELS 5   /* generate, extend, shade, shadow, finalize */
+typedef struct apt_stats {
+    int64_t n_samples;        /* pixel-samples generated */
+    int64_t n_extend;         /* closest-hit rays traced */
+    int64_t n_shade;          /* bounce-loop iterations that reached shading (after miss / RR / cut-off) */
+    int64_t n_shadow;         /* shadow rays the reference would cast (valid emitter sample) */
+    int64_t n_shadow_traced;  /* of those, rays with a non-zero contribution that were actually traced */
+    int64_t n_lit;            /* traced shadow rays found unoccluded */
+    int64_t n_draws;          /* RNG draws consumed */
+    int64_t launches[APT_N_KERNELS];
+    double  kernel_ms[APT_N_KERNELS];   /* summed HIP-event time per kernel (profile=1 only) */
+    double  render_ms;                  /* HIP-event time of all apt_render calls so far */
+} apt_stats;
+
+/* ---- BVH build (host, own layout; replaces bvh_cpp.bvh_build) */
+int apt_bvh_build(const float* prims /* n_prims*9 */, int32_t n_prims,
+                  const int32_t* obj_info /* n_objects*3 */, int32_t n_objects, apt_bvh** out);
+int apt_bvh_counts(const apt_bvh*, int32_t* n_nodes, int32_t* n_leaf_prims, int32_t* max_depth);
+/* nodes: n_nodes*16 floats (two child boxes + two child links); prim_order: n_prims ints (BVH order -> original prim) */
+int apt_bvh_export(const apt_bvh*, float* nodes, int32_t* prim_order);
+void apt_bvh_free(apt_bvh*);
+
+/* ---- scene / renderer lifetime */
+int apt_scene_create(const apt_scene_desc* desc, int32_t device, apt_scene** out);
+void apt_scene_destroy(apt_scene*);
+int apt_renderer_create(const apt_scene*, const apt_render_cfg* cfg, apt_renderer** out);
+void apt_renderer_destroy(apt_renderer*);
+
+/* ---- rendering */
+int apt_render(apt_renderer*, int32_t n_spp);             /* accumulates n_spp more samples per owned pixel */
+int apt_synchronize(apt_renderer*);
+int apt_tile_shape(const apt_renderer*, int32_t* n_cols, int32_t* height);   /* owned framebuffer = n_cols*height*3 */
+int apt_read_pixels(apt_renderer*, float* out);           /* owned tile, [local col][y][rgb], color / cnt */
+int apt_get_accum(apt_renderer*, float* out, int32_t* cnt);
+int apt_set_accum(apt_renderer*, const float* in, int32_t cnt);
+int apt_reset(apt_renderer*);                             /* color = 0, cnt = 0, stats = 0 */
+int apt_get_stats(apt_renderer*, apt_stats* out);
+int apt_device_ptr(apt_renderer*, void** accum_dev, int32_t* cnt); /* device float[n_cols*height*3] accumulation buffer */
+int apt_stream(apt_renderer*, void** hip_stream);         /* the hipStream_t every kernel of this renderer runs on */
+
+/* ---- unit entry points used by the parity tests (same device code paths as apt_render) */
+int apt_intersect(apt_renderer*, int32_t n, const float* o, const float* d,
+                  int32_t* prim_out, float* t_out, float* uv_out);
+int apt_occluded(apt_renderer*, int32_t n, const float* o, const float* d, const float* tmax, int32_t* occ_out);
+int apt_rng_stream(int32_t device, uint32_t pixel, uint32_t seed, uint32_t sample, int32_t n, uint32_t* out);
+
+const char* apt_last_error(void);
+const char* apt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADAPT_MI_H */
