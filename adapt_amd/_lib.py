@@ -40,11 +40,11 @@ class RenderCfg(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_samples", C.c_int64), ("n_extend", C.c_int64), ("n_shade", C.c_int64), ("n_shadow", C.c_int64),
-                ("n_shadow_traced", C.c_int64), ("n_lit", C.c_int64), ("n_draws", C.c_int64),
+                ("n_shadow_traced", C.c_int64), ("n_lit", C.c_int64), ("n_draws", C.c_int64), ("n_poisoned", C.c_int64),
                 ("launches", C.c_int64 * APT_N_KERNELS), ("kernel_ms", C.c_double * APT_N_KERNELS), ("render_ms", C.c_double)]
 
     def as_dict(self):
-        d = {k: int(getattr(self, k)) for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws")}
+        d = {k: int(getattr(self, k)) for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws", "n_poisoned")}
         d["launches"] = dict(zip(KERNEL_NAMES, [int(x) for x in self.launches]))
         d["kernel_ms"] = dict(zip(KERNEL_NAMES, [float(x) for x in self.kernel_ms]))
         d["render_ms"] = float(self.render_ms)
@@ -74,6 +74,9 @@ SYMBOLS = {
     "apt_intersect": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, i32p, f32p, f32p]),
     "apt_occluded": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, f32p, i32p]),
     "apt_rng_stream": (C.c_int, [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, u32p]),
+    "apt_bxdf_probe": (C.c_int, [C.c_int32, C.c_int32, i32p, f32p, f32p, C.c_float, C.c_int32, C.c_uint32, f32p]),
+    "apt_emitter_probe": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_uint32, f32p]),
+    "apt_renderer_info": (C.c_int, [C.c_void_p, i32p, i32p, C.POINTER(C.c_int64), i32p, C.POINTER(C.c_char_p)]),
     "apt_last_error": (C.c_char_p, []),
     "apt_version": (C.c_char_p, []),
 }

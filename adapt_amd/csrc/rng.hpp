@@ -1,7 +1,7 @@
 // rng.hpp — counter-based RNG for the path tracer: Philox-4x32-10 (Salmon et al., SC'11).
 //
 // Replaces the reference's stateful `ti.random` (third-party Taichi; call sites listed in
-// SURVEY.md A.4).  Stream definition (shared with oracle/ and the golden generator):
+// SURVEY.md A.4).  Stream definition (the CPU checker and the golden generator implement the same stream):
 //   key     = (global pixel index x*H + y, seed)
 //   counter = (sample counter `cnt` of that pixel-sample, draw_index / 4, 0, 0)
 //   draw d  = word (d & 3) of that block; floats use the top 24 bits -> [0,1); ints are the raw word

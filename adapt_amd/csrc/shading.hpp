@@ -301,43 +301,53 @@ APT_D float thin_coat_fresnel(const DevBxdf& b, const Hit& it, f3 in) {
     return fresnel_dielectric(1.f, b.k_g.z, fabsf(d_in), sqrtf(cos_r2));
 }
 
+// Material-set masks: bit t (0..7) = BRDF type t present, bit 8 = det-refraction BSDF, bit 9 = Lambertian
+// transmission BSDF, bit 10 = null BSDF.  Emitter mask: bit = emitter type (0 point, 1 area, 2 spot, 4 collimated).
+// The dispatchers take the scene's mask as a template argument so that a shade kernel specialised for,
+// say, {Lambertian} x {point} carries none of the other models' registers or code.
+#define APT_BX_ALL 0x7ff
+#define APT_SRC_ALL 0x17
+#define BXHAS(M, bit) (((M) >> (bit)) & 1)
+
 // BRDF.eval: f * cos, zero unless incid/out are on opposite sides of the GEOMETRIC normal
+template <int BM>
 APT_D f3 brdf_eval(const DevBxdf& b, const Hit& it, f3 incid, f3 out) {
     f3 ret = splat3(0.f);
     if (dot(incid, it.n_g) * dot(out, it.n_g) < 0.f) {
         switch (b.type) {
-            case 0: ret = blinn_phong_eval(b, it, incid, out); break;
-            case 1: ret = lambert_eval(b, it.n_s, out); break;
-            case 4: ret = mod_phong_eval(b, it, incid, out); break;
-            case 5: { m33 R; rotation_between(mk3(0.f, 1.f, 0.f), it.n_s, R); ret = fresnel_blend_eval(b, it, incid, out, R); break; }
-            case 6: ret = oren_nayar_eval(b, it, incid, out); break;
-            case 7: ret = thin_coat_eval(b, it, incid, out); break;
+            case 0: if (BXHAS(BM, 0)) ret = blinn_phong_eval(b, it, incid, out); break;
+            case 1: if (BXHAS(BM, 1)) ret = lambert_eval(b, it.n_s, out); break;
+            case 4: if (BXHAS(BM, 4)) ret = mod_phong_eval(b, it, incid, out); break;
+            case 5: if (BXHAS(BM, 5)) { m33 R; rotation_between(mk3(0.f, 1.f, 0.f), it.n_s, R); ret = fresnel_blend_eval(b, it, incid, out, R); } break;
+            case 6: if (BXHAS(BM, 6)) ret = oren_nayar_eval(b, it, incid, out); break;
+            case 7: if (BXHAS(BM, 7)) ret = thin_coat_eval(b, it, incid, out); break;
             default: break;
         }
     }
     return ret;
 }
+template <int BM>
 APT_D f3 brdf_sample(const DevBxdf& b, const Hit& it, f3 incid, Philox& r, f3& spec, float& pdf, bool& is_specular) {
     f3 dir = mk3(0.f, 1.f, 0.f);
     spec = splat3(1.f); pdf = 1.0f; is_specular = false;
     switch (b.type) {
-        case 0: {
+        case 0: if (BXHAS(BM, 0)) {
             f3 local = sample_cosine_hemisphere(r, pdf);
             dir = delocalize(it.n_s, local);
             spec = blinn_phong_eval(b, it, incid, dir);
-            break;
-        }
-        case 1: case 6: dir = lambert_sample(b, it.n_s, r, spec, pdf); break;
-        case 2: dir = reflect_in(incid, it.n_s); spec = b.k_d; pdf = 1.0f; break;
-        case 7: dir = thin_coat_sample(b, it, incid, r, spec, pdf, is_specular); break;
-        case 4: dir = mod_phong_sample(b, it, incid, r, spec, pdf); break;
-        case 5: dir = fresnel_blend_sample(b, it, incid, r, spec, pdf); break;
+        } break;
+        case 1: case 6: if (BXHAS(BM, 1) || BXHAS(BM, 6)) dir = lambert_sample(b, it.n_s, r, spec, pdf); break;
+        case 2: if (BXHAS(BM, 2)) { dir = reflect_in(incid, it.n_s); spec = b.k_d; pdf = 1.0f; } break;
+        case 7: if (BXHAS(BM, 7)) dir = thin_coat_sample(b, it, incid, r, spec, pdf, is_specular); break;
+        case 4: if (BXHAS(BM, 4)) dir = mod_phong_sample(b, it, incid, r, spec, pdf); break;
+        case 5: if (BXHAS(BM, 5)) dir = fresnel_blend_sample(b, it, incid, r, spec, pdf); break;
         case 3: spec = splat3(0.f); break;
         default: break;
     }
     if (!(dot(dir, it.n_g) > 0.f)) spec = splat3(0.f);
     return dir;
 }
+template <int BM>
 APT_D float brdf_pdf(const DevBxdf& b, const Hit& it, f3 outdir, f3 incid) {
     float pdf = 0.f;
     float d_out = dot(it.n_s, outdir);
@@ -345,30 +355,27 @@ APT_D float brdf_pdf(const DevBxdf& b, const Hit& it, f3 outdir, f3 incid) {
     if (d_out * d_in < 0.f) {
         switch (b.type) {
             case 0: case 1: case 6: pdf = d_out * APT_INV_PI; break;
-            case 4: {
+            case 4: if (BXHAS(BM, 4)) {
                 float g = b.mean.z;
                 f3 rv = reflect_in(incid, it.n_s);
                 float dro = fmaxf(0.f, dot(rv, outdir));
                 float dpdf = d_out * APT_INV_PI;
                 float spdf = 0.5f * (g + 1.f) * APT_INV_PI * apt_pow(dro, g);
                 pdf = max3(b.k_d) * dpdf + max3(b.k_s) * spdf;
-                break;
-            }
-            case 7: {
+            } break;
+            case 7: if (BXHAS(BM, 7)) {
                 f3 refl = reflect_in(incid, it.n_s);
                 float F = thin_coat_fresnel(b, it, incid);
                 pdf = (fabsf(dot(outdir, refl)) > (1.f - 1e-3f)) ? F : (1.f - F) * d_out * APT_INV_PI;
-                break;
-            }
-            case 5: {
+            } break;
+            case 5: if (BXHAS(BM, 5)) {
                 f3 h = normalize(outdir - incid);
                 float d_half = dot(h, it.n_s);
                 m33 R; rotation_between(mk3(0.f, 1.f, 0.f), it.n_s, R);
                 float c2, s2; fb_cos2_sin2(h, it.n_s, R, d_half, c2, s2);
                 pdf = b.k_g.z * apt_pow(d_half, b.k_g.x * c2 + b.k_g.y * s2) / fabsf(dot(incid, h));
                 pdf = 0.5f * (pdf + d_out * APT_INV_PI);
-                break;
-            }
+            } break;
             default: break;
         }
     }
@@ -487,21 +494,24 @@ APT_D float bsdf_pdf(const DevBxdf& b, const Hit& it, f3 outdir, f3 incid, float
 APT_D void flip_if_two_sided(Hit& it, f3 incid, int two_sides) {
     if (two_sides && dot(incid, it.n_s) > 0.f) { it.n_s = -it.n_s; it.n_g = -it.n_g; }
 }
+template <int BM>
 APT_D f3 surface_sample(const DevBxdf& b, Hit& it, f3 incid, float world_ior, int two_sides, Philox& r, f3& spec, float& pdf, bool& is_specular) {
-    if (!b.is_bsdf) { flip_if_two_sided(it, incid, two_sides); return brdf_sample(b, it, incid, r, spec, pdf, is_specular); }
+    if (!(BM & 0x700) || !b.is_bsdf) { flip_if_two_sided(it, incid, two_sides); return brdf_sample<BM>(b, it, incid, r, spec, pdf, is_specular); }
     spec = splat3(0.f); pdf = 0.f; is_specular = false;
-    if (b.type == 0) return glass_sample(b, it, incid, world_ior, r, spec, pdf);
-    if (b.type == 1) return lambert_trans_sample(b, it, incid, world_ior, r, spec, pdf, is_specular);
+    if (BXHAS(BM, 8) && b.type == 0) return glass_sample(b, it, incid, world_ior, r, spec, pdf);
+    if (BXHAS(BM, 9) && b.type == 1) return lambert_trans_sample(b, it, incid, world_ior, r, spec, pdf, is_specular);
     return splat3(0.f);
 }
+template <int BM>
 APT_D f3 surface_eval(const DevBxdf& b, Hit& it, f3 incid, f3 out, float world_ior, int two_sides) {
-    if (!b.is_bsdf) { flip_if_two_sided(it, incid, two_sides); return brdf_eval(b, it, incid, out); }
-    if (b.type == 0) return glass_eval(b, it, incid, out, world_ior);
-    if (b.type == 1) return lambert_trans_eval(b, it, incid, out, world_ior);
+    if (!(BM & 0x700) || !b.is_bsdf) { flip_if_two_sided(it, incid, two_sides); return brdf_eval<BM>(b, it, incid, out); }
+    if (BXHAS(BM, 8) && b.type == 0) return glass_eval(b, it, incid, out, world_ior);
+    if (BXHAS(BM, 9) && b.type == 1) return lambert_trans_eval(b, it, incid, out, world_ior);
     return splat3(0.f);
 }
+template <int BM>
 APT_D float surface_pdf(const DevBxdf& b, Hit& it, f3 outdir, f3 incid, float world_ior, int two_sides) {
-    if (!b.is_bsdf) { flip_if_two_sided(it, incid, two_sides); return brdf_pdf(b, it, outdir, incid); }
+    if (!(BM & 0x700) || !b.is_bsdf) { flip_if_two_sided(it, incid, two_sides); return brdf_pdf<BM>(b, it, outdir, incid); }
     return bsdf_pdf(b, it, outdir, incid, world_ior);
 }
 
@@ -515,14 +525,15 @@ APT_D f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
 // NEE sample: returns the point on the emitter; `inten` is already divided by the
 // area->solid-angle pdf for area emitters (abtract_source.py:129-132)
+template <int SM>
 APT_D f3 emitter_sample_hit(const DevSrc& s, const EmitterGeom& g, f3 hit_pos, Philox& r, f3& inten, float& pdf) {
     inten = s.intensity;
     f3 pos = s.pos;
     pdf = 1.0f;
-    if (s.type == 0) {
+    if (BXHAS(SM, 0) && s.type == 0) {
         f3 x = hit_pos - pos;
         inten = inten * fminf(1.0f / fmaxf(norm2(x), 1e-5f), 1.0f);
-    } else if (s.type == 1) {
+    } else if (BXHAS(SM, 1) && s.type == 1) {
         pdf = s.inv_area;
         f3 normal;
         const int* oi = g.obj_info + 3 * s.obj_ref_id;
@@ -549,13 +560,13 @@ APT_D f3 emitter_sample_hit(const DevSrc& s, const EmitterGeom& g, f3 hit_pos, P
             pdf *= norm2(diff) / dl;
             inten = (pdf > 0.0f) ? inten / pdf : splat3(0.f);
         }
-    } else if (s.type == 2) {
+    } else if (BXHAS(SM, 2) && s.type == 2) {
         f3 to_hit = hit_pos - pos;
         float depth = fmaxf(norm(to_hit), 1e-5f);
         to_hit = to_hit / depth;
         if (dot(to_hit, s.dir) > s.r) inten = inten / (depth * depth);
         else inten = splat3(0.f);
-    } else if (s.type == 4) {
+    } else if (BXHAS(SM, 4) && s.type == 4) {
         pdf = 0.f;
         if (s.r > 0.f) {
             f3 to_hit = hit_pos - s.pos;

@@ -1,0 +1,507 @@
+// stages.hpp — the wavefront stage kernels of the gfx950 path tracer.
+//
+// Hot path being replaced: AdaPT's megakernel `Renderer.render`
+// (renderer/vanilla_renderer.py:32-120: one launch per spp, one thread per pixel carrying a
+// whole path through every bounce).  Here the same path-space computation is decomposed
+// into stages that each stream dense SoA queues in HBM:
+//
+//   generate : camera ray per (pixel, sample) slot                       tracer_base.py:136-157
+//   extend   : closest hit for every queued ray                          tracer_base.py:168-237 / path_tracer.py:338-394
+//   shade    : emission + MIS, RR, NEE sampling -> shadow queue,         vanilla_renderer.py:44-117
+//              BSDF sampling -> next ray queue (ballot-compacted)
+//   shadow   : any-hit for every shadow ray; unoccluded ones add         tracer_base.py:239-278 / path_tracer.py:396-422
+//              their contribution to the owning path's radiance
+//   finalize : per pixel, sum the batch's samples in sample order,       vanilla_renderer.py:119-120
+//              NaN -> 0, accumulate into the float3 framebuffer
+//
+// Queue organisation.  A batch holds P = owned_pixels * spp_batch paths.  Every queue is split
+// into `nq` sub-queues (32 by default), each with its own region [q*subcap, (q+1)*subcap) and
+// its own counters on private 128-byte lines.  Workgroup b serves sub-queue b % nq in every
+// stage, and survivors of sub-queue q are appended to sub-queue q of the next queue, so
+//   * queue-tail atomics are spread over nq addresses (one hot counter saturates at ~90
+//     atomics/us on MI355X, which throttled the single-queue version), and
+//   * with the dispatcher's observed block->XCD map (b % 8), a sub-queue is produced and
+//     consumed under the same XCD's L2 in consecutive stages (speed only, never correctness).
+// A path is identified for life by id = sample_in_batch * npix + local_pixel: the RNG is keyed
+// by (global pixel, sample counter) and only a draw index travels with the path, and the
+// radiance accumulator L[] is indexed by id, so results do not depend on queue position.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rng.hpp"
+#include "shading.hpp"
+#include "traverse.hpp"
+#include "vec.hpp"
+
+// ------------------------------------------------------------- device views
+struct DevScene {
+    DevBvh bvh;
+    const float* normals;     // n_prims*3
+    const float* vnormals;    // n_prims*9
+    const float* precom;      // n_prims*9  (v1-v0, v2-v0, v0) | sphere (centre, rrr, centre)
+    const int* prim_obj;      // n_prims
+    const int* obj_info;      // n_objects*3
+    const int* emitter_id;    // n_objects
+    const DevBxdf* bxdf;      // n_objects
+    const DevSrc* src;        // n_sources
+    int n_prims, n_objects, n_sources, has_vn;
+    float world_ior;
+};
+
+struct Params {
+    float cam_r[9], cam_t[3];
+    float inv_focal, half_w, half_h;
+    int W, H, n_cols, npix;
+    int band_width, rank, world;
+    int do_crop, sx, ex, sy, ey;
+    int max_bounce, S;
+    float inv_S;
+    int use_rr, use_mis, anti_alias, stratified, two_sides, rr_bounce_th;
+    float rr_threshold;
+    uint32_t seed;
+    int cnt_base, spp_batch;
+    uint32_t cap;             // nq * subcap: component stride of every path-indexed array
+    uint32_t subcap;          // slots per sub-queue
+    int nq;
+};
+
+// SoA queues; every array has `cap` (shadow: sh_cap) entries per component
+struct Queues {
+    float* ray_o[2]; float* ray_d[2];           // 3 components each
+    float* hit_t; int* hit_prim; float* hit_u; float* hit_v;
+    float* thr[2]; uint32_t* id[2]; uint32_t* meta[2]; float* pdf[2];
+    float* sh_o; float* sh_d; float* sh_tmax; float* sh_c; uint32_t* sh_id;
+    float* L;                                    // 3 components, indexed by path id
+    uint32_t sh_cap, sh_subcap;
+};
+
+#define APT_MAX_NQ 32
+#define CNT_PAD 32                               // one counter per 128-byte line
+enum { ST_SAMPLES = 0, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_SHADOW_TRACED, ST_LIT, ST_DRAWS, ST_POISON, ST_COUNT };
+struct Counters {
+    uint32_t n_active[2][APT_MAX_NQ * CNT_PAD];
+    uint32_t n_shadow[APT_MAX_NQ * CNT_PAD];
+    unsigned long long stats[APT_MAX_NQ][16];    // [q][ST_*], 128 bytes per sub-queue
+};
+
+// meta word: draw index [0,16) | bounce [16,24) | is_specular bit 24
+APT_D uint32_t pack_meta(uint32_t draw, uint32_t bounce, bool spec) { return (draw & 0xffffu) | (bounce << 16) | (spec ? (1u << 24) : 0u); }
+
+#define BLOCK 256
+
+// LDS carve for the traversal stages (dynamic, sized per scene by the host):
+//   [ lds_nodes * 64 B node records | lds_prims * 48 B primitive records | stack_depth * BLOCK ints ]
+struct LdsPlan { int lds_nodes, lds_prims, stack_depth; };
+extern __shared__ float4 s_dyn[];
+APT_D int* carve_lds(const DevBvh& b, const LdsPlan& plan, StagedBvh& out) {
+    float4* s_nodes = s_dyn;
+    float4* s_prims = s_dyn + 4 * plan.lds_nodes;
+    stage_bvh(b, s_nodes, plan.lds_nodes, s_prims, plan.lds_prims, out);
+    __syncthreads();
+    return reinterpret_cast<int*>(s_prims + 3 * plan.lds_prims) + threadIdx.x;
+}
+
+APT_D uint32_t lane_id() { return threadIdx.x & 63u; }
+// append `flag` lanes of the wave to the queue counted by *counter; returns this lane's position
+APT_D uint32_t wave_append(bool flag, uint32_t* counter) {
+    unsigned long long m = __ballot(flag);
+    uint32_t base = 0;
+    if (lane_id() == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, 0);
+    return base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+}
+// end-of-kernel statistics: per-lane register tallies -> one atomic per wave per counter
+APT_D void flush_stat(uint32_t v, unsigned long long* counter) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if (lane_id() == 0 && v) atomicAdd(counter, (unsigned long long)v);
+}
+
+// local pixel -> (global column, row)
+APT_D void local_to_global(const Params& p, uint32_t lp, int& i, int& j) {
+    int lc = (int)(lp / (uint32_t)p.H);
+    j = (int)(lp % (uint32_t)p.H);
+    int lb = lc / p.band_width, w = lc % p.band_width;
+    i = (lb * p.world + p.rank) * p.band_width + w;
+}
+
+// workgroup -> (sub-queue, first slot, stride) of the persistent loop over a sub-queue
+struct SubLoop { int q; uint32_t first, stride; };
+APT_D SubLoop sub_loop(int nq) {
+    SubLoop s;
+    s.q = (int)(blockIdx.x % (uint32_t)nq);
+    s.first = (blockIdx.x / (uint32_t)nq) * BLOCK;
+    s.stride = (gridDim.x / (uint32_t)nq) * BLOCK;
+    return s;
+}
+
+// ----------------------------------------------------------------- generate
+// wave w of the id space feeds sub-queue w % nq at position (w / nq) * 64 + lane: dense and
+// atomic-free unless a crop window makes some lanes inactive.
+__global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters* cnt) {
+    const uint32_t total = (uint32_t)p.npix * (uint32_t)p.spp_batch;
+    const uint32_t n_waves = (total + 63u) / 64u;
+    const uint32_t wave_stride = gridDim.x * (BLOCK / 64);
+    uint32_t t_samples = 0, t_draws = 0;
+    for (uint32_t w = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64u; w < n_waves; w += wave_stride) {
+        const uint32_t idx = w * 64u + lane_id();
+        const int sq = (int)(w % (uint32_t)p.nq);
+        bool valid = idx < total, alive = false;
+        f3 dir = mk3(0.f, 0.f, 1.f);
+        uint32_t draws = 0;
+        if (valid) {
+            uint32_t lp = idx % (uint32_t)p.npix, s = idx / (uint32_t)p.npix;
+            int i, j; local_to_global(p, lp, i, j);
+            q.L[idx] = 0.f; q.L[p.cap + idx] = 0.f; q.L[2 * p.cap + idx] = 0.f;
+            alive = !p.do_crop || (i >= p.sx && i < p.ex && j >= p.sy && j < p.ey);
+            if (alive) {
+                int sample_cnt = p.cnt_base + (int)s + 1;        // cnt is incremented before the pixel loop
+                Philox rng; rng_init(rng, (uint32_t)(i * p.H + j), p.seed, (uint32_t)sample_cnt, 0u);
+                float vx = 0.5f, vy = 0.5f;
+                if (p.anti_alias) {
+                    if (p.stratified) {
+                        int mod_val = pymod(sample_cnt, 16);
+                        vx = (float)(mod_val % 4) * 0.25f + rng_float(rng) * 0.25f;
+                        vy = (float)(mod_val / 4) * 0.25f + rng_float(rng) * 0.25f;
+                    } else {
+                        const float eps = 1e-4f, inv_eps = (float)(1 - 1e-4 * 2.);
+                        vx = rng_float(rng) * inv_eps + eps;
+                        vy = rng_float(rng) * inv_eps + eps;
+                    }
+                }
+                f3 cd = mk3((p.half_w + vx - (float)i) * p.inv_focal, ((float)j - p.half_h - vy) * p.inv_focal, 1.f);
+                m33 R;
+                for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) R.m[a][b] = p.cam_r[3 * a + b];
+                dir = normalize(mul(R, cd));
+                draws = rng.draw;
+            }
+        }
+        uint32_t pos;
+        if (p.do_crop) pos = wave_append(alive, &cnt->n_active[0][sq * CNT_PAD]);
+        else {
+            pos = (w / (uint32_t)p.nq) * 64u + lane_id();
+            unsigned long long m = __ballot(alive);
+            if (lane_id() == 0) atomicAdd(&cnt->n_active[0][sq * CNT_PAD], (uint32_t)__popcll(m));   // nq-way spread, ordered by w
+        }
+        if (alive) {
+            const uint32_t slot = (uint32_t)sq * p.subcap + pos;
+            q.ray_o[0][slot] = p.cam_t[0]; q.ray_o[0][p.cap + slot] = p.cam_t[1]; q.ray_o[0][2 * p.cap + slot] = p.cam_t[2];
+            q.ray_d[0][slot] = dir.x; q.ray_d[0][p.cap + slot] = dir.y; q.ray_d[0][2 * p.cap + slot] = dir.z;
+            q.thr[0][slot] = 1.f; q.thr[0][p.cap + slot] = 1.f; q.thr[0][2 * p.cap + slot] = 1.f;
+            q.id[0][slot] = idx;
+            q.meta[0][slot] = pack_meta(draws, 0u, false);
+            q.pdf[0][slot] = 1.f;
+            t_samples++;
+        }
+        t_draws += draws;
+    }
+    const int sq0 = (int)((blockIdx.x * (BLOCK / 64) + threadIdx.x / 64u) % (uint32_t)p.nq);
+    flush_stat(t_samples, &cnt->stats[sq0][ST_SAMPLES]);
+    flush_stat(t_draws, &cnt->stats[sq0][ST_DRAWS]);
+}
+
+// ------------------------------------------------------------------- extend
+// closest hit for ray queue `cur`.  Also recycles the counters nobody reads any more: the
+// next-ray queue of this bounce (it was the current queue of the previous bounce) and the
+// shadow queue.  `n_src` = per-sub-queue counts (normally cnt->n_active[cur]).
+__global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
+    StagedBvh bvh;
+    int* my_stack = carve_lds(sc.bvh, plan, bvh);
+    const SubLoop sl = sub_loop(p.nq);
+    const uint32_t n = n_src[sl.q * CNT_PAD];
+    if (cnt && sl.first == 0 && threadIdx.x == 0) {
+        cnt->n_shadow[sl.q * CNT_PAD] = 0; cnt->n_active[cur ^ 1][sl.q * CNT_PAD] = 0;
+        cnt->stats[sl.q][ST_EXTEND] += n;
+    }
+    const float* ro = q.ray_o[cur]; const float* rd = q.ray_d[cur];
+    const uint32_t qbase = (uint32_t)sl.q * p.subcap;
+    for (uint32_t pos = sl.first + threadIdx.x; pos < n; pos += sl.stride) {
+        const uint32_t idx = qbase + pos;
+        f3 o = mk3(ro[idx], ro[p.cap + idx], ro[2 * p.cap + idx]);
+        f3 d = mk3(rd[idx], rd[p.cap + idx], rd[2 * p.cap + idx]);
+        HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
+        traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
+        q.hit_t[idx] = rec.t; q.hit_prim[idx] = rec.prim; q.hit_u[idx] = rec.u; q.hit_v[idx] = rec.v;
+    }
+}
+
+// -------------------------------------------------------------------- shade
+APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3 o, f3 d, Hit& it) {
+    it.prim_id = prim; it.min_depth = t;
+    it.obj_id = sc.prim_obj[prim];
+    if (sc.obj_info[3 * it.obj_id + 2]) {
+        // sphere: precom row 0 = centre; normal from the hit point (tracer_base.py:217-223)
+        f3 c = ld3(sc.precom + 9 * prim);
+        it.n_g = normalize((o + d * t) - c);
+        it.n_s = it.n_g;
+    } else {
+        it.n_g = ld3(sc.normals + 3 * prim);
+        if (sc.has_vn) {
+            const float* vn = sc.vnormals + 9 * prim;
+            // interpolated vertex normal, NOT re-normalised (tracer_base.py:228-230)
+            it.n_s = (ld3(vn) * (1.f - u - v) + ld3(vn + 3) * u) + ld3(vn + 6) * v;
+        } else it.n_s = it.n_g;
+    }
+}
+
+// BM / SM: material and emitter masks of the scene (shading.hpp); code for absent models is compiled out.
+template <int BM, int SM>
+__global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, int cur, int bounce) {
+    const int nxt = cur ^ 1;
+    const SubLoop sl = sub_loop(p.nq);
+    const uint32_t n = cnt->n_active[cur][sl.q * CNT_PAD];
+    const uint32_t qbase = (uint32_t)sl.q * p.subcap, sh_qbase = (uint32_t)sl.q * q.sh_subcap;
+    uint32_t* next_counter = &cnt->n_active[nxt][sl.q * CNT_PAD];
+    uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
+    const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
+    uint32_t t_shade = 0, t_shadow = 0, t_draws = 0, t_poison = 0;
+    for (uint32_t base = sl.first; base < n; base += sl.stride) {
+        const uint32_t pos = base + threadIdx.x;
+        const uint32_t idx = qbase + pos;
+        bool alive = pos < n;
+        f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), thr = splat3(0.f), hit_point = splat3(0.f);
+        uint32_t id = 0, draw0 = 0;
+        float ray_pdf = 1.f;
+        bool was_spec = false;
+        Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
+        Hit it; it.obj_id = -1; it.prim_id = -1; it.n_s = it.n_g = mk3(1.f, 0.f, 0.f); it.min_depth = 0.f;
+        int hit_light = -1;
+        float emission_weight = 1.0f;
+        DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
+        if (alive) {
+            int prim = q.hit_prim[idx];
+            if (prim < 0) alive = false;                         // nothing hit: path ends (vanilla_renderer.py:49)
+            else {
+                o = mk3(q.ray_o[cur][idx], q.ray_o[cur][p.cap + idx], q.ray_o[cur][2 * p.cap + idx]);
+                d = mk3(q.ray_d[cur][idx], q.ray_d[cur][p.cap + idx], q.ray_d[cur][2 * p.cap + idx]);
+                thr = mk3(q.thr[cur][idx], q.thr[cur][p.cap + idx], q.thr[cur][2 * p.cap + idx]);
+                id = q.id[cur][idx];
+                uint32_t meta = q.meta[cur][idx];
+                ray_pdf = q.pdf[cur][idx];
+                was_spec = (meta >> 24) & 1u;
+                build_hit(sc, prim, q.hit_t[idx], q.hit_u[idx], q.hit_v[idx], o, d, it);
+                bx = sc.bxdf[it.obj_id];
+                hit_light = sc.emitter_id[it.obj_id];
+                uint32_t lp = id % (uint32_t)p.npix, s = id / (uint32_t)p.npix;
+                int gi, gj; local_to_global(p, lp, gi, gj);
+                draw0 = meta & 0xffffu;
+                rng_init(rng, (uint32_t)(gi * p.H + gj), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
+                // tail of the previous iteration: emission MIS weight for this hit (vanilla_renderer.py:111-117)
+                if (bounce > 0 && p.use_mis) {
+                    float e_pdf = 0.0f;
+                    if (hit_light >= 0 && bx.is_delta == 0 && !was_spec) e_pdf = emitter_solid_angle_pdf(sc.src[hit_light], it, d);
+                    emission_weight = balance(ray_pdf, e_pdf);
+                }
+                // Russian roulette / cut-off (vanilla_renderer.py:50-57)
+                if (p.use_rr) {
+                    float mx = max3(thr);
+                    if (mx < p.rr_threshold && bounce >= p.rr_bounce_th) {
+                        if (rng_float(rng) > mx) alive = false;
+                        else thr = thr * (1.f / (mx + 1e-7f));
+                    }
+                } else if (max3(thr) < 1e-4f) alive = false;
+            }
+        }
+        if (alive) { t_shade++; hit_point = d * it.min_depth + o; }
+
+        // ---- next-event estimation: one shadow-queue entry per useful light sample
+        bool break_flag = false;
+        for (int s = 0; s < p.S; s++) {
+            bool want = false;
+            f3 light_dir = splat3(0.f), contrib = splat3(0.f);
+            float emitter_d = 0.f;
+            if (alive && !break_flag) {
+                // sample_light (path_tracer.py:537-554): one int is always drawn
+                int ns = sc.n_sources;
+                int sidx = pymod(rng_int(rng), ns);
+                float emitter_pdf = 1.f / (float)ns;
+                bool valid = true;
+                if (hit_light >= 0) {
+                    if (ns <= 1) valid = false;
+                    else {
+                        sidx = pymod(rng_int(rng), ns - 1);
+                        if (sidx >= hit_light) sidx += 1;
+                        emitter_pdf = 1.f / (float)(ns - 1);
+                    }
+                }
+                if (!valid) break_flag = true;
+                else {
+                    const DevSrc src = sc.src[sidx];
+                    f3 shadow_int; float direct_pdf;
+                    f3 emit_pos = emitter_sample_hit<SM>(src, geom, hit_point, rng, shadow_int, direct_pdf);
+                    f3 to_emitter = emit_pos - hit_point;
+                    emitter_d = norm(to_emitter);
+                    light_dir = to_emitter / emitter_d;
+                    t_shadow++;
+                    f3 direct_spec = surface_eval<BM>(bx, it, d, light_dir, sc.world_ior, p.two_sides);
+                    float mis_w = 1.0f;
+                    if (p.use_mis && !(src.bool_bits & 0x01)) {
+                        float light_pdf = emitter_pdf * direct_pdf;
+                        float bsdf_pdf_v = surface_pdf<BM>(bx, it, light_dir, d, sc.world_ior, p.two_sides);
+                        mis_w = balance(light_pdf, bsdf_pdf_v);
+                    }
+                    if (isnan(mis_w)) {
+                        // Upstream the MIS weight multiplies the light sample even when the shadow ray is
+                        // occluded (0 * NaN), so a NaN weight poisons the whole pixel-sample, which is then
+                        // zeroed at the end (vanilla_renderer.py:87-95,119).  Reproduce that without tracing.
+                        q.L[id] = mis_w; q.L[p.cap + id] = mis_w; q.L[2 * p.cap + id] = mis_w;
+                        t_poison++;
+                    } else {
+                        f3 c = ((direct_spec * shadow_int) * mis_w) / emitter_pdf;
+                        contrib = (c * p.inv_S) * thr;
+                        want = !(contrib.x == 0.f && contrib.y == 0.f && contrib.z == 0.f);
+                    }
+                }
+            }
+            uint32_t spos = wave_append(want, shadow_counter);
+            if (want && spos < q.sh_subcap) {
+                const uint32_t slot = sh_qbase + spos, sc_ = q.sh_cap;
+                q.sh_o[slot] = hit_point.x; q.sh_o[sc_ + slot] = hit_point.y; q.sh_o[2 * sc_ + slot] = hit_point.z;
+                q.sh_d[slot] = light_dir.x; q.sh_d[sc_ + slot] = light_dir.y; q.sh_d[2 * sc_ + slot] = light_dir.z;
+                q.sh_tmax[slot] = emitter_d;
+                q.sh_c[slot] = contrib.x; q.sh_c[sc_ + slot] = contrib.y; q.sh_c[2 * sc_ + slot] = contrib.z;
+                q.sh_id[slot] = id;
+            }
+        }
+
+        // ---- emission of the surface we are on, then sample the continuation
+        bool cont = false;
+        f3 new_d = mk3(0.f, 1.f, 0.f);
+        float new_pdf = 1.f;
+        bool is_spec = false;
+        if (alive) {
+            if ((SM & 2) && hit_light >= 0) {
+                f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_s);
+                if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
+                    f3 add = (emit_int * emission_weight) * thr;
+                    q.L[id] += add.x; q.L[p.cap + id] += add.y; q.L[2 * p.cap + id] += add.z;
+                }
+            }
+            f3 spec;
+            new_d = surface_sample<BM>(bx, it, d, sc.world_ior, p.two_sides, rng, spec, new_pdf, is_spec);
+            thr = thr * (spec / new_pdf);
+            cont = (bounce + 1) < p.max_bounce;
+        }
+        t_draws += rng.draw - draw0;
+        uint32_t npos = wave_append(cont, next_counter);
+        if (cont) {
+            const uint32_t slot = qbase + npos;
+            q.ray_o[nxt][slot] = hit_point.x; q.ray_o[nxt][p.cap + slot] = hit_point.y; q.ray_o[nxt][2 * p.cap + slot] = hit_point.z;
+            q.ray_d[nxt][slot] = new_d.x; q.ray_d[nxt][p.cap + slot] = new_d.y; q.ray_d[nxt][2 * p.cap + slot] = new_d.z;
+            q.thr[nxt][slot] = thr.x; q.thr[nxt][p.cap + slot] = thr.y; q.thr[nxt][2 * p.cap + slot] = thr.z;
+            q.id[nxt][slot] = id;
+            q.meta[nxt][slot] = pack_meta(rng.draw, (uint32_t)(bounce + 1), is_spec);
+            q.pdf[nxt][slot] = new_pdf;
+        }
+    }
+    flush_stat(t_shade, &cnt->stats[sl.q][ST_SHADE]);
+    flush_stat(t_shadow, &cnt->stats[sl.q][ST_SHADOW]);
+    flush_stat(t_draws, &cnt->stats[sl.q][ST_DRAWS]);
+    flush_stat(t_poison, &cnt->stats[sl.q][ST_POISON]);
+}
+
+// ------------------------------------------------------------------- shadow
+__global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
+    StagedBvh bvh;
+    int* my_stack = carve_lds(sc.bvh, plan, bvh);
+    const SubLoop sl = sub_loop(p.nq);
+    const uint32_t n = min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
+    if (sl.first == 0 && threadIdx.x == 0) cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
+    const uint32_t qbase = (uint32_t)sl.q * q.sh_subcap, sc_ = q.sh_cap;
+    uint32_t t_lit = 0;
+    for (uint32_t pos = sl.first + threadIdx.x; pos < n; pos += sl.stride) {
+        const uint32_t idx = qbase + pos;
+        f3 o = mk3(q.sh_o[idx], q.sh_o[sc_ + idx], q.sh_o[2 * sc_ + idx]);
+        f3 d = mk3(q.sh_d[idx], q.sh_d[sc_ + idx], q.sh_d[2 * sc_ + idx]);
+        float dist = q.sh_tmax[idx];
+        HitRec rec; rec.t = (dist > 0.0f) ? dist - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
+        if (!traverse<true>(bvh, my_stack, BLOCK, o, d, rec)) {
+            uint32_t id = q.sh_id[idx];
+            atomicAdd(&q.L[id], q.sh_c[idx]);
+            atomicAdd(&q.L[p.cap + id], q.sh_c[sc_ + idx]);
+            atomicAdd(&q.L[2 * p.cap + id], q.sh_c[2 * sc_ + idx]);
+            t_lit++;
+        }
+    }
+    flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);
+}
+
+// ----------------------------------------------------------------- finalize
+// one thread per owned pixel: samples summed in sample order -> bit-reproducible, no atomics
+__global__ void __launch_bounds__(BLOCK) k_finalize(Params p, Queues q, float* accum) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t lp = blockIdx.x * BLOCK + threadIdx.x; lp < (uint32_t)p.npix; lp += stride) {
+        float r = accum[3 * lp], g = accum[3 * lp + 1], b = accum[3 * lp + 2];
+        for (int s = 0; s < p.spp_batch; s++) {
+            uint32_t id = (uint32_t)s * (uint32_t)p.npix + lp;
+            float cr = q.L[id], cg = q.L[p.cap + id], cb = q.L[2 * p.cap + id];
+            r += isnan(cr) ? 0.f : cr; g += isnan(cg) ? 0.f : cg; b += isnan(cb) ? 0.f : cb;
+        }
+        accum[3 * lp] = r; accum[3 * lp + 1] = g; accum[3 * lp + 2] = b;
+    }
+}
+
+__global__ void k_divide(const float* accum, float* out, uint32_t n, float cnt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = accum[i] / cnt;        // pixels = color / cnt (vanilla_renderer.py:120)
+}
+
+// ------------------------------------------------------- unit entry kernels
+__global__ void __launch_bounds__(BLOCK) k_occluded(DevScene sc, uint32_t n, const float* o_, const float* d_, const float* tmax, int* occ, LdsPlan plan) {
+    StagedBvh bvh;
+    int* my_stack = carve_lds(sc.bvh, plan, bvh);
+    for (uint32_t idx = blockIdx.x * BLOCK + threadIdx.x; idx < n; idx += gridDim.x * BLOCK) {
+        f3 o = mk3(o_[idx], o_[n + idx], o_[2 * n + idx]), d = mk3(d_[idx], d_[n + idx], d_[2 * n + idx]);
+        HitRec rec; rec.t = (tmax[idx] > 0.0f) ? tmax[idx] - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
+        occ[idx] = traverse<true>(bvh, my_stack, BLOCK, o, d, rec) ? 1 : 0;
+    }
+}
+__global__ void k_rng_stream(uint32_t pixel, uint32_t seed, uint32_t sample, int n, uint32_t* out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        Philox r; rng_init(r, pixel, seed, sample, 0u);
+        for (int k = 0; k < n; k++) out[k] = rng_u32(r);
+    }
+}
+// BxDF eval / pdf / sample on explicit inputs, RNG = Philox stream keyed by (test index, seed, 1)
+// in : per test 10 floats n_s n_g incid [+ out for eval]; bx: one DevBxdf per test
+__global__ void k_bxdf_eval(int n, const DevBxdf* bx, const float* in, float world_ior, float* out4) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* x = in + 12 * k;
+    Hit it; it.obj_id = 0; it.prim_id = 0; it.min_depth = 1.f; it.n_s = ld3(x); it.n_g = ld3(x + 3);
+    f3 wi = ld3(x + 6), wo = ld3(x + 9);
+    DevBxdf b = bx[k];
+    f3 e = surface_eval<APT_BX_ALL>(b, it, wi, wo, world_ior, 0);
+    float pdf = surface_pdf<APT_BX_ALL>(b, it, wo, wi, world_ior, 0);
+    out4[4 * k] = e.x; out4[4 * k + 1] = e.y; out4[4 * k + 2] = e.z; out4[4 * k + 3] = pdf;
+}
+__global__ void k_bxdf_sample(int n, const DevBxdf* bx, const float* in, float world_ior, uint32_t seed, float* out9) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* x = in + 12 * k;
+    Hit it; it.obj_id = 0; it.prim_id = 0; it.min_depth = 1.f; it.n_s = ld3(x); it.n_g = ld3(x + 3);
+    f3 wi = ld3(x + 6);
+    DevBxdf b = bx[k];
+    Philox r; rng_init(r, (uint32_t)k, seed, 1u, 0u);
+    f3 spec; float pdf; bool sp;
+    f3 dir = surface_sample<APT_BX_ALL>(b, it, wi, world_ior, 0, r, spec, pdf, sp);
+    float* o = out9 + 9 * k;
+    o[0] = dir.x; o[1] = dir.y; o[2] = dir.z; o[3] = spec.x; o[4] = spec.y; o[5] = spec.z; o[6] = pdf; o[7] = sp ? 1.f : 0.f; o[8] = (float)r.draw;
+}
+// emitter sample_hit / eval_le / solid_angle_pdf on explicit inputs: in = src index, hit_pos, normal, ray_d, min_depth (11 floats)
+__global__ void k_emitter_probe(DevScene sc, int n, const float* in, uint32_t seed, float* out12) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float* x = in + 11 * k;
+    const DevSrc s = sc.src[(int)x[0]];
+    const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
+    Philox r; rng_init(r, (uint32_t)k, seed, 1u, 0u);
+    f3 inten; float pdf;
+    f3 pos = emitter_sample_hit<APT_SRC_ALL>(s, geom, ld3(x + 1), r, inten, pdf);
+    Hit it; it.obj_id = 0; it.prim_id = 0; it.n_s = it.n_g = ld3(x + 4); it.min_depth = x[10];
+    f3 rd = ld3(x + 7);
+    f3 le = emitter_eval_le(s, rd * x[10], ld3(x + 4));
+    float sap = emitter_solid_angle_pdf(s, it, rd);
+    float* o = out12 + 12 * k;
+    o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = inten.x; o[4] = inten.y; o[5] = inten.z; o[6] = pdf; o[7] = (float)r.draw;
+    o[8] = le.x; o[9] = le.y; o[10] = le.z; o[11] = sap;
+}

@@ -27,7 +27,7 @@ from . import _lib
 from .scene_pack import FlatScene, RenderConfig, make_config, pack_scene
 from .tiles import TilePlan
 
-__all__ = ["Renderer", "DeviceScene"]
+__all__ = ["Renderer", "DeviceScene", "bxdf_probe", "rng_stream"]
 
 
 def _fp(a):
@@ -36,6 +36,27 @@ def _fp(a):
 
 def _ip(a):
     return a.ctypes.data_as(_lib.i32p)
+
+
+def bxdf_probe(bxdf_i, bxdf_f, dirs12, world_ior: float = 1.0, sample: bool = False, seed: int = 0, device: int = 0) -> np.ndarray:
+    """Run the device surface models on explicit inputs (apt_bxdf_probe): eval+pdf -> (n,4), sample -> (n,9)."""
+    lib = _lib.load()
+    bi = np.ascontiguousarray(bxdf_i, np.int32).reshape(-1, 4)
+    bf = np.ascontiguousarray(bxdf_f, np.float32).reshape(-1, 13)
+    dd = np.ascontiguousarray(dirs12, np.float32).reshape(-1, 12)
+    n = bi.shape[0]
+    out = np.zeros((n, 9 if sample else 4), np.float32)
+    _lib.check(lib.apt_bxdf_probe(int(device), n, _ip(bi), _fp(bf), _fp(dd), float(world_ior), int(bool(sample)), int(seed) & 0xffffffff, _fp(out)),
+               "apt_bxdf_probe")
+    return out
+
+
+def rng_stream(pixel: int, seed: int, sample: int, n: int, device: int = 0) -> np.ndarray:
+    lib = _lib.load()
+    out = np.zeros(n, np.uint32)
+    _lib.check(lib.apt_rng_stream(int(device), pixel & 0xffffffff, seed & 0xffffffff, sample & 0xffffffff, int(n),
+                                  out.ctypes.data_as(_lib.u32p)), "apt_rng_stream")
+    return out
 
 
 class DeviceScene:
@@ -213,6 +234,21 @@ class Renderer:
         occ = np.zeros(o.shape[0], np.int32)
         _lib.check(self.lib.apt_occluded(self.handle, o.shape[0], _fp(o), _fp(d), _fp(tmax), _ip(occ)), "apt_occluded")
         return occ
+
+    def emitter_probe(self, in11, seed: int = 0) -> np.ndarray:
+        """apt_emitter_probe: rows (src index, hit_pos, normal, ray_d, min_depth) -> (n,12)."""
+        x = np.ascontiguousarray(in11, np.float32).reshape(-1, 11)
+        out = np.zeros((x.shape[0], 12), np.float32)
+        _lib.check(self.lib.apt_emitter_probe(self.scene.handle, x.shape[0], _fp(x), int(seed) & 0xffffffff, _fp(out)), "apt_emitter_probe")
+        return out
+
+    def info(self) -> dict:
+        b, nq, lds = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        qb = C.c_int64(0)
+        name = C.c_char_p()
+        _lib.check(self.lib.apt_renderer_info(self.handle, C.byref(b), C.byref(nq), C.byref(qb), C.byref(lds), C.byref(name)), "apt_renderer_info")
+        return {"spp_per_batch": b.value, "n_subqueues": nq.value, "queue_bytes": qb.value, "lds_bytes": lds.value,
+                "shade_variant": name.value.decode() if name.value else ""}
 
     # ------------------------------------------------------------ checkpoint
     def get_check_point(self) -> dict:

@@ -79,9 +79,9 @@ def gather_tiles(tile, plan: TilePlan, rank: int, world_size: int, group=None) -
     mc = plan.max_cols()
     padded = torch.zeros((mc, plan.height, 3), dtype=torch.float32, device=t.device)
     padded[:t.shape[0]] = t
-    out = torch.empty((world_size, mc, plan.height, 3), dtype=torch.float32, device=t.device)
+    out = torch.empty((world_size * mc, plan.height, 3), dtype=torch.float32, device=t.device)    # rank-major concatenation
     dist.all_gather_into_tensor(out, padded, group=group)
-    return assemble(plan, out.cpu().numpy())
+    return assemble(plan, out.view(world_size, mc, plan.height, 3).cpu().numpy())
 
 
 def gather_image(rdr, normalised: bool = True, group=None) -> np.ndarray:

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the HIP wavefront path tracer on BASELINE.json's headline config.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = one complete render of the workload: every owned pixel receives `spp` samples through the
+generate/extend/shade/shadow/finalize stages (+ the tile all-gather when N > 1).  N = 1 workload = BASELINE
+configs[1]: cornell box, 512x512, 1024 spp, 8 bounces.  For N > 1 the film is sharded in interleaved
+column bands and the sample count is scaled by N, so every GPU does the N = 1 amount of work (weak scaling);
+the only collective is the all_gather of the tile framebuffers over RCCL.
+
+Prints ONE JSON line on rank 0 with the contract's fields plus
+  roofline     : dominant kernel's algorithmic bytes per launch / its mean launch time (HIP events on the
+                 renderer's own stream, recorded inside the timed region) against the 8 TB/s HBM3E peak
+  cpu_baseline : the CPU oracle (C port of the reference path) on a bounded sample of the same workload
+  parity       : HIP vs that CPU render of the same pixels/samples/seed (per-pixel L2 -> relMSE, max abs)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+CONFIGS = {
+    # name: (scene dir, file, width, height, spp, max_bounce, label)
+    "c1": ("cbox", "c2_cbox.xml", 256, 256, 64, 4, "cbox 256x256, 64 spp, 4 bounces (BASELINE configs[0])"),
+    "c2": ("cbox", "c2_cbox.xml", 512, 512, 1024, 8, "cbox 512x512, 1024 spp, 8 bounces (BASELINE configs[1])"),
+    "c3": ("csphere", "c3_balls_mono.xml", 512, 512, 1024, 16, "csphere balls-mono 512x512, 1024 spp, 16 bounces (BASELINE configs[2])"),
+}
+
+
+def kernel_bytes(st):
+    """Algorithmic HBM bytes per stage from the path statistics (DESIGN.md 'bytes each stage moves'):
+    4-byte SoA lanes; ray = o,d 24 B; hit = t,prim,u,v 16 B; state = throughput,id,meta,pdf 24 B;
+    shadow entry = o,d,tmax,contribution,id 44 B; radiance L = 12 B (24 B per read-modify-write)."""
+    n_s, n_e, n_sh, n_lit = st["n_samples"], st["n_extend"], st["n_shadow_traced"], st["n_lit"]
+    n_cont = n_e - n_s                       # queue entries written by shade for the next bounce
+    return {
+        "generate": 60 * n_s,                # ray 24 + state 24 + zeroed L 12
+        "extend": 40 * n_e,                  # read ray 24, write hit 16
+        "shade": 64 * n_e + 48 * n_cont + 44 * n_sh,     # read ray+hit+state, write next ray+state, write shadow entries
+        "shadow": 44 * n_sh + 24 * n_lit,    # read entry, RMW radiance of unoccluded ones
+        "finalize": 12 * n_s,                # read L (framebuffer RMW is 24 B per pixel per batch: negligible)
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per step")
+    ap.add_argument("--spp-per-batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded oracle sample")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no HIP device visible; the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+
+    from adapt_amd import scene_parsing
+    from adapt_amd.renderer import Renderer
+    from adapt_amd.tiles import gather_image
+
+    sdir, sfile, W, H, spp, bounces, label = CONFIGS[args.config]
+    if args.spp > 0:
+        spp = args.spp
+    spp_step = spp * world                  # weak scaling: per-GPU samples stay at the N = 1 amount
+    parsed = scene_parsing(os.path.join(ROOT, "scenes", sdir), sfile)
+    rdr = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world,
+                   band_width=32, profile=True, spp_per_batch=args.spp_per_batch)
+    info = rdr.info()
+
+    def step():
+        rdr.render(n_spp=spp_step)
+        if world > 1:
+            gather_image(rdr, normalised=False)          # all_gather of the per-rank tiles over RCCL
+        else:
+            rdr.synchronize()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        rdr.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    rdr.clear()                              # zero accumulation + statistics + event timers: the timed region starts clean
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = rdr.stats()
+
+    # statistics of all ranks (weak scaling: per-rank work is equal up to image content)
+    total_samples = W * H * spp_step * args.steps
+    value = total_samples / dt / 1e6
+
+    kb = kernel_bytes(st)
+    kms = st["kernel_ms"]
+    dom = max(kms, key=lambda k: kms[k])
+    launches = st["launches"][dom]
+    per_launch_bytes = kb[dom] / max(1, launches)
+    avg_ms = kms[dom] / max(1, launches)
+    achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
+                "per_kernel": {k: {"ms": round(kms[k], 3), "launches": int(st["launches"][k]), "alg_bytes": int(kb[k]),
+                                   "GB/s": round(kb[k] / (kms[k] * 1e-3) / 1e9, 1) if kms[k] > 0 else 0.0} for k in kms},
+                "pipeline_GB/s": round(sum(kb.values()) / (st["render_ms"] * 1e-3) / 1e9, 1) if st["render_ms"] > 0 else 0.0,
+                "bytes_per_sample": round(sum(kb.values()) / max(1, st["n_samples"]), 1)}
+
+    out = {
+        "metric": "Msamples/s (W*H*spp/s), unidirectional MIS path tracing", "value": round(value, 3), "unit": "Msamples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "bundled cornell-box scene (same inputs as AdaPT scenes/cbox/cbox.xml); no dataset involved",
+        "config": {"workload": label, "scene": f"scenes/{sdir}/{sfile}", "width": W, "height": H, "spp_per_step": spp_step,
+                   "max_bounce": bounces, "num_shadow_ray": rdr.num_shadow_ray, "tiling": f"{world} x interleaved 32-column bands",
+                   "spp_per_batch": info["spp_per_batch"], "sub_queues": info["n_subqueues"], "shade_variant": info["shade_variant"],
+                   "queue_MiB": round(info["queue_bytes"] / 2 ** 20, 1), "seed": 0},
+        "per_sample": {k: round(st[k] / max(1, st["n_samples"]), 4) for k in ("n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws")},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from adapt_amd.scene_pack import make_config, pack_scene
+        from oracle import binding as ob
+        rc = make_config(parsed[3], width=W, height=H, max_bounce=bounces)
+        osc = ob.OracleScene(pack_scene(*parsed), rc.cam_t)
+        cores = ob.num_threads()
+        t = time.perf_counter(); osc.render(rc, 1, threads=cores); one = time.perf_counter() - t
+        n_cpu = int(max(1, min(64, round(args.cpu_seconds / max(one, 1e-3)))))
+        t = time.perf_counter(); ref, cnt, ost = osc.render(rc, n_cpu, threads=cores); cpu_dt = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": round(W * H * n_cpu / cpu_dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                               "sample": f"{W}x{H} x {n_cpu} spp of the same workload (same scene, bounces, seed), {cpu_dt:.1f} s on {cores} OpenMP threads; "
+                                         "oracle/pt_oracle.c = C restatement of the reference path (real AdaPT needs taichi, absent here)"}
+        chk = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank)
+        chk.render(n_spp=n_cpu)
+        a, b = chk.pixels.to_numpy().astype(np.float64), (ref / np.float32(cnt)).astype(np.float64)
+        out["parity"] = {"vs": "cpu_baseline render (same pixels, samples, Philox stream)", "spp": n_cpu,
+                         "relMSE": float(np.mean((a - b) ** 2 / (b ** 2 + 1e-2))), "l2_per_pixel_mean": float(np.sqrt(((a - b) ** 2).sum(axis=2)).mean()),
+                         "max_abs": float(np.abs(a - b).max()),
+                         "frac_within_1e-3": float(np.mean(np.all(np.abs(a - b) <= 1e-3 * (1 + np.abs(b)), axis=2)))}
+        out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        chk.close()
+    if rank == 0:
+        print(json.dumps(out))
+    rdr.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

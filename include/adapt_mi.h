@@ -86,6 +86,7 @@ typedef struct apt_stats {
     int64_t n_shadow_traced;  /* of those, rays with a non-zero contribution that were actually traced */
     int64_t n_lit;            /* traced shadow rays found unoccluded */
     int64_t n_draws;          /* RNG draws consumed */
+    int64_t n_poisoned;       /* light samples whose MIS weight was NaN (sample zeroed, as upstream) */
     int64_t launches[APT_N_KERNELS];
     double  kernel_ms[APT_N_KERNELS];   /* summed HIP-event time per kernel (profile=1 only) */
     double  render_ms;                  /* HIP-event time of all apt_render calls so far */
@@ -122,6 +123,16 @@ int apt_intersect(apt_renderer*, int32_t n, const float* o, const float* d,
                   int32_t* prim_out, float* t_out, float* uv_out);
 int apt_occluded(apt_renderer*, int32_t n, const float* o, const float* d, const float* tmax, int32_t* occ_out);
 int apt_rng_stream(int32_t device, uint32_t pixel, uint32_t seed, uint32_t sample, int32_t n, uint32_t* out);
+/* Surface-model probe: test k uses material (bxdf_i[4k..], bxdf_f[13k..]) and dirs12[12k..] = n_s, n_g, incid, out.
+ * do_sample = 0: out[4k..] = eval rgb (f*cos), pdf(out | incid).   [BRDF.eval/get_pdf, BSDF.eval_surf/get_pdf]
+ * do_sample = 1: out[9k..] = dir xyz, f*cos rgb, pdf, is_specular, draws; RNG = Philox(key=(k, seed), sample 1). */
+int apt_bxdf_probe(int32_t device, int32_t n, const int32_t* bxdf_i, const float* bxdf_f, const float* dirs12,
+                   float world_ior, int32_t do_sample, uint32_t seed, float* out);
+/* Emitter probe: in11[11k..] = source index, hit_pos, normal, ray_d, min_depth;
+ * out12[12k..] = sampled pos, intensity (/pdf), pdf, draws, eval_le rgb, solid_angle_pdf; RNG as above. */
+int apt_emitter_probe(const apt_scene*, int32_t n, const float* in11, uint32_t seed, float* out12);
+int apt_renderer_info(const apt_renderer*, int32_t* spp_batch, int32_t* n_subqueues, int64_t* queue_bytes,
+                      int32_t* lds_bytes, const char** shade_variant);
 
 const char* apt_last_error(void);
 const char* apt_version(void);

@@ -172,11 +172,12 @@ class OracleScene:
         lib().orc_pix2ray(self.handle, C.byref(cfg), int(i), int(j), int(cnt), sc.ctypes.data_as(f64p), len(sc), _fp(out))
         return out
 
-    def src_sample_hit(self, src_idx, hit_pos, script):
-        sc = np.ascontiguousarray(script, np.float64)
+    def src_sample_hit(self, src_idx, hit_pos, script=None, key=0, seed=0):
+        """script given: scripted RNG; script None: Philox stream (key, seed), sample 1."""
+        sp, sn = _script(script)
         pos, inten = np.zeros(3, np.float32), np.zeros(3, np.float32)
         pdf, nd = C.c_float(0), C.c_int(0)
-        lib().orc_src_sample_hit(self.handle, int(src_idx), _fp(_f3(hit_pos)), sc.ctypes.data_as(f64p), len(sc),
+        lib().orc_src_sample_hit(self.handle, int(src_idx), _fp(_f3(hit_pos)), sp, sn, C.c_uint32(key), C.c_uint32(seed),
                                  _fp(pos), _fp(inten), C.byref(pdf), C.byref(nd))
         return pos, inten, pdf.value, nd.value
 
@@ -197,13 +198,22 @@ def bxdf_eval_pdf(bi, bf, world_ior, n_s, n_g, incid, out):
     return ev, pdf.value
 
 
-def bxdf_sample(bi, bf, world_ior, n_s, n_g, incid, script):
-    bi, bf = np.ascontiguousarray(bi, np.int32), np.ascontiguousarray(bf, np.float32)
+def _script(script):
+    if script is None:
+        return None, 0
     sc = np.ascontiguousarray(script, np.float64)
+    _script.keep = sc
+    return sc.ctypes.data_as(f64p), len(sc)
+
+
+def bxdf_sample(bi, bf, world_ior, n_s, n_g, incid, script=None, key=0, seed=0):
+    """script given: scripted RNG; script None: Philox stream (key, seed), sample 1."""
+    bi, bf = np.ascontiguousarray(bi, np.int32), np.ascontiguousarray(bf, np.float32)
+    spt, sn = _script(script)
     d, s = np.zeros(3, np.float32), np.zeros(3, np.float32)
     pdf, sp, nd = C.c_float(0), C.c_int(0), C.c_int(0)
     lib().orc_bxdf_sample(_ip(bi), _fp(bf), C.c_float(world_ior), _fp(_f3(n_s)), _fp(_f3(n_g)), _fp(_f3(incid)),
-                          sc.ctypes.data_as(f64p), len(sc), _fp(d), _fp(s), C.byref(pdf), C.byref(sp), C.byref(nd))
+                          spt, sn, C.c_uint32(key), C.c_uint32(seed), _fp(d), _fp(s), C.byref(pdf), C.byref(sp), C.byref(nd))
     return d, s, pdf.value, bool(sp.value), nd.value
 
 
@@ -225,3 +235,11 @@ def rng_stream(pixel, seed, sample, n):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+def philox(counter4, key2):
+    c = (C.c_uint32 * 4)(*[int(x) & 0xffffffff for x in counter4])
+    k = (C.c_uint32 * 2)(*[int(x) & 0xffffffff for x in key2])
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox(c, k, out)
+    return [int(x) for x in out]

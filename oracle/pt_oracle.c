@@ -1447,11 +1447,15 @@ ORC_API void orc_bxdf_eval_pdf(const int bi[4], const float bf[13], float world_
     }
 }
 /* sample with a scripted RNG */
+static void unit_rng(rng_t* r, const double* script, int script_n, uint32_t key, uint32_t seed) {
+    if (script) { memset(r, 0, sizeof(*r)); r->mode = 1; r->script = script; r->script_n = script_n; }
+    else rng_seed(r, key, seed, 1u);          /* Philox stream keyed like a pixel-sample: (key, seed), sample 1 */
+}
 ORC_API void orc_bxdf_sample(const int bi[4], const float bf[13], float world_ior, const float n_s[3], const float n_g[3],
-                             const float incid[3], const double* script, int script_n,
+                             const float incid[3], const double* script, int script_n, uint32_t key, uint32_t seed,
                              float dir_out[3], float spec_out[3], float* pdf_out, int* is_specular, int* n_draws) {
     bxdf_t b; load_bxdf(&b, bi, bf); isect_t it; load_it(&it, n_s, n_g, 1.f);
-    rng_t r; memset(&r, 0, sizeof(r)); r.mode = 1; r.script = script; r.script_n = script_n;
+    rng_t r; unit_rng(&r, script, script_n, key, seed);
     v3 spec; float pdf; int sp = 0; v3 dir;
     if (!b.is_bsdf) dir = brdf_sample(&b, &it, LD3(incid), &r, &spec, &pdf, &sp);
     else {
@@ -1471,9 +1475,9 @@ ORC_API void orc_snell_refraction(const float incid[3], const float normal[3], f
 }
 /* emitter sample_hit with scripted RNG; needs a scene for attached geometry */
 ORC_API void orc_src_sample_hit(const scene_t* sc, int src_idx, const float hit_pos[3], const double* script, int script_n,
-                                float pos_out[3], float int_out[3], float* pdf_out, int* n_draws) {
+                                uint32_t key, uint32_t seed, float pos_out[3], float int_out[3], float* pdf_out, int* n_draws) {
     ctx_t c; memset(&c, 0, sizeof(c)); c.sc = sc;
-    rng_t r; memset(&r, 0, sizeof(r)); r.mode = 1; r.script = script; r.script_n = script_n;
+    rng_t r; unit_rng(&r, script, script_n, key, seed);
     v3 ri; float rp;
     v3 p = src_sample_hit(&c, &sc->src[src_idx], LD3(hit_pos), &r, &ri, &rp);
     st3(pos_out, p); st3(int_out, ri); *pdf_out = rp; *n_draws = (int)r.draw;
@@ -1511,6 +1515,7 @@ ORC_API void orc_rng_stream(uint32_t pixel, uint32_t seed, uint32_t sample, int 
     rng_t r; rng_seed(&r, pixel, seed, sample);
     for (int k = 0; k < n; k++) out[k] = rng_u32(&r);
 }
+ORC_API void orc_philox(const uint32_t c[4], const uint32_t k[2], uint32_t out[4]) { philox4x32_10(c[0], c[1], c[2], c[3], k[0], k[1], out); }
 ORC_API int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

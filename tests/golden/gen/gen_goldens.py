@@ -166,8 +166,8 @@ def gen_functions():
                 e = obj.eval(it, vec3(incid), vec3(outd))
                 p = obj.get_pdf(it, vec3(outd), vec3(incid))
             ev_in.append(np.concatenate([[mi], n_s, n_g, incid, outd])); ev_out.append(np.concatenate([e.to_numpy(), [p]]))
-            script = RS.rand(8)
-            ti.RNG.set_script(script)
+            script = np.zeros(8)                      # kept for shape compatibility; the stream is Philox(key = test index, seed 777, sample 1)
+            ti.RNG.set_philox(len(sm_in), 777, 1)
             it = Interaction(n_s=vec3(n_s), n_g=vec3(n_g), tex=INVALID)
             if m["is_bsdf"]:
                 d, s, pdf, spec = obj.sample_surf_rays(it, vec3(incid), world_medium, -1)
@@ -236,8 +236,8 @@ def gen_scene(scene_dir, xml, tag, w, h, spp, overrides, seed=0, n_rays=192):
     for s_idx in range(rdr.src_num):
         for _ in range(16):
             hp = np.float32(RS.uniform([0.2, 0.1, 0.2], [5.3, 5.0, 5.3]))
-            scr = np.concatenate([[RS.randint(-2 ** 31, 2 ** 31)], RS.rand(3)])
-            ti.RNG.set_script(scr)
+            scr = np.zeros(4)                          # Philox(key = test index, seed 778, sample 1)
+            ti.RNG.set_philox(len(ein), 778, 1)
             pos, inten, pdf, _n = rdr.src_field[s_idx].sample_hit(rdr.precom_vec, rdr.normals, rdr.obj_info, vec3(hp))
             nrm, rd = rand_dir(), rand_dir()
             md = np.float32(RS.uniform(0.5, 5))

@@ -1,0 +1,90 @@
+"""The CPU oracle (oracle/pt_oracle.c) against fixtures recorded from the REFERENCE's own source
+(tests/golden/gen: unchanged /root/reference code run under a float32 stand-in for the absent taichi
+package, same libm, RNG wired to the shared Philox stream).  Arithmetic is float32 on both sides in the
+same operation order, so the bar here is bit equality; the one allowed slack is stated where used."""
+import numpy as np
+import pytest
+
+from conftest import SCENES, golden
+from adapt_amd.scene_pack import make_config
+from oracle import binding as ob
+
+F = golden("functions.npz")
+
+
+def same(a, b):
+    """bit equality, NaN == NaN (the fresnel-blend pdf is NaN for some geometries, upstream too)"""
+    return np.array_equal(np.asarray(a, np.float32), np.asarray(b, np.float32), equal_nan=True)
+
+
+def test_rotation_between_bit_exact():
+    for a, b, R in zip(F["rot_a"], F["rot_b"], F["rot_R"]):
+        assert np.array_equal(ob.rotation_between(a, b), R)
+
+
+def test_fresnel_known_answer_and_vectors():
+    assert ob.fresnel_equation(1.0, 1.5, 1.0, 1.0) == pytest.approx(0.04, abs=1e-7)     # ((1-1.5)/(1+1.5))^2
+    for x, y in zip(F["fresnel_in"], F["fresnel_out"]):
+        assert np.float32(ob.fresnel_equation(*map(float, x))) == y
+
+
+def test_bxdf_eval_pdf_bit_exact():
+    mi, mf = F["mat_i"], F["mat_f"]
+    nonzero = 0
+    for x, y in zip(F["eval_in"], F["eval_out"]):
+        m = int(x[0])
+        ev, pdf = ob.bxdf_eval_pdf(mi[m], mf[m], 1.0, x[1:4], x[4:7], x[7:10], x[10:13])
+        assert same(ev, y[:3]) and same(pdf, y[3]), (m, x)
+        nonzero += bool(np.any(y != 0))
+    assert nonzero > 80          # the vectors exercise the non-trivial branches
+
+
+def test_bxdf_sample_bit_exact():
+    mi, mf = F["mat_i"], F["mat_f"]
+    for k, (x, y) in enumerate(zip(F["sample_in"], F["sample_out"])):
+        m = int(x[0])
+        d, s, pdf, spec, nd = ob.bxdf_sample(mi[m], mf[m], 1.0, x[1:4], x[4:7], x[7:10], None, key=k, seed=777)
+        assert same(d, y[:3]) and same(s, y[3:6]) and same(pdf, y[6]), (m, k)
+        assert spec == bool(y[7]) and nd == int(y[8])
+
+
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box"])
+def test_scene_functions_bit_exact(tag, parsed, oracle_scene):
+    g = golden(f"scene_{SCENES[tag][2]}.npz")
+    rc = make_config(parsed(tag)[3], width=int(g["width"]), height=int(g["height"]), max_bounce=int(g["max_bounce"]))
+    sc = oracle_scene(tag)
+    for x, y in zip(g["pix2ray_in"], g["pix2ray_out"]):
+        assert np.array_equal(sc.pix2ray(rc, int(x[0]), int(x[1]), int(x[2]), x[3:5]), y)
+    obj, prim, t, uv, ns = sc.intersect(g["ray_o"], g["ray_d"])
+    h = g["ray_hit"]
+    assert np.array_equal(obj, h[:, 0]) and np.array_equal(prim, h[:, 1]) and np.array_equal(t, h[:, 2])
+    assert np.array_equal(uv, h[:, 3:5]) and np.array_equal(ns, h[:, 5:8])
+    assert (obj >= 0).sum() > 100
+    assert np.array_equal(sc.occluded(g["ray_o"], g["ray_d"], g["ray_tmax"]), g["ray_occ"])
+    for k, (x, y) in enumerate(zip(g["emit_in"], g["emit_out"])):
+        pos, inten, pdf, nd = sc.src_sample_hit(int(x[0]), x[1:4], None, key=k, seed=778)
+        le, sap = sc.src_eval(int(x[0]), x[7:10] * x[10], x[4:7], float(x[10]), x[7:10])
+        assert same(pos, y[:3]) and same(inten, y[3:6]) and same(pdf, y[6]) and nd == int(y[7])
+        assert same(le, y[8:11]) and same(sap, y[11])
+
+
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box"])
+def test_whole_kernel_matches_reference_run(tag, parsed, oracle_scene):
+    """Renderer.render of the reference, spp by spp on the Philox stream, vs orc_render."""
+    g = golden(f"scene_{SCENES[tag][2]}.npz")
+    rc = make_config(parsed(tag)[3], width=int(g["width"]), height=int(g["height"]), max_bounce=int(g["max_bounce"]))
+    assert rc.num_shadow_ray == int(g["num_shadow_ray"])
+    sc = oracle_scene(tag)
+    img, cnt, st = sc.render(rc, int(g["spp"]), threads=0)
+    assert cnt == int(g["spp"]) and st["n_draws"] == int(g["draws"].sum())         # every path consumed the same number of randoms
+    # first sample per pixel: colour and draw count
+    W, H = rc.width, rc.height
+    for i in range(0, W, 3):
+        for j in range(0, H, 3):
+            col, ev, nd = sc.trace_sample(rc, i, j, 1)
+            assert np.array_equal(col, g["first_sample"][i, j]) and nd == g["draws"][0, i, j], (i, j)
+    diff = np.abs(img - g["accum"])
+    # bit equality except where a libm call rounds differently between numpy's scalar path and C: <= 2 ulp of the sum
+    assert diff.max() <= 4.8e-7 * max(1.0, float(np.abs(g["accum"]).max())), diff.max()
+    assert (diff.max(axis=2) > 0).mean() < 0.01
+    np.testing.assert_array_equal(img / np.float32(cnt), img / np.float32(int(g["spp"])))

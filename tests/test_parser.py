@@ -1,0 +1,142 @@
+"""Scene front end (adapt_amd/parsers) against dumps of the REFERENCE parser's output on its own scene files
+(tests/golden/parse_*.npz, produced by tests/golden/gen/gen_goldens.py)."""
+import os
+import xml.etree.ElementTree as xet
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENES, golden
+from adapt_amd.parsers.general_parser import parse_str, rgb_parse, transform_parse, vec3d_parse
+from adapt_amd.parsers.obj_loader import apply_transform, calculate_surface_area, extract_obj_info, read_obj
+from adapt_amd.parsers.obj_desc import get_aabb
+from adapt_amd.parsers.xml_parser import scene_parsing
+from adapt_amd.scene_pack import fov2focal, make_config, np_rotation_between, pack_scene
+
+
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box"])
+def test_parse_matches_reference_dump(tag, parsed, flat):
+    g = golden(f"parse_{SCENES[tag][2]}.npz")
+    em, arr, objs, cfg = parsed(tag)
+    fs = flat(tag)
+    for k in ("primitives", "n_g", "n_s", "uvs"):
+        assert arr[k].dtype == np.float32 and np.array_equal(arr[k], g[k]), k
+    idx = arr["indices"] if arr["indices"] is not None else np.int64([])
+    assert np.array_equal(idx, g["indices"])
+    assert np.array_equal(fs.obj_aabb, g["aabb"])
+    assert np.array_equal(fs.obj_info[:, 1], g["tri_num"]) and np.array_equal(fs.obj_info[:, 2], g["obj_type"])
+    assert np.array_equal(fs.obj_info[:, 0], np.concatenate([[0], np.cumsum(g["tri_num"])[:-1]]))
+    assert np.array_equal(fs.emitter_id, g["emitter_ref"])
+    assert np.array_equal(fs.bxdf_i[:, 0], g["bxdf_type"]) and np.array_equal(fs.bxdf_i[:, 1], g["bxdf_delta"])
+    assert np.array_equal(fs.bxdf_i[:, 2], g["bxdf_is_bsdf"])
+    assert np.array_equal(fs.bxdf_f[:, 0:3], g["k_d"]) and np.array_equal(fs.bxdf_f[:, 3:6], g["k_s"]) and np.array_equal(fs.bxdf_f[:, 6:9], g["k_g"])
+    assert np.array_equal(fs.bxdf_f[:, 12], g["ior"])
+    assert np.array_equal(fs.src_f[:, 0:3], g["src_intensity"]) and np.array_equal(fs.src_f[:, 9], g["src_inv_area"])
+    assert [e.type for e in em] == list(g["src_type"])
+    rc = make_config(cfg)
+    assert np.array_equal(rc.cam_r, g["cam_r"]) and np.array_equal(rc.cam_t, g["cam_pos"])
+    assert rc.focal == float(g["focal"])
+    assert fs.has_vertex_normal == bool(g["has_vertex_normal"]) and fs.world_ior == float(g["world_ior"])
+    assert cfg["num_shadow_ray"] == int(g["num_shadow_ray"])
+    # area emitters point back at the object they are attached to
+    for s in range(fs.n_sources):
+        if fs.src_i[s, 0] == 1:
+            assert fs.emitter_id[fs.src_i[s, 2]] == s
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scenes"), reason="reference tree only exists in the authoring container")
+@pytest.mark.parametrize("d,f,tag", [("cbox", "cbox.xml", "cbox"), ("csphere", "balls-mono.xml", "balls_mono"), ("cbox", "complex.xml", "complex")])
+def test_reference_scene_files_load_unchanged(d, f, tag):
+    """Drop-in: the reference's own XML files parse to the same arrays as its own parser produced."""
+    g = golden(f"parse_{tag}.npz")
+    em, arr, objs, cfg = scene_parsing(os.path.join("/root/reference/scenes", d), f)
+    assert np.array_equal(arr["primitives"], g["primitives"]) and np.array_equal(arr["n_s"], g["n_s"])
+    assert cfg["max_bounce"] == int(g["max_bounce"]) and cfg["film"]["width"] == int(g["width"])
+
+
+def test_known_answers():
+    # SURVEY §4.3 analytic pins
+    assert abs(fov2focal(39.3077, 512) - 716.79898) < 1e-4
+    assert abs(rgb_parse(xet.fromstring('<rgb value="#BCBCBC"/>'))[0] - 0.7372549) < 1e-7
+    np.testing.assert_array_equal(rgb_parse(xet.fromstring('<rgb r="10" g="1000"/>')), np.float32([10, 1000, 0]))
+    np.testing.assert_array_equal(rgb_parse(xet.fromstring('<rgb value="0.25"/>')), np.float32([0.25] * 3))
+    np.testing.assert_array_equal(parse_str("1, 2,3"), np.float32([1, 2, 3]))
+    np.testing.assert_array_equal(parse_str("1 2 3"), np.float32([1, 2, 3]))
+    with pytest.raises(ValueError):
+        parse_str("1.0", no_else_branch=True)
+    with pytest.raises(ValueError):
+        rgb_parse(xet.fromstring("<rgb/>"))
+    np.testing.assert_array_equal(vec3d_parse(xet.fromstring('<point x="1" z="3"/>')), np.float32([1, 0, 3]))
+    d, o, s = transform_parse(xet.fromstring('<transform><lookat target="2.78, 2.73, -7.99" origin="2.78, 2.73, -8.00"/></transform>'))
+    np.testing.assert_allclose(d, [0, 0, 1], atol=1e-6)
+    assert s is None and o.dtype == np.float32
+    with pytest.raises(ValueError):
+        transform_parse(xet.fromstring('<transform><lookat target="1,1,1" origin="1,1,1"/></transform>'))
+    with pytest.raises(ValueError):
+        transform_parse(xet.fromstring('<transform><shear/></transform>'))
+    # fresnel-blend cached coefficient: sqrt(11 * 1001) / 8pi
+    from adapt_amd.materials import BRDF_np
+    b = BRDF_np(xet.fromstring('<brdf type="fresnel-blend" id="f"><rgb name="k_g" r="10" g="1000"/></brdf>'))
+    assert abs(b.k_g[2] - 4.1752) < 1e-3
+    assert BRDF_np(xet.fromstring('<brdf type="specular" id="m"/>')).is_delta
+    assert BRDF_np(xet.fromstring('<brdf type="microfacet" id="m"/>')).type_id == 1      # compiled out upstream -> Lambertian
+    with pytest.raises(NotImplementedError):
+        BRDF_np(xet.fromstring('<brdf type="velvet" id="m"/>'))
+
+
+def test_rotation_between_matches_scipy_free_cases():
+    np.testing.assert_array_equal(np_rotation_between(np.float32([0, 0, 1]), np.float32([0, 0, 1])), np.eye(3, dtype=np.float32))
+    np.testing.assert_array_equal(np_rotation_between(np.float32([0, 0, 1]), np.float32([0, 0, -1])), -np.eye(3, dtype=np.float32))
+    t = np.float32([0.3, 0.4, 0.8660254])
+    t /= np.linalg.norm(t)
+    R = np_rotation_between(np.float32([0, 0, 1]), t)
+    np.testing.assert_allclose(R @ np.float32([0, 0, 1]), t, atol=1e-6)
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)
+
+
+def test_obj_reader(tmp_path):
+    p = tmp_path / "quad.obj"
+    p.write_text("# quad as one polygon, negative indices, no normals\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf -4/-4 -3/-3 -2/-2 -1/-1\n")
+    meshes, uvs, vns = read_obj(str(p))
+    assert meshes.shape == (2, 3, 3) and uvs.shape == (2, 3, 2) and vns is None
+    np.testing.assert_array_equal(meshes[1], np.float32([[0, 0, 0], [1, 1, 0], [0, 1, 0]]))     # fan (0, i, i+1)
+    m, n, vn, uv = extract_obj_info(str(p))
+    np.testing.assert_allclose(n, [[0, 0, 1], [0, 0, 1]])
+    assert abs(calculate_surface_area(m) - 1.0) < 1e-6
+    (tmp_path / "empty.obj").write_text("v 0 0 0\n")
+    with pytest.raises(ValueError):
+        read_obj(str(tmp_path / "empty.obj"))
+    lum = extract_obj_info(os.path.join(ROOT, "scenes", "meshes", "cornell", "cbox_luminaire.obj"))[0]
+    assert abs(calculate_surface_area(lum) - 1.365) < 1e-5                                    # SURVEY §8(c) probe value
+    assert abs(calculate_surface_area(np.float32([[[0, 0, 0], [0.5] * 3, [0] * 3]]), 1) - np.pi) < 1e-6
+
+
+def test_transform_dtype_flow_and_aabb():
+    m = np.float32([[[0, 0, 0], [1, 0, 0], [0, 0, 1]]])
+    out, _ = apply_transform(m.copy(), None, None, np.float32([0, -0.001, 0]), None)
+    assert out.dtype == np.float32 and out[0, 0, 1] == np.float32(-0.001)
+    rot, _ = apply_transform(m.copy(), np.float32([[0, 1, 0]]), np.eye(3), None, None)
+    assert rot.dtype == np.float64                    # float64 until the final pack, as upstream
+    box = get_aabb(m)
+    np.testing.assert_allclose(box, [[0, -0.02, 0], [1, 0.02, 1]], atol=1e-7)       # flat axis padded by 2e-2
+    np.testing.assert_array_equal(get_aabb(np.float32([[[1, 2, 3], [0.5] * 3, [0] * 3]]), 1), np.float32([[0.5, 1.5, 2.5], [1.5, 2.5, 3.5]]))
+
+
+def test_scene_errors(tmp_path):
+    (tmp_path / "bad.xml").write_text('<scene version="0.9"><sensor/></scene>')
+    with pytest.raises(ValueError):
+        scene_parsing(str(tmp_path), "bad.xml")
+    (tmp_path / "tex.xml").write_text('<scene version="1.1"><texture id="t"/><sensor/></scene>')
+    with pytest.raises(NotImplementedError):
+        scene_parsing(str(tmp_path), "tex.xml")
+
+
+def test_config_overrides_and_crop(parsed):
+    cfg = dict(parsed("cbox")[3])
+    rc = make_config(cfg, width=256, height=128, max_bounce=4)
+    assert (rc.width, rc.height, rc.max_bounce) == (256, 128, 4)
+    assert rc.focal == fov2focal(39.3077, 128) and rc.half_w == 128 and rc.half_h == 64 and not rc.do_crop
+    cfg["film"] = {"width": 64, "height": 64, "crop_x": 32, "crop_y": 20, "crop_rx": 8, "crop_ry": 4}
+    rc = make_config(cfg)
+    assert rc.do_crop and (rc.start_x, rc.end_x, rc.start_y, rc.end_y) == (24, 40, 16, 24)
+    assert rc.rr_bounce_th == 4 and abs(rc.rr_threshold - 0.1) < 1e-12 and rc.use_bvh is False
