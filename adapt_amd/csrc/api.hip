@@ -33,6 +33,13 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 // ------------------------------------------------- shade kernel specialisations
 // (material mask, emitter mask) -> instantiation; the host picks the first one that covers the scene
 typedef void (*shade_fn)(DevScene, Params, Queues, Counters*, int, int);
+typedef void (*extend_fn)(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan);
+typedef void (*shadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan);
+typedef void (*occluded_fn)(DevScene, uint32_t, const float*, const float*, const float*, int*, LdsPlan);
+static const extend_fn kExtend[2] = {k_extend<0>, k_extend<1>};
+static const shadow_fn kShadow[2] = {k_shadow<0>, k_shadow<1>};
+static const occluded_fn kOccluded[2] = {k_occluded<0>, k_occluded<1>};
+#define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
 struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; };
 static const ShadeVariant kShadeVariants[] = {
     {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point"},
@@ -60,9 +67,10 @@ struct apt_scene {
     int device = 0;
     DevScene dev{};
     apt::BvhData bvh;
-    DevBuf nodes, prims, normals, vnormals, precom, prim_obj, obj_info, emitter_id, bxdf, src;
+    DevBuf nodes, prims, normals, vnormals, precom, prim_obj, obj_info, emitter_id, bxdf, src, sweep_recs, obj_aabb;
     int n_prims = 0, n_objects = 0, n_sources = 0;
     int bx_mask = 0, src_mask = 0;
+    bool has_aabb = false;
 };
 
 struct EventPair { hipEvent_t a, b; int kernel; };
@@ -79,6 +87,7 @@ struct apt_renderer {
     Counters host_counters{};
     int grid_small = 0, grid_trace = 0, nq = APT_MAX_NQ;
     const ShadeVariant* shade = nullptr;
+    int trace_mode = 0;           // 0 = BVH traversal, 1 = wave-uniform sweep (small scenes)
     LdsPlan plan{};
     size_t lds_bytes = 0;
     std::vector<EventPair> pending;
@@ -160,6 +169,19 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         else { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = pc[0]; r[4] = pc[1]; r[5] = pc[2]; r[6] = pc[3]; r[7] = pc[4]; r[8] = pc[5]; }
         memcpy(&r[9], &kid, 4); memcpy(&r[10], &flag, 4);
     }
+    // sweep records, ORIGINAL primitive order (traverse.hpp SweepScene); the t-row cofactors of [e1 e2 .] are
+    // ray-independent, so they are computed once here with the same float operations the device would use
+    std::vector<float> sw((size_t)N * 16, 0.f);
+    for (int k = 0; k < N; k++) {
+        const float* v = d->prims + 9 * (size_t)k; const float* pc = prec.data() + 9 * (size_t)k; float* r = sw.data() + 16 * (size_t)k;
+        if (sphere[(size_t)k]) { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; continue; }
+        r[0] = v[0]; r[1] = v[1]; r[2] = v[2];
+        for (int a_ = 0; a_ < 6; a_++) r[3 + a_] = pc[a_];
+        const float a00 = pc[0], a10 = pc[1], a20 = pc[2], a01 = pc[3], a11 = pc[4], a21 = pc[5];
+        r[9] = a10 * a21 - a20 * a11; r[10] = a20 * a01 - a00 * a21; r[11] = a00 * a11 - a10 * a01;
+    }
+    std::vector<float> aabb((size_t)O * 6, 0.f);
+    if (d->obj_aabb) aabb.assign(d->obj_aabb, d->obj_aabb + (size_t)O * 6);
     std::vector<DevBxdf> bx((size_t)O);
     for (int o = 0; o < O; o++) {
         const int32_t* bi = d->bxdf_i + 4 * o; const float* bf = d->bxdf_f + 13 * o;
@@ -183,10 +205,12 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     std::vector<int> oi(d->obj_info, d->obj_info + (size_t)O * 3), ei(d->emitter_id, d->emitter_id + (size_t)O);
 #define UP(buf, vec) do { hipError_t e_ = upload(s->buf, vec); if (e_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload " #buf ": ") + hipGetErrorString(e_)); } } while (0)
     UP(nodes, s->bvh.nodes); UP(prims, recs); UP(normals, nrm); UP(vnormals, vn); UP(precom, prec); UP(prim_obj, prim_obj);
-    UP(obj_info, oi); UP(emitter_id, ei); UP(bxdf, bx); UP(src, sr);
+    UP(obj_info, oi); UP(emitter_id, ei); UP(bxdf, bx); UP(src, sr); UP(sweep_recs, sw); UP(obj_aabb, aabb);
 #undef UP
     DevScene& ds = s->dev;
     ds.bvh.nodes = s->nodes.as<float4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.n_nodes = s->bvh.n_nodes(); ds.bvh.n_prims = N;
+    ds.sweep.recs = s->sweep_recs.as<float4>(); ds.sweep.obj_aabb = s->obj_aabb.as<float>(); ds.sweep.obj_info = s->obj_info.as<int>(); ds.sweep.n_objects = O;
+    s->has_aabb = d->obj_aabb != nullptr;
     ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float>(); ds.precom = s->precom.as<float>();
     ds.prim_obj = s->prim_obj.as<int>(); ds.obj_info = s->obj_info.as<int>(); ds.emitter_id = s->emitter_id.as<int>();
     ds.bxdf = s->bxdf.as<DevBxdf>(); ds.src = s->src.as<DevSrc>();
@@ -263,6 +287,12 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c.device));
     int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // traversal mode: small scenes sweep all primitives wave-uniformly in the reference's brute-force order
+    r->trace_mode = (sc->n_prims <= APT_SWEEP_MAX_PRIMS && sc->has_aabb) ? 1 : 0;
+    if (const char* force = getenv("APT_TRAVERSAL")) {
+        if (!strcmp(force, "bvh")) r->trace_mode = 0;
+        else if (!strcmp(force, "sweep") && sc->has_aabb) r->trace_mode = 1;
+    }
     // LDS plan: the per-lane stack must cover the tree depth; what is left of a ~40 KiB
     // per-workgroup budget (4 workgroups per CU) stages the top of the tree and, when they
     // all fit, the primitive records.
@@ -281,10 +311,11 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         if (r->lds_bytes > 160 * 1024) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: BVH too deep for the LDS traversal stack"); }
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->lds_bytes));
         r->grid_trace = cus * per_cu;
+        if (r->trace_mode == 1) { r->lds_bytes = 0; r->grid_trace = cus * 8; }
         if (r->lds_bytes > 64 * 1024) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_extend, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_shadow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
-            HIP_TRY(hipFuncSetAttribute((const void*)k_occluded, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute((const void*)kShadow[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute((const void*)kOccluded[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         }
     }
     r->grid_small = cus * 8;       // streaming stages: up to 8 x 256-thread workgroups per CU
@@ -360,9 +391,9 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
         { LaunchTimer t(r, 0); hipLaunchKernelGGL(k_generate, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, r->stream, p, r->q, cnt); }
         int cur = 0;
         for (int b = 0; b < p.max_bounce; b++) {
-            { LaunchTimer t(r, 1); hipLaunchKernelGGL(k_extend, dim3(grid_for(total, r->grid_trace, nq)), dim3(BLOCK), r->lds_bytes, r->stream, sc, p, r->q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
+            { LaunchTimer t(r, 1); hipLaunchKernelGGL(kExtend[r->trace_mode], dim3(grid_for(total, r->grid_trace, nq)), dim3(BLOCK), r->lds_bytes, r->stream, sc, p, r->q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
             { LaunchTimer t(r, 2); hipLaunchKernelGGL(r->shade->fn, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, r->stream, sc, p, r->q, cnt, cur, b); }
-            if (p.S > 0) { LaunchTimer t(r, 3); hipLaunchKernelGGL(k_shadow, dim3(grid_for(total * (size_t)p.S, r->grid_trace, nq)), dim3(BLOCK), r->lds_bytes, r->stream, sc, p, r->q, cnt, r->plan); }
+            if (p.S > 0) { LaunchTimer t(r, 3); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_trace, nq)), dim3(BLOCK), r->lds_bytes, r->stream, sc, p, r->q, cnt, r->plan); }
             cur ^= 1;
         }
         { LaunchTimer t(r, 4); hipLaunchKernelGGL(k_finalize, dim3(grid_for((size_t)r->npix, r->grid_small, 1)), dim3(BLOCK), 0, r->stream, p, r->q, r->accum.as<float>()); }
@@ -461,7 +492,7 @@ APT_EXPORT int apt_intersect(apt_renderer* r, int32_t n, const float* o, const f
     uint32_t un = (uint32_t)n;
     HIP_TRY(hipMemcpy(r->scratch.p, &un, 4, hipMemcpyHostToDevice));
     Params flat = r->par; flat.nq = 1; flat.subcap = flat.cap;          // one flat queue for explicit rays
-    hipLaunchKernelGGL(k_extend, dim3(grid_for((size_t)n, r->grid_trace, 1)), dim3(BLOCK), r->lds_bytes, r->stream, r->scene->dev, flat, r->q, (Counters*)nullptr, 0,
+    hipLaunchKernelGGL(kExtend[r->trace_mode], dim3(grid_for((size_t)n, r->grid_trace, 1)), dim3(BLOCK), r->lds_bytes, r->stream, r->scene->dev, flat, r->q, (Counters*)nullptr, 0,
                        (const uint32_t*)r->scratch.p, r->plan);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -485,7 +516,7 @@ APT_EXPORT int apt_occluded(apt_renderer* r, int32_t n, const float* o, const fl
     HIP_TRY(upload(bo, so)); HIP_TRY(upload(bd, sd));
     std::vector<float> tm(tmax, tmax + n);
     HIP_TRY(upload(bt, tm)); HIP_TRY(bocc.alloc((size_t)n * 4));
-    hipLaunchKernelGGL(k_occluded, dim3(grid_for((size_t)n, r->grid_trace, 1)), dim3(BLOCK), r->lds_bytes, r->stream, r->scene->dev, (uint32_t)n,
+    hipLaunchKernelGGL(kOccluded[r->trace_mode], dim3(grid_for((size_t)n, r->grid_trace, 1)), dim3(BLOCK), r->lds_bytes, r->stream, r->scene->dev, (uint32_t)n,
                        bo.as<float>(), bd.as<float>(), bt.as<float>(), bocc.as<int>(), r->plan);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -543,12 +574,13 @@ APT_EXPORT int apt_emitter_probe(const apt_scene* sc, int32_t n, const float* in
     HIP_TRY(hipMemcpy(out12, dout.p, (size_t)n * 48, hipMemcpyDeviceToHost));
     return APT_OK;
 }
-APT_EXPORT int apt_renderer_info(const apt_renderer* r, int32_t* spp_batch, int32_t* n_subqueues, int64_t* queue_bytes, int32_t* lds_bytes, const char** shade_variant) {
+APT_EXPORT int apt_renderer_info(const apt_renderer* r, int32_t* spp_batch, int32_t* n_subqueues, int64_t* queue_bytes, int32_t* lds_bytes, const char** shade_variant, int32_t* trace_mode) {
     if (!r) return fail(APT_E_INVALID, "apt_renderer_info: null handle");
     if (spp_batch) *spp_batch = r->spp_batch;
     if (n_subqueues) *n_subqueues = r->nq;
     if (queue_bytes) *queue_bytes = (int64_t)r->pool.bytes;
     if (lds_bytes) *lds_bytes = (int32_t)r->lds_bytes;
     if (shade_variant) *shade_variant = r->shade->name;
+    if (trace_mode) *trace_mode = r->trace_mode;
     return APT_OK;
 }

@@ -36,6 +36,7 @@
 // ------------------------------------------------------------- device views
 struct DevScene {
     DevBvh bvh;
+    SweepScene sweep;         // small scenes: uniform brute-force sweep instead of the BVH
     const float* normals;     // n_prims*3
     const float* vnormals;    // n_prims*9
     const float* precom;      // n_prims*9  (v1-v0, v2-v0, v0) | sphere (centre, rrr, centre)
@@ -203,9 +204,12 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
 // closest hit for ray queue `cur`.  Also recycles the counters nobody reads any more: the
 // next-ray queue of this bounce (it was the current queue of the previous bounce) and the
 // shadow queue.  `n_src` = per-sub-queue counts (normally cnt->n_active[cur]).
+// MODE 0: BVH traversal (LDS-staged nodes + per-lane LDS stack); MODE 1: wave-uniform sweep (small scenes)
+template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
     StagedBvh bvh;
-    int* my_stack = carve_lds(sc.bvh, plan, bvh);
+    int* my_stack = nullptr;
+    if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
     const SubLoop sl = sub_loop(p.nq);
     const uint32_t n = n_src[sl.q * CNT_PAD];
     if (cnt && sl.first == 0 && threadIdx.x == 0) {
@@ -214,13 +218,16 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, Params p, Queues 
     }
     const float* ro = q.ray_o[cur]; const float* rd = q.ray_d[cur];
     const uint32_t qbase = (uint32_t)sl.q * p.subcap;
-    for (uint32_t pos = sl.first + threadIdx.x; pos < n; pos += sl.stride) {
-        const uint32_t idx = qbase + pos;
+    for (uint32_t base = sl.first; base < n; base += sl.stride) {
+        const uint32_t pos = base + threadIdx.x;
+        const bool valid = pos < n;
+        const uint32_t idx = qbase + (valid ? pos : n - 1);            // idle lanes shadow the last ray: the sweep stays convergent
         f3 o = mk3(ro[idx], ro[p.cap + idx], ro[2 * p.cap + idx]);
         f3 d = mk3(rd[idx], rd[p.cap + idx], rd[2 * p.cap + idx]);
         HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
-        traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
-        q.hit_t[idx] = rec.t; q.hit_prim[idx] = rec.prim; q.hit_u[idx] = rec.u; q.hit_v[idx] = rec.v;
+        if (MODE == 0) traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
+        else sweep<false>(sc.sweep, o, d, rec);
+        if (valid) { q.hit_t[idx] = rec.t; q.hit_prim[idx] = rec.prim; q.hit_u[idx] = rec.u; q.hit_v[idx] = rec.v; }
     }
 }
 
@@ -400,26 +407,39 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
 }
 
 // ------------------------------------------------------------------- shadow
+template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
     StagedBvh bvh;
-    int* my_stack = carve_lds(sc.bvh, plan, bvh);
+    int* my_stack = nullptr;
+    if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
     const SubLoop sl = sub_loop(p.nq);
     const uint32_t n = min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
     if (sl.first == 0 && threadIdx.x == 0) cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
     const uint32_t qbase = (uint32_t)sl.q * q.sh_subcap, sc_ = q.sh_cap;
     uint32_t t_lit = 0;
-    for (uint32_t pos = sl.first + threadIdx.x; pos < n; pos += sl.stride) {
-        const uint32_t idx = qbase + pos;
+    for (uint32_t base = sl.first; base < n; base += sl.stride) {
+        const uint32_t pos = base + threadIdx.x;
+        const bool valid = pos < n;
+        const uint32_t idx = qbase + (valid ? pos : n - 1);
         f3 o = mk3(q.sh_o[idx], q.sh_o[sc_ + idx], q.sh_o[2 * sc_ + idx]);
         f3 d = mk3(q.sh_d[idx], q.sh_d[sc_ + idx], q.sh_d[2 * sc_ + idx]);
         float dist = q.sh_tmax[idx];
         HitRec rec; rec.t = (dist > 0.0f) ? dist - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        if (!traverse<true>(bvh, my_stack, BLOCK, o, d, rec)) {
-            uint32_t id = q.sh_id[idx];
-            atomicAdd(&q.L[id], q.sh_c[idx]);
-            atomicAdd(&q.L[p.cap + id], q.sh_c[sc_ + idx]);
-            atomicAdd(&q.L[2 * p.cap + id], q.sh_c[2 * sc_ + idx]);
-            t_lit++;
+        const bool occluded = (MODE == 0) ? traverse<true>(bvh, my_stack, BLOCK, o, d, rec) : sweep_any(sc.sweep, o, d, rec);
+        if (valid) {
+            f3 c = mk3(q.sh_c[idx], q.sh_c[sc_ + idx], q.sh_c[2 * sc_ + idx]);
+            // Upstream an occluded light sample still enters the sum as 0 * throughput; with a non-finite
+            // throughput (pdf == 0 upstream, quirk A.3 #11) that is NaN, so the sample component is zeroed at
+            // the end.  c carries the throughput factor: c * 0 reproduces exactly that, and is 0 for finite c.
+            const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
+            if (occluded && weird) c = c * 0.f;
+            if (!occluded || weird) {
+                uint32_t id = q.sh_id[idx];
+                atomicAdd(&q.L[id], c.x);
+                atomicAdd(&q.L[p.cap + id], c.y);
+                atomicAdd(&q.L[2 * p.cap + id], c.z);
+            }
+            if (!occluded) t_lit++;
         }
     }
     flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);
@@ -446,13 +466,19 @@ __global__ void k_divide(const float* accum, float* out, uint32_t n, float cnt) 
 }
 
 // ------------------------------------------------------- unit entry kernels
+template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_occluded(DevScene sc, uint32_t n, const float* o_, const float* d_, const float* tmax, int* occ, LdsPlan plan) {
     StagedBvh bvh;
-    int* my_stack = carve_lds(sc.bvh, plan, bvh);
-    for (uint32_t idx = blockIdx.x * BLOCK + threadIdx.x; idx < n; idx += gridDim.x * BLOCK) {
+    int* my_stack = nullptr;
+    if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
+    for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
+        const uint32_t pos = base + threadIdx.x;
+        const bool valid = pos < n;
+        const uint32_t idx = valid ? pos : n - 1;
         f3 o = mk3(o_[idx], o_[n + idx], o_[2 * n + idx]), d = mk3(d_[idx], d_[n + idx], d_[2 * n + idx]);
         HitRec rec; rec.t = (tmax[idx] > 0.0f) ? tmax[idx] - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        occ[idx] = traverse<true>(bvh, my_stack, BLOCK, o, d, rec) ? 1 : 0;
+        const bool hit = (MODE == 0) ? traverse<true>(bvh, my_stack, BLOCK, o, d, rec) : sweep_any(sc.sweep, o, d, rec);
+        if (valid) occ[idx] = hit ? 1 : 0;
     }
 }
 __global__ void k_rng_stream(uint32_t pixel, uint32_t seed, uint32_t sample, int n, uint32_t* out) {

@@ -124,3 +124,80 @@ APT_D bool traverse(const StagedBvh& bvh, int* stack, int stride, f3 o, f3 d, Hi
     }
     return false;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Uniform sweep for small scenes (a few dozen primitives: the Cornell configs).
+//
+// This is the reference's brute-force intersector (tracer_base.py:168-278) kept in its own
+// iteration order — objects in scene order, per-object slab cull with the reference's
+// division-by-direction formula, then that object's primitives — but executed wave-wide:
+// the object / primitive loop counters are wave-uniform, so primitive records come in through
+// scalar loads (SGPR operands, no LDS, no per-lane stack) and there is no traversal divergence;
+// an object is skipped for the whole wave only when no lane's ray needs it.  Because the order
+// and every arithmetic operation are the reference's, ties resolve exactly as upstream.
+// Scene tables are immutable while a renderer exists, so the sweep reads them through the constant
+// address space: with a wave-uniform index the backend then selects s_load_dwordx4 (SGPR operands,
+// scalar cache) instead of a vector global load per lane.
+typedef const float4 __attribute__((address_space(4))) * cf4_ptr;
+typedef const float __attribute__((address_space(4))) * cf_ptr;
+typedef const int __attribute__((address_space(4))) * ci_ptr;
+struct SweepScene {
+    const float4* recs;       // 4 float4 per primitive, ORIGINAL order:
+                              //   triangle (p0, e1.x) (e1.yz, e2.xy) (e2.z, n.xyz) with n = t-row cofactors of [e1 e2 .]
+                              //   sphere   (centre, r)
+    const float* obj_aabb;    // n_objects * 6
+    const int* obj_info;      // n_objects * 3: first prim, count, is_sphere
+    int n_objects;
+};
+
+template <bool ANY>
+APT_D bool sweep(const SweepScene& sc, f3 o, f3 d, HitRec& rec) {
+    bool found = false;                                   // ANY: this lane already has its answer
+    const cf4_ptr recs = (cf4_ptr)sc.recs;
+    const cf_ptr aabb = (cf_ptr)sc.obj_aabb;
+    const ci_ptr info = (ci_ptr)sc.obj_info;
+    for (int ob = 0; ob < sc.n_objects; ob++) {
+        const cf_ptr bb = aabb + 6 * ob;
+        // TracerBase.aabb_test (tracer_base.py:159-166): divides by the ray direction
+        f3 t0 = (mk3(bb[0], bb[1], bb[2]) - o) / d, t1 = (mk3(bb[3], bb[4], bb[5]) - o) / d;
+        float tn = max3(min3v(t0, t1)), tf = min3(max3v(t0, t1));
+        bool need = !found && (tn < tf) && tf > 0.f && !(tn > rec.t);
+        if (!__any(need)) continue;                       // wave-uniform skip
+        const int first = info[3 * ob], count = info[3 * ob + 1];
+        if (info[3 * ob + 2]) {
+            float4 q0 = recs[4 * first];
+            f3 s2c = mk3(q0.x, q0.y, q0.z) - o;
+            float r2 = q0.w * q0.w;
+            float cn2 = norm2(s2c), proj = dot(d, s2c);
+            float c2ray = cn2 - proj * proj;
+            float cut = sqrtf(r2 - c2ray);
+            float t = proj + ((cn2 > r2 + 1e-4f) ? -cut : cut);
+            if (need && c2ray < r2 && t > 1e-4f && t < rec.t) {
+                if (ANY) found = true;
+                else { rec.t = t; rec.prim = first; rec.u = 0.f; rec.v = 0.f; }
+            }
+        } else {
+            for (int k = first; k < first + count; k++) {
+                float4 q0 = recs[4 * k], q1 = recs[4 * k + 1], q2 = recs[4 * k + 2];
+                float a00 = q0.w, a10 = q1.x, a20 = q1.y;      // e1
+                float a01 = q1.z, a11 = q1.w, a21 = q2.x;      // e2
+                float a02 = -d.x, a12 = -d.y, a22 = -d.z;
+                float c00 = a11 * a22 - a21 * a12, c01 = a21 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
+                float det = (a00 * c00 + a10 * c01) + a20 * c02;
+                float inv_det = 1.0f / det;
+                f3 s = o - mk3(q0.x, q0.y, q0.z);
+                float c10 = a12 * a20 - a22 * a10, c11 = a22 * a00 - a02 * a20, c12 = a02 * a10 - a12 * a00;
+                float u = ((inv_det * c00) * s.x + (inv_det * c01) * s.y) + (inv_det * c02) * s.z;
+                float v = ((inv_det * c10) * s.x + (inv_det * c11) * s.y) + (inv_det * c12) * s.z;
+                float t = ((inv_det * q2.y) * s.x + (inv_det * q2.z) * s.y) + (inv_det * q2.w) * s.z;
+                if (need && u >= 0.f && v >= 0.f && u + v <= 1.0f && t > 1e-4f && t < rec.t) {
+                    if (ANY) { found = true; need = false; }
+                    else { rec.t = t; rec.prim = k; rec.u = u; rec.v = v; }
+                }
+            }
+        }
+        if (ANY && __all(found)) break;
+    }
+    return found;
+}
+APT_D bool sweep_any(const SweepScene& sc, f3 o, f3 d, HitRec& rec) { return sweep<true>(sc, o, d, rec); }

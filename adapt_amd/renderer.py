@@ -243,12 +243,13 @@ class Renderer:
         return out
 
     def info(self) -> dict:
-        b, nq, lds = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        b, nq, lds, tm = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
         qb = C.c_int64(0)
         name = C.c_char_p()
-        _lib.check(self.lib.apt_renderer_info(self.handle, C.byref(b), C.byref(nq), C.byref(qb), C.byref(lds), C.byref(name)), "apt_renderer_info")
+        _lib.check(self.lib.apt_renderer_info(self.handle, C.byref(b), C.byref(nq), C.byref(qb), C.byref(lds), C.byref(name), C.byref(tm)), "apt_renderer_info")
         return {"spp_per_batch": b.value, "n_subqueues": nq.value, "queue_bytes": qb.value, "lds_bytes": lds.value,
-                "shade_variant": name.value.decode() if name.value else ""}
+                "shade_variant": name.value.decode() if name.value else "",
+                "traversal": "sweep" if tm.value == 1 else "bvh"}
 
     # ------------------------------------------------------------ checkpoint
     def get_check_point(self) -> dict:

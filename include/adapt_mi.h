@@ -131,8 +131,9 @@ int apt_bxdf_probe(int32_t device, int32_t n, const int32_t* bxdf_i, const float
 /* Emitter probe: in11[11k..] = source index, hit_pos, normal, ray_d, min_depth;
  * out12[12k..] = sampled pos, intensity (/pdf), pdf, draws, eval_le rgb, solid_angle_pdf; RNG as above. */
 int apt_emitter_probe(const apt_scene*, int32_t n, const float* in11, uint32_t seed, float* out12);
+/* trace_mode: 0 = BVH traversal, 1 = wave-uniform sweep (scenes of <= 96 primitives; env APT_TRAVERSAL=bvh|sweep overrides) */
 int apt_renderer_info(const apt_renderer*, int32_t* spp_batch, int32_t* n_subqueues, int64_t* queue_bytes,
-                      int32_t* lds_bytes, const char** shade_variant);
+                      int32_t* lds_bytes, const char** shade_variant, int32_t* trace_mode);
 
 const char* apt_last_error(void);
 const char* apt_version(void);
