@@ -129,8 +129,8 @@ APT_D bool traverse(const StagedBvh& bvh, int* stack, int stride, f3 o, f3 d, Hi
 // Uniform sweep for small scenes (a few dozen primitives: the Cornell configs).
 //
 // This is the reference's brute-force intersector (tracer_base.py:168-278) kept in its own
-// iteration order — objects in scene order, per-object slab cull with the reference's
-// division-by-direction formula, then that object's primitives — but executed wave-wide:
+// iteration order — objects in scene order, a per-object slab cull, then that object's
+// primitives — but executed wave-wide:
 // the object / primitive loop counters are wave-uniform, so primitive records come in through
 // scalar loads (SGPR operands, no LDS, no per-lane stack) and there is no traversal divergence;
 // an object is skipped for the whole wave only when no lane's ray needs it.  Because the order
@@ -156,14 +156,21 @@ APT_D bool sweep(const SweepScene& sc, f3 o, f3 d, HitRec& rec) {
     const cf4_ptr recs = (cf4_ptr)sc.recs;
     const cf_ptr aabb = (cf_ptr)sc.obj_aabb;
     const ci_ptr info = (ci_ptr)sc.obj_info;
+    const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     for (int ob = 0; ob < sc.n_objects; ob++) {
-        const cf_ptr bb = aabb + 6 * ob;
-        // TracerBase.aabb_test (tracer_base.py:159-166): divides by the ray direction
-        f3 t0 = (mk3(bb[0], bb[1], bb[2]) - o) / d, t1 = (mk3(bb[3], bb[4], bb[5]) - o) / d;
-        float tn = max3(min3v(t0, t1)), tf = min3(max3v(t0, t1));
-        bool need = !found && (tn < tf) && tf > 0.f && !(tn > rec.t);
-        if (!__any(need)) continue;                       // wave-uniform skip
         const int first = info[3 * ob], count = info[3 * ob + 1];
+        // Per-object slab cull (TracerBase.aabb_test, tracer_base.py:159-166).  Upstream it is a per-ray
+        // filter in front of primitives that lie INSIDE the box (flat objects are padded by 2e-2), so it can
+        // only change which tests are skipped, never which hit wins.  Here it exists to skip an object for the
+        // whole wave; objects of one or two primitives are cheaper to test than to cull.
+        bool need = !found;
+        if (count > 2) {
+            const cf_ptr bb = aabb + 6 * ob;
+            f3 t0 = (mk3(bb[0], bb[1], bb[2]) - o) * inv_d, t1 = (mk3(bb[3], bb[4], bb[5]) - o) * inv_d;
+            float tn = max3(min3v(t0, t1)), tf = min3(max3v(t0, t1));
+            need = need && (tn <= tf) && tf > 0.f && !(tn > rec.t);
+        }
+        if (!__any(need)) continue;                       // wave-uniform skip
         if (info[3 * ob + 2]) {
             float4 q0 = recs[4 * first];
             f3 s2c = mk3(q0.x, q0.y, q0.z) - o;

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (rocpd sqlite: kernel trace + PMC passes) into one small text table per kernel.
+
+    python tools/summarize_prof.py gpurun_out/prof > profiles/<name>.txt
+"""
+import glob
+import os
+import sqlite3
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(name):
+    for k in ("k_generate", "k_extend", "k_shade", "k_shadow", "k_finalize", "k_divide"):
+        if k in name:
+            tag = k
+            if k in ("k_extend", "k_shadow"):
+                tag += "<sweep>" if "ILi1E" in name else "<bvh>"
+            if k == "k_shade":
+                import re
+                m = re.search(r"k_shadeILi(\d+)ELi(\d+)E", name)
+                if m:
+                    tag += f"<bx=0x{int(m.group(1)):x},src=0x{int(m.group(2)):x}>"
+            return tag
+    return name.split("(")[0][:48]
+
+
+def first_db(sub):
+    fs = glob.glob(os.path.join(out, sub, "**", "*.db"), recursive=True)
+    return sqlite3.connect(fs[0]) if fs else None
+
+
+db = first_db("stats")
+print("== kernel time (rocprofv3 --kernel-trace --stats), all dispatches of the run")
+if db:
+    q = ("select s.kernel_name, count(*), sum(d.end - d.start), avg(d.end - d.start), min(d.end - d.start), max(d.end - d.start), "
+         "max(s.arch_vgpr_count), max(s.sgpr_count), max(d.group_segment_size) "
+         "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.kernel_name order by 3 desc")
+    rows = list(db.execute(q))
+    tot = sum(r[2] for r in rows) or 1
+    print(f"{'kernel':40s} {'calls':>6s} {'total_us':>11s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s} {'vgpr':>5s} {'sgpr':>5s} {'lds_B':>7s}")
+    for r in rows:
+        print(f"{short(r[0]):40s} {r[1]:6d} {r[2] / 1e3:11.1f} {r[3] / 1e3:9.2f} {r[4] / 1e3:9.2f} {r[5] / 1e3:9.2f} {100 * r[2] / tot:6.2f} {r[6]:5d} {r[7]:5d} {r[8]:7d}")
+
+print("\n== PMC passes (summed over the run's dispatches, per kernel)")
+acc = defaultdict(lambda: defaultdict(float))
+disp = defaultdict(set)
+for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    d = first_db(sub)
+    if not d:
+        continue
+    q = ("select s.kernel_name, p.name, sum(e.value), count(distinct k.dispatch_id) from rocpd_pmc_event e "
+         "join rocpd_info_pmc p on e.pmc_id = p.id join rocpd_kernel_dispatch k on k.event_id = e.event_id "
+         "join rocpd_info_kernel_symbol s on k.kernel_id = s.id group by s.kernel_name, p.name")
+    for name, cname, val, nd in d.execute(q):
+        acc[short(name)][cname] += val
+        disp[short(name)].add(nd)
+for k, c in sorted(acc.items()):
+    if not k.startswith("k_"):
+        continue
+    print(f"{k}  (dispatches {max(disp[k])})")
+    print("    " + "  ".join(f"{n}={v:.5g}" for n, v in sorted(c.items())))
+    w = c.get("SQ_WAVES")
+    if w:
+        # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md, cycle constants)
+        print(f"    per wave: VALU {c.get('SQ_INSTS_VALU', 0) / w:.0f}  SALU {c.get('SQ_INSTS_SALU', 0) / w:.0f}  SMEM {c.get('SQ_INSTS_SMEM', 0) / w:.0f}  "
+              f"wave_cycles {4 * c.get('SQ_WAVE_CYCLES', 0) / w:.0f}  active_valu_cycles {4 * c.get('SQ_ACTIVE_INST_VALU', 0) / w:.0f}  "
+              f"wait_inst_any_cycles {4 * c.get('SQ_WAIT_INST_ANY', 0) / w:.0f}")
+    if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+        # KiB units; FETCH_SIZE on gfx950 counts a wide coalesced read at half its bytes (MI355X_MICROARCH.md, HBM): x2 shown
+        print(f"    HBM side: FETCH_SIZE {c.get('FETCH_SIZE', 0) / 1024:.1f} MiB raw, {2 * c.get('FETCH_SIZE', 0) / 1024:.1f} MiB x2-corrected;  "
+              f"WRITE_SIZE {c.get('WRITE_SIZE', 0) / 1024:.1f} MiB")
