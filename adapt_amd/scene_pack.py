@@ -15,7 +15,7 @@ from typing import List, Optional
 import numpy as np
 from scipy.spatial.transform import Rotation
 
-__all__ = ["FlatScene", "RenderConfig", "pack_scene", "make_config", "fov2focal", "np_rotation_between"]
+__all__ = ["FlatScene", "RenderConfig", "pack_scene", "pack_source", "pack_bxdf", "make_config", "fov2focal", "np_rotation_between"]
 
 
 def fov2focal(fov: float, img_size) -> float:
@@ -93,6 +93,43 @@ class RenderConfig:
     crop_ry: int = 0
 
 
+_SRC_IDS = {"point": 0, "area": 1, "spot": 2, "collimated": 4}
+
+
+def pack_source(e):
+    """Emitter host object -> (int32[4] type, bool_bits, obj_ref_id, 0 ; float32[11] intensity dir pos inv_area r).
+    Uses the object's own `pack()` when it has one (adapt_amd.emitters); otherwise reads the attributes of
+    AdaPT's host classes (emitters/{point,area,spot,collimated}.py) so the reference's parser output works too."""
+    if hasattr(e, "pack"):
+        return e.pack()
+    t = _SRC_IDS[e.type]
+    fs = int(bool(getattr(e, "in_free_space", True))) << 4
+    pos = np.float32(getattr(e, "pos", np.zeros(3))) if t != 1 else np.zeros(3, np.float32)
+    direc = np.float32(getattr(e, "dir", (0, 0, 1))) if t in (2, 4) else np.float32([0, 0, 1])
+    r = 0.0
+    if t == 0:
+        bits = 0x01 + fs
+    elif t == 1:
+        bits = fs | 0x04
+    elif t == 2:
+        bits, r = 0x01 + fs, float(e.half_cos)
+    else:
+        bits, r = int(e.radius == 0) + 0x02 + fs, float(e.radius)
+    return (np.int32([t, bits, -1, 0]),
+            np.concatenate([np.float32(e.intensity), direc, pos, [e.inv_area, r]]).astype(np.float32))
+
+
+def pack_bxdf(b):
+    """BRDF_np / BSDF_np host object -> (int32[4] type, is_delta, is_bsdf, 0 ; float32[13] k_d k_s k_g mean ior)."""
+    if hasattr(b, "pack"):
+        return b.pack()
+    is_bsdf = hasattr(b, "medium")
+    mean = np.float32([b.k_d.mean(), b.k_s.mean(), b.k_g.mean()])
+    ior = np.float32(b.medium.ior) if is_bsdf else np.float32(1.0)
+    return (np.int32([b.type_id, int(b.is_delta), int(is_bsdf), 0]),
+            np.concatenate([b.k_d, b.k_s, b.k_g, mean, [ior]]).astype(np.float32))
+
+
 def pack_scene(emitters: List, array_info: dict, objects: List, prop: dict) -> FlatScene:
     prims = np.ascontiguousarray(array_info["primitives"], dtype=np.float32)
     n_g = np.ascontiguousarray(array_info["n_g"], dtype=np.float32)
@@ -106,12 +143,12 @@ def pack_scene(emitters: List, array_info: dict, objects: List, prop: dict) -> F
     src_i = np.zeros((len(emitters), 4), np.int32)
     src_f = np.zeros((len(emitters), 11), np.float32)
     for s, em in enumerate(emitters):
-        src_i[s], src_f[s] = em.pack()
+        src_i[s], src_f[s] = pack_source(em)
     first = 0
     for i, obj in enumerate(objects):
         obj_info[i] = (first, obj.tri_num, obj.type)
         first += obj.tri_num
-        bxdf_i[i], bxdf_f[i] = obj.bsdf.pack()
+        bxdf_i[i], bxdf_f[i] = pack_bxdf(obj.bsdf)
         obj_aabb[i] = obj.aabb
         emitter_id[i] = obj.emitter_ref_id
         if obj.emitter_ref_id >= 0:

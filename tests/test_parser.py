@@ -140,3 +140,25 @@ def test_config_overrides_and_crop(parsed):
     rc = make_config(cfg)
     assert rc.do_crop and (rc.start_x, rc.end_x, rc.start_y, rc.end_y) == (24, 40, 16, 24)
     assert rc.rr_bounce_th == 4 and abs(rc.rr_threshold - 0.1) < 1e-12 and rc.use_bvh is False
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scenes"), reason="reference tree only exists in the authoring container")
+@pytest.mark.parametrize("d,f,tag", [("cbox", "cbox.xml", "cbox"), ("csphere", "balls-mono.xml", "balls_mono"), ("cbox", "complex.xml", "glass_box")])
+def test_reference_parser_objects_are_accepted(d, f, tag, flat):
+    """INTEGRATION.md option A: the objects AdaPT's own scene_parsing returns (its host classes, imported from the
+    reference tree under the golden generator's taichi stand-in) pack to the same flat scene as this repo's parser."""
+    import sys
+    gen = os.path.join(ROOT, "tests", "golden", "gen")
+    sys.path.insert(0, gen)
+    try:
+        import refenv
+        refenv.setup()
+        from parsers.xml_parser import scene_parsing as ref_scene_parsing      # the reference's module
+        em, arr, objs, cfg = ref_scene_parsing(os.path.join("/root/reference/scenes", d), f)
+    finally:
+        sys.path.remove(gen)
+    fs = pack_scene(em, arr, objs, cfg)
+    mine = flat(tag)
+    for name in ("prims", "normals", "v_normals", "obj_info", "obj_aabb", "emitter_id", "bxdf_i", "bxdf_f", "src_i", "src_f"):
+        assert np.array_equal(getattr(fs, name), getattr(mine, name)), name
+    assert fs.world_ior == mine.world_ior and fs.has_vertex_normal == mine.has_vertex_normal
