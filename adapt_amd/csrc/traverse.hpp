@@ -81,15 +81,18 @@ APT_D float prim_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float& u, flo
 // ANY = false: closest hit, rec.t starts at the search limit and ends at min_depth.
 // ANY = true : returns true on the first hit with 1e-4 < t < rec.t.
 // `stack` points at this lane's column of an LDS array [depth][stride].
+//
+// Loop shape ("while-while"): all lanes of the wave walk inner nodes together until each of them holds a
+// leaf (or is finished), then all of them test primitives together.  One mixed loop, where some lanes do a
+// box pair while others do up to four primitive tests, costs the sum of both bodies on every iteration.
+#define APT_TRAV_DONE ((int)0x80000000)      // not a valid leaf link: ~link would be first_prim = 2^27
 template <bool ANY>
 APT_D bool traverse(const StagedBvh& bvh, int* stack, int stride, f3 o, f3 d, HitRec& rec) {
-    f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     int sp = 0;
     int cur = 0;
-    bool running = true;
-    while (running) {
-        bool pop = false;
-        if (cur >= 0) {
+    while (cur != APT_TRAV_DONE) {
+        while (cur >= 0) {
             float4 q0 = bvh.node(cur, 0), q1 = bvh.node(cur, 1), q2 = bvh.node(cur, 2), q3 = bvh.node(cur, 3);
             float tl = box_entry(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, inv_d, rec.t);
             float tr = box_entry(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, inv_d, rec.t);
@@ -97,13 +100,14 @@ APT_D bool traverse(const StagedBvh& bvh, int* stack, int stride, f3 o, f3 d, Hi
             bool hl = tl >= 0.f, hr = tr >= 0.f;
             if (hl && hr) {
                 bool swap = tr < tl;
-                int near_ = swap ? r : l, far_ = swap ? l : r;
-                stack[sp * stride] = far_; sp++;
-                cur = near_;
+                stack[sp * stride] = swap ? l : r; sp++;          // far child waits
+                cur = swap ? r : l;
             } else if (hl) cur = l;
             else if (hr) cur = r;
-            else pop = true;
-        } else {
+            else if (sp > 0) { sp--; cur = stack[sp * stride]; }
+            else cur = APT_TRAV_DONE;
+        }
+        while (cur < 0 && cur != APT_TRAV_DONE) {
             int code = ~cur;
             int first = code >> 4, count = code & 15;
             for (int k = 0; k < count; k++) {
@@ -115,11 +119,8 @@ APT_D bool traverse(const StagedBvh& bvh, int* stack, int stride, f3 o, f3 d, Hi
                     rec.t = t; rec.prim = __float_as_int(p2.y); rec.u = u; rec.v = v;
                 }
             }
-            pop = true;
-        }
-        if (pop) {
             if (sp > 0) { sp--; cur = stack[sp * stride]; }
-            else running = false;
+            else cur = APT_TRAV_DONE;
         }
     }
     return false;

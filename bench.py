@@ -34,7 +34,18 @@ CONFIGS = {
     "c1": ("cbox", "c2_cbox.xml", 256, 256, 64, 4, "cbox 256x256, 64 spp, 4 bounces (BASELINE configs[0])"),
     "c2": ("cbox", "c2_cbox.xml", 512, 512, 1024, 8, "cbox 512x512, 1024 spp, 8 bounces (BASELINE configs[1])"),
     "c3": ("csphere", "c3_balls_mono.xml", 512, 512, 1024, 16, "csphere balls-mono 512x512, 1024 spp, 16 bounces (BASELINE configs[2])"),
+    # synthetic stand-ins (adapt_amd/synth.py): the reference does not ship these scenes' assets
+    "c4": ("synth", "three-bunnies", 800, 800, 512, 8, "three-bunnies stand-in, 95 050 tris, 800x800, 512 spp, 8 bounces (BASELINE configs[3])"),
+    "c5": ("synth", "bunny-field", 1280, 720, 2048, 16, "sports-car stand-in (bunny field), 285 134 tris, 1280x720, 2048 spp, 16 bounces (BASELINE configs[4])"),
 }
+
+
+def load_scene(sdir, sfile):
+    if sdir == "synth":
+        from adapt_amd.synth import SYNTH_SCENES
+        return SYNTH_SCENES[sfile]()
+    from adapt_amd import scene_parsing
+    return scene_parsing(os.path.join(ROOT, "scenes", sdir), sfile)
 
 
 def kernel_bytes(st):
@@ -89,7 +100,7 @@ def main():
     if args.spp > 0:
         spp = args.spp
     spp_step = spp * world                  # weak scaling: per-GPU samples stay at the N = 1 amount
-    parsed = scene_parsing(os.path.join(ROOT, "scenes", sdir), sfile)
+    parsed = load_scene(sdir, sfile)
     rdr = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world,
                    band_width=32, profile=True, spp_per_batch=args.spp_per_batch)
     info = rdr.info()
@@ -145,7 +156,7 @@ def main():
         "metric": "Msamples/s (W*H*spp/s), unidirectional MIS path tracing", "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "bundled cornell-box scene (same inputs as AdaPT scenes/cbox/cbox.xml); no dataset involved",
+        "data": ("synthetic stand-in scene (adapt_amd/synth.py; the reference ships no assets for it)" if sdir == "synth" else "bundled Cornell scene file (same inputs as the reference's); no dataset involved"),
         "config": {"workload": label, "scene": f"scenes/{sdir}/{sfile}", "width": W, "height": H, "spp_per_step": spp_step,
                    "max_bounce": bounces, "num_shadow_ray": rdr.num_shadow_ray, "tiling": f"{world} x interleaved 32-column bands",
                    "spp_per_batch": info["spp_per_batch"], "sub_queues": info["n_subqueues"], "shade_variant": info["shade_variant"],
@@ -158,7 +169,7 @@ def main():
         from adapt_amd.scene_pack import make_config, pack_scene
         from oracle import binding as ob
         rc = make_config(parsed[3], width=W, height=H, max_bounce=bounces)
-        osc = ob.OracleScene(pack_scene(*parsed), rc.cam_t)
+        osc = ob.OracleScene(pack_scene(*parsed), rc.cam_t, build_bvh=rc.use_bvh)
         cores = ob.num_threads()
         t = time.perf_counter(); osc.render(rc, 1, threads=cores); one = time.perf_counter() - t
         n_cpu = int(max(1, min(64, round(args.cpu_seconds / max(one, 1e-3)))))
