@@ -32,14 +32,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 // ------------------------------------------------- shade kernel specialisations
 // (material mask, emitter mask) -> instantiation; the host picks the first one that covers the scene
-typedef void (*shade_fn)(DevScene, Params, Queues, Counters*, int, int);
-typedef void (*extend_fn)(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan);
-typedef void (*shadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan);
-typedef void (*occluded_fn)(DevScene, uint32_t, const float*, const float*, const float*, int*, LdsPlan);
-static const extend_fn kExtend[2] = {k_extend<0>, k_extend<1>};
-static const shadow_fn kShadow[2] = {k_shadow<0>, k_shadow<1>};
-static const occluded_fn kOccluded[2] = {k_occluded<0>, k_occluded<1>};
-#define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
+typedef void (*shade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int, int);
 struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; };
 static const ShadeVariant kShadeVariants[] = {
     {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point"},
@@ -47,6 +40,34 @@ static const ShadeVariant kShadeVariants[] = {
     {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area"},
     {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models"},
 };
+// Material classes for sorted shading: (class mask) x (emitter mask: point+area | all)
+#define APT_N_CLASS_DEFS 6
+static const int kClassMask[APT_N_CLASS_DEFS] = {
+    0x043,      // diffuse-like: Blinn-Phong, Lambertian, Oren-Nayar
+    0x504,      // delta: mirror BRDF, det-refraction BSDF, null BSDF
+    0x010,      // modified Phong
+    0x020,      // Fresnel blend
+    0x080,      // thin coat
+    0x200,      // Lambertian transmission
+};
+static const char* kClassName[APT_N_CLASS_DEFS] = {"diffuse", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans"};
+static const shade_fn kClassShade[APT_N_CLASS_DEFS][2] = {
+    {k_shade<0x043, 0x03>, k_shade<0x043, APT_SRC_ALL>}, {k_shade<0x504, 0x03>, k_shade<0x504, APT_SRC_ALL>},
+    {k_shade<0x010, 0x03>, k_shade<0x010, APT_SRC_ALL>}, {k_shade<0x020, 0x03>, k_shade<0x020, APT_SRC_ALL>},
+    {k_shade<0x080, 0x03>, k_shade<0x080, APT_SRC_ALL>}, {k_shade<0x200, 0x03>, k_shade<0x200, APT_SRC_ALL>},
+};
+static int class_of(int is_bsdf, int type) {
+    const int bit = is_bsdf ? (type == 0 ? 8 : (type == 1 ? 9 : 10)) : (type & 7);
+    for (int c = 0; c < APT_N_CLASS_DEFS; c++) if ((kClassMask[c] >> bit) & 1) return c;
+    return 0;        // microfacet (compiled out upstream) shades as nothing; keep it with the diffuse class
+}
+typedef void (*extend_fn)(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan);
+typedef void (*shadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan);
+typedef void (*occluded_fn)(DevScene, uint32_t, const float*, const float*, const float*, int*, LdsPlan);
+static const extend_fn kExtend[2][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_extend<1, 0>, k_extend<1, 1>}};   // [mode][sorted]
+static const shadow_fn kShadow[2] = {k_shadow<0>, k_shadow<1>};
+static const occluded_fn kOccluded[2] = {k_occluded<0>, k_occluded<1>};
+#define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
 
 // ============================================================== host side
 struct DevBuf {
@@ -67,7 +88,9 @@ struct apt_scene {
     int device = 0;
     DevScene dev{};
     apt::BvhData bvh;
-    DevBuf nodes, prims, normals, vnormals, precom, prim_obj, obj_info, emitter_id, bxdf, src, sweep_recs, obj_aabb;
+    DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, obj_aabb;
+    int n_classes = 0;                   // material classes present (compact ids 0..n_classes-1)
+    int class_def[APT_N_CLASS_DEFS] = {0, 0, 0, 0, 0, 0};   // compact id -> class definition
     int n_prims = 0, n_objects = 0, n_sources = 0;
     int bx_mask = 0, src_mask = 0;
     bool has_aabb = false;
@@ -88,6 +111,9 @@ struct apt_renderer {
     int grid_small = 0, grid_trace = 0, nq = APT_MAX_NQ;
     const ShadeVariant* shade = nullptr;
     int trace_mode = 0;           // 0 = BVH traversal, 1 = wave-uniform sweep (small scenes)
+    int sorted = 0;               // 1 = material-sorted shading (>= 2 material classes in the scene)
+    shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::string shade_name;
     LdsPlan plan{};
     size_t lds_bytes = 0;
     std::vector<EventPair> pending;
@@ -190,6 +216,20 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         s->bx_mask |= b.is_bsdf ? (b.type == 0 ? 0x100 : (b.type == 1 ? 0x200 : 0x400)) : (1 << (b.type & 7));
         b.k_d = mk3(bf[0], bf[1], bf[2]); b.k_s = mk3(bf[3], bf[4], bf[5]); b.k_g = mk3(bf[6], bf[7], bf[8]); b.mean = mk3(bf[9], bf[10], bf[11]); b.ior = bf[12];
     }
+    // material classes present in this scene -> compact ids; per-primitive class table for the sorting extend
+    {
+        int compact[APT_N_CLASS_DEFS]; for (int c = 0; c < APT_N_CLASS_DEFS; c++) compact[c] = -1;
+        std::vector<int> obj_cls((size_t)O);
+        for (int o = 0; o < O; o++) {
+            int c = class_of(bx[(size_t)o].is_bsdf, bx[(size_t)o].type);
+            if (compact[c] < 0) { compact[c] = s->n_classes; s->class_def[s->n_classes++] = c; }
+            obj_cls[(size_t)o] = compact[c];
+        }
+        std::vector<int> pcls((size_t)N);
+        for (int k = 0; k < N; k++) pcls[(size_t)k] = obj_cls[(size_t)prim_obj[(size_t)k]];
+        hipError_t e_ = upload(s->prim_class, pcls);
+        if (e_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload prim_class: ") + hipGetErrorString(e_)); }
+    }
     std::vector<DevSrc> sr((size_t)S);
     for (int k = 0; k < S; k++) {
         const int32_t* si = d->src_i + 4 * k; const float* sf = d->src_f + 11 * k;
@@ -212,7 +252,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     ds.sweep.recs = s->sweep_recs.as<float4>(); ds.sweep.obj_aabb = s->obj_aabb.as<float>(); ds.sweep.obj_info = s->obj_info.as<int>(); ds.sweep.n_objects = O;
     s->has_aabb = d->obj_aabb != nullptr;
     ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float>(); ds.precom = s->precom.as<float>();
-    ds.prim_obj = s->prim_obj.as<int>(); ds.obj_info = s->obj_info.as<int>(); ds.emitter_id = s->emitter_id.as<int>();
+    ds.prim_obj = s->prim_obj.as<int>(); ds.prim_class = s->prim_class.as<int>(); ds.obj_info = s->obj_info.as<int>(); ds.emitter_id = s->emitter_id.as<int>();
     ds.bxdf = s->bxdf.as<DevBxdf>(); ds.src = s->src.as<DevSrc>();
     ds.n_prims = N; ds.n_objects = O; ds.n_sources = S; ds.has_vn = d->has_vertex_normal; ds.world_ior = d->world_ior;
     *out = s;
@@ -265,8 +305,17 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     p.max_bounce = c.max_bounce; p.S = S; p.inv_S = (S > 0) ? 1.f / (float)S : 1.f;
     p.use_rr = c.use_rr; p.use_mis = c.use_mis; p.anti_alias = c.anti_alias; p.stratified = c.stratified; p.two_sides = c.brdf_two_sides;
     p.rr_bounce_th = c.rr_bounce_th; p.rr_threshold = c.rr_threshold; p.seed = c.seed; p.cap = (uint32_t)cap; p.subcap = (uint32_t)subcap; p.nq = nq;
+    r->sorted = (sc->n_classes >= 2) ? 1 : 0;
+    if (const char* force = getenv("APT_SORTED")) r->sorted = (atoi(force) != 0 && sc->n_classes >= 1) ? 1 : 0;
+    const int ncls = r->sorted ? sc->n_classes : 0;
+    r->shade_name = r->shade->name;
+    if (r->sorted) {
+        const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : 1;
+        r->shade_name = "sorted:";
+        for (int c = 0; c < ncls; c++) { r->class_fn[c] = kClassShade[sc->class_def[c]][smi]; r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]]; }
+    }
     // one pool, carved into the SoA arrays (all 4-byte lanes)
-    const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 3) + sh_cap * (3 + 3 + 1 + 3 + 1);
+    const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 3) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls;
     hipError_t e = r->pool.alloc(words * 4);
     if (e != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("queue pool: ") + hipGetErrorString(e)); }
     float* w = r->pool.as<float>();
@@ -278,6 +327,12 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     q.L = take(3 * cap);
     q.sh_o = take(3 * sh_cap); q.sh_d = take(3 * sh_cap); q.sh_tmax = take(sh_cap); q.sh_c = take(3 * sh_cap); q.sh_id = (uint32_t*)take(sh_cap);
     q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
+    q.n_classes = ncls;
+    for (int c = 0; c < ncls; c++) {
+        Queues::ClassQ& k = q.cls[c];
+        k.ray_o = take(3 * cap); k.ray_d = take(3 * cap); k.thr = take(3 * cap); k.id = (uint32_t*)take(cap); k.meta = (uint32_t*)take(cap);
+        k.pdf = take(cap); k.t = take(cap); k.prim = (int*)take(cap); k.u = take(cap); k.v = take(cap);
+    }
     if ((e = r->counters.alloc(sizeof(Counters))) != hipSuccess || (e = r->accum.alloc((size_t)r->npix * 12)) != hipSuccess ||
         (e = r->scratch.alloc((size_t)r->npix * 12)) != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("framebuffer: ") + hipGetErrorString(e)); }
     HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
@@ -313,7 +368,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         r->grid_trace = cus * per_cu;
         if (r->trace_mode == 1) { r->lds_bytes = 0; r->grid_trace = cus * 8; }
         if (r->lds_bytes > 64 * 1024) {
-            HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kShadow[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kOccluded[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         }
@@ -391,8 +447,19 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
         { LaunchTimer t(r, 0); hipLaunchKernelGGL(k_generate, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, r->stream, p, r->q, cnt); }
         int cur = 0;
         for (int b = 0; b < p.max_bounce; b++) {
-            { LaunchTimer t(r, 1); hipLaunchKernelGGL(kExtend[r->trace_mode], dim3(grid_for(total, r->grid_trace, nq)), dim3(BLOCK), r->lds_bytes, r->stream, sc, p, r->q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
-            { LaunchTimer t(r, 2); hipLaunchKernelGGL(r->shade->fn, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, r->stream, sc, p, r->q, cnt, cur, b); }
+            { LaunchTimer t(r, 1); hipLaunchKernelGGL(kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq)), dim3(BLOCK), r->lds_bytes, r->stream, sc, p, r->q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
+            if (!r->sorted) {
+                ShadeIn in = {r->q.ray_o[cur], r->q.ray_d[cur], r->q.thr[cur], r->q.id[cur], r->q.meta[cur], r->q.pdf[cur],
+                              r->q.hit_t, r->q.hit_prim, r->q.hit_u, r->q.hit_v, (const uint32_t*)cnt->n_active[cur]};
+                LaunchTimer t(r, 2); hipLaunchKernelGGL(r->shade->fn, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, r->stream, sc, p, r->q, cnt, in, cur, b);
+            } else {
+                for (int c = 0; c < r->q.n_classes; c++) {
+                    const Queues::ClassQ& k = r->q.cls[c];
+                    ShadeIn in = {k.ray_o, k.ray_d, k.thr, k.id, k.meta, k.pdf, k.t, k.prim, k.u, k.v, (const uint32_t*)cnt->n_cls[c]};
+                    LaunchTimer t(r, 2); hipLaunchKernelGGL(r->class_fn[c], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, r->stream, sc, p, r->q, cnt, in, cur, b);
+                }
+                if (p.S <= 0) HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), r->stream));      // normally k_shadow recycles these
+            }
             if (p.S > 0) { LaunchTimer t(r, 3); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_trace, nq)), dim3(BLOCK), r->lds_bytes, r->stream, sc, p, r->q, cnt, r->plan); }
             cur ^= 1;
         }
@@ -492,7 +559,7 @@ APT_EXPORT int apt_intersect(apt_renderer* r, int32_t n, const float* o, const f
     uint32_t un = (uint32_t)n;
     HIP_TRY(hipMemcpy(r->scratch.p, &un, 4, hipMemcpyHostToDevice));
     Params flat = r->par; flat.nq = 1; flat.subcap = flat.cap;          // one flat queue for explicit rays
-    hipLaunchKernelGGL(kExtend[r->trace_mode], dim3(grid_for((size_t)n, r->grid_trace, 1)), dim3(BLOCK), r->lds_bytes, r->stream, r->scene->dev, flat, r->q, (Counters*)nullptr, 0,
+    hipLaunchKernelGGL(kExtend[r->trace_mode][0], dim3(grid_for((size_t)n, r->grid_trace, 1)), dim3(BLOCK), r->lds_bytes, r->stream, r->scene->dev, flat, r->q, (Counters*)nullptr, 0,
                        (const uint32_t*)r->scratch.p, r->plan);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -580,7 +647,7 @@ APT_EXPORT int apt_renderer_info(const apt_renderer* r, int32_t* spp_batch, int3
     if (n_subqueues) *n_subqueues = r->nq;
     if (queue_bytes) *queue_bytes = (int64_t)r->pool.bytes;
     if (lds_bytes) *lds_bytes = (int32_t)r->lds_bytes;
-    if (shade_variant) *shade_variant = r->shade->name;
+    if (shade_variant) *shade_variant = r->shade_name.c_str();
     if (trace_mode) *trace_mode = r->trace_mode;
     return APT_OK;
 }

@@ -41,6 +41,7 @@ struct DevScene {
     const float* vnormals;    // n_prims*9
     const float* precom;      // n_prims*9  (v1-v0, v2-v0, v0) | sphere (centre, rrr, centre)
     const int* prim_obj;      // n_prims
+    const int* prim_class;    // n_prims: material class of the owning object (sorted shading), see APT_CLASS_* in api.hip
     const int* obj_info;      // n_objects*3
     const int* emitter_id;    // n_objects
     const DevBxdf* bxdf;      // n_objects
@@ -74,6 +75,19 @@ struct Queues {
     float* sh_o; float* sh_d; float* sh_tmax; float* sh_c; uint32_t* sh_id;
     float* L;                                    // 3 components, indexed by path id
     uint32_t sh_cap, sh_subcap;
+    // Material-sorted shading (scenes with >= 2 material classes): extend drops misses and appends each hit
+    // path's full record (ray + state + hit, 64 B) to the dense queue of its material class, so every shade
+    // launch runs one specialised kernel over coherent waves.  n_classes == 0: unsorted (single-class scenes).
+    struct ClassQ { float* ray_o; float* ray_d; float* thr; uint32_t* id; uint32_t* meta; float* pdf; float* t; int* prim; float* u; float* v; };
+    ClassQ cls[6];
+    int n_classes;
+};
+#define APT_MAX_CLASSES 6
+// what one shade launch reads: either ray queue `cur` + the hit arrays (unsorted) or one class queue (sorted)
+struct ShadeIn {
+    const float* ray_o; const float* ray_d; const float* thr; const uint32_t* id; const uint32_t* meta; const float* pdf;
+    const float* t; const int* prim; const float* u; const float* v;
+    const uint32_t* counts;                      // per-sub-queue entry counts (stride CNT_PAD)
 };
 
 #define APT_MAX_NQ 32
@@ -82,6 +96,7 @@ enum { ST_SAMPLES = 0, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_SHADOW_TRACED, ST_LIT,
 struct Counters {
     uint32_t n_active[2][APT_MAX_NQ * CNT_PAD];
     uint32_t n_shadow[APT_MAX_NQ * CNT_PAD];
+    uint32_t n_cls[6][APT_MAX_NQ * CNT_PAD];
     unsigned long long stats[APT_MAX_NQ][16];    // [q][ST_*], 128 bytes per sub-queue
 };
 
@@ -205,7 +220,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
 // next-ray queue of this bounce (it was the current queue of the previous bounce) and the
 // shadow queue.  `n_src` = per-sub-queue counts (normally cnt->n_active[cur]).
 // MODE 0: BVH traversal (LDS-staged nodes + per-lane LDS stack); MODE 1: wave-uniform sweep (small scenes)
-template <int MODE>
+template <int MODE, int SORTED>
 __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
     StagedBvh bvh;
     int* my_stack = nullptr;
@@ -227,7 +242,25 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, Params p, Queues 
         HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
         if (MODE == 0) traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
         else sweep<false>(sc.sweep, o, d, rec);
-        if (valid) { q.hit_t[idx] = rec.t; q.hit_prim[idx] = rec.prim; q.hit_u[idx] = rec.u; q.hit_v[idx] = rec.v; }
+        if (!SORTED) {
+            if (valid) { q.hit_t[idx] = rec.t; q.hit_prim[idx] = rec.prim; q.hit_u[idx] = rec.u; q.hit_v[idx] = rec.v; }
+        } else {
+            // sort by material class: one ballot-compacted append per class present in the scene; misses vanish here
+            const int cls = (valid && rec.prim >= 0) ? sc.prim_class[rec.prim] : -1;
+            for (int c = 0; c < q.n_classes; c++) {
+                const bool mine = cls == c;
+                const uint32_t cpos = wave_append(mine, &cnt->n_cls[c][sl.q * CNT_PAD]);
+                if (mine) {
+                    const Queues::ClassQ& k = q.cls[c];
+                    const uint32_t slot = qbase + cpos;
+                    k.ray_o[slot] = o.x; k.ray_o[p.cap + slot] = o.y; k.ray_o[2 * p.cap + slot] = o.z;
+                    k.ray_d[slot] = d.x; k.ray_d[p.cap + slot] = d.y; k.ray_d[2 * p.cap + slot] = d.z;
+                    k.thr[slot] = q.thr[cur][idx]; k.thr[p.cap + slot] = q.thr[cur][p.cap + idx]; k.thr[2 * p.cap + slot] = q.thr[cur][2 * p.cap + idx];
+                    k.id[slot] = q.id[cur][idx]; k.meta[slot] = q.meta[cur][idx]; k.pdf[slot] = q.pdf[cur][idx];
+                    k.t[slot] = rec.t; k.prim[slot] = rec.prim; k.u[slot] = rec.u; k.v[slot] = rec.v;
+                }
+            }
+        }
     }
 }
 
@@ -252,10 +285,10 @@ APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3
 
 // BM / SM: material and emitter masks of the scene (shading.hpp); code for absent models is compiled out.
 template <int BM, int SM>
-__global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, int cur, int bounce) {
+__global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
-    const uint32_t n = cnt->n_active[cur][sl.q * CNT_PAD];
+    const uint32_t n = in.counts[sl.q * CNT_PAD];
     const uint32_t qbase = (uint32_t)sl.q * p.subcap, sh_qbase = (uint32_t)sl.q * q.sh_subcap;
     uint32_t* next_counter = &cnt->n_active[nxt][sl.q * CNT_PAD];
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
@@ -275,17 +308,17 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
         float emission_weight = 1.0f;
         DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
         if (alive) {
-            int prim = q.hit_prim[idx];
+            int prim = in.prim[idx];
             if (prim < 0) alive = false;                         // nothing hit: path ends (vanilla_renderer.py:49)
             else {
-                o = mk3(q.ray_o[cur][idx], q.ray_o[cur][p.cap + idx], q.ray_o[cur][2 * p.cap + idx]);
-                d = mk3(q.ray_d[cur][idx], q.ray_d[cur][p.cap + idx], q.ray_d[cur][2 * p.cap + idx]);
-                thr = mk3(q.thr[cur][idx], q.thr[cur][p.cap + idx], q.thr[cur][2 * p.cap + idx]);
-                id = q.id[cur][idx];
-                uint32_t meta = q.meta[cur][idx];
-                ray_pdf = q.pdf[cur][idx];
+                o = mk3(in.ray_o[idx], in.ray_o[p.cap + idx], in.ray_o[2 * p.cap + idx]);
+                d = mk3(in.ray_d[idx], in.ray_d[p.cap + idx], in.ray_d[2 * p.cap + idx]);
+                thr = mk3(in.thr[idx], in.thr[p.cap + idx], in.thr[2 * p.cap + idx]);
+                id = in.id[idx];
+                uint32_t meta = in.meta[idx];
+                ray_pdf = in.pdf[idx];
                 was_spec = (meta >> 24) & 1u;
-                build_hit(sc, prim, q.hit_t[idx], q.hit_u[idx], q.hit_v[idx], o, d, it);
+                build_hit(sc, prim, in.t[idx], in.u[idx], in.v[idx], o, d, it);
                 bx = sc.bxdf[it.obj_id];
                 hit_light = sc.emitter_id[it.obj_id];
                 uint32_t lp = id % (uint32_t)p.npix, s = id / (uint32_t)p.npix;
@@ -414,7 +447,10 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, Params p, Queues 
     if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
     const SubLoop sl = sub_loop(p.nq);
     const uint32_t n = min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
-    if (sl.first == 0 && threadIdx.x == 0) cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
+    if (sl.first == 0 && threadIdx.x == 0) {
+        cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
+        for (int c = 0; c < q.n_classes; c++) cnt->n_cls[c][sl.q * CNT_PAD] = 0;      // every shade of this bounce is done
+    }
     const uint32_t qbase = (uint32_t)sl.q * q.sh_subcap, sc_ = q.sh_cap;
     uint32_t t_lit = 0;
     for (uint32_t base = sl.first; base < n; base += sl.stride) {

@@ -139,9 +139,10 @@ APT_D bool traverse(const StagedBvh& bvh, int* stack, int stride, f3 o, f3 d, Hi
 // Scene tables are immutable while a renderer exists, so the sweep reads them through the constant
 // address space: with a wave-uniform index the backend then selects s_load_dwordx4 (SGPR operands,
 // scalar cache) instead of a vector global load per lane.
-typedef const float4 __attribute__((address_space(4))) * cf4_ptr;
 typedef const float __attribute__((address_space(4))) * cf_ptr;
 typedef const int __attribute__((address_space(4))) * ci_ptr;
+// 16-byte aligned record quarter -> float4 (four adjacent scalar dwords; merged into one s_load_dwordx4)
+APT_D float4 ld4c(cf_ptr p) { return make_float4(p[0], p[1], p[2], p[3]); }
 struct SweepScene {
     const float4* recs;       // 4 float4 per primitive, ORIGINAL order:
                               //   triangle (p0, e1.x) (e1.yz, e2.xy) (e2.z, n.xyz) with n = t-row cofactors of [e1 e2 .]
@@ -154,7 +155,7 @@ struct SweepScene {
 template <bool ANY>
 APT_D bool sweep(const SweepScene& sc, f3 o, f3 d, HitRec& rec) {
     bool found = false;                                   // ANY: this lane already has its answer
-    const cf4_ptr recs = (cf4_ptr)sc.recs;
+    const cf_ptr recs = (cf_ptr)(const float*)sc.recs;
     const cf_ptr aabb = (cf_ptr)sc.obj_aabb;
     const ci_ptr info = (ci_ptr)sc.obj_info;
     const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -173,7 +174,7 @@ APT_D bool sweep(const SweepScene& sc, f3 o, f3 d, HitRec& rec) {
         }
         if (!__any(need)) continue;                       // wave-uniform skip
         if (info[3 * ob + 2]) {
-            float4 q0 = recs[4 * first];
+            float4 q0 = ld4c(recs + 16 * first);
             f3 s2c = mk3(q0.x, q0.y, q0.z) - o;
             float r2 = q0.w * q0.w;
             float cn2 = norm2(s2c), proj = dot(d, s2c);
@@ -186,7 +187,7 @@ APT_D bool sweep(const SweepScene& sc, f3 o, f3 d, HitRec& rec) {
             }
         } else {
             for (int k = first; k < first + count; k++) {
-                float4 q0 = recs[4 * k], q1 = recs[4 * k + 1], q2 = recs[4 * k + 2];
+                float4 q0 = ld4c(recs + 16 * k), q1 = ld4c(recs + 16 * k + 4), q2 = ld4c(recs + 16 * k + 8);
                 float a00 = q0.w, a10 = q1.x, a20 = q1.y;      // e1
                 float a01 = q1.z, a11 = q1.w, a21 = q2.x;      // e2
                 float a02 = -d.x, a12 = -d.y, a22 = -d.z;
