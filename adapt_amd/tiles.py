@@ -18,7 +18,7 @@ from typing import Optional
 
 import numpy as np
 
-__all__ = ["TilePlan", "gather_tiles", "gather_image", "assemble"]
+__all__ = ["TilePlan", "gather_tiles", "gather_image", "assemble", "device_tile"]
 
 
 class TilePlan:
@@ -64,13 +64,15 @@ class _DevView:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
 
 
-def gather_tiles(tile, plan: TilePlan, rank: int, world_size: int, group=None) -> np.ndarray:
+def gather_tiles(tile, plan: TilePlan, rank: int, world_size: int, group=None, force_collective: bool = False) -> np.ndarray:
     """All-gather the per-rank tiles and assemble the full image (returned on every rank).
 
     `tile` is this rank's (n_cols, H, 3) float32 data: a numpy array (CPU / gloo) or a torch
-    tensor already on the GPU (nccl)."""
-    if world_size == 1:
-        return assemble(plan, [np.asarray(tile)])
+    tensor already on the GPU (nccl).  A single rank needs no collective unless `force_collective`
+    (used to exercise the RCCL path on a one-GPU box)."""
+    if world_size == 1 and not force_collective:
+        t = tile.detach().cpu().numpy() if hasattr(tile, "detach") else np.asarray(tile)
+        return assemble(plan, [t])
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
@@ -84,20 +86,32 @@ def gather_tiles(tile, plan: TilePlan, rank: int, world_size: int, group=None) -
     return assemble(plan, out.view(world_size, mc, plan.height, 3).cpu().numpy())
 
 
-def gather_image(rdr, normalised: bool = True, group=None) -> np.ndarray:
+def device_tile(rdr):
+    """This rank's accumulation tile as a torch tensor on its GPU: a zero-copy view of the renderer's
+    framebuffer (apt_device_ptr) when torch accepts the raw pointer, else a staged host copy."""
+    import torch
+    dev = torch.device(f"cuda:{rdr.device}")
+    try:
+        view = _DevView(rdr.device_accum_ptr(), (rdr.n_cols, rdr.h, 3))
+        return torch.as_tensor(view, device=dev).clone()
+    except Exception:
+        return torch.from_numpy(rdr.tile_accum()).to(dev)
+
+
+def gather_image(rdr, normalised: bool = True, group=None, force_collective: bool = False) -> np.ndarray:
     """Full (W, H, 3) image from a sharded `Renderer` (every rank must call)."""
     rdr.synchronize()
     tile: Optional[object] = None
-    try:
-        import torch
-        if torch.cuda.is_available() and rdr.world_size > 1:
-            view = _DevView(rdr.device_accum_ptr(), (rdr.n_cols, rdr.h, 3))
-            tile = torch.as_tensor(view, device=f"cuda:{rdr.device}").clone()
-    except ImportError:
-        tile = None
+    if rdr.world_size > 1 or force_collective:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                tile = device_tile(rdr)
+        except ImportError:
+            tile = None
     if tile is None:
         tile = rdr.tile_accum()
-    img = gather_tiles(tile, rdr.plan, rdr.rank, rdr.world_size, group)
+    img = gather_tiles(tile, rdr.plan, rdr.rank, rdr.world_size, group, force_collective)
     if normalised and rdr._cnt > 0:
         img = img / np.float32(rdr._cnt)
     return img

@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--spp-per-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded oracle sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
+    ap.add_argument("--single-device", action="store_true", help="dry run: every rank renders on cuda:0 (use with --backend gloo on a one-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -85,16 +87,21 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no HIP device visible; the render path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from adapt_amd import scene_parsing
     from adapt_amd.renderer import Renderer
-    from adapt_amd.tiles import gather_image
+    from adapt_amd.tiles import gather_image, gather_tiles
 
     sdir, sfile, W, H, spp, bounces, label = CONFIGS[args.config]
     if args.spp > 0:
@@ -107,8 +114,10 @@ def main():
 
     def step():
         rdr.render(n_spp=spp_step)
-        if world > 1:
+        if world > 1 and args.backend == "nccl":
             gather_image(rdr, normalised=False)          # all_gather of the per-rank tiles over RCCL
+        elif world > 1:
+            gather_tiles(rdr.tile_accum(), rdr.plan, rank, world)
         else:
             rdr.synchronize()
 
@@ -128,7 +137,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     st = rdr.stats()
@@ -144,8 +153,18 @@ def main():
     per_launch_bytes = kb[dom] / max(1, launches)
     avg_ms = kms[dom] / max(1, launches)
     achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM-side bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE/WRITE_SIZE cannot be read from inside the process):
+    # measured bytes per queue unit of that kernel (profiles/) x the units one launch of THIS run processed
+    traffic, traffic_src = None, None
+    tfile = os.path.join(ROOT, "profiles", f"r01_{args.config}_traffic.json")
+    if os.path.exists(tfile):
+        tj = json.load(open(tfile))
+        units = {"extend": st["n_extend"], "shade": st["n_extend"], "shadow": st["n_shadow_traced"]}
+        if dom in tj["kernels"] and dom in units:
+            traffic = int(tj["kernels"][dom]["bytes_per_unit"] * units[dom] / max(1, launches))
+            traffic_src = tj["source"]
     roofline = {"bound": "hbm", "kernel": f"k_{dom}", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_launch": int(per_launch_bytes), "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
                 "per_kernel": {k: {"ms": round(kms[k], 3), "launches": int(st["launches"][k]), "alg_bytes": int(kb[k]),
                                    "GB/s": round(kb[k] / (kms[k] * 1e-3) / 1e9, 1) if kms[k] > 0 else 0.0} for k in kms},

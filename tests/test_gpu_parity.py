@@ -309,3 +309,28 @@ def test_full_size_c4_scene_properties():
     m = image_metrics(win, img[352:448, 268:332])
     assert m["frac_within"] >= 0.995, m           # two shadow rays per bounce: float atomics may reorder, nothing else differs
     r.close(); c.close()
+
+
+def test_rccl_gather_path_on_one_gpu(renderer):
+    """The multi-GPU readback path with a world of one: torch.distributed backend "nccl" (= RCCL), the zero-copy view of the
+    renderer's device framebuffer, all_gather_into_tensor, tile assembly.  (N > 1 is covered by the gloo test on CPU.)"""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from adapt_amd.tiles import device_tile, gather_image
+    r = renderer("cbox", width=96, height=64)
+    r.render(n_spp=3)
+    local = r.color.to_numpy()
+    t = device_tile(r)
+    assert t.is_cuda and tuple(t.shape) == (96, 64, 3) and np.array_equal(t.cpu().numpy(), local)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        img = gather_image(r, normalised=False, force_collective=True)
+        assert np.array_equal(img, local)
+        img = gather_image(r, normalised=True, force_collective=True)
+        assert np.array_equal(img, local / np.float32(3))
+    finally:
+        dist.destroy_process_group()
