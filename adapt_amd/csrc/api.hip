@@ -283,7 +283,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     r->npix = r->n_cols * c.height;
     if (r->npix <= 0) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: this rank owns no pixels"); }
     int B = c.spp_per_batch;
-    if (B <= 0) { B = (int)((4u << 20) / (uint32_t)r->npix); if (B < 1) B = 1; if (B > 64) B = 64; }
+    if (B <= 0) { B = (int)((8u << 20) / (uint32_t)r->npix); if (B < 1) B = 1; if (B > 64) B = 64; }   // ~8 Mi paths in flight (measured plateau from ~4 Mi)
     r->spp_batch = B;
     const int S = c.num_shadow_ray;
     const int nq = r->nq;

@@ -334,3 +334,34 @@ def test_rccl_gather_path_on_one_gpu(renderer):
         assert np.array_equal(img, local / np.float32(3))
     finally:
         dist.destroy_process_group()
+
+
+def test_full_size_c4_crop_matches_brute_force_oracle():
+    """Full 95 050-triangle scene, a cropped window, HIP (BVH traversal) vs the oracle's BRUTE-FORCE intersector: the
+    HIP tree returns the brute-force hit.  (The reference's own BVH, as restated in the oracle, drops ~2e-4 of the hits
+    on this scene — its node boxes are unpadded — so it is compared statistically below, not per pixel.)"""
+    from adapt_amd.renderer import Renderer
+    from adapt_amd.scene_pack import pack_scene
+    from adapt_amd.synth import three_bunnies
+    from oracle import binding as ob
+    em, arr, objs, cfg = three_bunnies()
+    cfg = dict(cfg); cfg["film"] = {"width": 800, "height": 800, "crop_x": 330, "crop_y": 250, "crop_rx": 20, "crop_ry": 14}
+    r = Renderer(em, arr, objs, cfg)
+    r.render(n_spp=2)
+    img = r.color.to_numpy()[310:350, 236:264]
+    rc = make_config(cfg)
+    assert rc.do_crop and rc.use_bvh
+    sc = ob.OracleScene(pack_scene(em, arr, objs, cfg), rc.cam_t, build_bvh=True)
+    rc.use_bvh = False
+    ref, _, ost = sc.render(rc, 2)
+    m = image_metrics(img / 2, ref[310:350, 236:264] / 2)
+    st = r.stats()
+    assert st["n_samples"] == ost["n_samples"] == 2 * 40 * 28
+    assert m["frac_within"] >= 0.99 and m["relMSE"] <= 2e-4, m
+    assert abs(st["n_draws"] - ost["n_draws"]) <= 2e-3 * ost["n_draws"]
+    # reference-layout BVH in the oracle: same picture up to its rare lost hits
+    rc.use_bvh = True
+    ref_bvh, _, _ = sc.render(rc, 2)
+    mb = image_metrics(img / 2, ref_bvh[310:350, 236:264] / 2)
+    assert mb["frac_within"] >= 0.97, mb
+    r.close()

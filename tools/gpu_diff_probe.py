@@ -9,16 +9,20 @@ from adapt_amd.scene_pack import make_config, pack_scene
 from oracle import binding as ob
 
 d, f, w, h = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-parsed = scene_parsing(d, f)
+if d == "synth":
+    from adapt_amd.synth import SYNTH_SCENES
+    parsed = SYNTH_SCENES[f]()
+else:
+    parsed = scene_parsing(d, f)
 rdr = Renderer(*parsed, width=w, height=h)
 rdr.render(n_spp=1)
 acc = rdr.color.to_numpy()
 fs = pack_scene(*parsed); rc = make_config(parsed[3], width=w, height=h)
-osc = ob.OracleScene(fs, rc.cam_t)
+osc = ob.OracleScene(fs, rc.cam_t, build_bvh=rc.use_bvh)
 ref, _, _ = osc.render(rc, 1)
 diff = np.abs(acc - ref).max(axis=2)
 order = np.argsort(-diff.reshape(-1))[:12]
-print("pixels with |diff| > 1e-4:", int((diff > 1e-4).sum()), "of", w * h)
+print("pixels with |diff| > 1e-4:", int((diff > 1e-4).sum()), "of", w * h, "sum hip", float(acc.sum()), "sum ref", float(ref.sum()))
 types = fs.bxdf_i[:, 0]; isb = fs.bxdf_i[:, 2]
 for p in order:
     i, j = divmod(int(p), h)
