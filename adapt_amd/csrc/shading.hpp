@@ -76,7 +76,8 @@ APT_D f3 reflect_in(f3 ray, f3 normal, float& d) {
     d = dot(normal, ray);
     return normalize(ray - (normal * 2.f) * d);
 }
-APT_D float pow5(float x) { return apt_pow(x, 5.f); }
+// pow(x, 5) with a constant integer exponent: multiplication chain by squaring, x * ((x*x)*(x*x)) (float parity)
+APT_D float pow5(float x) { float x2 = x * x; float x4 = x2 * x2; return x * x4; }
 APT_D f3 schlick(f3 r_s, float dot_val) {
     float p = pow5(1.f - dot_val);
     return r_s + mk3(1.f - r_s.x, 1.f - r_s.y, 1.f - r_s.z) * p;

@@ -161,16 +161,29 @@ APT_D bool sweep(const SweepScene& sc, f3 o, f3 d, HitRec& rec) {
     const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     for (int ob = 0; ob < sc.n_objects; ob++) {
         const int first = info[3 * ob], count = info[3 * ob + 1];
-        // Per-object slab cull (TracerBase.aabb_test, tracer_base.py:159-166).  Upstream it is a per-ray
-        // filter in front of primitives that lie INSIDE the box (flat objects are padded by 2e-2), so it can
-        // only change which tests are skipped, never which hit wins.  Here it exists to skip an object for the
-        // whole wave; objects of one or two primitives are cheaper to test than to cull.
+        // Per-object slab cull (TracerBase.aabb_test, tracer_base.py:159-166 and the `t_near > min_depth`
+        // skip at :184).  It is part of the result, not just a speed-up: a ray with a zero direction
+        // component whose origin sits on (or a rounding error outside) a slab boundary is culled upstream
+        // even though the triangle test would accept it.  The reference divides by the ray; dividing six
+        // times per object costs more than testing a triangle, so a reciprocal-multiply version with an
+        // error band decides the clear cases and only lanes inside the band (or with non-finite slabs)
+        // take the division path.
         bool need = !found;
-        if (count > 2) {
+        {
             const cf_ptr bb = aabb + 6 * ob;
-            f3 t0 = (mk3(bb[0], bb[1], bb[2]) - o) * inv_d, t1 = (mk3(bb[3], bb[4], bb[5]) - o) * inv_d;
+            const f3 lo = mk3(bb[0], bb[1], bb[2]) - o, hi = mk3(bb[3], bb[4], bb[5]) - o;
+            f3 t0 = lo * inv_d, t1 = hi * inv_d;
             float tn = max3(min3v(t0, t1)), tf = min3(max3v(t0, t1));
-            need = need && (tn <= tf) && tf > 0.f && !(tn > rec.t);
+            const float band = 2e-6f * (fabsf(tn) + fabsf(tf));
+            const bool pass = (tn + band < tf) && (tf > 1e-30f) && (tn + band < rec.t);
+            const bool fail = (tn > tf + band) || (tf < 0.f) || (tn > rec.t + band);
+            bool ok = pass;
+            if (!(pass || fail)) {
+                t0 = mk3(lo.x / d.x, lo.y / d.y, lo.z / d.z); t1 = mk3(hi.x / d.x, hi.y / d.y, hi.z / d.z);
+                tn = max3(min3v(t0, t1)); tf = min3(max3v(t0, t1));
+                ok = (tn < tf) && tf > 0.f && !(tn > rec.t);
+            }
+            need = need && ok;
         }
         if (!__any(need)) continue;                       // wave-uniform skip
         if (info[3 * ob + 2]) {

@@ -132,7 +132,7 @@ class OracleScene:
     def trace_sample(self, rc, i, j, cnt, script=None, max_events=64):
         cfg = make_cfg(rc)
         col = np.zeros(3, np.float32)
-        ev = np.zeros((max_events, 12), np.float32)
+        ev = np.zeros((max_events, 18), np.float32)     # obj, prim, t, direct rgb, emit*w rgb, throughput rgb, next ray o, d
         ne, nd = C.c_int(0), C.c_int(0)
         if script is not None:
             sc = np.ascontiguousarray(script, np.float64)

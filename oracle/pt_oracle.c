@@ -20,7 +20,7 @@
  * (requirements.txt:1) supplies vector ops, the 3x3 inverse and the RNG.  Restated
  * here from Taichi's published matrix code: normalized(v) = (1/sqrt(v.v)) * v,
  * sum/dot accumulate left to right, 3x3 inverse = adjugate * (1/det) with
- * det expanded along column 0.  The RNG (ti.random) is replaced by a counter-based
+ * det expanded along column 0, pow(x, constant int) = multiplication chain by squaring.  The RNG (ti.random) is replaced by a counter-based
  * Philox-4x32-10 stream — key (pixel, seed), counter (sample, draw/4) — the same
  * stream the HIP path uses; draw ORDER follows the reference source.
  *
@@ -73,7 +73,10 @@ static inline v3 m3mulv(const m3* M, v3 a) {
              (M->m[1][0] * a.x + M->m[1][1] * a.y) + M->m[1][2] * a.z,
              (M->m[2][0] * a.x + M->m[2][1] * a.y) + M->m[2][2] * a.z);
 }
-static inline float sq(float x) { return x * x; }   /* ti.pow(x, 2) / x ** 2: integer power -> x*x */
+/* Integer powers: Taichi lowers pow(x, n) with a constant integer n to exponentiation by squaring
+ * (x^2 = x*x, x^5 = x * ((x*x)*(x*x))), not to a libm call. */
+static inline float sq(float x) { return x * x; }
+static inline float pow5i(float x) { float x2 = x * x; float x4 = x2 * x2; return x * x4; }
 static inline float signf_(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 
 static const v3 ZERO3 = {0.f, 0.f, 0.f};
@@ -282,7 +285,7 @@ static v3 inci_reflect_dir(v3 ray, v3 normal, float* dot_out) {
     return vnormalized(vsub(ray, vscale(vscale(normal, 2.f), d)));
 }
 static v3 schlick_fresnel(v3 r_s, float dot_val) {
-    float p = powf(1.f - dot_val, 5.f);
+    float p = pow5i(1.f - dot_val);
     return vadd(r_s, vscale(V(1.f - r_s.x, 1.f - r_s.y, 1.f - r_s.z), p));
 }
 static float fresnel_equation(float n_in, float n_out, float cos_inc, float cos_ref) {
@@ -435,8 +438,8 @@ static v3 eval_fresnel_blend(const bxdf_t* b, const isect_t* it, v3 ray_in, v3 r
         v3 kd = diffuse_color(b, it);
         v3 diffuse = vmul(vscale(kd, (float)(28. / (23. * 3.14159265358979323846))),
                           V(1.f - b->k_s.x, 1.f - b->k_s.y, 1.f - b->k_s.z));
-        float pow5_in = powf(1.f - dot_in / 2.f, 5.f);
-        float pow5_out = powf(1.f - dot_out / 2.f, 5.f);
+        float pow5_in = pow5i(1.f - dot_in / 2.f);
+        float pow5_out = pow5i(1.f - dot_out / 2.f);
         diffuse = vscale(diffuse, (1.f - pow5_in) * (1.f - pow5_out));
         spec = vscale(vadd(specular, diffuse), dot_out);
     }
@@ -1279,7 +1282,7 @@ static v3 pix2ray(const ctx_t* c, int i, int j, int cnt, rng_t* r) {
  * sample's colour with NaN components zeroed (line 119). */
 typedef struct {
     int max_events; int n_events;
-    float* ev;       /* per bounce: [obj_id, prim_id, min_depth, direct_int xyz, emit*w xyz, contribution xyz] = 12 floats */
+    float* ev;       /* per bounce: [obj_id, prim_id, min_depth, direct_int xyz, emit*w xyz, contribution xyz, next ray o xyz, d xyz] = 18 floats */
 } trace_t;
 
 static v3 render_sample(const ctx_t* c, int i, int j, int cnt, rng_t* rng, orc_stats* st, trace_t* tr) {
@@ -1339,12 +1342,13 @@ static v3 render_sample(const ctx_t* c, int i, int j, int cnt, rng_t* rng, orc_s
         v3 indirect_spec; float ray_pdf; int is_specular;
         v3 new_d = pt_sample_new_ray(c, &it, ray_d, rng, &indirect_spec, &ray_pdf, &is_specular);
         if (tr && tr->n_events < tr->max_events) {
-            float* e = tr->ev + 12 * tr->n_events++;
+            float* e = tr->ev + 18 * tr->n_events++;
             v3 ew = vscale(emit_int, emission_weight);
             e[0] = (float)it.obj_id; e[1] = (float)it.prim_id; e[2] = it.min_depth;
             e[3] = direct_int.x; e[4] = direct_int.y; e[5] = direct_int.z;
             e[6] = ew.x; e[7] = ew.y; e[8] = ew.z;
             e[9] = contribution.x; e[10] = contribution.y; e[11] = contribution.z;
+            e[12] = hit_point.x; e[13] = hit_point.y; e[14] = hit_point.z; e[15] = new_d.x; e[16] = new_d.y; e[17] = new_d.z;
         }
         ray_d = new_d;
         ray_o = hit_point;

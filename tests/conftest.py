@@ -15,7 +15,12 @@ SCENES = {
     "cbox": (os.path.join(ROOT, "scenes", "cbox"), "c2_cbox.xml", "cbox"),
     "balls_mono": (os.path.join(ROOT, "scenes", "csphere"), "c3_balls_mono.xml", "balls_mono"),
     "glass_box": (os.path.join(ROOT, "scenes", "cbox"), "glass_box.xml", "complex"),
+    # feature coverage (scenes/test): all five emitter types, the remaining surface models, the sensor flags
+    "features_a": (os.path.join(ROOT, "scenes", "test"), "features_a.xml", "features_a"),
+    "features_b": (os.path.join(ROOT, "scenes", "test"), "features_b.xml", "features_b"),
+    "features_c": (os.path.join(ROOT, "scenes", "test"), "features_c.xml", "features_c"),
 }
+ALL_TAGS = list(SCENES)
 
 
 def pytest_configure(config):

@@ -290,3 +290,9 @@ if __name__ == "__main__":
         gen_scene("cbox", "cbox.xml", "cbox", 32, 32, 6, {"max_bounce": 8})
         gen_scene("csphere", "balls-mono.xml", "balls_mono", 24, 24, 3, {})
         gen_scene("cbox", "complex.xml", "complex", 20, 20, 3, {})
+    if a.only in ("all", "image", "features"):
+        # feature-coverage scenes authored in this repo (scenes/test/*.xml), run through the reference's own parser + kernel
+        test_dir = os.path.join(refenv.REPO, "scenes", "test")
+        gen_scene(test_dir, "features_a.xml", "features_a", 40, 30, 3, {}, n_rays=96)
+        gen_scene(test_dir, "features_b.xml", "features_b", 40, 30, 3, {}, n_rays=96)
+        gen_scene(test_dir, "features_c.xml", "features_c", 40, 30, 3, {}, n_rays=96)

@@ -40,7 +40,8 @@ def make_renderer(scene_dir, xml, overrides=None):
     """reference scene_parsing -> Renderer, with optional sensor overrides (width/height/max_bounce...)."""
     from parsers.xml_parser import scene_parsing
     from renderer.vanilla_renderer import Renderer
-    emitters, array_info, objs, cfg = scene_parsing(os.path.join(REFERENCE, "scenes", scene_dir), xml)
+    base = scene_dir if os.path.isabs(scene_dir) else os.path.join(REFERENCE, "scenes", scene_dir)
+    emitters, array_info, objs, cfg = scene_parsing(base, xml)
     for k, v in (overrides or {}).items():
         if k in ("width", "height"):
             cfg["film"][k] = v

@@ -255,8 +255,17 @@ _powf, atan2 = _m2("powf"), _m2("atan2f")
 
 
 def pow(x, y):
-    if _is_int(y) and y == 2:
-        return x * x
+    """pow with a constant integer exponent is exponentiation by squaring (what Taichi's simplifier emits), else powf.
+    NB: numpy's own `np.float32 ** 2` on SCALARS (used by a few reference lines) goes through powf and can be 1 ulp off x*x."""
+    if _is_int(y) and not isinstance(y, bool) and 0 < y <= 16:
+        result, base, n = None, x, int(y)
+        while n:
+            if n & 1:
+                result = base if result is None else result * base
+            n >>= 1
+            if n:
+                base = base * base
+        return result
     return _powf(x, y)
 
 
@@ -477,7 +486,25 @@ def is_active(snode, idx):
 
 
 # ------------------------------------------------------------------ decorators
-def func(f): return f
+def _as_f32(v):
+    """Inside a kernel every float is an f32 value: Python floats leaving a @ti.func become np.float32 (a Python
+    float would also raise on x / 0.0 where Taichi, like numpy, yields inf / nan)."""
+    if isinstance(v, float):
+        return f32(v)
+    if isinstance(v, tuple):
+        return tuple(_as_f32(x) for x in v)
+    return v
+
+
+def func(f):
+    import functools
+
+    @functools.wraps(f)
+    def wrapped(*a, **k):
+        return _as_f32(f(*a, **k))
+    return wrapped
+
+
 def kernel(f): return f
 def data_oriented(c): return c
 pyfunc = func

@@ -77,7 +77,7 @@ def test_bxdf_sample_vs_reference_vectors():
     assert not bad, [(k, int(m[k]), out[k], y[k]) for k in bad[:5]]
 
 
-@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box"])
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a"])
 def test_intersection_vs_reference_vectors(tag, renderer):
     g = golden(f"scene_{SCENES[tag][2]}.npz")
     r = renderer(tag, width=64, height=64)
@@ -92,7 +92,7 @@ def test_intersection_vs_reference_vectors(tag, renderer):
     assert np.array_equal(r.occluded(g["ray_o"], g["ray_d"], g["ray_tmax"]), g["ray_occ"])
 
 
-@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box"])
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a"])
 def test_intersection_vs_oracle_random_rays(tag, renderer, oracle_scene):
     rs = np.random.RandomState(7)
     n = 20000
@@ -113,7 +113,7 @@ def test_intersection_vs_oracle_random_rays(tag, renderer, oracle_scene):
     assert np.array_equal(r.occluded(o, d, tmax), sc.occluded(o, d, tmax))
 
 
-@pytest.mark.parametrize("tag", ["balls_mono", "glass_box"])
+@pytest.mark.parametrize("tag", ["balls_mono", "glass_box", "features_a", "features_c"])      # features_a: all five emitter types
 def test_emitters_vs_reference_vectors(tag, renderer):
     g = golden(f"scene_{SCENES[tag][2]}.npz")
     r = renderer(tag, width=64, height=64)
@@ -135,6 +135,11 @@ IMAGE_CASES = [
     ("cbox", 96, 96, 16, {}),
     ("balls_mono", 96, 96, 8, {}),
     ("glass_box", 96, 96, 8, {}),
+    # feature coverage: five emitter types + every remaining surface model; no RR / no MIS / two-sided / uniform jitter;
+    # single sphere emitter with pixel-centre rays and aggressive RR
+    ("features_a", 64, 48, 16, {}),
+    ("features_b", 64, 48, 16, {}),
+    ("features_c", 64, 48, 16, {}),
 ]
 
 
@@ -156,7 +161,7 @@ def test_image_matches_oracle_same_stream(tag, w, h, spp, ov, renderer, parsed, 
     assert r.cnt[None] == spp and np.array_equal(r.pixels.to_numpy(), acc / np.float32(spp))
 
 
-@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box"])
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_b", "features_c"])
 def test_image_matches_reference_run(tag, renderer):
     """Directly against the fixture recorded from the reference's own kernel (same Philox stream)."""
     g = golden(f"scene_{SCENES[tag][2]}.npz")
