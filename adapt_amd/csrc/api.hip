@@ -88,7 +88,7 @@ struct apt_scene {
     int device = 0;
     DevScene dev{};
     apt::BvhData bvh;
-    DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, obj_aabb;
+    DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
     int n_classes = 0;                   // material classes present (compact ids 0..n_classes-1)
     int class_def[APT_N_CLASS_DEFS] = {0, 0, 0, 0, 0, 0};   // compact id -> class definition
     int n_prims = 0, n_objects = 0, n_sources = 0;
@@ -195,16 +195,31 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         else { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = pc[0]; r[4] = pc[1]; r[5] = pc[2]; r[6] = pc[3]; r[7] = pc[4]; r[8] = pc[5]; }
         memcpy(&r[9], &kid, 4); memcpy(&r[10], &flag, 4);
     }
-    // sweep records, ORIGINAL primitive order (traverse.hpp SweepScene); the t-row cofactors of [e1 e2 .] are
+    // sweep stream in scene order (layout: traverse.hpp SweepScene); the t-row cofactors of [e1 e2 .] are
     // ray-independent, so they are computed once here with the same float operations the device would use
-    std::vector<float> sw((size_t)N * 16, 0.f);
-    for (int k = 0; k < N; k++) {
-        const float* v = d->prims + 9 * (size_t)k; const float* pc = prec.data() + 9 * (size_t)k; float* r = sw.data() + 16 * (size_t)k;
-        if (sphere[(size_t)k]) { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; continue; }
-        r[0] = v[0]; r[1] = v[1]; r[2] = v[2];
-        for (int a_ = 0; a_ < 6; a_++) r[3 + a_] = pc[a_];
-        const float a00 = pc[0], a10 = pc[1], a20 = pc[2], a01 = pc[3], a11 = pc[4], a21 = pc[5];
-        r[9] = a10 * a21 - a20 * a11; r[10] = a20 * a01 - a00 * a21; r[11] = a00 * a11 - a10 * a01;
+    std::vector<float> sw;
+    std::vector<int> sw_tab((size_t)O * 4, 0);
+    for (int o = 0; o < O; o++) {
+        const int first = d->obj_info[3 * o], count = d->obj_info[3 * o + 1], is_sphere = d->obj_info[3 * o + 2] != 0;
+        sw_tab[4 * (size_t)o] = (int)sw.size(); sw_tab[4 * (size_t)o + 1] = count; sw_tab[4 * (size_t)o + 2] = is_sphere; sw_tab[4 * (size_t)o + 3] = first;
+        size_t base = sw.size();
+        sw.resize(base + 8, 0.f);
+        if (d->obj_aabb) for (int a = 0; a < 3; a++) { sw[base + 2 * a] = d->obj_aabb[6 * o + a]; sw[base + 2 * a + 1] = d->obj_aabb[6 * o + 3 + a]; }
+        if (is_sphere) {
+            size_t at = sw.size(); sw.resize(at + 8, 0.f);
+            for (int a = 0; a < 4; a++) sw[at + a] = d->prims[9 * (size_t)first + a];
+            continue;
+        }
+        const int n_pairs = (count + 1) / 2;
+        size_t at = sw.size(); sw.resize(at + (size_t)n_pairs * 24, 0.f);
+        for (int k = 0; k < count; k++) {
+            const float* v = d->prims + 9 * (size_t)(first + k); const float* pc = prec.data() + 9 * (size_t)(first + k);
+            float* r = sw.data() + at + 24 * (size_t)(k / 2) + (k & 1);
+            const float a00 = pc[0], a10 = pc[1], a20 = pc[2], a01 = pc[3], a11 = pc[4], a21 = pc[5];
+            for (int a = 0; a < 3; a++) r[2 * a] = v[a];
+            for (int a = 0; a < 6; a++) r[6 + 2 * a] = pc[a];
+            r[18] = a10 * a21 - a20 * a11; r[20] = a20 * a01 - a00 * a21; r[22] = a00 * a11 - a10 * a01;
+        }
     }
     std::vector<float> aabb((size_t)O * 6, 0.f);
     if (d->obj_aabb) aabb.assign(d->obj_aabb, d->obj_aabb + (size_t)O * 6);
@@ -245,11 +260,11 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     std::vector<int> oi(d->obj_info, d->obj_info + (size_t)O * 3), ei(d->emitter_id, d->emitter_id + (size_t)O);
 #define UP(buf, vec) do { hipError_t e_ = upload(s->buf, vec); if (e_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload " #buf ": ") + hipGetErrorString(e_)); } } while (0)
     UP(nodes, s->bvh.nodes); UP(prims, recs); UP(normals, nrm); UP(vnormals, vn); UP(precom, prec); UP(prim_obj, prim_obj);
-    UP(obj_info, oi); UP(emitter_id, ei); UP(bxdf, bx); UP(src, sr); UP(sweep_recs, sw); UP(obj_aabb, aabb);
+    UP(obj_info, oi); UP(emitter_id, ei); UP(bxdf, bx); UP(src, sr); UP(sweep_recs, sw); UP(sweep_tab, sw_tab); UP(obj_aabb, aabb);
 #undef UP
     DevScene& ds = s->dev;
     ds.bvh.nodes = s->nodes.as<float4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.n_nodes = s->bvh.n_nodes(); ds.bvh.n_prims = N;
-    ds.sweep.recs = s->sweep_recs.as<float4>(); ds.sweep.obj_aabb = s->obj_aabb.as<float>(); ds.sweep.obj_info = s->obj_info.as<int>(); ds.sweep.n_objects = O;
+    ds.sweep.stream = s->sweep_recs.as<float>(); ds.sweep.obj_tab = s->sweep_tab.as<int>(); ds.sweep.n_objects = O;
     s->has_aabb = d->obj_aabb != nullptr;
     ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float>(); ds.precom = s->precom.as<float>();
     ds.prim_obj = s->prim_obj.as<int>(); ds.prim_class = s->prim_class.as<int>(); ds.obj_info = s->obj_info.as<int>(); ds.emitter_id = s->emitter_id.as<int>();

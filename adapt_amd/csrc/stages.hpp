@@ -224,6 +224,7 @@ template <int MODE, int SORTED>
 __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
     StagedBvh bvh;
     int* my_stack = nullptr;
+    __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
     if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
     const SubLoop sl = sub_loop(p.nq);
     const uint32_t n = n_src[sl.q * CNT_PAD];
@@ -241,7 +242,7 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, Params p, Queues 
         f3 d = mk3(rd[idx], rd[p.cap + idx], rd[2 * p.cap + idx]);
         HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
         if (MODE == 0) traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
-        else sweep<false>(sc.sweep, o, d, rec);
+        else sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
         if (!SORTED) {
             if (valid) { q.hit_t[idx] = rec.t; q.hit_prim[idx] = rec.prim; q.hit_u[idx] = rec.u; q.hit_v[idx] = rec.v; }
         } else {
@@ -444,6 +445,7 @@ template <int MODE>
 __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
     StagedBvh bvh;
     int* my_stack = nullptr;
+    __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
     if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
     const SubLoop sl = sub_loop(p.nq);
     const uint32_t n = min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
@@ -461,7 +463,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, Params p, Queues 
         f3 d = mk3(q.sh_d[idx], q.sh_d[sc_ + idx], q.sh_d[2 * sc_ + idx]);
         float dist = q.sh_tmax[idx];
         HitRec rec; rec.t = (dist > 0.0f) ? dist - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        const bool occluded = (MODE == 0) ? traverse<true>(bvh, my_stack, BLOCK, o, d, rec) : sweep_any(sc.sweep, o, d, rec);
+        const bool occluded = (MODE == 0) ? traverse<true>(bvh, my_stack, BLOCK, o, d, rec) : sweep_wg<true, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
         if (valid) {
             f3 c = mk3(q.sh_c[idx], q.sh_c[sc_ + idx], q.sh_c[2 * sc_ + idx]);
             // Upstream an occluded light sample still enters the sum as 0 * throughput; with a non-finite

@@ -141,84 +141,194 @@ APT_D bool traverse(const StagedBvh& bvh, int* stack, int stride, f3 o, f3 d, Hi
 // scalar cache) instead of a vector global load per lane.
 typedef const float __attribute__((address_space(4))) * cf_ptr;
 typedef const int __attribute__((address_space(4))) * ci_ptr;
-// 16-byte aligned record quarter -> float4 (four adjacent scalar dwords; merged into one s_load_dwordx4)
+// Two triangles per lane per instruction: gfx950 issues v_pk_mul_f32 / v_pk_add_f32 at the rate of their
+// scalar forms, and a packed multiply or add rounds each half exactly like the scalar instruction, so testing
+// triangles k and k+1 in the two halves of a 64-bit register pair halves the VALU work without touching a bit
+// of the result.  (No packed FMA is formed: -ffp-contract=off applies to vectors too.)
+typedef float v2f __attribute__((ext_vector_type(2)));
 APT_D float4 ld4c(cf_ptr p) { return make_float4(p[0], p[1], p[2], p[3]); }
+APT_D v2f ld2c(cf_ptr p) { v2f r; r.x = p[0]; r.y = p[1]; return r; }
+APT_D v2f sp2(float s) { v2f r; r.x = s; r.y = s; return r; }
+
+// Sweep stream (built in apt_scene_create), one block per object in scene order, 8-float aligned:
+//   [ (lo.x hi.x) (lo.y hi.y) (lo.z hi.z) 0 0 ]                        object slab bounds, interleaved
+//   sphere   : [ centre.xyz r 0 0 0 0 ]
+//   triangles: ceil(count/2) pair records of 24 floats, every quantity stored as (tri 2j, tri 2j+1):
+//              p0.x p0.y p0.z  e1.x e1.y e1.z  e2.x e2.y e2.z  n.x n.y n.z      n = t-row cofactors of [e1 e2 .]
+//              an odd tail is padded with an all-zero triangle (det = 0 -> NaN barycentrics -> never accepted)
 struct SweepScene {
-    const float4* recs;       // 4 float4 per primitive, ORIGINAL order:
-                              //   triangle (p0, e1.x) (e1.yz, e2.xy) (e2.z, n.xyz) with n = t-row cofactors of [e1 e2 .]
-                              //   sphere   (centre, r)
-    const float* obj_aabb;    // n_objects * 6
-    const int* obj_info;      // n_objects * 3: first prim, count, is_sphere
+    const float* stream;
+    const int* obj_tab;       // n_objects * 4: block offset (floats), primitive count, is_sphere, first primitive
     int n_objects;
 };
 
+// per-lane state shared by the object loop: packed broadcasts of the ray
+struct SweepRay {
+    v2f ox, oy, oz, a02, a12, a22;
+    APT_D void set(f3 o, f3 d) { ox = sp2(o.x); oy = sp2(o.y); oz = sp2(o.z); a02 = sp2(-d.x); a12 = sp2(-d.y); a22 = sp2(-d.z); }
+};
+
+// Per-object slab cull (TracerBase.aabb_test, tracer_base.py:159-166 and the `t_near > min_depth` skip at
+// :184).  It is part of the result, not just a speed-up: a ray with a zero direction component whose origin
+// sits on (or a rounding error outside) a slab boundary is culled upstream even though the triangle test
+// would accept it.  The reference divides by the ray; dividing six times per object costs more than testing
+// a triangle, so a reciprocal-multiply version with an error band decides the clear cases and only lanes
+// inside the band (or with non-finite slabs) take the division path.
+APT_D bool object_cull(cf_ptr blk, const SweepRay& r, f3 d, f3 inv_d, float t_best) {
+    const v2f bx = ld2c(blk) - r.ox, by = ld2c(blk + 2) - r.oy, bz = ld2c(blk + 4) - r.oz;     // (lo - o, hi - o) per axis
+    v2f tx = bx * sp2(inv_d.x), ty = by * sp2(inv_d.y), tz = bz * sp2(inv_d.z);
+    float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
+    float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
+    const float band = 2e-6f * (fabsf(tn) + fabsf(tf));
+    const bool pass = (tn + band < tf) && (tf > 1e-30f) && (tn + band < t_best);
+    const bool fail = (tn > tf + band) || (tf < 0.f) || (tn > t_best + band);
+    bool ok = pass;
+    if (!(pass || fail)) {
+        tx.x = bx.x / d.x; tx.y = bx.y / d.x; ty.x = by.x / d.y; ty.y = by.y / d.y; tz.x = bz.x / d.z; tz.y = bz.y / d.z;
+        tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
+        tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
+        ok = (tn < tf) && tf > 0.f && !(tn > t_best);
+    }
+    return ok;
+}
+
+// sphere record against the ray (tracer_base.py:184-199)
+template <bool ANY>
+APT_D void sphere_test(cf_ptr rec4, int first, f3 o, f3 d, bool need, bool& found, HitRec& rec) {
+    float4 q0 = ld4c(rec4);
+    f3 s2c = mk3(q0.x, q0.y, q0.z) - o;
+    float r2 = q0.w * q0.w;
+    float cn2 = norm2(s2c), proj = dot(d, s2c);
+    float c2ray = cn2 - proj * proj;
+    float cut = sqrtf(r2 - c2ray);
+    float t = proj + ((cn2 > r2 + 1e-4f) ? -cut : cut);
+    if (need && c2ray < r2 && t > 1e-4f && t < rec.t) {
+        if (ANY) found = true;
+        else { rec.t = t; rec.prim = first; rec.u = 0.f; rec.v = 0.f; }
+    }
+}
+
+// all pair records of one mesh object against the ray, in primitive order
+template <bool ANY>
+APT_D void pair_tests(cf_ptr recs, int count, int first, const SweepRay& s, bool& need, bool& found, HitRec& rec) {
+    const int n_pairs = (count + 1) >> 1;
+    for (int j = 0; j < n_pairs; j++) {
+        const cf_ptr r = recs + 24 * j;
+        const v2f a00 = ld2c(r + 6), a10 = ld2c(r + 8), a20 = ld2c(r + 10);      // e1
+        const v2f a01 = ld2c(r + 12), a11 = ld2c(r + 14), a21 = ld2c(r + 16);    // e2
+        const v2f c00 = a11 * s.a22 - a21 * s.a12, c01 = a21 * s.a02 - a01 * s.a22, c02 = a01 * s.a12 - a11 * s.a02;
+        const v2f det = (a00 * c00 + a10 * c01) + a20 * c02;
+        v2f inv_det; inv_det.x = 1.0f / det.x; inv_det.y = 1.0f / det.y;
+        const v2f sx = s.ox - ld2c(r), sy = s.oy - ld2c(r + 2), sz = s.oz - ld2c(r + 4);
+        const v2f c10 = s.a12 * a20 - s.a22 * a10, c11 = s.a22 * a00 - s.a02 * a20, c12 = s.a02 * a10 - s.a12 * a00;
+        const v2f u = ((inv_det * c00) * sx + (inv_det * c01) * sy) + (inv_det * c02) * sz;
+        const v2f v = ((inv_det * c10) * sx + (inv_det * c11) * sy) + (inv_det * c12) * sz;
+        const v2f t = ((inv_det * ld2c(r + 18)) * sx + (inv_det * ld2c(r + 20)) * sy) + (inv_det * ld2c(r + 22)) * sz;
+        const v2f uv = u + v;
+        // triangle 2j, then 2j+1: the reference's sequential `t < min_depth` update order
+        if (need && u.x >= 0.f && v.x >= 0.f && uv.x <= 1.0f && t.x > 1e-4f && t.x < rec.t) {
+            if (ANY) { found = true; need = false; }
+            else { rec.t = t.x; rec.prim = first + 2 * j; rec.u = u.x; rec.v = v.x; }
+        }
+        if (need && u.y >= 0.f && v.y >= 0.f && uv.y <= 1.0f && t.y > 1e-4f && t.y < rec.t) {
+            if (ANY) { found = true; need = false; }
+            else { rec.t = t.y; rec.prim = first + 2 * j + 1; rec.u = u.y; rec.v = v.y; }
+        }
+    }
+}
+
+// Wave-level sweep (unit-test entry kernels and anything launched without the workgroup scratch)
 template <bool ANY>
 APT_D bool sweep(const SweepScene& sc, f3 o, f3 d, HitRec& rec) {
     bool found = false;                                   // ANY: this lane already has its answer
-    const cf_ptr recs = (cf_ptr)(const float*)sc.recs;
-    const cf_ptr aabb = (cf_ptr)sc.obj_aabb;
-    const ci_ptr info = (ci_ptr)sc.obj_info;
+    const cf_ptr stream = (cf_ptr)sc.stream;
+    const ci_ptr tab = (ci_ptr)sc.obj_tab;
     const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    SweepRay sr; sr.set(o, d);
     for (int ob = 0; ob < sc.n_objects; ob++) {
-        const int first = info[3 * ob], count = info[3 * ob + 1];
-        // Per-object slab cull (TracerBase.aabb_test, tracer_base.py:159-166 and the `t_near > min_depth`
-        // skip at :184).  It is part of the result, not just a speed-up: a ray with a zero direction
-        // component whose origin sits on (or a rounding error outside) a slab boundary is culled upstream
-        // even though the triangle test would accept it.  The reference divides by the ray; dividing six
-        // times per object costs more than testing a triangle, so a reciprocal-multiply version with an
-        // error band decides the clear cases and only lanes inside the band (or with non-finite slabs)
-        // take the division path.
-        bool need = !found;
-        {
-            const cf_ptr bb = aabb + 6 * ob;
-            const f3 lo = mk3(bb[0], bb[1], bb[2]) - o, hi = mk3(bb[3], bb[4], bb[5]) - o;
-            f3 t0 = lo * inv_d, t1 = hi * inv_d;
-            float tn = max3(min3v(t0, t1)), tf = min3(max3v(t0, t1));
-            const float band = 2e-6f * (fabsf(tn) + fabsf(tf));
-            const bool pass = (tn + band < tf) && (tf > 1e-30f) && (tn + band < rec.t);
-            const bool fail = (tn > tf + band) || (tf < 0.f) || (tn > rec.t + band);
-            bool ok = pass;
-            if (!(pass || fail)) {
-                t0 = mk3(lo.x / d.x, lo.y / d.y, lo.z / d.z); t1 = mk3(hi.x / d.x, hi.y / d.y, hi.z / d.z);
-                tn = max3(min3v(t0, t1)); tf = min3(max3v(t0, t1));
-                ok = (tn < tf) && tf > 0.f && !(tn > rec.t);
-            }
-            need = need && ok;
-        }
+        const cf_ptr blk = stream + tab[4 * ob];
+        const int count = tab[4 * ob + 1], first = tab[4 * ob + 3];
+        bool need = !found && object_cull(blk, sr, d, inv_d, rec.t);
         if (!__any(need)) continue;                       // wave-uniform skip
-        if (info[3 * ob + 2]) {
-            float4 q0 = ld4c(recs + 16 * first);
-            f3 s2c = mk3(q0.x, q0.y, q0.z) - o;
-            float r2 = q0.w * q0.w;
-            float cn2 = norm2(s2c), proj = dot(d, s2c);
-            float c2ray = cn2 - proj * proj;
-            float cut = sqrtf(r2 - c2ray);
-            float t = proj + ((cn2 > r2 + 1e-4f) ? -cut : cut);
-            if (need && c2ray < r2 && t > 1e-4f && t < rec.t) {
-                if (ANY) found = true;
-                else { rec.t = t; rec.prim = first; rec.u = 0.f; rec.v = 0.f; }
-            }
-        } else {
-            for (int k = first; k < first + count; k++) {
-                float4 q0 = ld4c(recs + 16 * k), q1 = ld4c(recs + 16 * k + 4), q2 = ld4c(recs + 16 * k + 8);
-                float a00 = q0.w, a10 = q1.x, a20 = q1.y;      // e1
-                float a01 = q1.z, a11 = q1.w, a21 = q2.x;      // e2
-                float a02 = -d.x, a12 = -d.y, a22 = -d.z;
-                float c00 = a11 * a22 - a21 * a12, c01 = a21 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
-                float det = (a00 * c00 + a10 * c01) + a20 * c02;
-                float inv_det = 1.0f / det;
-                f3 s = o - mk3(q0.x, q0.y, q0.z);
-                float c10 = a12 * a20 - a22 * a10, c11 = a22 * a00 - a02 * a20, c12 = a02 * a10 - a12 * a00;
-                float u = ((inv_det * c00) * s.x + (inv_det * c01) * s.y) + (inv_det * c02) * s.z;
-                float v = ((inv_det * c10) * s.x + (inv_det * c11) * s.y) + (inv_det * c12) * s.z;
-                float t = ((inv_det * q2.y) * s.x + (inv_det * q2.z) * s.y) + (inv_det * q2.w) * s.z;
-                if (need && u >= 0.f && v >= 0.f && u + v <= 1.0f && t > 1e-4f && t < rec.t) {
-                    if (ANY) { found = true; need = false; }
-                    else { rec.t = t; rec.prim = k; rec.u = u; rec.v = v; }
-                }
+        if (tab[4 * ob + 2]) sphere_test<ANY>(blk + 8, first, o, d, need, found, rec);
+        else pair_tests<ANY>(blk + 8, count, first, sr, need, found, rec);
+        if (ANY && __all(found)) break;
+    }
+    return found;
+}
+
+// Workgroup-cooperative sweep.  A wave's 64 rays are incoherent after the first bounce, so the wave-uniform
+// skip above almost never fires for an object like a Cornell block even though only ~1/4 of the lanes pass its
+// slab cull.  For objects with APT_SWEEP_LIST_MIN or more primitives the block therefore gathers the lanes that
+// DO need the object into an LDS work list and its waves run the pair records over dense 64-ray chunks of that
+// list (ray and running-best state go through LDS).  Everything a ray sees is unchanged — objects in scene order,
+// the cull against its own running t, primitives in order — so the hit is bit-identical to sweep().
+// Must be called by every thread of the block (barriers inside); `lds` = APT_SWEEP_LDS_FLOATS floats.
+#define APT_SWEEP_LIST_MIN 6
+#define APT_SWEEP_MAX_LISTS 128
+#define APT_SWEEP_LDS_FLOATS(block) (11 * (block) + APT_SWEEP_MAX_LISTS)
+template <bool ANY, int NT>
+APT_D bool sweep_wg(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active, float* lds) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* s_ray = lds;                                    // o.xyz d.xyz, SoA over the block
+    float* s_t = lds + 6 * NT; int* s_prim = (int*)(lds + 7 * NT); float* s_u = lds + 8 * NT; float* s_v = lds + 9 * NT;
+    int* s_list = (int*)(lds + 10 * NT); int* s_count = (int*)(lds + 11 * NT);
+    bool found = false, staged = false;
+    int n_lists = 0;
+    const cf_ptr stream = (cf_ptr)sc.stream;
+    const ci_ptr tab = (ci_ptr)sc.obj_tab;
+    const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    SweepRay sr; sr.set(o, d);
+    for (int ob = 0; ob < sc.n_objects; ob++) {
+        const cf_ptr blk = stream + tab[4 * ob];
+        const int count = tab[4 * ob + 1], first = tab[4 * ob + 3], is_sphere = tab[4 * ob + 2];
+        bool need = active && !found && object_cull(blk, sr, d, inv_d, rec.t);
+        if (is_sphere || count < APT_SWEEP_LIST_MIN || n_lists >= APT_SWEEP_MAX_LISTS) {
+            if (!__any(need)) continue;
+            if (is_sphere) sphere_test<ANY>(blk + 8, first, o, d, need, found, rec);
+            else pair_tests<ANY>(blk + 8, count, first, sr, need, found, rec);
+            continue;
+        }
+        if (!staged) {
+            __syncthreads();                               // scratch may still be read by the previous tile
+            s_ray[tid] = o.x; s_ray[NT + tid] = o.y; s_ray[2 * NT + tid] = o.z;
+            s_ray[3 * NT + tid] = d.x; s_ray[4 * NT + tid] = d.y; s_ray[5 * NT + tid] = d.z;
+            if (tid < APT_SWEEP_MAX_LISTS) s_count[tid] = 0;
+            __syncthreads();
+            staged = true;
+        }
+        {   // gather the lanes that need this object
+            const unsigned long long m = __ballot(need);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_count[n_lists], (int)__popcll(m));
+            base = __shfl(base, 0);
+            if (need) {
+                s_list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = tid;
+                s_t[tid] = rec.t; s_prim[tid] = -1;
             }
         }
-        if (ANY && __all(found)) break;
+        __syncthreads();
+        const int L = s_count[n_lists];
+        for (int c = wave; c * 64 < L; c += NT / 64) {
+            const int li = c * 64 + lane;
+            bool has = li < L;
+            const int ti = s_list[has ? li : L - 1];
+            const f3 ro = mk3(s_ray[ti], s_ray[NT + ti], s_ray[2 * NT + ti]);
+            const f3 rd = mk3(s_ray[3 * NT + ti], s_ray[4 * NT + ti], s_ray[5 * NT + ti]);
+            SweepRay s2; s2.set(ro, rd);
+            HitRec r2; r2.t = s_t[ti]; r2.prim = -1; r2.u = r2.v = 0.f;
+            bool got = false;
+            const bool mine = has;
+            pair_tests<ANY>(blk + 8, count, first, s2, has, got, r2);
+            if (ANY) { if (mine && got) s_prim[ti] = 1; }
+            else if (mine && r2.prim >= 0) { s_t[ti] = r2.t; s_prim[ti] = r2.prim; s_u[ti] = r2.u; s_v[ti] = r2.v; }
+        }
+        __syncthreads();
+        if (need && s_prim[tid] >= 0) {
+            if (ANY) found = true;
+            else { rec.t = s_t[tid]; rec.prim = s_prim[tid]; rec.u = s_u[tid]; rec.v = s_v[tid]; }
+        }
+        n_lists++;
     }
     return found;
 }
