@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libadapt_mi.so")
+# ADAPT_MI_LIB: load another build of the same library (kernel tuning experiments); still no fallback.
+LIB_PATH = os.environ.get("ADAPT_MI_LIB") or os.path.join(_HERE, "libadapt_mi.so")
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)

@@ -20,7 +20,10 @@ HEADERS = ["vec.hpp", "rng.hpp", "shading.hpp", "traverse.hpp", "stages.hpp", "b
 # -ffp-contract=off: the arithmetic written in csrc/ is the arithmetic executed (no FMA fusion), which is what
 # lets the HIP path and the CPU oracle agree bit-for-bit on almost every path (DESIGN.md "float parity").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
-         "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+         # every queue/list append here is already aggregated per wave by hand (ballot + one atomic from lane 0);
+         # LLVM's atomic optimizer would wrap that in a second aggregation and serialise independent atomics
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 
 
 def hipcc() -> str:

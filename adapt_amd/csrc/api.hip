@@ -64,9 +64,9 @@ static int class_of(int is_bsdf, int type) {
 typedef void (*extend_fn)(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan);
 typedef void (*shadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan);
 typedef void (*occluded_fn)(DevScene, uint32_t, const float*, const float*, const float*, int*, LdsPlan);
-static const extend_fn kExtend[2][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_extend<1, 0>, k_extend<1, 1>}};   // [mode][sorted]
-static const shadow_fn kShadow[2] = {k_shadow<0>, k_shadow<1>};
-static const occluded_fn kOccluded[2] = {k_occluded<0>, k_occluded<1>};
+static const extend_fn kExtend[3][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_extend<1, 0>, k_extend<1, 1>}, {k_extend<2, 0>, k_extend<2, 1>}};   // [mode][sorted]
+static const shadow_fn kShadow[3] = {k_shadow<0>, k_shadow<1>, k_shadow<2>};
+static const occluded_fn kOccluded[3] = {k_occluded<0>, k_occluded<1>, k_occluded<2>};
 #define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
 
 // ============================================================== host side
@@ -91,7 +91,7 @@ struct apt_scene {
     DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
     int n_classes = 0;                   // material classes present (compact ids 0..n_classes-1)
     int class_def[APT_N_CLASS_DEFS] = {0, 0, 0, 0, 0, 0};   // compact id -> class definition
-    int n_prims = 0, n_objects = 0, n_sources = 0;
+    int n_prims = 0, n_objects = 0, n_sources = 0, max_obj_prims = 0;
     int bx_mask = 0, src_mask = 0;
     bool has_aabb = false;
 };
@@ -110,7 +110,8 @@ struct apt_renderer {
     Counters host_counters{};
     int grid_small = 0, grid_trace = 0, nq = APT_MAX_NQ;
     const ShadeVariant* shade = nullptr;
-    int trace_mode = 0;           // 0 = BVH traversal, 1 = wave-uniform sweep (small scenes)
+    int trace_mode = 0;           // 0 = BVH traversal, 1 = wave-uniform sweep, 2 = tiled sweep (small scenes)
+    int trace_nt = BLOCK;         // workgroup size of the trace kernels
     int sorted = 0;               // 1 = material-sorted shading (>= 2 material classes in the scene)
     shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string shade_name;
@@ -201,6 +202,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     std::vector<int> sw_tab((size_t)O * 4, 0);
     for (int o = 0; o < O; o++) {
         const int first = d->obj_info[3 * o], count = d->obj_info[3 * o + 1], is_sphere = d->obj_info[3 * o + 2] != 0;
+        if (!is_sphere) s->max_obj_prims = std::max(s->max_obj_prims, count);
         sw_tab[4 * (size_t)o] = (int)sw.size(); sw_tab[4 * (size_t)o + 1] = count; sw_tab[4 * (size_t)o + 2] = is_sphere; sw_tab[4 * (size_t)o + 3] = first;
         size_t base = sw.size();
         sw.resize(base + 8, 0.f);
@@ -264,7 +266,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
 #undef UP
     DevScene& ds = s->dev;
     ds.bvh.nodes = s->nodes.as<float4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.n_nodes = s->bvh.n_nodes(); ds.bvh.n_prims = N;
-    ds.sweep.stream = s->sweep_recs.as<float>(); ds.sweep.obj_tab = s->sweep_tab.as<int>(); ds.sweep.n_objects = O;
+    ds.sweep.stream = s->sweep_recs.as<float>(); ds.sweep.obj_tab = s->sweep_tab.as<int>(); ds.sweep.prim_obj = s->prim_obj.as<int>(); ds.sweep.n_objects = O;
     s->has_aabb = d->obj_aabb != nullptr;
     ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float>(); ds.precom = s->precom.as<float>();
     ds.prim_obj = s->prim_obj.as<int>(); ds.prim_class = s->prim_class.as<int>(); ds.obj_info = s->obj_info.as<int>(); ds.emitter_id = s->emitter_id.as<int>();
@@ -358,10 +360,14 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     HIP_TRY(hipGetDeviceProperties(&prop, c.device));
     int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     // traversal mode: small scenes sweep all primitives wave-uniformly in the reference's brute-force order
-    r->trace_mode = (sc->n_prims <= APT_SWEEP_MAX_PRIMS && sc->has_aabb) ? 1 : 0;
+    // the tiled sweep pays off once some object has enough primitives that skipping it per ray matters;
+    // scenes of spheres and quads only are as fast in the plain wave sweep
+    const bool tile_ok = sc->has_aabb && sc->n_objects <= APT_TILE_MAX_OBJECTS && sc->n_prims < 65536;
+    r->trace_mode = (sc->n_prims <= APT_SWEEP_MAX_PRIMS && sc->has_aabb) ? ((tile_ok && sc->max_obj_prims >= APT_SWEEP_LIST_MIN) ? 2 : 1) : 0;
     if (const char* force = getenv("APT_TRAVERSAL")) {
         if (!strcmp(force, "bvh")) r->trace_mode = 0;
         else if (!strcmp(force, "sweep") && sc->has_aabb) r->trace_mode = 1;
+        else if (!strcmp(force, "tile") && tile_ok) r->trace_mode = 2;
     }
     // LDS plan: the per-lane stack must cover the tree depth; what is left of a ~40 KiB
     // per-workgroup budget (4 workgroups per CU) stages the top of the tree and, when they
@@ -382,7 +388,17 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->lds_bytes));
         r->grid_trace = cus * per_cu;
         if (r->trace_mode == 1) { r->lds_bytes = 0; r->grid_trace = cus * 8; }
-        if (r->lds_bytes > 64 * 1024) {
+        if (r->trace_mode == 2) {
+            r->trace_nt = APT_TILE_NT;
+            r->lds_bytes = APT_TILE_LDS_BYTES(APT_TILE_NT, sc->n_objects);
+            r->grid_trace = cus * (int)std::max<size_t>(1, std::min<size_t>(2048 / APT_TILE_NT, (160 * 1024) / r->lds_bytes));
+            if (r->lds_bytes > 64 * 1024) {
+                HIP_TRY(hipFuncSetAttribute((const void*)kExtend[2][0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+                HIP_TRY(hipFuncSetAttribute((const void*)kExtend[2][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+                HIP_TRY(hipFuncSetAttribute((const void*)kShadow[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+                HIP_TRY(hipFuncSetAttribute((const void*)kOccluded[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+            }
+        } else if (r->lds_bytes > 64 * 1024) {
             HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kShadow[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
@@ -408,8 +424,8 @@ APT_EXPORT void apt_renderer_destroy(apt_renderer* r) {
 }
 
 // persistent grid: enough workgroups for n items, capped, and a multiple of the sub-queue count
-static int grid_for(size_t n, int cap_blocks, int nq) {
-    size_t b = (n + BLOCK - 1) / BLOCK;
+static int grid_for(size_t n, int cap_blocks, int nq, int nt = BLOCK) {
+    size_t b = (n + nt - 1) / nt;
     b = ((b + nq - 1) / nq) * nq;
     if (b < (size_t)nq) b = nq;
     return (int)(b < (size_t)cap_blocks ? b : (size_t)cap_blocks);
@@ -462,7 +478,7 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
         { LaunchTimer t(r, 0); hipLaunchKernelGGL(k_generate, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, r->stream, p, r->q, cnt); }
         int cur = 0;
         for (int b = 0; b < p.max_bounce; b++) {
-            { LaunchTimer t(r, 1); hipLaunchKernelGGL(kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq)), dim3(BLOCK), r->lds_bytes, r->stream, sc, p, r->q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
+            { LaunchTimer t(r, 1); hipLaunchKernelGGL(kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, r->stream, sc, p, r->q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
             if (!r->sorted) {
                 ShadeIn in = {r->q.ray_o[cur], r->q.ray_d[cur], r->q.thr[cur], r->q.id[cur], r->q.meta[cur], r->q.pdf[cur],
                               r->q.hit_t, r->q.hit_prim, r->q.hit_u, r->q.hit_v, (const uint32_t*)cnt->n_active[cur]};
@@ -475,7 +491,7 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
                 }
                 if (p.S <= 0) HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), r->stream));      // normally k_shadow recycles these
             }
-            if (p.S > 0) { LaunchTimer t(r, 3); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_trace, nq)), dim3(BLOCK), r->lds_bytes, r->stream, sc, p, r->q, cnt, r->plan); }
+            if (p.S > 0) { LaunchTimer t(r, 3); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, r->stream, sc, p, r->q, cnt, r->plan); }
             cur ^= 1;
         }
         { LaunchTimer t(r, 4); hipLaunchKernelGGL(k_finalize, dim3(grid_for((size_t)r->npix, r->grid_small, 1)), dim3(BLOCK), 0, r->stream, p, r->q, r->accum.as<float>()); }
@@ -542,6 +558,10 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
     out->n_samples = sum(ST_SAMPLES); out->n_extend = sum(ST_EXTEND); out->n_shade = sum(ST_SHADE);
     out->n_shadow = sum(ST_SHADOW); out->n_shadow_traced = sum(ST_SHADOW_TRACED); out->n_lit = sum(ST_LIT);
     out->n_draws = sum(ST_DRAWS); out->n_poisoned = sum(ST_POISON);
+#ifdef APT_TILE_PROF
+    fprintf(stderr, "[tile prof] wave-cycles: stage %lld | A %lld | wait %lld | B %lld | wait %lld | sweep total %lld | append %lld | tiles*waves %lld\n",
+            (long long)sum(8), (long long)sum(9), (long long)sum(10), (long long)sum(11), (long long)sum(12), (long long)sum(13), (long long)sum(14), (long long)sum(15));
+#endif
     for (int k = 0; k < APT_N_KERNELS; k++) { out->launches[k] = r->launches[k]; out->kernel_ms[k] = r->kernel_ms[k]; }
     out->render_ms = r->render_ms;
     return APT_OK;
@@ -574,7 +594,7 @@ APT_EXPORT int apt_intersect(apt_renderer* r, int32_t n, const float* o, const f
     uint32_t un = (uint32_t)n;
     HIP_TRY(hipMemcpy(r->scratch.p, &un, 4, hipMemcpyHostToDevice));
     Params flat = r->par; flat.nq = 1; flat.subcap = flat.cap;          // one flat queue for explicit rays
-    hipLaunchKernelGGL(kExtend[r->trace_mode][0], dim3(grid_for((size_t)n, r->grid_trace, 1)), dim3(BLOCK), r->lds_bytes, r->stream, r->scene->dev, flat, r->q, (Counters*)nullptr, 0,
+    hipLaunchKernelGGL(kExtend[r->trace_mode][0], dim3(grid_for((size_t)n, r->grid_trace, 1, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, r->stream, r->scene->dev, flat, r->q, (Counters*)nullptr, 0,
                        (const uint32_t*)r->scratch.p, r->plan);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -598,7 +618,7 @@ APT_EXPORT int apt_occluded(apt_renderer* r, int32_t n, const float* o, const fl
     HIP_TRY(upload(bo, so)); HIP_TRY(upload(bd, sd));
     std::vector<float> tm(tmax, tmax + n);
     HIP_TRY(upload(bt, tm)); HIP_TRY(bocc.alloc((size_t)n * 4));
-    hipLaunchKernelGGL(kOccluded[r->trace_mode], dim3(grid_for((size_t)n, r->grid_trace, 1)), dim3(BLOCK), r->lds_bytes, r->stream, r->scene->dev, (uint32_t)n,
+    hipLaunchKernelGGL(kOccluded[r->trace_mode], dim3(grid_for((size_t)n, r->grid_trace, 1, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, r->stream, r->scene->dev, (uint32_t)n,
                        bo.as<float>(), bd.as<float>(), bt.as<float>(), bocc.as<int>(), r->plan);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(r->stream));

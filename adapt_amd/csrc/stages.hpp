@@ -142,13 +142,18 @@ APT_D void local_to_global(const Params& p, uint32_t lp, int& i, int& j) {
 
 // workgroup -> (sub-queue, first slot, stride) of the persistent loop over a sub-queue
 struct SubLoop { int q; uint32_t first, stride; };
-APT_D SubLoop sub_loop(int nq) {
+APT_D SubLoop sub_loop(int nq, int nt = BLOCK) {
     SubLoop s;
     s.q = (int)(blockIdx.x % (uint32_t)nq);
-    s.first = (blockIdx.x / (uint32_t)nq) * BLOCK;
-    s.stride = (gridDim.x / (uint32_t)nq) * BLOCK;
+    s.first = (blockIdx.x / (uint32_t)nq) * (uint32_t)nt;
+    s.stride = (gridDim.x / (uint32_t)nq) * (uint32_t)nt;
     return s;
 }
+// trace kernels: MODE 0 BVH walk, 1 wave/workgroup sweep, 2 tiled sweep (its own, larger workgroup)
+#ifndef APT_TILE_NT
+#define APT_TILE_NT 512
+#endif
+#define TRACE_NT(MODE) ((MODE) == 2 ? APT_TILE_NT : BLOCK)
 
 // ----------------------------------------------------------------- generate
 // wave w of the id space feeds sub-queue w % nq at position (w / nq) * 64 + lane: dense and
@@ -221,12 +226,12 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
 // shadow queue.  `n_src` = per-sub-queue counts (normally cnt->n_active[cur]).
 // MODE 0: BVH traversal (LDS-staged nodes + per-lane LDS stack); MODE 1: wave-uniform sweep (small scenes)
 template <int MODE, int SORTED>
-__global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
+__global__ void __launch_bounds__(TRACE_NT(MODE)) k_extend(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
     StagedBvh bvh;
     int* my_stack = nullptr;
     __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
     if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
-    const SubLoop sl = sub_loop(p.nq);
+    const SubLoop sl = sub_loop(p.nq, TRACE_NT(MODE));
     const uint32_t n = n_src[sl.q * CNT_PAD];
     if (cnt && sl.first == 0 && threadIdx.x == 0) {
         cnt->n_shadow[sl.q * CNT_PAD] = 0; cnt->n_active[cur ^ 1][sl.q * CNT_PAD] = 0;
@@ -234,15 +239,28 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, Params p, Queues 
     }
     const float* ro = q.ray_o[cur]; const float* rd = q.ray_d[cur];
     const uint32_t qbase = (uint32_t)sl.q * p.subcap;
+#ifdef APT_TILE_PROF
+    unsigned long long tile_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
         const uint32_t pos = base + threadIdx.x;
         const bool valid = pos < n;
-        const uint32_t idx = qbase + (valid ? pos : n - 1);            // idle lanes shadow the last ray: the sweep stays convergent
-        f3 o = mk3(ro[idx], ro[p.cap + idx], ro[2 * p.cap + idx]);
-        f3 d = mk3(rd[idx], rd[p.cap + idx], rd[2 * p.cap + idx]);
+        const uint32_t idx = qbase + (valid ? pos : n - 1);            // idle lanes re-read the last ray (never written back)
+#ifdef APT_TILE_PROF
+        unsigned long long tile_t0 = __builtin_readcyclecounter();
+#endif
+        const f3 o = mk3(ro[idx], ro[p.cap + idx], ro[2 * p.cap + idx]);
+        const f3 d = mk3(rd[idx], rd[p.cap + idx], rd[2 * p.cap + idx]);
         HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
         if (MODE == 0) traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
-        else sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
+        else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
+#ifdef APT_TILE_PROF
+        else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn), tile_prof);
+        unsigned long long tile_t1 = __builtin_readcyclecounter();
+        (void)tile_t0;
+#else
+        else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
+#endif
         if (!SORTED) {
             if (valid) { q.hit_t[idx] = rec.t; q.hit_prim[idx] = rec.prim; q.hit_u[idx] = rec.u; q.hit_v[idx] = rec.v; }
         } else {
@@ -262,7 +280,13 @@ __global__ void __launch_bounds__(BLOCK) k_extend(DevScene sc, Params p, Queues 
                 }
             }
         }
+#ifdef APT_TILE_PROF
+        if (MODE == 2) { unsigned long long t2_ = __builtin_readcyclecounter(); tile_prof[5] += tile_t1 - tile_t0; tile_prof[6] += t2_ - tile_t1; tile_prof[7] += 1; }
+#endif
     }
+#ifdef APT_TILE_PROF
+    if (MODE == 2 && cnt && (threadIdx.x & 63) == 0) for (int k = 0; k < 8; k++) atomicAdd(&cnt->stats[sl.q][8 + k], tile_prof[k]);
+#endif
 }
 
 // -------------------------------------------------------------------- shade
@@ -442,12 +466,12 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
 
 // ------------------------------------------------------------------- shadow
 template <int MODE>
-__global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
+__global__ void __launch_bounds__(TRACE_NT(MODE)) k_shadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
     StagedBvh bvh;
     int* my_stack = nullptr;
     __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
     if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
-    const SubLoop sl = sub_loop(p.nq);
+    const SubLoop sl = sub_loop(p.nq, TRACE_NT(MODE));
     const uint32_t n = min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
     if (sl.first == 0 && threadIdx.x == 0) {
         cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
@@ -459,11 +483,13 @@ __global__ void __launch_bounds__(BLOCK) k_shadow(DevScene sc, Params p, Queues 
         const uint32_t pos = base + threadIdx.x;
         const bool valid = pos < n;
         const uint32_t idx = qbase + (valid ? pos : n - 1);
-        f3 o = mk3(q.sh_o[idx], q.sh_o[sc_ + idx], q.sh_o[2 * sc_ + idx]);
-        f3 d = mk3(q.sh_d[idx], q.sh_d[sc_ + idx], q.sh_d[2 * sc_ + idx]);
-        float dist = q.sh_tmax[idx];
+        const f3 o = mk3(q.sh_o[idx], q.sh_o[sc_ + idx], q.sh_o[2 * sc_ + idx]);
+        const f3 d = mk3(q.sh_d[idx], q.sh_d[sc_ + idx], q.sh_d[2 * sc_ + idx]);
+        const float dist = q.sh_tmax[idx];
         HitRec rec; rec.t = (dist > 0.0f) ? dist - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        const bool occluded = (MODE == 0) ? traverse<true>(bvh, my_stack, BLOCK, o, d, rec) : sweep_wg<true, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
+        const bool occluded = (MODE == 0) ? traverse<true>(bvh, my_stack, BLOCK, o, d, rec)
+                            : (MODE == 1) ? sweep_wg<true, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep)
+                                          : sweep_tile<true, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         if (valid) {
             f3 c = mk3(q.sh_c[idx], q.sh_c[sc_ + idx], q.sh_c[2 * sc_ + idx]);
             // Upstream an occluded light sample still enters the sum as 0 * throughput; with a non-finite
@@ -505,17 +531,19 @@ __global__ void k_divide(const float* accum, float* out, uint32_t n, float cnt) 
 
 // ------------------------------------------------------- unit entry kernels
 template <int MODE>
-__global__ void __launch_bounds__(BLOCK) k_occluded(DevScene sc, uint32_t n, const float* o_, const float* d_, const float* tmax, int* occ, LdsPlan plan) {
+__global__ void __launch_bounds__(TRACE_NT(MODE)) k_occluded(DevScene sc, uint32_t n, const float* o_, const float* d_, const float* tmax, int* occ, LdsPlan plan) {
     StagedBvh bvh;
     int* my_stack = nullptr;
     if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
-    for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
+    for (uint32_t base = blockIdx.x * TRACE_NT(MODE); base < n; base += gridDim.x * TRACE_NT(MODE)) {
         const uint32_t pos = base + threadIdx.x;
         const bool valid = pos < n;
         const uint32_t idx = valid ? pos : n - 1;
         f3 o = mk3(o_[idx], o_[n + idx], o_[2 * n + idx]), d = mk3(d_[idx], d_[n + idx], d_[2 * n + idx]);
         HitRec rec; rec.t = (tmax[idx] > 0.0f) ? tmax[idx] - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        const bool hit = (MODE == 0) ? traverse<true>(bvh, my_stack, BLOCK, o, d, rec) : sweep_any(sc.sweep, o, d, rec);
+        const bool hit = (MODE == 0) ? traverse<true>(bvh, my_stack, BLOCK, o, d, rec)
+                       : (MODE == 1) ? sweep_any(sc.sweep, o, d, rec)
+                                     : sweep_tile<true, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         if (valid) occ[idx] = hit ? 1 : 0;
     }
 }

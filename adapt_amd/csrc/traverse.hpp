@@ -159,6 +159,7 @@ APT_D v2f sp2(float s) { v2f r; r.x = s; r.y = s; return r; }
 struct SweepScene {
     const float* stream;
     const int* obj_tab;       // n_objects * 4: block offset (floats), primitive count, is_sphere, first primitive
+    const int* prim_obj;      // primitive -> object
     int n_objects;
 };
 
@@ -174,8 +175,8 @@ struct SweepRay {
 // would accept it.  The reference divides by the ray; dividing six times per object costs more than testing
 // a triangle, so a reciprocal-multiply version with an error band decides the clear cases and only lanes
 // inside the band (or with non-finite slabs) take the division path.
-APT_D bool object_cull(cf_ptr blk, const SweepRay& r, f3 d, f3 inv_d, float t_best) {
-    const v2f bx = ld2c(blk) - r.ox, by = ld2c(blk + 2) - r.oy, bz = ld2c(blk + 4) - r.oz;     // (lo - o, hi - o) per axis
+APT_D bool object_cull(v2f bound_x, v2f bound_y, v2f bound_z, const SweepRay& r, f3 d, f3 inv_d, float t_best, float& t_entry) {
+    const v2f bx = bound_x - r.ox, by = bound_y - r.oy, bz = bound_z - r.oz;                     // (lo - o, hi - o) per axis
     v2f tx = bx * sp2(inv_d.x), ty = by * sp2(inv_d.y), tz = bz * sp2(inv_d.z);
     float tn = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
     float tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
@@ -189,8 +190,10 @@ APT_D bool object_cull(cf_ptr blk, const SweepRay& r, f3 d, f3 inv_d, float t_be
         tf = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
         ok = (tn < tf) && tf > 0.f && !(tn > t_best);
     }
+    t_entry = tn;
     return ok;
 }
+APT_D bool object_cull(cf_ptr blk, const SweepRay& r, f3 d, f3 inv_d, float t_best) { float tn; return object_cull(ld2c(blk), ld2c(blk + 2), ld2c(blk + 4), r, d, inv_d, t_best, tn); }
 
 // sphere record against the ray (tracer_base.py:184-199)
 template <bool ANY>
@@ -208,22 +211,30 @@ APT_D void sphere_test(cf_ptr rec4, int first, f3 o, f3 d, bool need, bool& foun
     }
 }
 
+// one pair record in SGPRs
+struct PairRec { v2f p0x, p0y, p0z, a00, a10, a20, a01, a11, a21, nx, ny, nz; };
+APT_D PairRec ld_pair(cf_ptr r) {
+    PairRec p;
+    p.p0x = ld2c(r); p.p0y = ld2c(r + 2); p.p0z = ld2c(r + 4);
+    p.a00 = ld2c(r + 6); p.a10 = ld2c(r + 8); p.a20 = ld2c(r + 10);
+    p.a01 = ld2c(r + 12); p.a11 = ld2c(r + 14); p.a21 = ld2c(r + 16);
+    p.nx = ld2c(r + 18); p.ny = ld2c(r + 20); p.nz = ld2c(r + 22);
+    return p;
+}
 // all pair records of one mesh object against the ray, in primitive order
 template <bool ANY>
 APT_D void pair_tests(cf_ptr recs, int count, int first, const SweepRay& s, bool& need, bool& found, HitRec& rec) {
     const int n_pairs = (count + 1) >> 1;
     for (int j = 0; j < n_pairs; j++) {
-        const cf_ptr r = recs + 24 * j;
-        const v2f a00 = ld2c(r + 6), a10 = ld2c(r + 8), a20 = ld2c(r + 10);      // e1
-        const v2f a01 = ld2c(r + 12), a11 = ld2c(r + 14), a21 = ld2c(r + 16);    // e2
-        const v2f c00 = a11 * s.a22 - a21 * s.a12, c01 = a21 * s.a02 - a01 * s.a22, c02 = a01 * s.a12 - a11 * s.a02;
-        const v2f det = (a00 * c00 + a10 * c01) + a20 * c02;
+        const PairRec p = ld_pair(recs + 24 * j);
+        const v2f c00 = p.a11 * s.a22 - p.a21 * s.a12, c01 = p.a21 * s.a02 - p.a01 * s.a22, c02 = p.a01 * s.a12 - p.a11 * s.a02;
+        const v2f det = (p.a00 * c00 + p.a10 * c01) + p.a20 * c02;
         v2f inv_det; inv_det.x = 1.0f / det.x; inv_det.y = 1.0f / det.y;
-        const v2f sx = s.ox - ld2c(r), sy = s.oy - ld2c(r + 2), sz = s.oz - ld2c(r + 4);
-        const v2f c10 = s.a12 * a20 - s.a22 * a10, c11 = s.a22 * a00 - s.a02 * a20, c12 = s.a02 * a10 - s.a12 * a00;
+        const v2f sx = s.ox - p.p0x, sy = s.oy - p.p0y, sz = s.oz - p.p0z;
+        const v2f c10 = s.a12 * p.a20 - s.a22 * p.a10, c11 = s.a22 * p.a00 - s.a02 * p.a20, c12 = s.a02 * p.a10 - s.a12 * p.a00;
         const v2f u = ((inv_det * c00) * sx + (inv_det * c01) * sy) + (inv_det * c02) * sz;
         const v2f v = ((inv_det * c10) * sx + (inv_det * c11) * sy) + (inv_det * c12) * sz;
-        const v2f t = ((inv_det * ld2c(r + 18)) * sx + (inv_det * ld2c(r + 20)) * sy) + (inv_det * ld2c(r + 22)) * sz;
+        const v2f t = ((inv_det * p.nx) * sx + (inv_det * p.ny) * sy) + (inv_det * p.nz) * sz;
         const v2f uv = u + v;
         // triangle 2j, then 2j+1: the reference's sequential `t < min_depth` update order
         if (need && u.x >= 0.f && v.x >= 0.f && uv.x <= 1.0f && t.x > 1e-4f && t.x < rec.t) {
@@ -331,5 +342,117 @@ APT_D bool sweep_wg(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active, 
         n_lists++;
     }
     return found;
+}
+
+// Tiled sweep: the block's NT rays against every object, with no wave ever testing a primitive for a lane
+// that does not need it.
+//
+// The reference loop is sequential per ray (cull against the running t, then `t < min_depth` updates), but its
+// RESULT is an order-independent reduction except on near-ties:  let t_i be object i's own first-minimal hit
+// below the initial bound t0, tn_i its slab entry.  Upstream accepts i when !(tn_i > cur) and t_i < cur, cur being
+// the minimum accepted so far.  Since a hit lies inside the box, tn_i <= t_i up to rounding, so `tn_i > cur`
+// implies `t_i >= cur` unless cur falls in the rounding gap between t_i and tn_i — which needs a second surface
+// within that gap.  Hence:  winner = min over (t_i, primitive index)  [strict `<` keeps the first of equal t],
+// and any ray where (a) two candidates come within TIE_EPS of each other at the running minimum, or (b) a
+// candidate's t_i undershoots its tn_i by more than TIE_EPS, is re-done by its owner with the sequential sweep.
+// That makes the result exact in every case while the bulk runs as independent (ray, object) work items:
+//   phase A  every thread culls its ray against every object (static bound t0) and appends itself to the LDS
+//            list of each object it needs;
+//   phase B  the block's waves walk all lists in dense 64-entry chunks (object wave-uniform -> scalar record
+//            loads), reduce with a 64-bit LDS atomicMin on (t bits, primitive, list slot) and leave (u, v) in
+//            the entry's slot;
+//   phase C  the owner picks up its minimum (or its occlusion flag), or runs the fallback.
+// LDS: NT * 40 B + n_objects * (NT * 8 B + 4 B).  Must be called by every thread of the block.
+#define APT_TILE_MAX_OBJECTS 48
+#define APT_TILE_LDS_BYTES(nt, n_obj) ((size_t)(nt) * 40 + (size_t)(n_obj) * ((size_t)(nt) * 8 + 4) + 16)
+struct TileEntry { uint32_t a; float b; };                 // (ray, tn) going in, (u, v) coming out
+#ifdef APT_TILE_PROF
+#define TILE_TICK(k) do { unsigned long long now_ = __builtin_readcyclecounter(); prof[k] += now_ - tick_; tick_ = now_; } while (0)
+#else
+#define TILE_TICK(k) do { } while (0)
+#endif
+template <bool ANY, int NT>
+APT_D bool sweep_tile(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active, float* lds, unsigned long long* prof = nullptr) {
+#ifdef APT_TILE_PROF
+    unsigned long long tick_ = __builtin_readcyclecounter();
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_obj = sc.n_objects;
+    float* s_ray = lds;                                                     // o.xyz d.xyz t0, SoA
+    int* s_flag = reinterpret_cast<int*>(lds + 7 * NT);
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(lds + 8 * NT);    // 8-byte aligned
+    TileEntry* s_ent = reinterpret_cast<TileEntry*>(lds + 10 * NT);          // [object][slot]
+    int* s_cnt = reinterpret_cast<int*>(s_ent + (size_t)n_obj * NT);
+    const float t0 = rec.t;
+    const cf_ptr stream = (cf_ptr)sc.stream;
+    const ci_ptr tab = (ci_ptr)sc.obj_tab;
+    s_ray[tid] = o.x; s_ray[NT + tid] = o.y; s_ray[2 * NT + tid] = o.z;
+    s_ray[3 * NT + tid] = d.x; s_ray[4 * NT + tid] = d.y; s_ray[5 * NT + tid] = d.z; s_ray[6 * NT + tid] = t0;
+    s_flag[tid] = 0; s_best[tid] = ~0ull;
+    if (tid < n_obj) s_cnt[tid] = 0;
+    __syncthreads();
+    TILE_TICK(0);
+    {   // phase A
+        const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+        SweepRay sr; sr.set(o, d);
+        for (int ob = 0; ob < n_obj; ob++) {
+            const cf_ptr blk = stream + tab[4 * ob];
+            float tn;
+            const bool need = object_cull(ld2c(blk), ld2c(blk + 2), ld2c(blk + 4), sr, d, inv_d, t0, tn) && active;
+            const unsigned long long m = __ballot(need);
+            if (!m) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt[ob], (int)__popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (need) { TileEntry e; e.a = (uint32_t)tid; e.b = tn; s_ent[ob * NT + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = e; }
+        }
+    }
+    TILE_TICK(1);
+    __syncthreads();
+    TILE_TICK(2);
+    {   // phase B: global chunk g of the concatenated lists -> (object, chunk)
+        int g = wave;
+        for (int ob = 0; ob < n_obj; ob++) {
+            const int L = s_cnt[ob], n_chunks = (L + 63) >> 6;
+            if (g >= n_chunks) { g -= n_chunks; continue; }
+            const cf_ptr blk = stream + tab[4 * ob];
+            const int count = tab[4 * ob + 1], first = tab[4 * ob + 3], is_sphere = tab[4 * ob + 2];
+            for (; g < n_chunks; g += NT / 64) {
+                const int li = g * 64 + lane;
+                const bool has = li < L;
+                TileEntry* slot = s_ent + ob * NT + (has ? li : L - 1);
+                const TileEntry e = *slot;
+                const int ti = (int)e.a;
+                const f3 ro = mk3(s_ray[ti], s_ray[NT + ti], s_ray[2 * NT + ti]);
+                const f3 rd = mk3(s_ray[3 * NT + ti], s_ray[4 * NT + ti], s_ray[5 * NT + ti]);
+                HitRec r2; r2.t = s_ray[6 * NT + ti]; r2.prim = -1; r2.u = r2.v = 0.f;
+                bool nd = has, got = false;
+                if (is_sphere) sphere_test<ANY>(blk + 8, first, ro, rd, nd, got, r2);
+                else { SweepRay s2; s2.set(ro, rd); pair_tests<ANY>(blk + 8, count, first, s2, nd, got, r2); }
+                if (ANY) { if (has && got) s_flag[ti] = 1; }
+                else if (has && r2.prim >= 0) {
+                    const float eps = 1e-5f * r2.t + 1e-6f;
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(r2.t) << 32) | ((unsigned long long)(uint32_t)r2.prim << 16) | (unsigned long long)(uint32_t)li;
+                    const unsigned long long old = atomicMin(&s_best[ti], key);
+                    bool redo = e.b - r2.t > eps;
+                    if (old != ~0ull) redo = redo || fabsf(__uint_as_float((uint32_t)(old >> 32)) - r2.t) <= eps;
+                    if (redo) s_flag[ti] = 1;
+                    TileEntry w; w.a = __float_as_uint(r2.u); w.b = r2.v; *slot = w;
+                }
+            }
+            g -= n_chunks;
+        }
+    }
+    TILE_TICK(3);
+    __syncthreads();
+    TILE_TICK(4);
+    if (ANY) return s_flag[tid] != 0;
+    if (s_flag[tid]) { rec.t = t0; rec.prim = -1; rec.u = rec.v = 0.f; sweep<false>(sc, o, d, rec); return false; }
+    const unsigned long long key = s_best[tid];
+    if (key != ~0ull) {
+        rec.t = __uint_as_float((uint32_t)(key >> 32)); rec.prim = (int)((key >> 16) & 0xffffu);
+        const TileEntry w = s_ent[sc.prim_obj[rec.prim] * NT + (int)(key & 0xffffu)];
+        rec.u = __uint_as_float(w.a); rec.v = w.b;
+    }
+    return false;
 }
 APT_D bool sweep_any(const SweepScene& sc, f3 o, f3 d, HitRec& rec) { return sweep<true>(sc, o, d, rec); }

@@ -249,7 +249,7 @@ class Renderer:
         _lib.check(self.lib.apt_renderer_info(self.handle, C.byref(b), C.byref(nq), C.byref(qb), C.byref(lds), C.byref(name), C.byref(tm)), "apt_renderer_info")
         return {"spp_per_batch": b.value, "n_subqueues": nq.value, "queue_bytes": qb.value, "lds_bytes": lds.value,
                 "shade_variant": name.value.decode() if name.value else "",
-                "traversal": "sweep" if tm.value == 1 else "bvh"}
+                "traversal": {0: "bvh", 1: "sweep", 2: "tile"}.get(tm.value, str(tm.value))}
 
     # ------------------------------------------------------------ checkpoint
     def get_check_point(self) -> dict:

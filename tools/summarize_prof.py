@@ -17,7 +17,7 @@ def short(name):
         if k in name:
             tag = k
             if k in ("k_extend", "k_shadow"):
-                tag += "<sweep>" if "ILi1E" in name else "<bvh>"
+                tag += "<sweep>" if "ILi1E" in name else ("<tile>" if "ILi2E" in name else "<bvh>")
             if k == "k_shade":
                 import re
                 m = re.search(r"k_shadeILi(\d+)ELi(\d+)E", name)
@@ -47,7 +47,7 @@ if db:
 print("\n== PMC passes (summed over the run's dispatches, per kernel)")
 acc = defaultdict(lambda: defaultdict(float))
 disp = defaultdict(set)
-for sub in ("pmc_sq", "pmc_fetch", "pmc_write"):
+for sub in ("pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_fetch", "pmc_write"):
     d = first_db(sub)
     if not d:
         continue
