@@ -191,7 +191,7 @@ def main():
         osc = ob.OracleScene(pack_scene(*parsed), rc.cam_t, build_bvh=rc.use_bvh)
         cores = ob.num_threads()
         t = time.perf_counter(); osc.render(rc, 1, threads=cores); one = time.perf_counter() - t
-        n_cpu = int(max(1, min(64, round(args.cpu_seconds / max(one, 1e-3)))))
+        n_cpu = int(max(1, min(512, round(args.cpu_seconds / max(one, 1e-3)))))
         t = time.perf_counter(); ref, cnt, ost = osc.render(rc, n_cpu, threads=cores); cpu_dt = time.perf_counter() - t
         out["cpu_baseline"] = {"value": round(W * H * n_cpu / cpu_dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
                                "sample": f"{W}x{H} x {n_cpu} spp of the same workload (same scene, bounces, seed), {cpu_dt:.1f} s on {cores} OpenMP threads; "
