@@ -331,6 +331,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         r->shade_name = "sorted:";
         for (int c = 0; c < ncls; c++) { r->class_fn[c] = kClassShade[sc->class_def[c]][smi]; r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]]; }
     }
+    // the kernels address queue slots with 32-bit byte offsets (stages.hpp "Queue addressing")
+    if (cap >= ((size_t)1 << 30) || sh_cap >= ((size_t)1 << 30)) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: batch too large (queue capacity must stay below 2^30 slots)"); }
     // one pool, carved into the SoA arrays (all 4-byte lanes)
     const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 3) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls;
     hipError_t e = r->pool.alloc(words * 4);
@@ -406,6 +408,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         }
     }
     r->grid_small = cus * 8;       // streaming stages: up to 8 x 256-thread workgroups per CU
+    if (const char* g = getenv("APT_GRID_SMALL")) r->grid_small = cus * std::max(1, atoi(g));       // tuning knobs: workgroups per CU
+    if (const char* g = getenv("APT_GRID_TRACE")) r->grid_trace = cus * std::max(1, atoi(g));
     r->grid_trace = ((r->grid_trace + nq - 1) / nq) * nq;          // persistent grids are multiples of nq
     r->grid_small = ((r->grid_small + nq - 1) / nq) * nq;
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -558,6 +562,25 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
     out->n_samples = sum(ST_SAMPLES); out->n_extend = sum(ST_EXTEND); out->n_shade = sum(ST_SHADE);
     out->n_shadow = sum(ST_SHADOW); out->n_shadow_traced = sum(ST_SHADOW_TRACED); out->n_lit = sum(ST_LIT);
     out->n_draws = sum(ST_DRAWS); out->n_poisoned = sum(ST_POISON);
+#ifdef APT_SHADE_PROF
+    {
+        std::vector<unsigned long long> dbg(2 * 16384);
+        (void)hipMemcpy(dbg.data(), (const char*)r->counters.p + offsetof(Counters, dbg), dbg.size() * 8, hipMemcpyDeviceToHost);
+        unsigned long long t0 = ~0ull, t1 = 0; int nw = 0;
+        for (int w = 0; w < 16384; w++) if (dbg[2 * w]) { t0 = std::min(t0, dbg[2 * w]); t1 = std::max(t1, dbg[2 * w + 1]); nw++; }
+        if (nw) {
+            int hist_s[10] = {0}, hist_e[10] = {0}; double span = (double)(t1 - t0) + 1;
+            for (int w = 0; w < 16384; w++) if (dbg[2 * w]) { hist_s[(int)(10 * (dbg[2 * w] - t0) / span)]++; hist_e[(int)(10 * (dbg[2 * w + 1] - t0) / span)]++; }
+            fprintf(stderr, "[shade waves] last launch: %d waves, span %.1f us; start deciles:", nw, span / 100.0);
+            for (int k = 0; k < 10; k++) fprintf(stderr, " %d", hist_s[k]);
+            fprintf(stderr, " ; end deciles:");
+            for (int k = 0; k < 10; k++) fprintf(stderr, " %d", hist_e[k]);
+            fprintf(stderr, "\n");
+        }
+    }
+    fprintf(stderr, "[shade prof] wave-cycles: load+hit %lld | mis/rr %lld | nee %lld | shadow append %lld | bsdf sample %lld | wave lifetime (100MHz ticks) %lld | wave lifetime (cycles) %lld | iterations %lld ; launches %lld kernel_ms %.3f\n",
+            (long long)sum(8), (long long)sum(9), (long long)sum(10), (long long)sum(11), (long long)sum(12), (long long)sum(13), (long long)sum(14), (long long)sum(15), (long long)r->launches[2], r->kernel_ms[2]);
+#endif
 #ifdef APT_TILE_PROF
     fprintf(stderr, "[tile prof] wave-cycles: stage %lld | A %lld | wait %lld | B %lld | wait %lld | sweep total %lld | append %lld | tiles*waves %lld\n",
             (long long)sum(8), (long long)sum(9), (long long)sum(10), (long long)sum(11), (long long)sum(12), (long long)sum(13), (long long)sum(14), (long long)sum(15));

@@ -98,6 +98,9 @@ struct Counters {
     uint32_t n_shadow[APT_MAX_NQ * CNT_PAD];
     uint32_t n_cls[6][APT_MAX_NQ * CNT_PAD];
     unsigned long long stats[APT_MAX_NQ][16];    // [q][ST_*], 128 bytes per sub-queue
+#ifdef APT_SHADE_PROF
+    unsigned long long dbg[2 * 16384];           // per-wave (start, end) of the last k_shade launch, 100 MHz ticks
+#endif
 };
 
 // meta word: draw index [0,16) | bounce [16,24) | is_specular bit 24
@@ -126,6 +129,16 @@ APT_D uint32_t wave_append(bool flag, uint32_t* counter) {
     base = __shfl(base, 0);
     return base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
 }
+
+// Queue addressing.  Every queue array is indexed by a 32-bit slot whose BYTE offset also fits 32 bits (the host
+// refuses batches with 12 * capacity >= 4 GiB), and every base pointer is wave-uniform.  Written as
+// `uniform base + zero-extended 32-bit byte offset` the backend selects the SGPR-base form
+// `global_load_dword v, v_off, s[base:base+1]`: one VGPR offset serves all arrays of a record and the component
+// strides are added on the scalar unit.  With `ptr[index]` each access costs a 64-bit VALU address and a VGPR pair.
+template <typename T> APT_D T ldq(const T* base, uint32_t off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + off); }
+template <typename T> APT_D void stq(T* base, uint32_t off, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + off) = v; }
+APT_D f3 ld3q(const float* base, uint32_t stride, uint32_t off) { return mk3(ldq(base, off), ldq(base + stride, off), ldq(base + 2 * stride, off)); }
+APT_D void st3q(float* base, uint32_t stride, uint32_t off, f3 v) { stq(base, off, v.x); stq(base + stride, off, v.y); stq(base + 2 * stride, off, v.z); }
 // end-of-kernel statistics: per-lane register tallies -> one atomic per wave per counter
 APT_D void flush_stat(uint32_t v, unsigned long long* counter) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -153,6 +166,14 @@ APT_D SubLoop sub_loop(int nq, int nt = BLOCK) {
 #ifndef APT_TILE_NT
 #define APT_TILE_NT 512
 #endif
+// occupancy targets (waves per SIMD the register allocator must allow): the stages are latency-bound on dependent
+// table lookups and LDS round trips, so more resident waves beat a few spilled registers (measured)
+#ifndef APT_SHADE_WAVES
+#define APT_SHADE_WAVES 1
+#endif
+#ifndef APT_TILE_WAVES
+#define APT_TILE_WAVES 6
+#endif
 #define TRACE_NT(MODE) ((MODE) == 2 ? APT_TILE_NT : BLOCK)
 
 // ----------------------------------------------------------------- generate
@@ -172,7 +193,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
         if (valid) {
             uint32_t lp = idx % (uint32_t)p.npix, s = idx / (uint32_t)p.npix;
             int i, j; local_to_global(p, lp, i, j);
-            q.L[idx] = 0.f; q.L[p.cap + idx] = 0.f; q.L[2 * p.cap + idx] = 0.f;
+            st3q(q.L, p.cap, idx << 2, splat3(0.f));
             alive = !p.do_crop || (i >= p.sx && i < p.ex && j >= p.sy && j < p.ey);
             if (alive) {
                 int sample_cnt = p.cnt_base + (int)s + 1;        // cnt is incremented before the pixel loop
@@ -204,13 +225,13 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
             if (lane_id() == 0) atomicAdd(&cnt->n_active[0][sq * CNT_PAD], (uint32_t)__popcll(m));   // nq-way spread, ordered by w
         }
         if (alive) {
-            const uint32_t slot = (uint32_t)sq * p.subcap + pos;
-            q.ray_o[0][slot] = p.cam_t[0]; q.ray_o[0][p.cap + slot] = p.cam_t[1]; q.ray_o[0][2 * p.cap + slot] = p.cam_t[2];
-            q.ray_d[0][slot] = dir.x; q.ray_d[0][p.cap + slot] = dir.y; q.ray_d[0][2 * p.cap + slot] = dir.z;
-            q.thr[0][slot] = 1.f; q.thr[0][p.cap + slot] = 1.f; q.thr[0][2 * p.cap + slot] = 1.f;
-            q.id[0][slot] = idx;
-            q.meta[0][slot] = pack_meta(draws, 0u, false);
-            q.pdf[0][slot] = 1.f;
+            const uint32_t so = ((uint32_t)sq * p.subcap + pos) << 2;
+            st3q(q.ray_o[0], p.cap, so, mk3(p.cam_t[0], p.cam_t[1], p.cam_t[2]));
+            st3q(q.ray_d[0], p.cap, so, dir);
+            st3q(q.thr[0], p.cap, so, splat3(1.f));
+            stq(q.id[0], so, idx);
+            stq(q.meta[0], so, pack_meta(draws, 0u, false));
+            stq(q.pdf[0], so, 1.f);
             t_samples++;
         }
         t_draws += draws;
@@ -226,7 +247,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
 // shadow queue.  `n_src` = per-sub-queue counts (normally cnt->n_active[cur]).
 // MODE 0: BVH traversal (LDS-staged nodes + per-lane LDS stack); MODE 1: wave-uniform sweep (small scenes)
 template <int MODE, int SORTED>
-__global__ void __launch_bounds__(TRACE_NT(MODE)) k_extend(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
+__global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 1)) k_extend(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
     StagedBvh bvh;
     int* my_stack = nullptr;
     __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
@@ -249,8 +270,9 @@ __global__ void __launch_bounds__(TRACE_NT(MODE)) k_extend(DevScene sc, Params p
 #ifdef APT_TILE_PROF
         unsigned long long tile_t0 = __builtin_readcyclecounter();
 #endif
-        const f3 o = mk3(ro[idx], ro[p.cap + idx], ro[2 * p.cap + idx]);
-        const f3 d = mk3(rd[idx], rd[p.cap + idx], rd[2 * p.cap + idx]);
+        const uint32_t io = idx << 2;
+        const f3 o = ld3q(ro, p.cap, io);
+        const f3 d = ld3q(rd, p.cap, io);
         HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
         if (MODE == 0) traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
         else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
@@ -262,7 +284,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE)) k_extend(DevScene sc, Params p
         else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
 #endif
         if (!SORTED) {
-            if (valid) { q.hit_t[idx] = rec.t; q.hit_prim[idx] = rec.prim; q.hit_u[idx] = rec.u; q.hit_v[idx] = rec.v; }
+            if (valid) { stq(q.hit_t, io, rec.t); stq(q.hit_prim, io, rec.prim); stq(q.hit_u, io, rec.u); stq(q.hit_v, io, rec.v); }
         } else {
             // sort by material class: one ballot-compacted append per class present in the scene; misses vanish here
             const int cls = (valid && rec.prim >= 0) ? sc.prim_class[rec.prim] : -1;
@@ -271,12 +293,12 @@ __global__ void __launch_bounds__(TRACE_NT(MODE)) k_extend(DevScene sc, Params p
                 const uint32_t cpos = wave_append(mine, &cnt->n_cls[c][sl.q * CNT_PAD]);
                 if (mine) {
                     const Queues::ClassQ& k = q.cls[c];
-                    const uint32_t slot = qbase + cpos;
-                    k.ray_o[slot] = o.x; k.ray_o[p.cap + slot] = o.y; k.ray_o[2 * p.cap + slot] = o.z;
-                    k.ray_d[slot] = d.x; k.ray_d[p.cap + slot] = d.y; k.ray_d[2 * p.cap + slot] = d.z;
-                    k.thr[slot] = q.thr[cur][idx]; k.thr[p.cap + slot] = q.thr[cur][p.cap + idx]; k.thr[2 * p.cap + slot] = q.thr[cur][2 * p.cap + idx];
-                    k.id[slot] = q.id[cur][idx]; k.meta[slot] = q.meta[cur][idx]; k.pdf[slot] = q.pdf[cur][idx];
-                    k.t[slot] = rec.t; k.prim[slot] = rec.prim; k.u[slot] = rec.u; k.v[slot] = rec.v;
+                    const uint32_t so = (qbase + cpos) << 2;
+                    st3q(k.ray_o, p.cap, so, o);
+                    st3q(k.ray_d, p.cap, so, d);
+                    st3q(k.thr, p.cap, so, ld3q(q.thr[cur], p.cap, io));
+                    stq(k.id, so, ldq(q.id[cur], io)); stq(k.meta, so, ldq(q.meta[cur], io)); stq(k.pdf, so, ldq(q.pdf[cur], io));
+                    stq(k.t, so, rec.t); stq(k.prim, so, rec.prim); stq(k.u, so, rec.u); stq(k.v, so, rec.v);
                 }
             }
         }
@@ -288,6 +310,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE)) k_extend(DevScene sc, Params p
     if (MODE == 2 && cnt && (threadIdx.x & 63) == 0) for (int k = 0; k < 8; k++) atomicAdd(&cnt->stats[sl.q][8 + k], tile_prof[k]);
 #endif
 }
+
 
 // -------------------------------------------------------------------- shade
 APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3 o, f3 d, Hit& it) {
@@ -310,7 +333,7 @@ APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3
 
 // BM / SM: material and emitter masks of the scene (shading.hpp); code for absent models is compiled out.
 template <int BM, int SM>
-__global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
+__global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
     const uint32_t n = in.counts[sl.q * CNT_PAD];
@@ -319,7 +342,19 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
     const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
     uint32_t t_shade = 0, t_shadow = 0, t_draws = 0, t_poison = 0;
+#ifdef APT_SHADE_PROF
+    unsigned long long sprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long life0_ = __builtin_readcyclecounter();
+    const unsigned long long wall0_ = wall_clock64();
+#define SH_TICK(k) do { unsigned long long now_ = __builtin_readcyclecounter(); sprof[k] += now_ - stick_; stick_ = now_; } while (0)
+#else
+#define SH_TICK(k) do { } while (0)
+#endif
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
+#ifdef APT_SHADE_PROF
+        unsigned long long stick_ = __builtin_readcyclecounter();
+        sprof[7] += 1;
+#endif
         const uint32_t pos = base + threadIdx.x;
         const uint32_t idx = qbase + pos;
         bool alive = pos < n;
@@ -333,19 +368,21 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
         float emission_weight = 1.0f;
         DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
         if (alive) {
-            int prim = in.prim[idx];
+            const uint32_t io = idx << 2;
+            int prim = ldq(in.prim, io);
             if (prim < 0) alive = false;                         // nothing hit: path ends (vanilla_renderer.py:49)
             else {
-                o = mk3(in.ray_o[idx], in.ray_o[p.cap + idx], in.ray_o[2 * p.cap + idx]);
-                d = mk3(in.ray_d[idx], in.ray_d[p.cap + idx], in.ray_d[2 * p.cap + idx]);
-                thr = mk3(in.thr[idx], in.thr[p.cap + idx], in.thr[2 * p.cap + idx]);
-                id = in.id[idx];
-                uint32_t meta = in.meta[idx];
-                ray_pdf = in.pdf[idx];
+                o = ld3q(in.ray_o, p.cap, io);
+                d = ld3q(in.ray_d, p.cap, io);
+                thr = ld3q(in.thr, p.cap, io);
+                id = ldq(in.id, io);
+                uint32_t meta = ldq(in.meta, io);
+                ray_pdf = ldq(in.pdf, io);
                 was_spec = (meta >> 24) & 1u;
-                build_hit(sc, prim, in.t[idx], in.u[idx], in.v[idx], o, d, it);
+                build_hit(sc, prim, ldq(in.t, io), ldq(in.u, io), ldq(in.v, io), o, d, it);
                 bx = sc.bxdf[it.obj_id];
                 hit_light = sc.emitter_id[it.obj_id];
+                SH_TICK(0);
                 uint32_t lp = id % (uint32_t)p.npix, s = id / (uint32_t)p.npix;
                 int gi, gj; local_to_global(p, lp, gi, gj);
                 draw0 = meta & 0xffffu;
@@ -367,6 +404,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
             }
         }
         if (alive) { t_shade++; hit_point = d * it.min_depth + o; }
+        SH_TICK(1);
 
         // ---- next-event estimation: one shadow-queue entry per useful light sample
         bool break_flag = false;
@@ -408,7 +446,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
                         // Upstream the MIS weight multiplies the light sample even when the shadow ray is
                         // occluded (0 * NaN), so a NaN weight poisons the whole pixel-sample, which is then
                         // zeroed at the end (vanilla_renderer.py:87-95,119).  Reproduce that without tracing.
-                        q.L[id] = mis_w; q.L[p.cap + id] = mis_w; q.L[2 * p.cap + id] = mis_w;
+                        st3q(q.L, p.cap, id << 2, splat3(mis_w));
                         t_poison++;
                     } else {
                         f3 c = ((direct_spec * shadow_int) * mis_w) / emitter_pdf;
@@ -417,17 +455,19 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
                     }
                 }
             }
+            SH_TICK(2);
             uint32_t spos = wave_append(want, shadow_counter);
             if (want && spos < q.sh_subcap) {
-                const uint32_t slot = sh_qbase + spos, sc_ = q.sh_cap;
-                q.sh_o[slot] = hit_point.x; q.sh_o[sc_ + slot] = hit_point.y; q.sh_o[2 * sc_ + slot] = hit_point.z;
-                q.sh_d[slot] = light_dir.x; q.sh_d[sc_ + slot] = light_dir.y; q.sh_d[2 * sc_ + slot] = light_dir.z;
-                q.sh_tmax[slot] = emitter_d;
-                q.sh_c[slot] = contrib.x; q.sh_c[sc_ + slot] = contrib.y; q.sh_c[2 * sc_ + slot] = contrib.z;
-                q.sh_id[slot] = id;
+                const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
+                st3q(q.sh_o, sc_, so, hit_point);
+                st3q(q.sh_d, sc_, so, light_dir);
+                stq(q.sh_tmax, so, emitter_d);
+                st3q(q.sh_c, sc_, so, contrib);
+                stq(q.sh_id, so, id);
             }
         }
 
+        SH_TICK(3);
         // ---- emission of the surface we are on, then sample the continuation
         bool cont = false;
         f3 new_d = mk3(0.f, 1.f, 0.f);
@@ -438,7 +478,9 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
                 f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_s);
                 if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
                     f3 add = (emit_int * emission_weight) * thr;
-                    q.L[id] += add.x; q.L[p.cap + id] += add.y; q.L[2 * p.cap + id] += add.z;
+                    const uint32_t lo_ = id << 2;
+                    f3 cur_L = ld3q(q.L, p.cap, lo_);
+                    st3q(q.L, p.cap, lo_, mk3(cur_L.x + add.x, cur_L.y + add.y, cur_L.z + add.z));
                 }
             }
             f3 spec;
@@ -447,17 +489,25 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
             cont = (bounce + 1) < p.max_bounce;
         }
         t_draws += rng.draw - draw0;
+        SH_TICK(4);
         uint32_t npos = wave_append(cont, next_counter);
         if (cont) {
-            const uint32_t slot = qbase + npos;
-            q.ray_o[nxt][slot] = hit_point.x; q.ray_o[nxt][p.cap + slot] = hit_point.y; q.ray_o[nxt][2 * p.cap + slot] = hit_point.z;
-            q.ray_d[nxt][slot] = new_d.x; q.ray_d[nxt][p.cap + slot] = new_d.y; q.ray_d[nxt][2 * p.cap + slot] = new_d.z;
-            q.thr[nxt][slot] = thr.x; q.thr[nxt][p.cap + slot] = thr.y; q.thr[nxt][2 * p.cap + slot] = thr.z;
-            q.id[nxt][slot] = id;
-            q.meta[nxt][slot] = pack_meta(rng.draw, (uint32_t)(bounce + 1), is_spec);
-            q.pdf[nxt][slot] = new_pdf;
+            const uint32_t so = (qbase + npos) << 2;
+            st3q(q.ray_o[nxt], p.cap, so, hit_point);
+            st3q(q.ray_d[nxt], p.cap, so, new_d);
+            st3q(q.thr[nxt], p.cap, so, thr);
+            stq(q.id[nxt], so, id);
+            stq(q.meta[nxt], so, pack_meta(rng.draw, (uint32_t)(bounce + 1), is_spec));
+            stq(q.pdf[nxt], so, new_pdf);
         }
+        SH_TICK(5);
     }
+#ifdef APT_SHADE_PROF
+    sprof[6] = __builtin_readcyclecounter() - life0_;
+    sprof[5] = wall_clock64() - wall0_;          // 100 MHz constant clock: calibrates the cycle counter
+    if ((threadIdx.x & 63) == 0) { const uint32_t w_ = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64; if (w_ < 16384) { cnt->dbg[2 * w_] = wall0_; cnt->dbg[2 * w_ + 1] = wall_clock64(); } }
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; k++) atomicAdd(&cnt->stats[sl.q][8 + k], sprof[k]);
+#endif
     flush_stat(t_shade, &cnt->stats[sl.q][ST_SHADE]);
     flush_stat(t_shadow, &cnt->stats[sl.q][ST_SHADOW]);
     flush_stat(t_draws, &cnt->stats[sl.q][ST_DRAWS]);
@@ -466,7 +516,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
 
 // ------------------------------------------------------------------- shadow
 template <int MODE>
-__global__ void __launch_bounds__(TRACE_NT(MODE)) k_shadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
+__global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 1)) k_shadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
     StagedBvh bvh;
     int* my_stack = nullptr;
     __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
@@ -483,25 +533,27 @@ __global__ void __launch_bounds__(TRACE_NT(MODE)) k_shadow(DevScene sc, Params p
         const uint32_t pos = base + threadIdx.x;
         const bool valid = pos < n;
         const uint32_t idx = qbase + (valid ? pos : n - 1);
-        const f3 o = mk3(q.sh_o[idx], q.sh_o[sc_ + idx], q.sh_o[2 * sc_ + idx]);
-        const f3 d = mk3(q.sh_d[idx], q.sh_d[sc_ + idx], q.sh_d[2 * sc_ + idx]);
-        const float dist = q.sh_tmax[idx];
+        const uint32_t io = idx << 2;
+        const f3 o = ld3q(q.sh_o, sc_, io);
+        const f3 d = ld3q(q.sh_d, sc_, io);
+        const float dist = ldq(q.sh_tmax, io);
         HitRec rec; rec.t = (dist > 0.0f) ? dist - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
         const bool occluded = (MODE == 0) ? traverse<true>(bvh, my_stack, BLOCK, o, d, rec)
                             : (MODE == 1) ? sweep_wg<true, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep)
                                           : sweep_tile<true, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         if (valid) {
-            f3 c = mk3(q.sh_c[idx], q.sh_c[sc_ + idx], q.sh_c[2 * sc_ + idx]);
+            f3 c = ld3q(q.sh_c, sc_, io);
             // Upstream an occluded light sample still enters the sum as 0 * throughput; with a non-finite
             // throughput (pdf == 0 upstream, quirk A.3 #11) that is NaN, so the sample component is zeroed at
             // the end.  c carries the throughput factor: c * 0 reproduces exactly that, and is 0 for finite c.
             const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
             if (occluded && weird) c = c * 0.f;
             if (!occluded || weird) {
-                uint32_t id = q.sh_id[idx];
-                atomicAdd(&q.L[id], c.x);
-                atomicAdd(&q.L[p.cap + id], c.y);
-                atomicAdd(&q.L[2 * p.cap + id], c.z);
+                const uint32_t lo_ = ldq(q.sh_id, io) << 2;
+                char* Lb = reinterpret_cast<char*>(q.L);
+                atomicAdd(reinterpret_cast<float*>(Lb + lo_), c.x);
+                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 4 + lo_), c.y);
+                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 8 + lo_), c.z);
             }
             if (!occluded) t_lit++;
         }
@@ -516,8 +568,9 @@ __global__ void __launch_bounds__(BLOCK) k_finalize(Params p, Queues q, float* a
     for (uint32_t lp = blockIdx.x * BLOCK + threadIdx.x; lp < (uint32_t)p.npix; lp += stride) {
         float r = accum[3 * lp], g = accum[3 * lp + 1], b = accum[3 * lp + 2];
         for (int s = 0; s < p.spp_batch; s++) {
-            uint32_t id = (uint32_t)s * (uint32_t)p.npix + lp;
-            float cr = q.L[id], cg = q.L[p.cap + id], cb = q.L[2 * p.cap + id];
+            const uint32_t lo_ = ((uint32_t)s * (uint32_t)p.npix + lp) << 2;
+            const f3 c_ = ld3q(q.L, p.cap, lo_);
+            float cr = c_.x, cg = c_.y, cb = c_.z;
             r += isnan(cr) ? 0.f : cr; g += isnan(cg) ? 0.f : cg; b += isnan(cb) ? 0.f : cb;
         }
         accum[3 * lp] = r; accum[3 * lp + 1] = g; accum[3 * lp + 2] = b;
