@@ -106,7 +106,7 @@ struct apt_renderer {
     int n_cols = 0, npix = 0, spp_batch = 1;
     int cnt = 0;
     hipStream_t stream = nullptr;
-    DevBuf pool, counters, accum, scratch;
+    DevBuf pool, counters, accum, scratch, pix_key;
     Counters host_counters{};
     int grid_small = 0, grid_trace = 0, nq = APT_MAX_NQ;
     const ShadeVariant* shade = nullptr;
@@ -322,6 +322,20 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     p.max_bounce = c.max_bounce; p.S = S; p.inv_S = (S > 0) ? 1.f / (float)S : 1.f;
     p.use_rr = c.use_rr; p.use_mis = c.use_mis; p.anti_alias = c.anti_alias; p.stratified = c.stratified; p.two_sides = c.brdf_two_sides;
     p.rr_bounce_th = c.rr_bounce_th; p.rr_threshold = c.rr_threshold; p.seed = c.seed; p.cap = (uint32_t)cap; p.subcap = (uint32_t)subcap; p.nq = nq;
+    p.inv_ns = 1.f / (float)sc->n_sources; p.inv_ns1 = (sc->n_sources > 1) ? 1.f / (float)(sc->n_sources - 1) : 1.f;
+    p.pix_bits = 0; while ((1u << p.pix_bits) < (uint32_t)r->npix) p.pix_bits++;
+    if (((uint64_t)B << p.pix_bits) > (1ull << 32)) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: spp_per_batch x pixels does not fit the 32-bit path id"); }
+    {   // local pixel -> RNG key (global pixel index), same mapping as local_to_global in stages.hpp
+        std::vector<uint32_t> key((size_t)r->npix);
+        for (int lp = 0; lp < r->npix; lp++) {
+            const int lc = lp / c.height, j = lp % c.height, lb = lc / c.band_width, w_ = lc % c.band_width;
+            const int i = (lb * c.world_size + c.rank) * c.band_width + w_;
+            key[(size_t)lp] = (uint32_t)(i * c.height + j);
+        }
+        hipError_t e_ = upload(r->pix_key, key);
+        if (e_ != hipSuccess) { delete r; return fail(APT_E_HIP, std::string("upload pix_key: ") + hipGetErrorString(e_)); }
+        p.pix_key = r->pix_key.as<uint32_t>();
+    }
     r->sorted = (sc->n_classes >= 2) ? 1 : 0;
     if (const char* force = getenv("APT_SORTED")) r->sorted = (atoi(force) != 0 && sc->n_classes >= 1) ? 1 : 0;
     const int ncls = r->sorted ? sc->n_classes : 0;

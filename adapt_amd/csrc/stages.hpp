@@ -65,6 +65,11 @@ struct Params {
     uint32_t cap;             // nq * subcap: component stride of every path-indexed array
     uint32_t subcap;          // slots per sub-queue
     int nq;
+    // A path's id word is (sample in batch << pix_bits) | local pixel: both halves come out with a shift and a mask
+    // (no integer division per bounce); the radiance slot is sample * npix + local pixel.
+    uint32_t pix_bits;
+    const uint32_t* pix_key;  // local pixel -> global pixel index x * H + y = the RNG key (host-built; band mapping folded in)
+    float inv_ns, inv_ns1;    // 1 / n_sources, 1 / (n_sources - 1): sample_light's pdfs (path_tracer.py:537-554)
 };
 
 // SoA queues; every array has `cap` (shadow: sh_cap) entries per component
@@ -90,7 +95,9 @@ struct ShadeIn {
     const uint32_t* counts;                      // per-sub-queue entry counts (stride CNT_PAD)
 };
 
+#ifndef APT_MAX_NQ
 #define APT_MAX_NQ 32
+#endif
 #define CNT_PAD 32                               // one counter per 128-byte line
 enum { ST_SAMPLES = 0, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_SHADOW_TRACED, ST_LIT, ST_DRAWS, ST_POISON, ST_COUNT };
 struct Counters {
@@ -229,7 +236,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
             st3q(q.ray_o[0], p.cap, so, mk3(p.cam_t[0], p.cam_t[1], p.cam_t[2]));
             st3q(q.ray_d[0], p.cap, so, dir);
             st3q(q.thr[0], p.cap, so, splat3(1.f));
-            stq(q.id[0], so, idx);
+            stq(q.id[0], so, ((idx / (uint32_t)p.npix) << p.pix_bits) | (idx % (uint32_t)p.npix));
             stq(q.meta[0], so, pack_meta(draws, 0u, false));
             stq(q.pdf[0], so, 1.f);
             t_samples++;
@@ -359,7 +366,7 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
         const uint32_t idx = qbase + pos;
         bool alive = pos < n;
         f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), thr = splat3(0.f), hit_point = splat3(0.f);
-        uint32_t id = 0, draw0 = 0;
+        uint32_t id = 0, draw0 = 0, l_off = 0;                 // l_off: byte offset of this path's radiance slot
         float ray_pdf = 1.f;
         bool was_spec = false;
         Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
@@ -383,10 +390,10 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
                 bx = sc.bxdf[it.obj_id];
                 hit_light = sc.emitter_id[it.obj_id];
                 SH_TICK(0);
-                uint32_t lp = id % (uint32_t)p.npix, s = id / (uint32_t)p.npix;
-                int gi, gj; local_to_global(p, lp, gi, gj);
+                const uint32_t lp = id & ((1u << p.pix_bits) - 1u), s = id >> p.pix_bits;
+                l_off = (s * (uint32_t)p.npix + lp) << 2;
                 draw0 = meta & 0xffffu;
-                rng_init(rng, (uint32_t)(gi * p.H + gj), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
+                rng_init(rng, ldq(p.pix_key, lp << 2), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
                 // tail of the previous iteration: emission MIS weight for this hit (vanilla_renderer.py:111-117)
                 if (bounce > 0 && p.use_mis) {
                     float e_pdf = 0.0f;
@@ -414,16 +421,18 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
             float emitter_d = 0.f;
             if (alive && !break_flag) {
                 // sample_light (path_tracer.py:537-554): one int is always drawn
-                int ns = sc.n_sources;
-                int sidx = pymod(rng_int(rng), ns);
-                float emitter_pdf = 1.f / (float)ns;
+                const int ns = sc.n_sources;                    // wave-uniform: one light needs no modulo
+                int sidx = rng_int(rng);
+                sidx = (ns == 1) ? 0 : pymod(sidx, ns);
+                float emitter_pdf = p.inv_ns;
                 bool valid = true;
                 if (hit_light >= 0) {
                     if (ns <= 1) valid = false;
                     else {
-                        sidx = pymod(rng_int(rng), ns - 1);
+                        sidx = rng_int(rng);
+                        sidx = (ns == 2) ? 0 : pymod(sidx, ns - 1);
                         if (sidx >= hit_light) sidx += 1;
-                        emitter_pdf = 1.f / (float)(ns - 1);
+                        emitter_pdf = p.inv_ns1;
                     }
                 }
                 if (!valid) break_flag = true;
@@ -446,7 +455,7 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
                         // Upstream the MIS weight multiplies the light sample even when the shadow ray is
                         // occluded (0 * NaN), so a NaN weight poisons the whole pixel-sample, which is then
                         // zeroed at the end (vanilla_renderer.py:87-95,119).  Reproduce that without tracing.
-                        st3q(q.L, p.cap, id << 2, splat3(mis_w));
+                        st3q(q.L, p.cap, l_off, splat3(mis_w));
                         t_poison++;
                     } else {
                         f3 c = ((direct_spec * shadow_int) * mis_w) / emitter_pdf;
@@ -463,7 +472,7 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
                 st3q(q.sh_d, sc_, so, light_dir);
                 stq(q.sh_tmax, so, emitter_d);
                 st3q(q.sh_c, sc_, so, contrib);
-                stq(q.sh_id, so, id);
+                stq(q.sh_id, so, l_off);
             }
         }
 
@@ -478,9 +487,8 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
                 f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_s);
                 if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
                     f3 add = (emit_int * emission_weight) * thr;
-                    const uint32_t lo_ = id << 2;
-                    f3 cur_L = ld3q(q.L, p.cap, lo_);
-                    st3q(q.L, p.cap, lo_, mk3(cur_L.x + add.x, cur_L.y + add.y, cur_L.z + add.z));
+                    f3 cur_L = ld3q(q.L, p.cap, l_off);
+                    st3q(q.L, p.cap, l_off, mk3(cur_L.x + add.x, cur_L.y + add.y, cur_L.z + add.z));
                 }
             }
             f3 spec;
@@ -549,7 +557,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
             const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
             if (occluded && weird) c = c * 0.f;
             if (!occluded || weird) {
-                const uint32_t lo_ = ldq(q.sh_id, io) << 2;
+                const uint32_t lo_ = ldq(q.sh_id, io);                  // byte offset of the path's radiance slot
                 char* Lb = reinterpret_cast<char*>(q.L);
                 atomicAdd(reinterpret_cast<float*>(Lb + lo_), c.x);
                 atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 4 + lo_), c.y);
