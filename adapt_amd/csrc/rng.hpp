@@ -18,6 +18,12 @@ struct Philox {
 };
 
 APT_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // A stage calls this from several inlined draw sites with the same key.  Left alone, the compiler shares the ten
+    // per-round keys (k0 + r * 0x9E3779B9) between the sites and keeps them in ~10 VGPRs for the whole kernel; making the
+    // key opaque per call re-derives them with ten adds each time and frees those registers.
+    asm volatile("" : "+v"(k0));
+#endif
 #pragma unroll
     for (int r = 0; r < 10; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;

@@ -128,13 +128,15 @@ APT_D int* carve_lds(const DevBvh& b, const LdsPlan& plan, StagedBvh& out) {
 }
 
 APT_D uint32_t lane_id() { return threadIdx.x & 63u; }
+// number of set bits of a ballot mask below this lane (v_mbcnt: no lane-mask registers to keep alive)
+APT_D uint32_t rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 // append `flag` lanes of the wave to the queue counted by *counter; returns this lane's position
 APT_D uint32_t wave_append(bool flag, uint32_t* counter) {
     unsigned long long m = __ballot(flag);
     uint32_t base = 0;
     if (lane_id() == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m));
     base = __shfl(base, 0);
-    return base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+    return base + rank_in(m);
 }
 
 // Queue addressing.  Every queue array is indexed by a 32-bit slot whose BYTE offset also fits 32 bits (the host
@@ -146,6 +148,9 @@ template <typename T> APT_D T ldq(const T* base, uint32_t off) { return *reinter
 template <typename T> APT_D void stq(T* base, uint32_t off, T v) { *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + off) = v; }
 APT_D f3 ld3q(const float* base, uint32_t stride, uint32_t off) { return mk3(ldq(base, off), ldq(base + stride, off), ldq(base + 2 * stride, off)); }
 APT_D void st3q(float* base, uint32_t stride, uint32_t off, f3 v) { stq(base, off, v.x); stq(base + stride, off, v.y); stq(base + 2 * stride, off, v.z); }
+// wave-uniform tally: how many lanes of the wave have `flag` set (lives in an SGPR)
+APT_D uint32_t wave_count(bool flag) { return (uint32_t)__popcll(__ballot(flag)); }
+APT_D void flush_uniform(uint32_t v, unsigned long long* counter) { if (lane_id() == 0 && v) atomicAdd(counter, (unsigned long long)v); }
 // end-of-kernel statistics: per-lane register tallies -> one atomic per wave per counter
 APT_D void flush_stat(uint32_t v, unsigned long long* counter) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
@@ -348,7 +353,9 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
     uint32_t* next_counter = &cnt->n_active[nxt][sl.q * CNT_PAD];
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
     const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
-    uint32_t t_shade = 0, t_shadow = 0, t_draws = 0, t_poison = 0;
+    uint32_t t_shade = 0, t_shadow = 0, t_poison = 0;        // wave-uniform tallies (SGPRs)
+    __shared__ uint32_t s_draws[BLOCK / 64];                  // RNG draws of this wave: a per-lane tally would hold a VGPR for the whole kernel
+    if (lane_id() == 0) s_draws[threadIdx.x >> 6] = 0;
 #ifdef APT_SHADE_PROF
     unsigned long long sprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long life0_ = __builtin_readcyclecounter();
@@ -410,13 +417,16 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
                 } else if (max3(thr) < 1e-4f) alive = false;
             }
         }
-        if (alive) { t_shade++; hit_point = d * it.min_depth + o; }
+        t_shade += wave_count(alive);
+        if (alive) {
+            hit_point = d * it.min_depth + o;
+        }
         SH_TICK(1);
 
         // ---- next-event estimation: one shadow-queue entry per useful light sample
         bool break_flag = false;
         for (int s = 0; s < p.S; s++) {
-            bool want = false;
+            bool want = false, sampled = false, poisoned = false;
             f3 light_dir = splat3(0.f), contrib = splat3(0.f);
             float emitter_d = 0.f;
             if (alive && !break_flag) {
@@ -443,7 +453,7 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
                     f3 to_emitter = emit_pos - hit_point;
                     emitter_d = norm(to_emitter);
                     light_dir = to_emitter / emitter_d;
-                    t_shadow++;
+                    sampled = true;
                     f3 direct_spec = surface_eval<BM>(bx, it, d, light_dir, sc.world_ior, p.two_sides);
                     float mis_w = 1.0f;
                     if (p.use_mis && !(src.bool_bits & 0x01)) {
@@ -456,7 +466,7 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
                         // occluded (0 * NaN), so a NaN weight poisons the whole pixel-sample, which is then
                         // zeroed at the end (vanilla_renderer.py:87-95,119).  Reproduce that without tracing.
                         st3q(q.L, p.cap, l_off, splat3(mis_w));
-                        t_poison++;
+                        poisoned = true;
                     } else {
                         f3 c = ((direct_spec * shadow_int) * mis_w) / emitter_pdf;
                         contrib = (c * p.inv_S) * thr;
@@ -465,6 +475,7 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
                 }
             }
             SH_TICK(2);
+            t_shadow += wave_count(sampled); t_poison += wave_count(poisoned);
             uint32_t spos = wave_append(want, shadow_counter);
             if (want && spos < q.sh_subcap) {
                 const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
@@ -483,6 +494,8 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
         float new_pdf = 1.f;
         bool is_spec = false;
         if (alive) {
+            // emission of the surface we are on (vanilla_renderer.py:99-104).  It has to stay AFTER the light sampling: with
+            // two-sided BRDFs the evaluation above flips it.n_s in place, upstream as here, and eval_le sees the flipped normal.
             if ((SM & 2) && hit_light >= 0) {
                 f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_s);
                 if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
@@ -496,7 +509,7 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
             thr = thr * (spec / new_pdf);
             cont = (bounce + 1) < p.max_bounce;
         }
-        t_draws += rng.draw - draw0;
+        if (rng.draw != draw0) atomicAdd(&s_draws[threadIdx.x >> 6], rng.draw - draw0);      // also paths that died in the roulette
         SH_TICK(4);
         uint32_t npos = wave_append(cont, next_counter);
         if (cont) {
@@ -516,10 +529,10 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
     if ((threadIdx.x & 63) == 0) { const uint32_t w_ = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64; if (w_ < 16384) { cnt->dbg[2 * w_] = wall0_; cnt->dbg[2 * w_ + 1] = wall_clock64(); } }
     if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; k++) atomicAdd(&cnt->stats[sl.q][8 + k], sprof[k]);
 #endif
-    flush_stat(t_shade, &cnt->stats[sl.q][ST_SHADE]);
-    flush_stat(t_shadow, &cnt->stats[sl.q][ST_SHADOW]);
-    flush_stat(t_draws, &cnt->stats[sl.q][ST_DRAWS]);
-    flush_stat(t_poison, &cnt->stats[sl.q][ST_POISON]);
+    flush_uniform(t_shade, &cnt->stats[sl.q][ST_SHADE]);
+    flush_uniform(t_shadow, &cnt->stats[sl.q][ST_SHADOW]);
+    if (lane_id() == 0 && s_draws[threadIdx.x >> 6]) atomicAdd(&cnt->stats[sl.q][ST_DRAWS], (unsigned long long)s_draws[threadIdx.x >> 6]);
+    flush_uniform(t_poison, &cnt->stats[sl.q][ST_POISON]);
 }
 
 // ------------------------------------------------------------------- shadow

@@ -314,7 +314,7 @@ APT_D bool sweep_wg(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active, 
             if (lane == 0 && m) base = atomicAdd(&s_count[n_lists], (int)__popcll(m));
             base = __shfl(base, 0);
             if (need) {
-                s_list[base + (int)__popcll(m & ((1ull << lane) - 1ull))] = tid;
+                s_list[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = tid;
                 s_t[tid] = rec.t; s_prim[tid] = -1;
             }
         }
@@ -403,7 +403,7 @@ APT_D bool sweep_tile(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active
             int base = 0;
             if (lane == 0) base = atomicAdd(&s_cnt[ob], (int)__popcll(m));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (need) { TileEntry e; e.a = (uint32_t)tid; e.b = tn; s_ent[ob * NT + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = e; }
+            if (need) { TileEntry e; e.a = (uint32_t)tid; e.b = tn; s_ent[ob * NT + base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = e; }
         }
     }
     TILE_TICK(1);

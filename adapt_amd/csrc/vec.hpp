@@ -58,7 +58,32 @@ APT_HD f3 mul(const m33& M, f3 a) {
 #if APT_EXACT_MATH
 APT_D float apt_cos(float x) { return (float)cos((double)x); }
 APT_D float apt_sin(float x) { return (float)sin((double)x); }
-APT_D void apt_sincos(float x, float* s, float* c) { double ds, dc; sincos((double)x, &ds, &dc); *s = (float)ds; *c = (float)dc; }
+// sin and cos of an azimuth in [0, 2 pi] (the only use: polar_dir), in double, rounded once.  Same contract as the generic
+// versions above, but OCML's double sincos carries its large-argument reduction through the whole shade kernel (+16 VGPRs,
+// one occupancy step); for |x| < 8 two fused steps against a two-word pi/2 and the fdlibm kernels on [-pi/4, pi/4]
+// (error < 1 ulp in double, i.e. invisible after the rounding to float except on ~1e-8 of arguments) are enough.
+APT_D void apt_sincos(float xf, float* s, float* c) {
+#ifdef APT_SINCOS_OCML
+    { double ds, dc; sincos((double)xf, &ds, &dc); *s = (float)ds; *c = (float)dc; return; }
+#endif
+    const double x = (double)xf;
+    const double k = __builtin_rint(x * 6.36619772367581382433e-01);                 // nearest multiple of pi/2
+    double r = __builtin_fma(-k, 1.57079632679489655800e+00, x);
+    r = __builtin_fma(-k, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06); ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03); ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = __builtin_fma(z * r, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07); pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03); pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double cs = __builtin_fma(z * z, pc, __builtin_fma(z, -0.5, 1.0));
+    const int q = (int)k & 3;
+    const double so = (q & 1) ? cs : sn, co = (q & 1) ? sn : cs;
+    *s = (float)((q & 2) ? -so : so);
+    *c = (float)(((q + 1) & 2) ? -co : co);
+}
 APT_D float apt_tan(float x) { return (float)tan((double)x); }
 APT_D float apt_pow(float x, float y) { return (float)pow((double)x, (double)y); }
 #else
