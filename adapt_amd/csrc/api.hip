@@ -124,6 +124,14 @@ struct apt_renderer {
     double render_ms = 0.0;
     hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;
     bool render_pending = false;
+    // Render lanes: independent batch pipelines (own stream, queue pool, counters) whose kernels overlap on the GPU —
+    // one lane's latency-bound shade runs beside another lane's VALU-bound extend.  Lane 0 is {stream, pool, counters, q}
+    // above; the framebuffer is shared and the finalize kernels are chained by events so that samples are still added to
+    // a pixel in sample order (bit-identical to the single-lane result).
+    struct Lane { hipStream_t stream = nullptr; DevBuf pool, counters; Queues q{}; hipEvent_t fin = nullptr; };
+    std::vector<Lane> extra;      // lanes 1..n-1
+    hipEvent_t fin0 = nullptr;    // lane 0's "finalize done" event
+    int n_lanes = 1;
 };
 
 static int count_device(int* n) {
@@ -300,7 +308,9 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     r->npix = r->n_cols * c.height;
     if (r->npix <= 0) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: this rank owns no pixels"); }
     int B = c.spp_per_batch;
-    if (B <= 0) { B = (int)((8u << 20) / (uint32_t)r->npix); if (B < 1) B = 1; if (B > 64) B = 64; }   // ~8 Mi paths in flight (measured plateau from ~4 Mi)
+    r->n_lanes = 3;               // measured on C2: 1 lane 1 827, 2 lanes 2 196, 3 lanes 2 268, 4 lanes 2 178 Msamples/s (64 spp per lane-batch)
+    if (const char* nl = getenv("APT_LANES")) r->n_lanes = std::min(4, std::max(1, atoi(nl)));
+    if (B <= 0) { B = (int)((16u << 20) / (uint32_t)r->npix); if (B < 1) B = 1; if (B > 64) B = 64; }   // ~16 Mi paths per lane: 2.7 GB of queues each, of 288 GB
     r->spp_batch = B;
     const int S = c.num_shadow_ray;
     const int nq = r->nq;
@@ -347,29 +357,44 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     }
     // the kernels address queue slots with 32-bit byte offsets (stages.hpp "Queue addressing")
     if (cap >= ((size_t)1 << 30) || sh_cap >= ((size_t)1 << 30)) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: batch too large (queue capacity must stay below 2^30 slots)"); }
-    // one pool, carved into the SoA arrays (all 4-byte lanes)
+    // one pool per lane, carved into the SoA arrays (all 4-byte lanes)
     const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 3) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls;
-    hipError_t e = r->pool.alloc(words * 4);
+    auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
+        hipError_t e_ = pool.alloc(words * 4);
+        if (e_ != hipSuccess) return e_;
+        float* w = pool.as<float>();
+        auto take = [&](size_t n) { float* x = w; w += n; return x; };
+        for (int k = 0; k < 2; k++) { q.ray_o[k] = take(3 * cap); q.ray_d[k] = take(3 * cap); }
+        q.hit_t = take(cap); q.hit_prim = (int*)take(cap); q.hit_u = take(cap); q.hit_v = take(cap);
+        for (int k = 0; k < 2; k++) { q.thr[k] = take(3 * cap); q.id[k] = (uint32_t*)take(cap); q.meta[k] = (uint32_t*)take(cap); q.pdf[k] = take(cap); }
+        q.L = take(3 * cap);
+        q.sh_o = take(3 * sh_cap); q.sh_d = take(3 * sh_cap); q.sh_tmax = take(sh_cap); q.sh_c = take(3 * sh_cap); q.sh_id = (uint32_t*)take(sh_cap);
+        q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
+        q.n_classes = ncls;
+        for (int c = 0; c < ncls; c++) {
+            Queues::ClassQ& k = q.cls[c];
+            k.ray_o = take(3 * cap); k.ray_d = take(3 * cap); k.thr = take(3 * cap); k.id = (uint32_t*)take(cap); k.meta = (uint32_t*)take(cap);
+            k.pdf = take(cap); k.t = take(cap); k.prim = (int*)take(cap); k.u = take(cap); k.v = take(cap);
+        }
+        return hipSuccess;
+    };
+    hipError_t e = carve(r->pool, r->q);
     if (e != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("queue pool: ") + hipGetErrorString(e)); }
-    float* w = r->pool.as<float>();
-    auto take = [&](size_t n) { float* x = w; w += n; return x; };
-    Queues& q = r->q;
-    for (int k = 0; k < 2; k++) { q.ray_o[k] = take(3 * cap); q.ray_d[k] = take(3 * cap); }
-    q.hit_t = take(cap); q.hit_prim = (int*)take(cap); q.hit_u = take(cap); q.hit_v = take(cap);
-    for (int k = 0; k < 2; k++) { q.thr[k] = take(3 * cap); q.id[k] = (uint32_t*)take(cap); q.meta[k] = (uint32_t*)take(cap); q.pdf[k] = take(cap); }
-    q.L = take(3 * cap);
-    q.sh_o = take(3 * sh_cap); q.sh_d = take(3 * sh_cap); q.sh_tmax = take(sh_cap); q.sh_c = take(3 * sh_cap); q.sh_id = (uint32_t*)take(sh_cap);
-    q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
-    q.n_classes = ncls;
-    for (int c = 0; c < ncls; c++) {
-        Queues::ClassQ& k = q.cls[c];
-        k.ray_o = take(3 * cap); k.ray_d = take(3 * cap); k.thr = take(3 * cap); k.id = (uint32_t*)take(cap); k.meta = (uint32_t*)take(cap);
-        k.pdf = take(cap); k.t = take(cap); k.prim = (int*)take(cap); k.u = take(cap); k.v = take(cap);
+    r->extra.resize((size_t)r->n_lanes - 1);
+    for (auto& ln : r->extra) {
+        if ((e = carve(ln.pool, ln.q)) != hipSuccess || (e = ln.counters.alloc(sizeof(Counters))) != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("queue pool (lane): ") + hipGetErrorString(e)); }
     }
     if ((e = r->counters.alloc(sizeof(Counters))) != hipSuccess || (e = r->accum.alloc((size_t)r->npix * 12)) != hipSuccess ||
         (e = r->scratch.alloc((size_t)r->npix * 12)) != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("framebuffer: ") + hipGetErrorString(e)); }
     HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
     HIP_TRY(hipMemsetAsync(r->counters.p, 0, sizeof(Counters), r->stream));
+    HIP_TRY(hipEventCreateWithFlags(&r->fin0, hipEventDisableTiming));
+    for (auto& ln : r->extra) {
+        HIP_TRY(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ln.fin, hipEventDisableTiming));
+        HIP_TRY(hipMemsetAsync(ln.counters.p, 0, sizeof(Counters), ln.stream));
+        HIP_TRY(hipStreamSynchronize(ln.stream));
+    }
     HIP_TRY(hipMemsetAsync(r->accum.p, 0, (size_t)r->npix * 12, r->stream));
     HIP_TRY(hipEventCreate(&r->ev_r0)); HIP_TRY(hipEventCreate(&r->ev_r1));
     hipDeviceProp_t prop;
@@ -433,7 +458,9 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
 APT_EXPORT void apt_renderer_destroy(apt_renderer* r) {
     if (!r) return;
     (void)hipSetDevice(r->cfg.device);
+    for (auto& ln : r->extra) { if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); } if (ln.fin) (void)hipEventDestroy(ln.fin); }
     if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+    if (r->fin0) (void)hipEventDestroy(r->fin0);
     for (auto& ev : r->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto& ev : r->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     if (r->ev_r0) (void)hipEventDestroy(r->ev_r0);
@@ -450,16 +477,16 @@ static int grid_for(size_t n, int cap_blocks, int nq, int nt = BLOCK) {
 }
 
 struct LaunchTimer {      // brackets one kernel launch with events when profiling is on
-    apt_renderer* r; int kernel; EventPair ev{}; bool on;
-    LaunchTimer(apt_renderer* r_, int k) : r(r_), kernel(k), on(r_->cfg.profile != 0) {
+    apt_renderer* r; int kernel; EventPair ev{}; bool on; hipStream_t st;
+    LaunchTimer(apt_renderer* r_, int k, hipStream_t stream = nullptr) : r(r_), kernel(k), on(r_->cfg.profile != 0), st(stream ? stream : r_->stream) {
         r->launches[k]++;
         if (!on) return;
         if (!r->free_events.empty()) { ev = r->free_events.back(); r->free_events.pop_back(); }
         else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
         ev.kernel = k;
-        (void)hipEventRecord(ev.a, r->stream);
+        (void)hipEventRecord(ev.a, st);
     }
-    ~LaunchTimer() { if (on) { (void)hipEventRecord(ev.b, r->stream); r->pending.push_back(ev); } }
+    ~LaunchTimer() { if (on) { (void)hipEventRecord(ev.b, st); r->pending.push_back(ev); } }
 };
 
 static int resolve_events(apt_renderer* r) {
@@ -484,38 +511,51 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
     HIP_TRY(hipSetDevice(r->cfg.device));
     if (r->render_pending) { if (int rc = resolve_events(r)) return rc; }
     const DevScene& sc = r->scene->dev;
-    Counters* cnt = r->counters.as<Counters>();
     HIP_TRY(hipEventRecord(r->ev_r0, r->stream));
-    int done = 0;
+    for (auto& ln : r->extra) HIP_TRY(hipStreamWaitEvent(ln.stream, r->ev_r0, 0));     // lanes start after whatever the main stream did before
+    int done = 0, batch = 0;
+    hipEvent_t prev_fin = nullptr;
+    // a call smaller than one full round of lane-batches is split evenly so that every lane has work
+    const int batch_cap = (r->cfg.spp_per_batch <= 0 && n_spp < r->n_lanes * r->spp_batch) ? std::max(1, (n_spp + r->n_lanes - 1) / r->n_lanes) : r->spp_batch;
     while (done < n_spp) {
-        const int B = (n_spp - done < r->spp_batch) ? (n_spp - done) : r->spp_batch;
+        const int B = (n_spp - done < batch_cap) ? (n_spp - done) : batch_cap;
+        const int li = batch % r->n_lanes;
+        hipStream_t st = li ? r->extra[(size_t)li - 1].stream : r->stream;
+        const Queues& q = li ? r->extra[(size_t)li - 1].q : r->q;
+        Counters* cnt = li ? r->extra[(size_t)li - 1].counters.as<Counters>() : r->counters.as<Counters>();
+        hipEvent_t fin = li ? r->extra[(size_t)li - 1].fin : r->fin0;
         Params p = r->par; p.cnt_base = r->cnt; p.spp_batch = B;
         const size_t total = (size_t)r->npix * (size_t)B;
-        HIP_TRY(hipMemsetAsync(cnt, 0, offsetof(Counters, stats), r->stream));   // queue counters only; statistics keep accumulating
+        HIP_TRY(hipMemsetAsync(cnt, 0, offsetof(Counters, stats), st));   // queue counters only; statistics keep accumulating
         const int nq = r->nq;
-        { LaunchTimer t(r, 0); hipLaunchKernelGGL(k_generate, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, r->stream, p, r->q, cnt); }
+        { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, p, q, cnt); }
         int cur = 0;
         for (int b = 0; b < p.max_bounce; b++) {
-            { LaunchTimer t(r, 1); hipLaunchKernelGGL(kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, r->stream, sc, p, r->q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
+            { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
             if (!r->sorted) {
-                ShadeIn in = {r->q.ray_o[cur], r->q.ray_d[cur], r->q.thr[cur], r->q.id[cur], r->q.meta[cur], r->q.pdf[cur],
-                              r->q.hit_t, r->q.hit_prim, r->q.hit_u, r->q.hit_v, (const uint32_t*)cnt->n_active[cur]};
-                LaunchTimer t(r, 2); hipLaunchKernelGGL(r->shade->fn, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, r->stream, sc, p, r->q, cnt, in, cur, b);
+                ShadeIn in = {q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.id[cur], q.meta[cur], q.pdf[cur],
+                              q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur]};
+                LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->shade->fn, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
             } else {
-                for (int c = 0; c < r->q.n_classes; c++) {
-                    const Queues::ClassQ& k = r->q.cls[c];
+                for (int c = 0; c < q.n_classes; c++) {
+                    const Queues::ClassQ& k = q.cls[c];
                     ShadeIn in = {k.ray_o, k.ray_d, k.thr, k.id, k.meta, k.pdf, k.t, k.prim, k.u, k.v, (const uint32_t*)cnt->n_cls[c]};
-                    LaunchTimer t(r, 2); hipLaunchKernelGGL(r->class_fn[c], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, r->stream, sc, p, r->q, cnt, in, cur, b);
+                    LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->class_fn[c], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
                 }
-                if (p.S <= 0) HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), r->stream));      // normally k_shadow recycles these
+                if (p.S <= 0) HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st));      // normally k_shadow recycles these
             }
-            if (p.S > 0) { LaunchTimer t(r, 3); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, r->stream, sc, p, r->q, cnt, r->plan); }
+            if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, r->plan); }
             cur ^= 1;
         }
-        { LaunchTimer t(r, 4); hipLaunchKernelGGL(k_finalize, dim3(grid_for((size_t)r->npix, r->grid_small, 1)), dim3(BLOCK), 0, r->stream, p, r->q, r->accum.as<float>()); }
+        // the framebuffer is shared: batch k's samples are added after batch k-1's, whichever lanes they ran on
+        if (prev_fin && r->n_lanes > 1) HIP_TRY(hipStreamWaitEvent(st, prev_fin, 0));
+        { LaunchTimer t(r, 4, st); hipLaunchKernelGGL(k_finalize, dim3(grid_for((size_t)r->npix, r->grid_small, 1)), dim3(BLOCK), 0, st, p, q, r->accum.as<float>()); }
+        HIP_TRY(hipEventRecord(fin, st));
+        prev_fin = fin;
         HIP_TRY(hipGetLastError());
-        r->cnt += B; done += B;
+        r->cnt += B; done += B; batch++;
     }
+    for (auto& ln : r->extra) { HIP_TRY(hipEventRecord(ln.fin, ln.stream)); HIP_TRY(hipStreamWaitEvent(r->stream, ln.fin, 0)); }   // join
     HIP_TRY(hipEventRecord(r->ev_r1, r->stream));
     r->render_pending = true;
     return APT_OK;
@@ -559,6 +599,7 @@ APT_EXPORT int apt_reset(apt_renderer* r) {
     HIP_TRY(hipSetDevice(r->cfg.device));
     HIP_TRY(hipMemsetAsync(r->accum.p, 0, (size_t)r->npix * 12, r->stream));
     HIP_TRY(hipMemsetAsync(r->counters.p, 0, sizeof(Counters), r->stream));
+    for (auto& ln : r->extra) HIP_TRY(hipMemsetAsync(ln.counters.p, 0, sizeof(Counters), r->stream));      // lanes are idle between render calls
     r->cnt = 0;
     if (int rc = resolve_events(r)) return rc;
     for (int k = 0; k < APT_N_KERNELS; k++) { r->kernel_ms[k] = 0; r->launches[k] = 0; }
@@ -569,8 +610,12 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
     if (!r || !out) return fail(APT_E_INVALID, "apt_get_stats: bad argument");
     HIP_TRY(hipSetDevice(r->cfg.device));
     if (int rc = resolve_events(r)) return rc;
-    std::vector<unsigned long long> st((size_t)APT_MAX_NQ * 16);
+    std::vector<unsigned long long> st((size_t)APT_MAX_NQ * 16), st2((size_t)APT_MAX_NQ * 16);
     HIP_TRY(hipMemcpy(st.data(), (const char*)r->counters.p + offsetof(Counters, stats), st.size() * 8, hipMemcpyDeviceToHost));
+    for (auto& ln : r->extra) {
+        HIP_TRY(hipMemcpy(st2.data(), (const char*)ln.counters.p + offsetof(Counters, stats), st2.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < st.size(); k++) st[k] += st2[k];
+    }
     memset(out, 0, sizeof(*out));
     auto sum = [&](int k) { unsigned long long a = 0; for (int q = 0; q < APT_MAX_NQ; q++) a += st[(size_t)q * 16 + k]; return (int64_t)a; };
     out->n_samples = sum(ST_SAMPLES); out->n_extend = sum(ST_EXTEND); out->n_shade = sum(ST_SHADE);
@@ -717,7 +762,7 @@ APT_EXPORT int apt_renderer_info(const apt_renderer* r, int32_t* spp_batch, int3
     if (!r) return fail(APT_E_INVALID, "apt_renderer_info: null handle");
     if (spp_batch) *spp_batch = r->spp_batch;
     if (n_subqueues) *n_subqueues = r->nq;
-    if (queue_bytes) *queue_bytes = (int64_t)r->pool.bytes;
+    if (queue_bytes) *queue_bytes = (int64_t)r->pool.bytes * (int64_t)r->n_lanes;
     if (lds_bytes) *lds_bytes = (int32_t)r->lds_bytes;
     if (shade_variant) *shade_variant = r->shade_name.c_str();
     if (trace_mode) *trace_mode = r->trace_mode;

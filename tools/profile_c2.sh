@@ -12,7 +12,7 @@ SPP=${2:-64}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-CMD="python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --spp $SPP --no-cpu-baseline"
+CMD="python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --spp $SPP --no-cpu-baseline --no-exclusive-pass ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/pmc_sq -o sq -- $CMD > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
