@@ -116,7 +116,8 @@ struct apt_renderer {
     shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string shade_name;
     LdsPlan plan{};
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, lds_bytes_any = 0;     // dynamic LDS of the closest-hit / any-hit trace kernels
+    int grid_shadow = 0;
     std::vector<EventPair> pending;
     std::vector<EventPair> free_events;
     double kernel_ms[APT_N_KERNELS] = {0, 0, 0, 0, 0};
@@ -432,7 +433,10 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         if (r->trace_mode == 2) {
             r->trace_nt = APT_TILE_NT;
             r->lds_bytes = APT_TILE_LDS_BYTES(APT_TILE_NT, sc->n_objects);
+            r->lds_bytes_any = APT_TILE_LDS_BYTES_ANY(APT_TILE_NT, sc->n_objects);
             r->grid_trace = cus * (int)std::max<size_t>(1, std::min<size_t>(2048 / APT_TILE_NT, (160 * 1024) / r->lds_bytes));
+            // 69 VGPRs allow 7 waves per SIMD = three 8-wave workgroups per CU; the slimmer LDS footprint leaves room for other lanes' kernels
+            r->grid_shadow = cus * (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / r->lds_bytes_any));
             if (r->lds_bytes > 64 * 1024) {
                 HIP_TRY(hipFuncSetAttribute((const void*)kExtend[2][0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
                 HIP_TRY(hipFuncSetAttribute((const void*)kExtend[2][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
@@ -449,7 +453,10 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     r->grid_small = cus * 8;       // streaming stages: up to 8 x 256-thread workgroups per CU
     if (const char* g = getenv("APT_GRID_SMALL")) r->grid_small = cus * std::max(1, atoi(g));       // tuning knobs: workgroups per CU
     if (const char* g = getenv("APT_GRID_TRACE")) r->grid_trace = cus * std::max(1, atoi(g));
+    if (r->trace_mode != 2) { r->lds_bytes_any = r->lds_bytes; r->grid_shadow = r->grid_trace; }
+    if (const char* g = getenv("APT_GRID_SHADOW")) r->grid_shadow = cus * std::max(1, atoi(g));
     r->grid_trace = ((r->grid_trace + nq - 1) / nq) * nq;          // persistent grids are multiples of nq
+    r->grid_shadow = ((r->grid_shadow + nq - 1) / nq) * nq;
     r->grid_small = ((r->grid_small + nq - 1) / nq) * nq;
     HIP_TRY(hipStreamSynchronize(r->stream));
     *out = r;
@@ -544,7 +551,7 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
                 }
                 if (p.S <= 0) HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st));      // normally k_shadow recycles these
             }
-            if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, r->plan); }
+            if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, r->plan); }
             cur ^= 1;
         }
         // the framebuffer is shared: batch k's samples are added after batch k-1's, whichever lanes they ran on
@@ -700,7 +707,7 @@ APT_EXPORT int apt_occluded(apt_renderer* r, int32_t n, const float* o, const fl
     HIP_TRY(upload(bo, so)); HIP_TRY(upload(bd, sd));
     std::vector<float> tm(tmax, tmax + n);
     HIP_TRY(upload(bt, tm)); HIP_TRY(bocc.alloc((size_t)n * 4));
-    hipLaunchKernelGGL(kOccluded[r->trace_mode], dim3(grid_for((size_t)n, r->grid_trace, 1, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, r->stream, r->scene->dev, (uint32_t)n,
+    hipLaunchKernelGGL(kOccluded[r->trace_mode], dim3(grid_for((size_t)n, r->grid_shadow, 1, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, r->stream, r->scene->dev, (uint32_t)n,
                        bo.as<float>(), bd.as<float>(), bt.as<float>(), bocc.as<int>(), r->plan);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(r->stream));

@@ -468,7 +468,8 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
                         st3q(q.L, p.cap, l_off, splat3(mis_w));
                         poisoned = true;
                     } else {
-                        f3 c = ((direct_spec * shadow_int) * mis_w) / emitter_pdf;
+                        f3 c = (direct_spec * shadow_int) * mis_w;
+                        if (ns != 1) c = c / emitter_pdf;               // one light: the pdf is exactly 1 and x / 1 == x (wave-uniform branch)
                         contrib = (c * p.inv_S) * thr;
                         want = !(contrib.x == 0.f && contrib.y == 0.f && contrib.z == 0.f);
                     }

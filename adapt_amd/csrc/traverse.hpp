@@ -362,9 +362,11 @@ APT_D bool sweep_wg(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active, 
 //            loads), reduce with a 64-bit LDS atomicMin on (t bits, primitive, list slot) and leave (u, v) in
 //            the entry's slot;
 //   phase C  the owner picks up its minimum (or its occlusion flag), or runs the fallback.
-// LDS: NT * 40 B + n_objects * (NT * 8 B + 4 B).  Must be called by every thread of the block.
+// LDS: NT * 40 B + n_objects * (NT * 8 B + 4 B); any-hit: NT * 32 B + n_objects * (NT * 2 B + 4 B).  Must be called by every thread of the block.
 #define APT_TILE_MAX_OBJECTS 48
 #define APT_TILE_LDS_BYTES(nt, n_obj) ((size_t)(nt) * 40 + (size_t)(n_obj) * ((size_t)(nt) * 8 + 4) + 16)
+// any-hit tiles need neither the (t, primitive) reduction slots nor (tn | u, v) per entry: 2-byte entries
+#define APT_TILE_LDS_BYTES_ANY(nt, n_obj) ((size_t)(nt) * 32 + (size_t)(n_obj) * ((size_t)(nt) * 2 + 4) + 16)
 struct TileEntry { uint32_t a; float b; };                 // (ray, tn) going in, (u, v) coming out
 #ifdef APT_TILE_PROF
 #define TILE_TICK(k) do { unsigned long long now_ = __builtin_readcyclecounter(); prof[k] += now_ - tick_; tick_ = now_; } while (0)
@@ -380,14 +382,16 @@ APT_D bool sweep_tile(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active
     float* s_ray = lds;                                                     // o.xyz d.xyz t0, SoA
     int* s_flag = reinterpret_cast<int*>(lds + 7 * NT);
     unsigned long long* s_best = reinterpret_cast<unsigned long long*>(lds + 8 * NT);    // 8-byte aligned
-    TileEntry* s_ent = reinterpret_cast<TileEntry*>(lds + 10 * NT);          // [object][slot]
-    int* s_cnt = reinterpret_cast<int*>(s_ent + (size_t)n_obj * NT);
+    TileEntry* s_ent = reinterpret_cast<TileEntry*>(lds + 10 * NT);          // closest hit: [object][slot] (ray, tn) -> (u, v)
+    uint16_t* s_idx = reinterpret_cast<uint16_t*>(lds + 8 * NT);            // any hit: [object][slot] ray only (overlays s_best, unused there)
+    int* s_cnt = ANY ? reinterpret_cast<int*>(s_idx + (size_t)n_obj * NT) : reinterpret_cast<int*>(s_ent + (size_t)n_obj * NT);
     const float t0 = rec.t;
     const cf_ptr stream = (cf_ptr)sc.stream;
     const ci_ptr tab = (ci_ptr)sc.obj_tab;
     s_ray[tid] = o.x; s_ray[NT + tid] = o.y; s_ray[2 * NT + tid] = o.z;
     s_ray[3 * NT + tid] = d.x; s_ray[4 * NT + tid] = d.y; s_ray[5 * NT + tid] = d.z; s_ray[6 * NT + tid] = t0;
-    s_flag[tid] = 0; s_best[tid] = ~0ull;
+    s_flag[tid] = 0;
+    if (!ANY) s_best[tid] = ~0ull;
     if (tid < n_obj) s_cnt[tid] = 0;
     __syncthreads();
     TILE_TICK(0);
@@ -403,7 +407,11 @@ APT_D bool sweep_tile(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active
             int base = 0;
             if (lane == 0) base = atomicAdd(&s_cnt[ob], (int)__popcll(m));
             base = __builtin_amdgcn_readfirstlane(base);
-            if (need) { TileEntry e; e.a = (uint32_t)tid; e.b = tn; s_ent[ob * NT + base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = e; }
+            if (need) {
+                const int at = ob * NT + base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (ANY) s_idx[at] = (uint16_t)tid;
+                else { TileEntry e; e.a = (uint32_t)tid; e.b = tn; s_ent[at] = e; }
+            }
         }
     }
     TILE_TICK(1);
@@ -419,8 +427,10 @@ APT_D bool sweep_tile(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active
             for (; g < n_chunks; g += NT / 64) {
                 const int li = g * 64 + lane;
                 const bool has = li < L;
-                TileEntry* slot = s_ent + ob * NT + (has ? li : L - 1);
-                const TileEntry e = *slot;
+                const int at = ob * NT + (has ? li : L - 1);
+                TileEntry* slot = s_ent + at;
+                TileEntry e; e.a = 0u; e.b = 0.f;
+                if (ANY) e.a = s_idx[at]; else e = *slot;
                 const int ti = (int)e.a;
                 const f3 ro = mk3(s_ray[ti], s_ray[NT + ti], s_ray[2 * NT + ti]);
                 const f3 rd = mk3(s_ray[3 * NT + ti], s_ray[4 * NT + ti], s_ray[5 * NT + ti]);
