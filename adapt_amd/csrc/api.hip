@@ -411,15 +411,18 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         else if (!strcmp(force, "sweep") && sc->has_aabb) r->trace_mode = 1;
         else if (!strcmp(force, "tile") && tile_ok) r->trace_mode = 2;
     }
-    // LDS plan: the per-lane stack must cover the tree depth; what is left of a ~40 KiB
-    // per-workgroup budget (4 workgroups per CU) stages the top of the tree and, when they
-    // all fit, the primitive records.
+    // LDS plan: the per-lane stack must cover the tree depth.  Staging the top of the tree (or the primitive records) in
+    // LDS was measured to lose against the occupancy the same bytes buy, so by default nothing is staged (knobs remain).
     {
         const apt::BvhData& bd = sc->bvh;
         LdsPlan pl;
         pl.stack_depth = bd.max_depth + 2;
         size_t stack_b = (size_t)pl.stack_depth * BLOCK * 4;
-        size_t budget = 40 * 1024 > stack_b + 8 * 1024 ? 40 * 1024 - stack_b : 8 * 1024;
+        size_t lds_target = 8 * 1024;                        // per-workgroup LDS target of the BVH walk beyond which nothing is staged: the stack alone is ~27 KiB on the 95 k / 285 k-triangle scenes
+        if (const char* kb = getenv("APT_BVH_LDS_KB")) lds_target = (size_t)std::max(8, atoi(kb)) * 1024;
+        size_t min_stage = 0;                                // staging the tree top in LDS buys nothing (C4 575 -> 605, C5 588 -> 621 Msamples/s without it): every KiB goes to occupancy
+        if (const char* kb = getenv("APT_BVH_STAGE_KB")) min_stage = (size_t)std::max(0, atoi(kb)) * 1024;
+        size_t budget = lds_target > stack_b + min_stage ? lds_target - stack_b : min_stage;
         int n_nodes = bd.n_nodes(), n_prims = sc->n_prims;
         pl.lds_prims = ((size_t)n_prims * 48 <= budget / 2) ? n_prims : 0;
         size_t left = budget - (size_t)pl.lds_prims * 48;
