@@ -94,3 +94,44 @@ def image_metrics(a, b):
     rel = np.mean((a - b) ** 2 / (b ** 2 + 1e-2))
     within = np.mean(np.all(np.abs(a - b) <= 1e-3 * (1 + np.abs(b)), axis=2))
     return {"relMSE": float(rel), "max_abs": float(np.abs(a - b).max()), "frac_within": float(within)}
+
+
+# ---- the reference's own bundled scenes, as arrays (tests/golden/refscene_*.npz; the XML files stay in /root/reference)
+REF_SCENE_TAGS = sorted(f[len("refscene_"):-4] for f in os.listdir(GOLDEN) if f.startswith("refscene_") and f.endswith(".npz"))
+
+
+class _Packed:
+    """host object that hands back its packed record (what adapt_amd.scene_pack asks of materials and emitters)"""
+    def __init__(self, ints, floats):
+        self._i, self._f = np.int32(ints), np.float32(floats)
+
+    def pack(self):
+        return self._i, self._f
+
+
+class _Obj:
+    def __init__(self, tri_num, kind, aabb, emitter_ref_id, bsdf):
+        self.tri_num, self.type, self.aabb, self.emitter_ref_id, self.bsdf = int(tri_num), int(kind), np.float32(aabb), int(emitter_ref_id), bsdf
+
+
+class _World:
+    class medium:
+        ior = 1.0
+
+
+def scene_from_golden(tag):
+    """refscene_<tag>.npz -> the 4-tuple `scene_parsing` returns (emitters, array_info, objects, prop) + the fixture"""
+    g = golden(f"refscene_{tag}.npz")
+    emitters = [_Packed(g["src_i"][k], g["src_f"][k]) for k in range(g["src_i"].shape[0])]
+    objs = [_Obj(g["obj_info"][k, 1], g["obj_info"][k, 2], g["obj_aabb"][k], g["emitter_id"][k], _Packed(g["bxdf_i"][k], g["bxdf_f"][k]))
+            for k in range(g["obj_info"].shape[0])]
+    n = g["prims"].shape[0]
+    arr = {"primitives": g["prims"], "n_g": g["normals"], "n_s": g["v_normals"], "uvs": np.zeros((n, 3, 2), np.float32), "indices": None}
+    world = _World(); world.medium = type("M", (), {"ior": float(g["world_ior"])})()
+    prop = {"film": {"width": int(g["width"]), "height": int(g["height"])}, "fov": float(g["fov"]), "max_bounce": int(g["max_bounce"]),
+            "num_shadow_ray": int(g["num_shadow_ray"]), "use_rr": bool(g["use_rr"]), "use_mis": bool(g["use_mis"]), "anti_alias": bool(g["anti_alias"]),
+            "stratified_sampling": bool(g["stratified_sampling"]), "brdf_two_sides": bool(g["brdf_two_sides"]),
+            "accelerator": "bvh" if int(g["accelerator_bvh"]) else "none", "rr_bounce_th": int(g["rr_bounce_th"]), "rr_threshold": float(g["rr_threshold"]),
+            "transform": (np.float32(g["cam_dir"]), np.float32(g["cam_pos"]), None), "world": world, "has_vertex_normal": bool(g["has_vertex_normal"]),
+            "packed_textures": None, "volume": []}
+    return (emitters, arr, objs, prop), g

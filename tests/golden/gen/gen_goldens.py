@@ -276,6 +276,52 @@ def gen_scene(scene_dir, xml, tag, w, h, spp, overrides, seed=0, n_rays=192):
           f"mean draws {draws.mean():.2f}, mean radiance {out['pixels'].mean():.4f}")
 
 
+# ------------------------------------------------------------------ sweep over the reference's own bundled scenes
+def gen_refscene(scene_dir, xml, tag, w, h, spp, seed=0):
+    """Whole-kernel run of one of the reference's bundled scene files (its own parser, its own kernel) plus the parsed
+    scene as flat arrays, so that the tests can render exactly that scene without the XML (which stays in /root/reference)."""
+    sys.path.insert(0, refenv.REPO)
+    from adapt_amd.scene_pack import pack_scene
+    t0 = time.time()
+    rdr, (emitters, arr, objs, cfg) = refenv.make_renderer(scene_dir, xml, {"width": w, "height": h})
+    fs = pack_scene(emitters, arr, objs, cfg)          # reads the reference's host objects attribute by attribute
+    out = {"prims": fs.prims, "normals": fs.normals, "v_normals": fs.v_normals, "obj_info": fs.obj_info, "obj_aabb": fs.obj_aabb,
+           "emitter_id": fs.emitter_id, "bxdf_i": fs.bxdf_i, "bxdf_f": fs.bxdf_f, "src_i": fs.src_i, "src_f": fs.src_f,
+           "has_vertex_normal": np.int32(fs.has_vertex_normal), "world_ior": np.float32(fs.world_ior),
+           "width": np.int32(w), "height": np.int32(h), "spp": np.int32(spp), "seed": np.int32(seed),
+           "fov": np.float64(cfg["fov"]), "max_bounce": np.int32(cfg["max_bounce"]), "num_shadow_ray": np.int32(cfg["num_shadow_ray"]),
+           "use_rr": np.int32(cfg["use_rr"]), "use_mis": np.int32(cfg["use_mis"]), "anti_alias": np.int32(cfg["anti_alias"]),
+           "stratified_sampling": np.int32(cfg["stratified_sampling"]), "brdf_two_sides": np.int32(cfg.get("brdf_two_sides", False)),
+           "accelerator_bvh": np.int32(cfg.get("accelerator", "none") == "bvh"),
+           "rr_bounce_th": np.int32(cfg.get("rr_bounce_th", 4)), "rr_threshold": np.float64(cfg.get("rr_threshold", 0.1)),
+           "cam_dir": np.float32(cfg["transform"][0]), "cam_pos": np.float32(cfg["transform"][1])}
+    draws = np.zeros((spp, w, h), np.int32)
+    state = {"prev": None}
+
+    def hook(i, j):
+        if state["prev"] is not None:
+            pi, pj = state["prev"]; draws[state["s"], pi, pj] = ti.RNG.draw
+        ti.RNG.set_philox(i * h + j, seed, rdr.cnt[None])
+        state["prev"] = (i, j)
+
+    ti.PIXEL_HOOK[0] = hook
+    for s_ in range(spp):
+        state["s"], state["prev"] = s_, None
+        rdr.render(0, 0, 0, 0, 0, 0)
+        pi, pj = state["prev"]; draws[s_, pi, pj] = ti.RNG.draw
+    ti.PIXEL_HOOK[0] = None
+    out["accum"], out["draws"] = rdr.color.to_numpy(), draws
+    np.savez_compressed(os.path.join(OUT, f"refscene_{tag}.npz"), **out)
+    print(f"refscene_{tag}: {fs.n_prims} prims, {fs.n_objects} objects, {fs.n_sources} sources, {w}x{h}x{spp}spp, bounces {int(cfg['max_bounce'])}, "
+          f"{time.time() - t0:.1f}s, mean draws {draws.mean():.2f}, mean radiance {np.nanmean(out['accum']) / spp:.4f}")
+
+
+REF_SCENES = [("cbox", "cbox-point.xml"), ("cbox", "cbox-vn.xml"), ("cbox", "smaller.xml"), ("cbox", "single-orb.xml"), ("cbox", "ite-orb.xml"),
+              ("cbox", "skeleton.xml"), ("cbox", "vader.xml"), ("cbox", "venus.xml"), ("cbox", "bvh-benchmark.xml"),
+              ("csphere", "balls-glossy.xml"), ("csphere", "balls-multi.xml"), ("csphere", "big.xml"), ("csphere", "mix-balls.xml"),
+              ("csphere", "single-ball.xml"), ("csphere", "whiskey.xml"), ("trans", "cbox-collimated.xml"), ("trans", "cbox-point.xml"), ("trans", "balls-mono.xml")]
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
@@ -290,6 +336,14 @@ if __name__ == "__main__":
         gen_scene("cbox", "cbox.xml", "cbox", 32, 32, 6, {"max_bounce": 8})
         gen_scene("csphere", "balls-mono.xml", "balls_mono", 24, 24, 3, {})
         gen_scene("cbox", "complex.xml", "complex", 20, 20, 3, {})
+    if a.only in ("all", "refscenes"):
+        # every pt-renderable scene file the reference bundles whose assets are in its tree
+        for sdir, xml in REF_SCENES:
+            tag = (sdir + "_" + xml[:-4]).replace("-", "_")
+            try:
+                gen_refscene(sdir, xml, tag, 32, 24, 2)
+            except Exception as e:                      # missing mesh / texture / volume assets: not loadable here
+                print(f"refscene_{tag}: SKIPPED ({type(e).__name__}: {str(e)[:120]})")
     if a.only in ("all", "image", "features"):
         # feature-coverage scenes authored in this repo (scenes/test/*.xml), run through the reference's own parser + kernel
         test_dir = os.path.join(refenv.REPO, "scenes", "test")

@@ -444,3 +444,35 @@ def test_full_size_c4_crop_matches_brute_force_oracle():
     mb = image_metrics(img / 2, ref_bvh[310:350, 236:264] / 2)
     assert mb["frac_within"] >= 0.97, mb
     r.close()
+
+
+# ---- the reference's own bundled scene files (arrays from its parser, tests/golden/refscene_*.npz)
+from conftest import REF_SCENE_TAGS, scene_from_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("tag", REF_SCENE_TAGS)
+def test_reference_bundled_scene_hip_vs_reference_run(tag):
+    """HIP render of one of the reference's bundled scenes vs (a) the image the reference's own kernel produced on the same
+    Philox stream (fixture) and (b) the oracle at more samples; path statistics exact."""
+    from adapt_amd.renderer import Renderer
+    from adapt_amd.scene_pack import make_config, pack_scene
+    from oracle import binding as ob
+    tup, g = scene_from_golden(tag)
+    w, h, spp = int(g["width"]), int(g["height"]), int(g["spp"])
+    r = Renderer(*tup, width=w, height=h)
+    try:
+        r.render(n_spp=spp)
+        acc = r.color.to_numpy()
+        m = image_metrics(acc / spp, g["accum"] / spp)
+        assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-3, (tag, m)        # 768 pixels: one flipped branch is 0.13 %
+        assert abs(r.stats()["n_draws"] - int(g["draws"].sum())) <= 2e-3 * int(g["draws"].sum())
+        r.clear(); r.render(n_spp=24)
+        rc = make_config(tup[3], width=w, height=h)
+        ref, _, ost = ob.OracleScene(pack_scene(*tup), rc.cam_t).render(rc, 24)
+        m = image_metrics(r.color.to_numpy() / 24, ref / 24)
+        assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-3, (tag, m)
+        st = r.stats()
+        for k in ("n_shade", "n_shadow", "n_draws"):
+            assert abs(st[k] - ost[k]) <= 5e-4 * ost[k], (tag, k, st[k], ost[k])
+    finally:
+        r.close()
