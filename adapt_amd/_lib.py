@@ -24,7 +24,8 @@ class SceneDesc(C.Structure):
     _fields_ = [("n_prims", C.c_int32), ("n_objects", C.c_int32), ("n_sources", C.c_int32), ("has_vertex_normal", C.c_int32),
                 ("prims", f32p), ("normals", f32p), ("v_normals", f32p), ("obj_info", i32p), ("obj_aabb", f32p),
                 ("emitter_id", i32p), ("bxdf_i", i32p), ("bxdf_f", f32p), ("src_i", i32p), ("src_f", f32p),
-                ("world_ior", C.c_float)]
+                ("world_ior", C.c_float),
+                ("uvs", f32p), ("tex_i", i32p), ("tex_f", f32p), ("atlas", f32p * 3), ("atlas_w", C.c_int32 * 3), ("atlas_h", C.c_int32 * 3)]
 
 
 class RenderCfg(C.Structure):
@@ -77,6 +78,7 @@ SYMBOLS = {
     "apt_rng_stream": (C.c_int, [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, u32p]),
     "apt_bxdf_probe": (C.c_int, [C.c_int32, C.c_int32, i32p, f32p, f32p, C.c_float, C.c_int32, C.c_uint32, f32p]),
     "apt_emitter_probe": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_uint32, f32p]),
+    "apt_texture_probe": (C.c_int, [C.c_void_p, C.c_int32, i32p, f32p, f32p]),
     "apt_renderer_info": (C.c_int, [C.c_void_p, i32p, i32p, C.POINTER(C.c_int64), i32p, C.POINTER(C.c_char_p), i32p]),
     "apt_last_error": (C.c_char_p, []),
     "apt_version": (C.c_char_p, []),

@@ -40,6 +40,7 @@ static const ShadeVariant kShadeVariants[] = {
     {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area"},
     {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models"},
 };
+static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures"};
 // Material classes for sorted shading: (class mask) x (emitter mask: point+area | all)
 #define APT_N_CLASS_DEFS 6
 static const int kClassMask[APT_N_CLASS_DEFS] = {
@@ -89,6 +90,7 @@ struct apt_scene {
     DevScene dev{};
     apt::BvhData bvh;
     DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
+    DevBuf uvs, tex_i, tex_f, atlas[3];      // image textures (empty when the scene has none)
     int n_classes = 0;                   // material classes present (compact ids 0..n_classes-1)
     int class_def[APT_N_CLASS_DEFS] = {0, 0, 0, 0, 0, 0};   // compact id -> class definition
     int n_prims = 0, n_objects = 0, n_sources = 0, max_obj_prims = 0;
@@ -272,7 +274,6 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
 #define UP(buf, vec) do { hipError_t e_ = upload(s->buf, vec); if (e_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload " #buf ": ") + hipGetErrorString(e_)); } } while (0)
     UP(nodes, s->bvh.nodes); UP(prims, recs); UP(normals, nrm); UP(vnormals, vn); UP(precom, prec); UP(prim_obj, prim_obj);
     UP(obj_info, oi); UP(emitter_id, ei); UP(bxdf, bx); UP(src, sr); UP(sweep_recs, sw); UP(sweep_tab, sw_tab); UP(obj_aabb, aabb);
-#undef UP
     DevScene& ds = s->dev;
     ds.bvh.nodes = s->nodes.as<float4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.n_nodes = s->bvh.n_nodes(); ds.bvh.n_prims = N;
     ds.sweep.stream = s->sweep_recs.as<float>(); ds.sweep.obj_tab = s->sweep_tab.as<int>(); ds.sweep.prim_obj = s->prim_obj.as<int>(); ds.sweep.n_objects = O;
@@ -281,6 +282,28 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     ds.prim_obj = s->prim_obj.as<int>(); ds.prim_class = s->prim_class.as<int>(); ds.obj_info = s->obj_info.as<int>(); ds.emitter_id = s->emitter_id.as<int>();
     ds.bxdf = s->bxdf.as<DevBxdf>(); ds.src = s->src.as<DevSrc>();
     ds.n_prims = N; ds.n_objects = O; ds.n_sources = S; ds.has_vn = d->has_vertex_normal; ds.world_ior = d->world_ior;
+    ds.uvs = nullptr; ds.tex_i = nullptr; ds.tex_f = nullptr;
+    for (int m = 0; m < 3; m++) { ds.atlas[m] = nullptr; ds.atlas_w[m] = 0; }
+    if (d->tex_i && d->tex_f && d->uvs) {
+        for (int o = 0; o < O; o++) for (int m = 0; m < 3; m++) {
+            const int32_t* t = d->tex_i + 15 * o + 5 * m;
+            if (t[0] <= -255) continue;
+            if (d->obj_info[3 * o + 2]) { delete s; return fail(APT_E_INVALID, "apt_scene_create: textured spheres are not supported"); }
+            if (!d->atlas[m] || t[3] < 2 || t[4] < 2 || t[1] < 0 || t[2] < 0 || t[1] + t[3] > d->atlas_w[m] || t[2] + t[4] > d->atlas_h[m]) {
+                delete s; return fail(APT_E_INVALID, "apt_scene_create: texture rectangle outside its atlas (or smaller than 2 x 2)");
+            }
+        }
+        std::vector<float> uv(d->uvs, d->uvs + (size_t)N * 6), tf(d->tex_f, d->tex_f + (size_t)O * 6);
+        std::vector<int> ti(d->tex_i, d->tex_i + (size_t)O * 15);
+        UP(uvs, uv); UP(tex_i, ti); UP(tex_f, tf);
+        ds.uvs = s->uvs.as<float>(); ds.tex_i = s->tex_i.as<int>(); ds.tex_f = s->tex_f.as<float>();
+        for (int m = 0; m < 3; m++) if (d->atlas[m]) {
+            std::vector<float> img(d->atlas[m], d->atlas[m] + (size_t)d->atlas_w[m] * (size_t)d->atlas_h[m] * 3);
+            UP(atlas[m], img);
+            ds.atlas[m] = s->atlas[m].as<float>(); ds.atlas_w[m] = d->atlas_w[m];
+        }
+    }
+#undef UP
     *out = s;
     return APT_OK;
 }
@@ -324,6 +347,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     for (const ShadeVariant& v : kShadeVariants)
         if ((sc->bx_mask & ~v.bm) == 0 && (sc->src_mask & ~v.sm) == 0) { r->shade = &v; break; }
     if (!r->shade) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: scene uses a material or emitter type the kernels do not know"); }
+    const bool textured = sc->dev.tex_i != nullptr;
+    if (textured) r->shade = &kTexturedShade;                   // the one kernel compiled with texture lookups; unsorted
     Params& p = r->par;
     memcpy(p.cam_r, c.cam_r, sizeof(p.cam_r)); memcpy(p.cam_t, c.cam_t, sizeof(p.cam_t));
     p.inv_focal = c.inv_focal; p.half_w = c.half_w; p.half_h = c.half_h;
@@ -349,6 +374,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     }
     r->sorted = (sc->n_classes >= 2) ? 1 : 0;
     if (const char* force = getenv("APT_SORTED")) r->sorted = (atoi(force) != 0 && sc->n_classes >= 1) ? 1 : 0;
+    if (textured) r->sorted = 0;
     const int ncls = r->sorted ? sc->n_classes : 0;
     r->shade_name = r->shade->name;
     if (r->sorted) {
@@ -766,6 +792,23 @@ APT_EXPORT int apt_emitter_probe(const apt_scene* sc, int32_t n, const float* in
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out12, dout.p, (size_t)n * 48, hipMemcpyDeviceToHost));
+    return APT_OK;
+}
+APT_EXPORT int apt_texture_probe(const apt_scene* sc, int32_t n, const int32_t* map_obj, const float* uv, float* out3) {
+    if (!sc || n <= 0 || !map_obj || !uv || !out3) return fail(APT_E_INVALID, "apt_texture_probe: bad argument");
+    if (!sc->dev.tex_i) return fail(APT_E_INVALID, "apt_texture_probe: the scene has no textures");
+    for (int k = 0; k < n; k++) {
+        const int m = map_obj[2 * k], o = map_obj[2 * k + 1];
+        if (m < 0 || m > 2 || o < 0 || o >= sc->n_objects || !sc->dev.atlas[m]) return fail(APT_E_INVALID, "apt_texture_probe: no such texture");
+    }
+    HIP_TRY(hipSetDevice(sc->device));
+    DevBuf dmo, duv, dout;
+    std::vector<int> mo(map_obj, map_obj + 2 * (size_t)n); std::vector<float> vuv(uv, uv + 2 * (size_t)n);
+    HIP_TRY(upload(dmo, mo)); HIP_TRY(upload(duv, vuv)); HIP_TRY(dout.alloc((size_t)n * 12));
+    hipLaunchKernelGGL(k_texture_probe, dim3((n + 63) / 64), dim3(64), 0, 0, sc->dev, n, dmo.as<int>(), duv.as<float>(), dout.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out3, dout.p, (size_t)n * 12, hipMemcpyDeviceToHost));
     return APT_OK;
 }
 APT_EXPORT int apt_renderer_info(const apt_renderer* r, int32_t* spp_batch, int32_t* n_subqueues, int64_t* queue_bytes, int32_t* lds_bytes, const char** shade_variant, int32_t* trace_mode) {

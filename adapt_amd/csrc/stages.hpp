@@ -48,6 +48,12 @@ struct DevScene {
     const DevSrc* src;        // n_sources
     int n_prims, n_objects, n_sources, has_vn;
     float world_ior;
+    // image textures (tex_i == nullptr: none).  Maps: 0 albedo, 1 normal, 2 bump
+    const float* uvs;         // n_prims*6
+    const int* tex_i;         // n_objects*3*5: type, off_x, off_y, w, h
+    const float* tex_f;       // n_objects*3*2: scale_u, scale_v
+    const float* atlas[3];
+    int atlas_w[3];
 };
 
 struct Params {
@@ -324,6 +330,35 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 }
 
 
+
+// ----------------------------------------------------------------- textures
+// Taichi's float `a % b` is a - b * floor(a / b) (python/taichi/lang/ops.py, mod)
+APT_D float ti_fmod(float a, float b) { float q = floorf(a / b); return a - b * q; }
+APT_D f3 mix3(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }          // taichi.math.mix: x * (1 - a) + y * a
+// Texture.query, bxdf/texture.py:111-139: bilinear lookup inside the texture's rectangle of the atlas
+APT_D f3 texture_query(const DevScene& sc, int map, int obj, float u, float v) {
+    const int* ti_ = sc.tex_i + 15 * obj + 5 * map; const float* tf = sc.tex_f + 6 * obj + 2 * map;
+    const float w = (float)ti_[3], h = (float)ti_[4];
+    const float scaled_u = ti_fmod((u * tf[0]) * w, w - 1.f), scaled_v = ti_fmod((v * tf[1]) * h, h - 1.f);
+    float floor_u = floorf(scaled_u), floor_v = floorf(scaled_v);
+    const float ratio_u = scaled_u - floor_u, ratio_v = scaled_v - floor_v;
+    floor_u = floor_u + (float)ti_[1]; floor_v = floor_v + (float)ti_[2];
+    const int fu = (int)floor_u, fv = (int)floor_v;
+    const float* img = sc.atlas[map]; const int W = sc.atlas_w[map];
+    const float* r0 = img + ((size_t)fv * W + fu) * 3; const float* r1 = r0 + (size_t)W * 3;
+    const f3 q_ff = mk3(r0[0], r0[1], r0[2]), q_cf = mk3(r0[3], r0[4], r0[5]), q_fc = mk3(r1[0], r1[1], r1[2]), q_cc = mk3(r1[3], r1[4], r1[5]);
+    return mix3(mix3(q_ff, q_cf, ratio_u), mix3(q_fc, q_cc, ratio_u), ratio_v);
+}
+// PathTracer.get_uv_item, path_tracer.py:276-289 (meshes only: textured spheres are refused at scene creation)
+APT_D bool get_uv_item(const DevScene& sc, int map, int obj, int prim, float bu, float bv, f3& out) {
+    if (sc.atlas[map] == nullptr || !(sc.tex_i[15 * obj + 5 * map] > -255)) return false;
+    const float* uv = sc.uvs + 6 * prim;
+    const float w0 = 1.f - bu - bv;
+    const float gu = (uv[2] * bu + uv[4] * bv) + uv[0] * w0, gv = (uv[3] * bu + uv[5] * bv) + uv[1] * w0;
+    out = texture_query(sc, map, obj, gu, gv);
+    return true;
+}
+
 // -------------------------------------------------------------------- shade
 APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3 o, f3 d, Hit& it) {
     it.prim_id = prim; it.min_depth = t;
@@ -344,7 +379,10 @@ APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3
 }
 
 // BM / SM: material and emitter masks of the scene (shading.hpp); code for absent models is compiled out.
-template <int BM, int SM>
+// TEX: image-texture lookups.  Only the all-models kernel is instantiated with TEX = 1 (textured scenes run unsorted through
+// it): inlined into the specialised kernels the lookup costs e.g. the mod-Phong class kernel its fourth wave per SIMD
+// (126 -> 129 VGPRs) in every scene WITHOUT textures, and out of line it costs a call frame in scratch.
+template <int BM, int SM, int TEX = 0>
 __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
@@ -396,6 +434,17 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
                 build_hit(sc, prim, ldq(in.t, io), ldq(in.u, io), ldq(in.v, io), o, d, it);
                 bx = sc.bxdf[it.obj_id];
                 hit_light = sc.emitter_id[it.obj_id];
+                if (TEX && sc.tex_i != nullptr) {                // the scene declares image textures (TEX kernels only, see below)
+                    const float bu = ldq(in.u, io), bv = ldq(in.v, io);
+                    f3 tx;
+                    if (bounce == 0) {                           // PathTracer.process_ns, applied to the camera ray's hit only (vanilla_renderer.py:42)
+                        if (get_uv_item(sc, 1, it.obj_id, prim, bu, bv, tx)) { m33 R; rotation_between(mk3(0.f, 1.f, 0.f), it.n_g, R); it.n_s = mul(R, tx); }
+                        if (get_uv_item(sc, 2, it.obj_id, prim, bu, bv, tx)) it.n_s = delocalize(it.n_s, tx);
+                    }
+                    // it.tex (vanilla_renderer.py:66): every surface model reads its diffuse colour as select(tex invalid, k_d, tex)
+                    // and nothing else reads k_d on the device, so a valid lookup simply replaces this path's copy of k_d
+                    if (get_uv_item(sc, 0, it.obj_id, prim, bu, bv, tx)) bx.k_d = tx;
+                }
                 SH_TICK(0);
                 const uint32_t lp = id & ((1u << p.pix_bits) - 1u), s = id >> p.pix_bits;
                 l_off = (s * (uint32_t)p.npix + lp) << 2;
@@ -653,6 +702,12 @@ __global__ void k_bxdf_sample(int n, const DevBxdf* bx, const float* in, float w
     f3 dir = surface_sample<APT_BX_ALL>(b, it, wi, world_ior, 0, r, spec, pdf, sp);
     float* o = out9 + 9 * k;
     o[0] = dir.x; o[1] = dir.y; o[2] = dir.z; o[3] = spec.x; o[4] = spec.y; o[5] = spec.z; o[6] = pdf; o[7] = sp ? 1.f : 0.f; o[8] = (float)r.draw;
+}
+__global__ void k_texture_probe(DevScene sc, int n, const int* map_obj, const float* uv, float* out3) {
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    f3 r = texture_query(sc, map_obj[2 * k], map_obj[2 * k + 1], uv[2 * k], uv[2 * k + 1]);
+    out3[3 * k] = r.x; out3[3 * k + 1] = r.y; out3[3 * k + 2] = r.z;
 }
 // emitter sample_hit / eval_le / solid_angle_pdf on explicit inputs: in = src index, hit_pos, normal, ray_d, min_depth (11 floats)
 __global__ void k_emitter_probe(DevScene sc, int n, const float* in, uint32_t seed, float* out12) {

@@ -11,10 +11,10 @@ Drop-in counterpart of reference `parsers/xml_parser.py:246-289`:
 * `all_objs`       list of ObjDescriptor
 * `configs`        sensor dict: every <integer|float|string|boolean name=..>
   child, + "transform" (look dir, origin, None), "film" {...}, "world",
-  "packed_textures" (None: textures are a §8(f) "next" row), "has_vertex_normal".
+  "packed_textures" ({tag: atlas | None} or None), "has_vertex_normal".
 
-Textures (`<texture>` + rectpack atlas, reference texture_packing.py) are NOT
-handled: a scene that declares them raises, so nothing renders silently wrong.
+Image textures (`<texture type="image">`, albedo / normal / bump maps on meshes) are read by adapt_amd/textures.py
+with its own atlas packer; checkerboard textures (no lookup upstream) and textured spheres are refused.
 """
 from __future__ import annotations
 
@@ -26,6 +26,7 @@ import numpy as np
 
 from ..emitters import SOURCE_MAP, LightSource
 from ..materials import BRDF_np, BSDF_np
+from ..textures import TEX_TAGS, parse_texture
 from .general_parser import get, parse_sphere_element, transform_parse
 from .obj_desc import ObjDescriptor
 from .obj_loader import SPHERE, TRIANGLE_MESH, apply_transform, calculate_surface_area, extract_obj_info
@@ -64,7 +65,7 @@ def parse_bxdf(nodes: List[xet.Element]):
     return table
 
 
-def parse_wavefront(directory: str, shapes: List[xet.Element], bsdf_dict: dict, emitter_dict: dict):
+def parse_wavefront(directory: str, shapes: List[xet.Element], bsdf_dict: dict, emitter_dict: dict, texture_dict=None):
     """Shapes in document order -> packed arrays + descriptors (xml_parser.py:93-176)."""
     objs, prims, uvs_all, ng_all, ns_all, sphere_rows = [], [], [], [], [], []
     area_of_emitter = {}
@@ -86,6 +87,7 @@ def parse_wavefront(directory: str, shapes: List[xet.Element], bsdf_dict: dict, 
             kind = SPHERE
         material = None
         emit_id = -1
+        group = {t: None for t in TEX_TAGS}
         for ref in shape.findall("ref"):
             rtype, rid = ref.get("type"), ref.get("id")
             if rtype == "material":
@@ -94,7 +96,15 @@ def parse_wavefront(directory: str, shapes: List[xet.Element], bsdf_dict: dict, 
                 emit_id = emitter_dict[rid]
                 area_of_emitter[emit_id] = calculate_surface_area(meshes, kind)
             elif rtype == "texture":
-                raise NotImplementedError("textured shapes are outside the pt hot-path scope (SURVEY §8(f) N2)")
+                tag = ref.get("tag", None)
+                if tag is None or tag not in group:
+                    tag = "albedo"                                   # xml_parser.py:142-147
+                if texture_dict is None or texture_dict.get(tag) is None or rid not in texture_dict[tag]:
+                    raise KeyError(f"Texture id '{rid}' does not have tag '{tag}' mapping, check if it is from other groups.")
+                if kind == SPHERE:
+                    raise NotImplementedError("textured spheres: upstream looks the texture up with whatever (u, v) the last accepted "
+                                              "triangle left behind (tracer_base.py:184-237); not reproduced")
+                group[tag] = texture_dict[tag][rid]
         if material is None:
             raise ValueError("Object should be attached with a BSDF for now since no default one implemented yet.")
         n = meshes.shape[0]
@@ -105,7 +115,6 @@ def parse_wavefront(directory: str, shapes: List[xet.Element], bsdf_dict: dict, 
         ng_all.append(normals)
         ns_all.append(_zeros_if_none(vns, n))
         uvs_all.append(_zeros_if_none(uvs, n, 2))
-        group = {"albedo": None, "normal": None, "bump": None, "roughness": None}
         objs.append(ObjDescriptor(meshes, normals, material, vns, uvs, group, rot, trans, emit_id, kind))
         row += n
     array_info = {
@@ -136,16 +145,15 @@ def scene_parsing(directory: str, file: str):
     version = root.attrib["version"]
     if version != SCENE_VERSION:
         raise ValueError(f"Unsupported version {version}. Only '{SCENE_VERSION}' is supported right now.")
-    if root.findall("texture"):
-        raise NotImplementedError("<texture> declarations are outside the pt hot-path scope (SURVEY §8(f) N2)")
     sensor = root.find("sensor")
     assert sensor is not None
     emitters, emitter_dict = parse_emitters(root.findall("emitter"))
     bsdf_dict = parse_bxdf(root.findall("bsdf") + root.findall("brdf"))
-    array_info, objs, areas, has_vn = parse_wavefront(directory, root.findall("shape"), bsdf_dict, emitter_dict)
+    teximgs, textures = parse_texture(root.findall("texture"), base_dir=directory)
+    array_info, objs, areas, has_vn = parse_wavefront(directory, root.findall("shape"), bsdf_dict, emitter_dict, textures)
     cfg = parse_global_sensor(sensor)
     cfg["world"] = World_np(root.find("world"))
-    cfg["packed_textures"] = None
+    cfg["packed_textures"] = teximgs
     cfg["has_vertex_normal"] = has_vn
     cfg["volume"] = root.findall("volume")[:1]
     for i, em in enumerate(emitters):

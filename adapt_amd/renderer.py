@@ -70,9 +70,25 @@ class DeviceScene:
         p, n, vn, oi, ab, ei, bi, bf, si, sf = keep
         desc = _lib.SceneDesc(fs.n_prims, fs.n_objects, fs.n_sources, int(fs.has_vertex_normal), _fp(p), _fp(n), _fp(vn), _ip(oi),
                               _fp(ab), _ip(ei), _ip(bi), _fp(bf), _ip(si), _fp(sf), float(fs.world_ior))
+        if fs.has_textures:                     # image textures: uv coordinates, per-object records, one atlas per map
+            tex = [np.ascontiguousarray(fs.uvs, np.float32), np.ascontiguousarray(fs.tex_i, np.int32), np.ascontiguousarray(fs.tex_f, np.float32)]
+            keep += tex
+            desc.uvs, desc.tex_i, desc.tex_f = _fp(tex[0]), _ip(tex[1]), _fp(tex[2])
+            for m, img in enumerate(fs.atlas):
+                if img is not None:
+                    img = np.ascontiguousarray(img, np.float32); keep.append(img)
+                    desc.atlas[m] = _fp(img); desc.atlas_h[m], desc.atlas_w[m] = int(img.shape[0]), int(img.shape[1])
         h = C.c_void_p()
         _lib.check(lib.apt_scene_create(C.byref(desc), int(device), C.byref(h)), "apt_scene_create")
         self.handle = h
+
+    def texture_query(self, maps, objs, uv):
+        """Texture.query on the device (parity probe): maps 0 albedo / 1 normal / 2 bump, (n,2) coordinates -> (n,3)"""
+        mo = np.ascontiguousarray(np.stack([np.int32(maps), np.int32(objs)], 1), np.int32)
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        out = np.zeros((uv.shape[0], 3), np.float32)
+        _lib.check(_lib.load().apt_texture_probe(self.handle, uv.shape[0], _ip(mo), _fp(uv), _fp(out)), "apt_texture_probe")
+        return out
 
     def close(self):
         if getattr(self, "handle", None):

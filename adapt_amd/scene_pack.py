@@ -51,6 +51,14 @@ class FlatScene:
     src_f: np.ndarray          # (s,11)  f32   intensity dir pos inv_area r
     has_vertex_normal: bool
     world_ior: float
+    # image textures (None when the scene has none).  Maps: 0 albedo, 1 normal, 2 bump
+    uvs: Optional[np.ndarray] = None        # (N,3,2) f32   per-vertex (u, v)
+    tex_i: Optional[np.ndarray] = None      # (n,3,5) i32   type (-255 none), off_x, off_y, w, h
+    tex_f: Optional[np.ndarray] = None      # (n,3,2) f32   scale_u, scale_v
+    atlas: Optional[list] = None            # three (H,W,3) f32 images or None
+
+    @property
+    def has_textures(self): return self.tex_i is not None
 
     @property
     def n_prims(self): return int(self.prims.shape[0])
@@ -130,6 +138,18 @@ def pack_bxdf(b):
             np.concatenate([b.k_d, b.k_s, b.k_g, mean, [ior]]).astype(np.float32))
 
 
+_TEX_MAPS = ("albedo", "normal", "bump")
+
+
+def pack_texture(t):
+    """Texture host object (adapt_amd.textures.Texture_np or AdaPT's bxdf/texture.py:33-94) -> (int32[5], float32[2])"""
+    if t is None:
+        return np.int32([-255, 0, 0, 0, 0]), np.float32([1, 1])
+    if getattr(t, "type", None) == "checkerboard":
+        raise NotImplementedError("checkerboard textures have no lookup upstream (bxdf/texture.py:96)")
+    return np.int32([0, t.off_x, t.off_y, t.w, t.h]), np.float32([t.scale_u, t.scale_v])
+
+
 def pack_scene(emitters: List, array_info: dict, objects: List, prop: dict) -> FlatScene:
     prims = np.ascontiguousarray(array_info["primitives"], dtype=np.float32)
     n_g = np.ascontiguousarray(array_info["n_g"], dtype=np.float32)
@@ -154,10 +174,23 @@ def pack_scene(emitters: List, array_info: dict, objects: List, prop: dict) -> F
         if obj.emitter_ref_id >= 0:
             src_i[obj.emitter_ref_id, 2] = i           # obj_ref_id back-pointer (path_tracer.py:272-274)
     assert first == prims.shape[0]
+    tex = {}
+    images = prop.get("packed_textures")
+    if images is not None and any(images.get(m) is not None for m in _TEX_MAPS):
+        tex_i = np.zeros((n_obj, 3, 5), np.int32); tex_f = np.ones((n_obj, 3, 2), np.float32)
+        for i, obj in enumerate(objects):
+            group = getattr(obj, "texture_group", None) or {}
+            for m, name in enumerate(_TEX_MAPS):
+                tex_i[i, m], tex_f[i, m] = pack_texture(group.get(name))
+                if tex_i[i, m, 0] > -255 and obj.type != 0:
+                    raise NotImplementedError("textured spheres are not supported (upstream reads stale barycentrics there)")
+        uvs = np.ascontiguousarray(array_info["uvs"], dtype=np.float32)
+        tex = dict(uvs=uvs, tex_i=tex_i, tex_f=tex_f,
+                   atlas=[None if images.get(m) is None else np.ascontiguousarray(images[m], np.float32) for m in _TEX_MAPS])
     return FlatScene(prims=prims, normals=n_g, v_normals=n_s, obj_info=obj_info, obj_aabb=obj_aabb,
                      emitter_id=emitter_id, bxdf_i=bxdf_i, bxdf_f=bxdf_f, src_i=src_i, src_f=src_f,
                      has_vertex_normal=bool(prop["has_vertex_normal"]),
-                     world_ior=float(prop["world"].medium.ior))
+                     world_ior=float(prop["world"].medium.ior), **tex)
 
 
 def make_config(prop: dict, *, width: Optional[int] = None, height: Optional[int] = None,

@@ -56,6 +56,13 @@ typedef struct apt_scene_desc {
     const int32_t* src_i;       /* n_sources*4 type, bool_bits, obj_ref_id, 0 (emitters/abtract_source.py:44-54) */
     const float*   src_f;       /* n_sources*11 intensity dir pos inv_area r */
     float          world_ior;   /* free-space medium ior */
+    /* Image textures on meshes (bxdf/texture.py:99-139, tracer/path_tracer.py:84-126,261-307): all NULL / 0 when the scene has
+     * none.  Maps: 0 albedo (replaces k_d, vanilla_renderer.py:66), 1 normal and 2 bump (camera-ray hit only, vanilla_renderer.py:42). */
+    const float*   uvs;         /* n_prims*6     per-vertex (u, v) of every triangle */
+    const int32_t* tex_i;       /* n_objects*3*5 per object and map: type (-255 = none, 0 = image), off_x, off_y, w, h inside the atlas */
+    const float*   tex_f;       /* n_objects*3*2 scale_u, scale_v */
+    const float*   atlas[3];    /* per map: atlas_h * atlas_w * 3 floats, row-major [y][x][rgb], or NULL */
+    int32_t        atlas_w[3], atlas_h[3];
 } apt_scene_desc;
 
 /* Per-renderer configuration: film, camera, sampling flags, tile ownership, batching. */
@@ -128,6 +135,8 @@ int apt_rng_stream(int32_t device, uint32_t pixel, uint32_t seed, uint32_t sampl
  * do_sample = 1: out[9k..] = dir xyz, f*cos rgb, pdf, is_specular, draws; RNG = Philox(key=(k, seed), sample 1). */
 int apt_bxdf_probe(int32_t device, int32_t n, const int32_t* bxdf_i, const float* bxdf_f, const float* dirs12,
                    float world_ior, int32_t do_sample, uint32_t seed, float* out);
+/* Texture probe: map_obj[2k..] = map (0 albedo, 1 normal, 2 bump), object; uv[2k..]; out3[3k..] = Texture.query. */
+int apt_texture_probe(const apt_scene*, int32_t n, const int32_t* map_obj, const float* uv, float* out3);
 /* Emitter probe: in11[11k..] = source index, hit_pos, normal, ray_d, min_depth;
  * out12[12k..] = sampled pos, intensity (/pdf), pdf, draws, eval_le rgb, solid_angle_pdf; RNG as above. */
 int apt_emitter_probe(const apt_scene*, int32_t n, const float* in11, uint32_t seed, float* out12);

@@ -24,7 +24,8 @@ class SceneDesc(C.Structure):
     _fields_ = [("n_prims", C.c_int), ("n_objects", C.c_int), ("n_sources", C.c_int), ("has_vertex_normal", C.c_int),
                 ("prims", f32p), ("normals", f32p), ("v_normals", f32p), ("obj_info", i32p), ("obj_aabb", f32p),
                 ("emitter_id", i32p), ("bxdf_i", i32p), ("bxdf_f", f32p), ("src_i", i32p), ("src_f", f32p),
-                ("world_ior", C.c_float)]
+                ("world_ior", C.c_float),
+                ("uvs", f32p), ("tex_i", i32p), ("tex_f", f32p), ("atlas", f32p * 3), ("atlas_w", C.c_int * 3), ("atlas_h", C.c_int * 3)]
 
 
 class Cfg(C.Structure):
@@ -64,6 +65,7 @@ def lib():
         _lib.orc_scene_create.restype = C.c_void_p
         _lib.orc_scene_create.argtypes = [C.POINTER(SceneDesc), f32p, C.c_int]
         _lib.orc_scene_destroy.argtypes = [C.c_void_p]
+        _lib.orc_texture_query.argtypes = [C.c_void_p, C.c_int, i32p, f32p, f32p]
         _lib.orc_render.argtypes = [C.c_void_p, C.POINTER(Cfg), f32p, i32p, C.c_int, C.c_int, C.POINTER(Stats)]
         _lib.orc_fresnel_equation.restype = C.c_float
         _lib.orc_fresnel_equation.argtypes = [C.c_float] * 4
@@ -107,6 +109,14 @@ class OracleScene:
         d = SceneDesc(fs.n_prims, fs.n_objects, fs.n_sources, int(fs.has_vertex_normal),
                       _fp(p), _fp(n), _fp(vn), _ip(oi), _fp(ab), _ip(ei), _ip(bi), _fp(bf), _ip(si), _fp(sf),
                       float(fs.world_ior))
+        if getattr(fs, "tex_i", None) is not None:                  # image textures (maps: albedo, normal, bump)
+            tex = [np.ascontiguousarray(fs.uvs, np.float32), np.ascontiguousarray(fs.tex_i, np.int32), np.ascontiguousarray(fs.tex_f, np.float32)]
+            self._keep += tex
+            d.uvs, d.tex_i, d.tex_f = _fp(tex[0]), _ip(tex[1]), _fp(tex[2])
+            for m, img in enumerate(fs.atlas):
+                if img is not None:
+                    img = np.ascontiguousarray(img, np.float32); self._keep.append(img)
+                    d.atlas[m] = _fp(img); d.atlas_h[m], d.atlas_w[m] = int(img.shape[0]), int(img.shape[1])
         ct = _f3(cam_t)
         self.handle = C.c_void_p(L.orc_scene_create(C.byref(d), _fp(ct), int(build_bvh)))
         self.fs = fs
@@ -118,6 +128,15 @@ class OracleScene:
                 self.handle = None
         except Exception:
             pass
+
+    def texture_query(self, maps, objs, uv):
+        """Texture.query (bxdf/texture.py:111-139): maps 0 albedo / 1 normal / 2 bump, (n,2) coordinates -> (n,3)"""
+        mo = np.ascontiguousarray(np.stack([np.int32(maps), np.int32(objs)], 1), np.int32)
+        uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+        out = np.zeros((uv.shape[0], 3), np.float32)
+        if lib().orc_texture_query(self.handle, uv.shape[0], _ip(mo), _fp(uv), _fp(out)) != 0:
+            raise ValueError("texture_query: no such texture")
+        return out
 
     # ---- whole-image render (Renderer.render x n_spp)
     def render(self, rc, n_spp: int, accum=None, cnt: int = 0, threads: int = 0):

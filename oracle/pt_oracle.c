@@ -196,6 +196,12 @@ typedef struct {
     const int*   src_i;       /* n_sources*4: type, bool_bits, obj_ref_id, 0 */
     const float* src_f;       /* n_sources*11: intensity dir pos inv_area r */
     float world_ior;
+    /* image textures (all NULL / 0 when the scene has none).  Maps: 0 albedo, 1 normal, 2 bump */
+    const float* uvs;         /* n_prims*6: per-vertex (u, v) of every triangle */
+    const int*   tex_i;       /* n_objects*3*5: per object and map: type (-255 = none), off_x, off_y, w, h */
+    const float* tex_f;       /* n_objects*3*2: scale_u, scale_v */
+    const float* atlas[3];    /* atlas_h * atlas_w * 3 floats, row-major [y][x] */
+    int atlas_w[3], atlas_h[3];
 } orc_scene_desc;
 
 typedef struct {
@@ -226,6 +232,12 @@ typedef struct {
     bxdf_t* bxdf;
     src_t* src;
     float world_ior;
+    /* textures: bxdf/texture.py:99-139, path_tracer.py:84-126,261-266 */
+    float (*uvs)[3][2];
+    int (*tex_i)[3][5];
+    float (*tex_f)[3][2];
+    float* atlas[3];
+    int atlas_w[3], atlas_h[3];
     /* BVH (reference layout) */
     int node_num, bvh_num;
     lin_node_t* nodes;
@@ -1217,6 +1229,16 @@ ORC_API scene_t* orc_scene_create(const orc_scene_desc* d, const float cam_t[3],
         int p = sc->obj_info[o][0];
         sc->precom[p][0] = sc->prims[p][0]; sc->precom[p][1] = sc->prims[p][1];
     }
+    if (d->tex_i && d->uvs) {
+        sc->uvs = malloc(sizeof(float) * 6 * (size_t)N); memcpy(sc->uvs, d->uvs, sizeof(float) * 6 * (size_t)N);
+        sc->tex_i = malloc(sizeof(int) * 15 * (size_t)O); memcpy(sc->tex_i, d->tex_i, sizeof(int) * 15 * (size_t)O);
+        sc->tex_f = malloc(sizeof(float) * 6 * (size_t)O); memcpy(sc->tex_f, d->tex_f, sizeof(float) * 6 * (size_t)O);
+        for (int m = 0; m < 3; m++) if (d->atlas[m]) {
+            size_t n = (size_t)d->atlas_w[m] * (size_t)d->atlas_h[m] * 3;
+            sc->atlas[m] = malloc(sizeof(float) * n); memcpy(sc->atlas[m], d->atlas[m], sizeof(float) * n);
+            sc->atlas_w[m] = d->atlas_w[m]; sc->atlas_h[m] = d->atlas_h[m];
+        }
+    }
     sc->bxdf = calloc((size_t)O, sizeof(bxdf_t));
     for (int o = 0; o < O; o++) {
         const int* bi = d->bxdf_i + 4 * o; const float* bf = d->bxdf_f + 13 * o;
@@ -1243,7 +1265,20 @@ ORC_API scene_t* orc_scene_create(const orc_scene_desc* d, const float cam_t[3],
 ORC_API void orc_scene_destroy(scene_t* sc) {
     if (!sc) return;
     free(sc->prims); free(sc->precom); free(sc->vnorm); free(sc->normals); free(sc->obj_info); free(sc->aabbs);
-    free(sc->emitter_id); free(sc->bxdf); free(sc->src); free(sc->nodes); free(sc->bvhs); free(sc);
+    free(sc->emitter_id); free(sc->bxdf); free(sc->src); free(sc->nodes); free(sc->bvhs);
+    free(sc->uvs); free(sc->tex_i); free(sc->tex_f); for (int m = 0; m < 3; m++) free(sc->atlas[m]);
+    free(sc);
+}
+static v3 texture_query(const scene_t* sc, int map, int obj, float u, float v);
+/* Texture.query on explicit coordinates (test entry): map 0 albedo, 1 normal, 2 bump */
+ORC_API int orc_texture_query(const scene_t* sc, int n, const int* map_obj, const float* uv, float* out3) {
+    for (int k = 0; k < n; k++) {
+        int m = map_obj[2 * k], o = map_obj[2 * k + 1];
+        if (!sc->tex_i || m < 0 || m > 2 || !sc->atlas[m] || o < 0 || o >= sc->n_objects || !(sc->tex_i[o][m][0] > -255)) return -1;
+        v3 r = texture_query(sc, m, o, uv[2 * k], uv[2 * k + 1]);
+        out3[3 * k] = r.x; out3[3 * k + 1] = r.y; out3[3 * k + 2] = r.z;
+    }
+    return 0;
 }
 ORC_API int orc_bvh_counts(const scene_t* sc, int* node_num, int* bvh_num) { *node_num = sc->node_num; *bvh_num = sc->bvh_num; return 0; }
 /* node_minmax[M*6], node_info[M*3] (base,cnt,all_offset), bvh_minmax[N*6], bvh_info[N*2] (obj,prim): bvh.cpp:215-251 */
@@ -1285,11 +1320,53 @@ typedef struct {
     float* ev;       /* per bounce: [obj_id, prim_id, min_depth, direct_int xyz, emit*w xyz, contribution xyz, next ray o xyz, d xyz] = 18 floats */
 } trace_t;
 
+/* Taichi's float `a % b` is a - b * floor(a / b) (python/taichi/lang/ops.py, mod) */
+static inline float ti_fmod(float a, float b) { float q = floorf(a / b); return a - b * q; }
+static inline v3 vmix(v3 a, v3 b, float t) { return vadd(vscale(a, 1.0f - t), vscale(b, t)); }       /* taichi.math.mix: x * (1 - a) + y * a */
+/* Texture.query, bxdf/texture.py:111-139: bilinear lookup inside the texture's rectangle of the atlas */
+static v3 texture_query(const scene_t* sc, int map, int obj, float u, float v) {
+    const int* ti_ = sc->tex_i[obj][map]; const float* tf = sc->tex_f[obj][map];
+    float w = (float)ti_[3], h = (float)ti_[4];
+    float scaled_u = ti_fmod((u * tf[0]) * w, w - 1.f);
+    float scaled_v = ti_fmod((v * tf[1]) * h, h - 1.f);
+    float floor_u = floorf(scaled_u), floor_v = floorf(scaled_v);
+    float ratio_u = scaled_u - floor_u, ratio_v = scaled_v - floor_v;
+    floor_u = floor_u + (float)ti_[1]; floor_v = floor_v + (float)ti_[2];
+    int fu = (int)floor_u, fv = (int)floor_v, cu = fu + 1, cv = fv + 1;
+    const float* img = sc->atlas[map]; int W = sc->atlas_w[map];
+#define TEXEL(y, x) V(img[((size_t)(y) * W + (x)) * 3], img[((size_t)(y) * W + (x)) * 3 + 1], img[((size_t)(y) * W + (x)) * 3 + 2])
+    v3 q_ff = TEXEL(fv, fu), q_cf = TEXEL(fv, cu), q_fc = TEXEL(cv, fu), q_cc = TEXEL(cv, cu);
+#undef TEXEL
+    return vmix(vmix(q_ff, q_cf, ratio_u), vmix(q_fc, q_cc, ratio_u), ratio_v);
+}
+/* PathTracer.get_uv_item, path_tracer.py:276-289 */
+static int get_uv_item(const scene_t* sc, int map, const isect_t* it, v3* out) {
+    *out = V(-1.f, -1.f, -1.f);
+    if (!sc->tex_i || !sc->atlas[map] || it->obj_id < 0 || !(sc->tex_i[it->obj_id][map][0] > -255)) return 0;
+    float u = it->u, v = it->v;
+    if (sc->obj_info[it->obj_id][2] == 0) {
+        const float (*uv)[2] = sc->uvs[it->prim_id];
+        float w0 = 1.f - it->u - it->v;
+        float gu = (uv[1][0] * it->u + uv[2][0] * it->v) + uv[0][0] * w0;
+        float gv = (uv[1][1] * it->u + uv[2][1] * it->v) + uv[0][1] * w0;
+        u = gu; v = gv;
+    }
+    *out = texture_query(sc, map, it->obj_id, u, v);
+    return 1;
+}
+/* PathTracer.process_ns, path_tracer.py:291-307: applied to the camera ray's hit only (vanilla_renderer.py:42) */
+static void process_ns(const scene_t* sc, isect_t* it) {
+    v3 t;
+    if (get_uv_item(sc, 1, it, &t)) { m3 R; rotation_between(V(0.f, 1.f, 0.f), it->n_g, &R); it->n_s = m3mulv(&R, t); }
+    if (get_uv_item(sc, 2, it, &t)) { m3 R; it->n_s = delocalize_rotate(it->n_s, t, &R); }
+}
+
 static v3 render_sample(const ctx_t* c, int i, int j, int cnt, rng_t* rng, orc_stats* st, trace_t* tr) {
     const orc_cfg* g = c->cfg; const scene_t* sc = c->sc;
     v3 ray_d = pix2ray(c, i, j, cnt, rng);
     v3 ray_o = c->cam_t;
     isect_t it; pt_ray_intersect(c, ray_d, ray_o, &it);
+    process_ns(sc, &it);
     int hit_light = sc->emitter_id[it.obj_id > 0 ? it.obj_id : 0];
     v3 color = ZERO3, contribution = V(1.f, 1.f, 1.f);
     float emission_weight = 1.0f;
@@ -1310,7 +1387,7 @@ static v3 render_sample(const ctx_t* c, int i, int j, int cnt, rng_t* rng, orc_s
         float direct_pdf = 1.0f, emitter_pdf = 1.0f;
         int break_flag = 0;
         v3 shadow_int = ZERO3, direct_int = ZERO3, direct_spec = V(1.f, 1.f, 1.f);
-        it.tex = V(-1.f, -1.f, -1.f);              /* get_uv_item: no textures -> INVALID */
+        get_uv_item(sc, 0, &it, &it.tex);          /* vanilla_renderer.py:66 */
         for (int s = 0; s < g->num_shadow_ray; s++) {
             int emitter_valid;
             const src_t* emitter = pt_sample_light(c, hit_light, rng, &emitter_pdf, &emitter_valid);

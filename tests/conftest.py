@@ -19,6 +19,8 @@ SCENES = {
     "features_a": (os.path.join(ROOT, "scenes", "test"), "features_a.xml", "features_a"),
     "features_b": (os.path.join(ROOT, "scenes", "test"), "features_b.xml", "features_b"),
     "features_c": (os.path.join(ROOT, "scenes", "test"), "features_c.xml", "features_c"),
+    # image textures (albedo / normal / bump maps on meshes); texture paths in the file are relative to the repository root
+    "textured": (os.path.join(ROOT, "scenes", "test"), "textured.xml", "textured"),
 }
 ALL_TAGS = list(SCENES)
 
@@ -56,7 +58,12 @@ def parsed():
     def get(tag):
         if tag not in cache:
             d, f, _ = SCENES[tag]
-            cache[tag] = scene_parsing(d, f)
+            cwd = os.getcwd()
+            os.chdir(ROOT)                      # texture paths are relative to the repository root
+            try:
+                cache[tag] = scene_parsing(d, f)
+            finally:
+                os.chdir(cwd)
         return cache[tag]
     return get
 

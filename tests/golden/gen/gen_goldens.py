@@ -247,6 +247,21 @@ def gen_scene(scene_dir, xml, tag, w, h, spp, overrides, seed=0, n_rays=192):
             eout.append(np.concatenate([pos.to_numpy(), inten.to_numpy(), [pdf, ti.RNG.draw], le.to_numpy(), [sap]]))
     out["emit_in"], out["emit_script"], out["emit_out"] = np.float32(ein), np.float64(escr), np.float32(eout)
 
+    # --- Texture.query (bilinear atlas lookup) on every declared map, coordinates also outside [0, 1] and negative
+    if cfg.get("packed_textures") is not None:
+        tq_in, tq_out = [], []
+        for m, name in enumerate(("albedo", "normal", "bump")):
+            if not getattr(rdr, f"has_{name}_map"):
+                continue
+            tmap, timg = getattr(rdr, f"{name}_map"), getattr(rdr, f"{name}_img")
+            for o in range(rdr.num_objects):
+                if tmap[o].type <= -255:
+                    continue
+                for _ in range(24):
+                    u, v = np.float32(RS.uniform(-1.5, 2.5)), np.float32(RS.uniform(-1.5, 2.5))
+                    tq_in.append([m, o, u, v]); tq_out.append(tmap[o].query(timg, u, v).to_numpy())
+        out["texq_in"], out["texq_out"] = np.float32(tq_in), np.float32(tq_out)
+
     # --- whole-kernel run on the Philox stream: per-sample colours and draw counts
     colors = np.zeros((spp, w, h, 3), np.float32)
     draws = np.zeros((spp, w, h), np.int32)
@@ -350,3 +365,6 @@ if __name__ == "__main__":
         gen_scene(test_dir, "features_a.xml", "features_a", 40, 30, 3, {}, n_rays=96)
         gen_scene(test_dir, "features_b.xml", "features_b", 40, 30, 3, {}, n_rays=96)
         gen_scene(test_dir, "features_c.xml", "features_c", 40, 30, 3, {}, n_rays=96)
+    if a.only in ("all", "image", "features", "textured"):
+        os.chdir(refenv.REPO)                           # texture paths in the scene file are relative to the repository root
+        gen_scene(os.path.join(refenv.REPO, "scenes", "test"), "textured.xml", "textured", 40, 30, 3, {}, n_rays=96)

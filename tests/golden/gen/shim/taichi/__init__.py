@@ -269,7 +269,7 @@ def pow(x, y):
     return _powf(x, y)
 
 
-def floor(x):
+def floor(x, dtype=None):
     return f32(_np.floor(f32(x)))
 
 

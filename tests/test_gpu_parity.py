@@ -194,6 +194,7 @@ IMAGE_CASES = [
     ("features_a", 64, 48, 16, {}),
     ("features_b", 64, 48, 16, {}),
     ("features_c", 64, 48, 16, {}),
+    ("textured", 64, 48, 16, {}),
 ]
 
 
@@ -215,7 +216,7 @@ def test_image_matches_oracle_same_stream(tag, w, h, spp, ov, renderer, parsed, 
     assert r.cnt[None] == spp and np.array_equal(r.pixels.to_numpy(), acc / np.float32(spp))
 
 
-@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_b", "features_c"])
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_b", "features_c", "textured"])
 def test_image_matches_reference_run(tag, renderer):
     """Directly against the fixture recorded from the reference's own kernel (same Philox stream)."""
     g = golden(f"scene_{SCENES[tag][2]}.npz")
@@ -476,3 +477,25 @@ def test_reference_bundled_scene_hip_vs_reference_run(tag):
             assert abs(st[k] - ost[k]) <= 5e-4 * ost[k], (tag, k, st[k], ost[k])
     finally:
         r.close()
+
+
+def test_texture_lookup_vs_reference_vectors_and_oracle(parsed, flat, oracle_scene):
+    """Texture.query on the device: the reference's own lookups (fixture) and the oracle on a dense coordinate sweep."""
+    from adapt_amd.renderer import DeviceScene
+    g = golden("scene_textured.npz")
+    sc = DeviceScene(flat("textured"))
+    try:
+        tin, tout = g["texq_in"], g["texq_out"]
+        got = sc.texture_query(tin[:, 0], tin[:, 1], tin[:, 2:4])
+        bad = (got.view(np.uint32) != tout.view(np.uint32)).any(axis=1)
+        assert bad.mean() <= 0.01, int(bad.sum())                      # wrap-seam rounding of the stand-in's float remainder, see the CPU test
+        rs = np.random.RandomState(3)
+        fs = flat("textured")
+        maps, objs = np.nonzero(fs.tex_i[:, :, 0].T > -255)
+        k = rs.randint(len(maps), size=20000)
+        uv = rs.uniform(-3, 4, size=(20000, 2)).astype(np.float32)
+        a = sc.texture_query(maps[k], objs[k], uv)
+        b = oracle_scene("textured").texture_query(maps[k], objs[k], uv)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    finally:
+        sc.close()

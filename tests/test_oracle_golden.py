@@ -50,7 +50,7 @@ def test_bxdf_sample_bit_exact():
         assert spec == bool(y[7]) and nd == int(y[8])
 
 
-@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_b", "features_c"])
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_b", "features_c", "textured"])
 def test_scene_functions_bit_exact(tag, parsed, oracle_scene):
     g = golden(f"scene_{SCENES[tag][2]}.npz")
     rc = make_config(parsed(tag)[3], width=int(g["width"]), height=int(g["height"]), max_bounce=int(g["max_bounce"]))
@@ -70,7 +70,7 @@ def test_scene_functions_bit_exact(tag, parsed, oracle_scene):
         assert same(le, y[8:11]) and same(sap, y[11])
 
 
-@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_b", "features_c"])
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_b", "features_c", "textured"])
 def test_whole_kernel_matches_reference_run(tag, parsed, oracle_scene):
     """Renderer.render of the reference, spp by spp on the Philox stream, vs orc_render."""
     g = golden(f"scene_{SCENES[tag][2]}.npz")
@@ -92,6 +92,19 @@ def test_whole_kernel_matches_reference_run(tag, parsed, oracle_scene):
     assert (diff > 0).sum() <= 2, (diff > 0).sum()
     assert (diff > 4.8e-7 * max(1.0, float(np.abs(g["accum"]).max()))).sum() <= 1
     np.testing.assert_array_equal(img / np.float32(cnt), img / np.float32(int(g["spp"])))
+
+
+def test_texture_query_bit_exact(oracle_scene):
+    """Texture.query of the reference (bilinear lookup inside the atlas rectangle, wrap at w-1 / h-1, coordinates outside
+    [0, 1] and negative) on every declared map of scenes/test/textured.xml."""
+    g = golden("scene_textured.npz")
+    tin, tout = g["texq_in"], g["texq_out"]
+    assert tin.shape[0] >= 100 and set(np.int32(tin[:, 0])) == {0, 1, 2}
+    got = oracle_scene("textured").texture_query(tin[:, 0], tin[:, 1], tin[:, 2:4])
+    bad = (got.view(np.uint32) != tout.view(np.uint32)).any(axis=1)
+    # the stand-in evaluates Taichi's `a % b` with numpy's float32 remainder; Taichi's a - b*floor(a/b) can differ from it when
+    # a/b rounds up to an integer (the wrap seam): tolerate that on at most 1 % of the lookups
+    assert bad.mean() <= 0.01, int(bad.sum())
 
 
 # ---- sweep over every pt-renderable scene file the reference bundles with its assets (tests/golden/refscene_*.npz)

@@ -126,9 +126,60 @@ def test_scene_errors(tmp_path):
     (tmp_path / "bad.xml").write_text('<scene version="0.9"><sensor/></scene>')
     with pytest.raises(ValueError):
         scene_parsing(str(tmp_path), "bad.xml")
-    (tmp_path / "tex.xml").write_text('<scene version="1.1"><texture id="t"/><sensor/></scene>')
-    with pytest.raises(NotImplementedError):
+    (tmp_path / "tex.xml").write_text('<scene version="1.1"><texture id="t" type="checkerboard"/><sensor/></scene>')
+    with pytest.raises(NotImplementedError):                       # no lookup for checkerboards upstream either (bxdf/texture.py:96)
         scene_parsing(str(tmp_path), "tex.xml")
+    (tmp_path / "tex2.xml").write_text('<scene version="1.1"><texture id="t" type="image"><string name="filename" value="nope.ppm"/></texture><sensor/></scene>')
+    with pytest.raises(ValueError):                                # missing image file, same message as upstream
+        scene_parsing(str(tmp_path), "tex2.xml")
+
+
+def test_textured_scene_parse(parsed, flat):
+    """scenes/test/textured.xml: texture records, uv coordinates and atlases reach the flat scene; lookups stay inside rectangles."""
+    from adapt_amd.parsers.image_io import imread_rgb
+    tup, fs = parsed("textured"), flat("textured")
+    assert fs.has_textures and fs.uvs.shape == (fs.n_prims, 3, 2) and fs.tex_i.shape == (fs.n_objects, 3, 5)
+    assert [None if a is None else a.shape[2] for a in fs.atlas] == [3, 3, 3]
+    used = fs.tex_i[:, :, 0] > -255
+    assert used.sum() == 6 and used[:, 0].sum() == 4 and used[:, 1].sum() == 1 and used[:, 2].sum() == 1
+    for o, m in zip(*np.nonzero(used)):
+        _, ox, oy, w, h = fs.tex_i[o, m]
+        H, W, _ = fs.atlas[m].shape
+        assert 0 <= ox and ox + w <= W and 0 <= oy and oy + h <= H and w >= 2 and h >= 2
+    # atlas content = the image file / 255 (bump maps with y and z swapped, bxdf/texture.py:69-71)
+    wood = imread_rgb(os.path.join(ROOT, "scenes", "test", "tex", "wood.ppm")).astype(np.float32) / 255.
+    o = int(np.nonzero(used[:, 0])[0][0]); _, ox, oy, w, h = fs.tex_i[o, 0]
+    assert (w, h) == (48, 32) and np.array_equal(fs.atlas[0][oy:oy + h, ox:ox + w], wood)
+    dents = imread_rgb(os.path.join(ROOT, "scenes", "test", "tex", "dents_bump.ppm")).astype(np.float32) / 255.
+    o = int(np.nonzero(used[:, 2])[0][0]); _, ox, oy, w, h = fs.tex_i[o, 2]
+    assert np.array_equal(fs.atlas[2][oy:oy + h, ox:ox + w], dents[..., [0, 2, 1]])
+    assert np.array_equal(fs.tex_f[o, 2], np.float32([1.0, 2.0]))
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/scenes"), reason="reference tree only exists in the authoring container")
+def test_textured_scene_matches_reference_parser(flat):
+    """The reference's own parser (OpenCV / rectpack replaced by the generator's stand-ins) on scenes/test/textured.xml: same
+    uv coordinates and texture records up to the atlas layout, same texels behind every record."""
+    import sys
+    gen = os.path.join(ROOT, "tests", "golden", "gen")
+    sys.path.insert(0, gen)
+    cwd = os.getcwd()
+    try:
+        import refenv
+        refenv.setup()
+        os.chdir(ROOT)
+        from parsers.xml_parser import scene_parsing as ref_parse
+        from adapt_amd.scene_pack import pack_scene
+        ref = pack_scene(*ref_parse(os.path.join(ROOT, "scenes", "test"), "textured.xml"))
+    finally:
+        os.chdir(cwd)
+        sys.path.remove(gen)
+    fs = flat("textured")
+    assert np.array_equal(ref.uvs, fs.uvs) and np.array_equal(ref.tex_f, fs.tex_f)
+    assert np.array_equal(ref.tex_i[:, :, [0, 3, 4]], fs.tex_i[:, :, [0, 3, 4]])          # type, w, h; offsets depend on the packer
+    for o, m in zip(*np.nonzero(fs.tex_i[:, :, 0] > -255)):
+        _, ox, oy, w, h = fs.tex_i[o, m]; _, rx, ry, _, _ = ref.tex_i[o, m]
+        assert np.array_equal(fs.atlas[m][oy:oy + h, ox:ox + w], ref.atlas[m][ry:ry + h, rx:rx + w])
 
 
 def test_config_overrides_and_crop(parsed):
