@@ -42,18 +42,23 @@ static const ShadeVariant kShadeVariants[] = {
 };
 static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures"};
 // Material classes for sorted shading: (class mask) x (emitter mask: point+area | all)
-#define APT_N_CLASS_DEFS 6
+// A kernel's register allocation is the maximum over the models it contains, so the classes are as fine as the models'
+// footprints differ: Lambertian alone runs at 4 waves per SIMD, together with Blinn-Phong (three double pows) at 2-3.
+#define APT_N_CLASS_DEFS 8
 static const int kClassMask[APT_N_CLASS_DEFS] = {
-    0x043,      // diffuse-like: Blinn-Phong, Lambertian, Oren-Nayar
+    0x00a,      // Lambertian (and the microfacet id, compiled out upstream: shades as Lambertian)
+    0x001,      // Blinn-Phong
+    0x040,      // Oren-Nayar
     0x504,      // delta: mirror BRDF, det-refraction BSDF, null BSDF
     0x010,      // modified Phong
     0x020,      // Fresnel blend
     0x080,      // thin coat
     0x200,      // Lambertian transmission
 };
-static const char* kClassName[APT_N_CLASS_DEFS] = {"diffuse", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans"};
+static const char* kClassName[APT_N_CLASS_DEFS] = {"lambertian", "blinn-phong", "oren-nayar", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans"};
 static const shade_fn kClassShade[APT_N_CLASS_DEFS][2] = {
-    {k_shade<0x043, 0x03>, k_shade<0x043, APT_SRC_ALL>}, {k_shade<0x504, 0x03>, k_shade<0x504, APT_SRC_ALL>},
+    {k_shade<0x00a, 0x03>, k_shade<0x00a, APT_SRC_ALL>}, {k_shade<0x001, 0x03>, k_shade<0x001, APT_SRC_ALL>},
+    {k_shade<0x040, 0x03>, k_shade<0x040, APT_SRC_ALL>}, {k_shade<0x504, 0x03>, k_shade<0x504, APT_SRC_ALL>},
     {k_shade<0x010, 0x03>, k_shade<0x010, APT_SRC_ALL>}, {k_shade<0x020, 0x03>, k_shade<0x020, APT_SRC_ALL>},
     {k_shade<0x080, 0x03>, k_shade<0x080, APT_SRC_ALL>}, {k_shade<0x200, 0x03>, k_shade<0x200, APT_SRC_ALL>},
 };
@@ -92,7 +97,7 @@ struct apt_scene {
     DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
     DevBuf uvs, tex_i, tex_f, atlas[3];      // image textures (empty when the scene has none)
     int n_classes = 0;                   // material classes present (compact ids 0..n_classes-1)
-    int class_def[APT_N_CLASS_DEFS] = {0, 0, 0, 0, 0, 0};   // compact id -> class definition
+    int class_def[APT_N_CLASS_DEFS] = {0, 0, 0, 0, 0, 0, 0, 0};   // compact id -> class definition
     int n_prims = 0, n_objects = 0, n_sources = 0, max_obj_prims = 0;
     int bx_mask = 0, src_mask = 0;
     bool has_aabb = false;
@@ -115,7 +120,7 @@ struct apt_renderer {
     int trace_mode = 0;           // 0 = BVH traversal, 1 = wave-uniform sweep, 2 = tiled sweep (small scenes)
     int trace_nt = BLOCK;         // workgroup size of the trace kernels
     int sorted = 0;               // 1 = material-sorted shading (>= 2 material classes in the scene)
-    shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string shade_name;
     LdsPlan plan{};
     size_t lds_bytes = 0, lds_bytes_any = 0;     // dynamic LDS of the closest-hit / any-hit trace kernels

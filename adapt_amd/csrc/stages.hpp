@@ -90,10 +90,10 @@ struct Queues {
     // path's full record (ray + state + hit, 64 B) to the dense queue of its material class, so every shade
     // launch runs one specialised kernel over coherent waves.  n_classes == 0: unsorted (single-class scenes).
     struct ClassQ { float* ray_o; float* ray_d; float* thr; uint32_t* id; uint32_t* meta; float* pdf; float* t; int* prim; float* u; float* v; };
-    ClassQ cls[6];
+    ClassQ cls[8];
     int n_classes;
 };
-#define APT_MAX_CLASSES 6
+#define APT_MAX_CLASSES 8
 // what one shade launch reads: either ray queue `cur` + the hit arrays (unsorted) or one class queue (sorted)
 struct ShadeIn {
     const float* ray_o; const float* ray_d; const float* thr; const uint32_t* id; const uint32_t* meta; const float* pdf;
@@ -109,7 +109,7 @@ enum { ST_SAMPLES = 0, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_SHADOW_TRACED, ST_LIT,
 struct Counters {
     uint32_t n_active[2][APT_MAX_NQ * CNT_PAD];
     uint32_t n_shadow[APT_MAX_NQ * CNT_PAD];
-    uint32_t n_cls[6][APT_MAX_NQ * CNT_PAD];
+    uint32_t n_cls[8][APT_MAX_NQ * CNT_PAD];
     unsigned long long stats[APT_MAX_NQ][16];    // [q][ST_*], 128 bytes per sub-queue
 #ifdef APT_SHADE_PROF
     unsigned long long dbg[2 * 16384];           // per-wave (start, end) of the last k_shade launch, 100 MHz ticks
