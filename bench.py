@@ -235,7 +235,12 @@ def main():
         t = time.perf_counter(); osc.render(rc, 1, threads=cores); one = time.perf_counter() - t
         n_cpu = int(max(1, min(512, round(args.cpu_seconds / max(one, 1e-3)))))
         t = time.perf_counter(); ref, cnt, ost = osc.render(rc, n_cpu, threads=cores); cpu_dt = time.perf_counter() - t
+        # AdaPT itself runs this kernel on 8 CPU threads (ti.loop_config(parallelize=8), vanilla_renderer.py:35): time that too, on a
+        # quarter of the sample so the leg stays bounded
+        n8 = max(1, min(n_cpu, int(round(n_cpu * min(cores, 8) / cores / 2)) or 1))
+        t = time.perf_counter(); osc.render(rc, n8, threads=min(cores, 8)); dt8 = time.perf_counter() - t
         out["cpu_baseline"] = {"value": round(W * H * n_cpu / cpu_dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+                               "at_8_threads": {"value": round(W * H * n8 / dt8 / 1e6, 4), "spp": n8, "seconds": round(dt8, 1)},
                                "sample": f"{W}x{H} x {n_cpu} spp of the same workload (same scene, bounces, seed), {cpu_dt:.1f} s on {cores} OpenMP threads; "
                                          "oracle/pt_oracle.c = C restatement of the reference path (real AdaPT needs taichi, absent here)"}
         chk = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank)

@@ -231,6 +231,25 @@ def test_image_matches_reference_run(tag, renderer):
     assert abs(r.stats()["n_draws"] - int(g["draws"].sum())) <= 2e-3 * int(g["draws"].sum())
 
 
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono"])
+def test_statistical_cross_check_other_seed(tag, renderer, parsed, oracle_scene):
+    """the HIP estimator is the same estimator, not merely the same stream -- against a CPU render with ANOTHER seed its
+    relMSE stays within 1.5x of the relMSE between two CPU renders with different seeds."""
+    w, h, spp = 48, 48, 64
+    def rel(a, b):
+        return float(np.mean((a - b) ** 2 / (b ** 2 + 1e-2)))
+    cpu = {}
+    for seed in (0, 1, 2):
+        rc = make_config(parsed(tag)[3], width=w, height=h, seed=seed)
+        cpu[seed] = oracle_scene(tag).render(rc, spp)[0].astype(np.float64) / spp
+    r = renderer(tag, width=w, height=h, seed=0)
+    r.render(n_spp=spp)
+    hip = r.pixels.to_numpy().astype(np.float64)
+    noise = rel(cpu[1], cpu[2])
+    assert noise > 0 and rel(hip, cpu[1]) <= 1.5 * noise and rel(hip, cpu[2]) <= 1.5 * noise, (rel(hip, cpu[1]), rel(hip, cpu[2]), noise)
+    assert rel(hip, cpu[0]) <= 1e-4 < noise              # and on the SAME seed it is the same image, far below the noise floor
+
+
 def test_cbox_is_bit_reproducible_and_batch_invariant(renderer):
     """One shadow ray per bounce => every float is added in a fixed order: bitwise reproducible, and
     independent of how samples are batched or the render call is split."""
