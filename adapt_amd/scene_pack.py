@@ -56,9 +56,15 @@ class FlatScene:
     tex_i: Optional[np.ndarray] = None      # (n,3,5) i32   type (-255 none), off_x, off_y, w, h
     tex_f: Optional[np.ndarray] = None      # (n,3,2) f32   scale_u, scale_v
     atlas: Optional[list] = None            # three (H,W,3) f32 images or None
+    # participating media for the volumetric path tracer: row o < n = medium attached to object o's BSDF, row n = the world's
+    med_i: Optional[np.ndarray] = None      # (n+1,)   i32   type: -1 transparent, 0 hg, 1 multi-hg, 2 rayleigh, 3 mie
+    med_f: Optional[np.ndarray] = None      # (n+1,16) f32   ior, u_s, u_a, u_e, par, pdf
 
     @property
     def has_textures(self): return self.tex_i is not None
+
+    @property
+    def has_scattering_media(self): return self.med_i is not None and bool((self.med_i >= 0).any())
 
     @property
     def n_prims(self): return int(self.prims.shape[0])
@@ -95,6 +101,7 @@ class RenderConfig:
     half_w: float = 0.0
     half_h: float = 0.0
     seed: int = 0
+    volumetric: bool = False      # False: Renderer (vanilla_renderer.py); True: VolumeRenderer (vpt.py)
     crop_x: int = 0
     crop_y: int = 0
     crop_rx: int = 0
@@ -138,6 +145,17 @@ def pack_bxdf(b):
             np.concatenate([b.k_d, b.k_s, b.k_g, mean, [ior]]).astype(np.float32))
 
 
+def pack_medium(m):
+    """Medium_np host object (adapt_amd.materials or AdaPT's bxdf/medium.py:24-68) -> (type, float32[16] ior u_s u_a u_e par pdf)."""
+    if m is None:
+        return -1, np.float32([1.0] + [0] * 12 + [1, 0, 0])
+    if hasattr(m, "packed_medium"):                 # already flat (scenes rebuilt from fixtures)
+        return m.packed_medium
+    if not hasattr(m, "type_id"):                   # only an index of refraction is known
+        return -1, np.float32([float(m.ior)] + [0] * 12 + [1, 0, 0])
+    return int(m.type_id), np.concatenate([[m.ior], m.u_s, m.u_a, m.u_e, m.par, m.pdf]).astype(np.float32)
+
+
 _TEX_MAPS = ("albedo", "normal", "bump")
 
 
@@ -174,6 +192,11 @@ def pack_scene(emitters: List, array_info: dict, objects: List, prop: dict) -> F
         if obj.emitter_ref_id >= 0:
             src_i[obj.emitter_ref_id, 2] = i           # obj_ref_id back-pointer (path_tracer.py:272-274)
     assert first == prims.shape[0]
+    med_i = np.full((n_obj + 1,), -1, np.int32)
+    med_f = np.zeros((n_obj + 1, 16), np.float32)
+    for i, obj in enumerate(objects):
+        med_i[i], med_f[i] = pack_medium(getattr(obj.bsdf, "medium", None))
+    med_i[n_obj], med_f[n_obj] = pack_medium(prop["world"].medium)
     tex = {}
     images = prop.get("packed_textures")
     if images is not None and any(images.get(m) is not None for m in _TEX_MAPS):
@@ -190,12 +213,12 @@ def pack_scene(emitters: List, array_info: dict, objects: List, prop: dict) -> F
     return FlatScene(prims=prims, normals=n_g, v_normals=n_s, obj_info=obj_info, obj_aabb=obj_aabb,
                      emitter_id=emitter_id, bxdf_i=bxdf_i, bxdf_f=bxdf_f, src_i=src_i, src_f=src_f,
                      has_vertex_normal=bool(prop["has_vertex_normal"]),
-                     world_ior=float(prop["world"].medium.ior), **tex)
+                     world_ior=float(prop["world"].medium.ior), med_i=med_i, med_f=med_f, **tex)
 
 
 def make_config(prop: dict, *, width: Optional[int] = None, height: Optional[int] = None,
                 max_bounce: Optional[int] = None, num_shadow_ray: Optional[int] = None,
-                seed: int = 0, use_bvh: Optional[bool] = None) -> RenderConfig:
+                seed: int = 0, use_bvh: Optional[bool] = None, volumetric: bool = False) -> RenderConfig:
     """Sensor dict -> RenderConfig.  Keyword overrides exist because the BASELINE
     configs differ from the values stored in the scene files."""
     film = prop["film"]
@@ -222,5 +245,5 @@ def make_config(prop: dict, *, width: Optional[int] = None, height: Optional[int
         stratified=bool(prop["stratified_sampling"]), brdf_two_sides=bool(prop.get("brdf_two_sides", False)),
         use_bvh=bool(use_bvh), rr_bounce_th=int(prop.get("rr_bounce_th", 4)), rr_threshold=float(prop.get("rr_threshold", 0.1)),
         cam_r=np.ascontiguousarray(cam_r, np.float32), cam_t=np.float32(prop["transform"][1]), cam_orient=orient,
-        focal=float(focal), inv_focal=float(1. / focal), half_w=w / 2, half_h=h / 2, seed=int(seed),
+        focal=float(focal), inv_focal=float(1. / focal), half_w=w / 2, half_h=h / 2, seed=int(seed), volumetric=bool(volumetric),
         crop_x=crop_x, crop_y=crop_y, crop_rx=crop_rx, crop_ry=crop_ry)

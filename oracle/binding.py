@@ -25,7 +25,8 @@ class SceneDesc(C.Structure):
                 ("prims", f32p), ("normals", f32p), ("v_normals", f32p), ("obj_info", i32p), ("obj_aabb", f32p),
                 ("emitter_id", i32p), ("bxdf_i", i32p), ("bxdf_f", f32p), ("src_i", i32p), ("src_f", f32p),
                 ("world_ior", C.c_float),
-                ("uvs", f32p), ("tex_i", i32p), ("tex_f", f32p), ("atlas", f32p * 3), ("atlas_w", C.c_int * 3), ("atlas_h", C.c_int * 3)]
+                ("uvs", f32p), ("tex_i", i32p), ("tex_f", f32p), ("atlas", f32p * 3), ("atlas_w", C.c_int * 3), ("atlas_h", C.c_int * 3),
+                ("med_i", i32p), ("med_f", f32p)]
 
 
 class Cfg(C.Structure):
@@ -35,12 +36,13 @@ class Cfg(C.Structure):
                 ("use_rr", C.c_int), ("use_mis", C.c_int), ("anti_alias", C.c_int), ("stratified", C.c_int),
                 ("brdf_two_sides", C.c_int), ("use_bvh", C.c_int), ("rr_bounce_th", C.c_int),
                 ("rr_threshold", C.c_float), ("cam_r", C.c_float * 9), ("cam_t", C.c_float * 3),
-                ("inv_focal", C.c_float), ("half_w", C.c_float), ("half_h", C.c_float), ("seed", C.c_uint32)]
+                ("inv_focal", C.c_float), ("half_w", C.c_float), ("half_h", C.c_float), ("seed", C.c_uint32),
+                ("volumetric", C.c_int)]
 
 
 class Stats(C.Structure):
     _fields_ = [("n_samples", C.c_longlong), ("n_shade", C.c_longlong), ("n_shadow", C.c_longlong),
-                ("n_lit", C.c_longlong), ("n_draws", C.c_longlong)]
+                ("n_lit", C.c_longlong), ("n_draws", C.c_longlong), ("n_extend", C.c_longlong), ("n_track", C.c_longlong)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -95,6 +97,7 @@ def make_cfg(rc) -> Cfg:
     c.cam_t = (C.c_float * 3)(*np.float32(rc.cam_t).tolist())
     c.inv_focal, c.half_w, c.half_h = float(rc.inv_focal), float(rc.half_w), float(rc.half_h)
     c.seed = int(rc.seed) & 0xffffffff
+    c.volumetric = int(bool(getattr(rc, "volumetric", False)))
     return c
 
 
@@ -117,6 +120,10 @@ class OracleScene:
                 if img is not None:
                     img = np.ascontiguousarray(img, np.float32); self._keep.append(img)
                     d.atlas[m] = _fp(img); d.atlas_h[m], d.atlas_w[m] = int(img.shape[0]), int(img.shape[1])
+        if getattr(fs, "med_i", None) is not None:                  # participating media (volumetric path tracer)
+            med = [np.ascontiguousarray(fs.med_i, np.int32), np.ascontiguousarray(fs.med_f, np.float32)]
+            self._keep += med
+            d.med_i, d.med_f = _ip(med[0]), _fp(med[1])
         ct = _f3(cam_t)
         self.handle = C.c_void_p(L.orc_scene_create(C.byref(d), _fp(ct), int(build_bvh)))
         self.fs = fs

@@ -202,6 +202,10 @@ typedef struct {
     const float* tex_f;       /* n_objects*3*2: scale_u, scale_v */
     const float* atlas[3];    /* atlas_h * atlas_w * 3 floats, row-major [y][x] */
     int atlas_w[3], atlas_h[3];
+    /* participating media (volumetric path tracer only; NULL = every medium transparent).  Row o < n_objects: the medium attached to
+       object o's BSDF; row n_objects: the world medium */
+    const int*   med_i;       /* (n_objects+1): type  -1 transparent, 0 hg, 1 multi-hg, 2 rayleigh, 3 mie */
+    const float* med_f;       /* (n_objects+1)*16: ior, u_s[3], u_a[3], u_e[3], par[3], pdf[3] */
 } orc_scene_desc;
 
 typedef struct {
@@ -214,11 +218,19 @@ typedef struct {
     float cam_r[9], cam_t[3];
     float inv_focal, half_w, half_h;
     uint32_t seed;
+    int volumetric;           /* 0: Renderer.render (vanilla_renderer.py), 1: VolumeRenderer.render (vpt.py) */
 } orc_cfg;
 
 typedef struct {
     long long n_samples, n_shade, n_shadow, n_lit, n_draws;
+    long long n_extend, n_track;          /* closest-hit queries by the main loop / by track_ray (vpt) */
 } orc_stats;
+
+typedef struct {              /* bxdf/medium.py:71-78 + bxdf/phase.py:33-37 */
+    int type;
+    float ior;
+    v3 u_s, u_a, u_e, par, pdf;
+} medium_t;
 
 typedef struct {
     int n_prims, n_objects, n_sources, has_vn;
@@ -232,6 +244,8 @@ typedef struct {
     bxdf_t* bxdf;
     src_t* src;
     float world_ior;
+    medium_t* med;            /* n_objects + 1 rows, the last one is the world's */
+    v3 w_aabb_min, w_aabb_max;    /* path_tracer.py:130-138 */
     /* textures: bxdf/texture.py:99-139, path_tracer.py:84-126,261-266 */
     float (*uvs)[3][2];
     int (*tex_i)[3][5];
@@ -1253,19 +1267,30 @@ ORC_API scene_t* orc_scene_create(const orc_scene_desc* d, const float cam_t[3],
         e->type = si[0]; e->bool_bits = si[1]; e->obj_ref_id = si[2];
         e->intensity = as_v3(sf)[0]; e->dir = as_v3(sf)[1]; e->pos = as_v3(sf)[2]; e->inv_area = sf[9]; e->r = sf[10];
     }
-    if (build_bvh) {
-        /* world AABB, path_tracer.py:130-138 */
+    sc->med = calloc((size_t)O + 1, sizeof(medium_t));
+    for (int o = 0; o <= O; o++) {
+        medium_t* m = &sc->med[o];
+        if (d->med_i && d->med_f) {
+            const float* f = d->med_f + 16 * o;
+            m->type = d->med_i[o]; m->ior = f[0];
+            m->u_s = as_v3(f + 1)[0]; m->u_a = as_v3(f + 1)[1]; m->u_e = as_v3(f + 1)[2]; m->par = as_v3(f + 1)[3]; m->pdf = as_v3(f + 1)[4];
+        } else {
+            m->type = -1; m->ior = (o < O) ? sc->bxdf[o].ior : sc->world_ior; m->pdf = V(1.f, 0.f, 0.f);
+        }
+    }
+    {   /* world AABB, path_tracer.py:130-138 */
         v3 lo = V(1e3f, 1e3f, 1e3f), hi = V(-1e3f, -1e3f, -1e3f);
         for (int o = 0; o < O; o++) { lo = vminv(lo, sc->aabbs[o][0]); hi = vmaxv(hi, sc->aabbs[o][1]); }
         v3 ct = V(cam_t[0], cam_t[1], cam_t[2]);
-        build_reference_bvh(sc, vadds(vminv(ct, lo), -0.1f), vadds(vmaxv(ct, hi), 0.1f));
+        sc->w_aabb_min = vadds(vminv(ct, lo), -0.1f); sc->w_aabb_max = vadds(vmaxv(ct, hi), 0.1f);
+        if (build_bvh) build_reference_bvh(sc, sc->w_aabb_min, sc->w_aabb_max);
     }
     return sc;
 }
 ORC_API void orc_scene_destroy(scene_t* sc) {
     if (!sc) return;
     free(sc->prims); free(sc->precom); free(sc->vnorm); free(sc->normals); free(sc->obj_info); free(sc->aabbs);
-    free(sc->emitter_id); free(sc->bxdf); free(sc->src); free(sc->nodes); free(sc->bvhs);
+    free(sc->emitter_id); free(sc->bxdf); free(sc->src); free(sc->med); free(sc->nodes); free(sc->bvhs);
     free(sc->uvs); free(sc->tex_i); free(sc->tex_f); for (int m = 0; m < 3; m++) free(sc->atlas[m]);
     free(sc);
 }
@@ -1449,6 +1474,285 @@ static v3 render_sample(const ctx_t* c, int i, int j, int cnt, rng_t* rng, orc_s
     return color;
 }
 
+/* ===================================================================== volumetric path tracer
+ * VolumeRenderer.render (renderer/vpt.py:145-258) with homogeneous media: the world medium and media attached to BSDF objects
+ * (bxdf/medium.py:71-125), their phase functions (bxdf/phase.py, sampler/phase_sampling.py), null surfaces (bsdf.py:214-216) and
+ * the transmittance walk track_ray (vpt.py:99-138).  Grid volumes (bxdf/volume.py) are not restated. */
+static float random_rgb(rng_t* r, v3 v) {                          /* general_sampling.py:17-27 */
+    int idx = pymod(rng_int(r), 3);
+    float res = (idx == 0) ? v.x : ((idx == 1) ? v.y : v.z);
+    return fmaxf(res, 1e-5f);
+}
+static inline v3 vexp_neg(v3 u_e, float d) { return V(expf(-u_e.x * d), expf(-u_e.y * d), expf(-u_e.z * d)); }
+static inline float vsum(v3 a) { return (a.x + a.y) + a.z; }
+static v3 medium_transmittance(const medium_t* m, float depth) { return vexp_neg(m->u_e, depth); }     /* medium.py:84-87 */
+/* Medium.sample_mfp, medium.py:89-108 */
+static int medium_sample_mfp(const medium_t* m, float max_depth, rng_t* r, float* t_out, v3* beta) {
+    float random_ue = random_rgb(r, m->u_e);
+    float sample_t = -logf(1.f - rng_float(r)) / random_ue;
+    int is_mi = 0;
+    if (sample_t >= max_depth) {
+        sample_t = max_depth;
+        v3 tr = vexp_neg(m->u_e, max_depth);
+        float pdf = vsum(tr) / 3.f;
+        pdf = (pdf > 0.f) ? pdf : 1.f;
+        *beta = vdivs(tr, pdf);
+    } else {
+        is_mi = 1;
+        v3 tr = vexp_neg(m->u_e, sample_t);
+        float pdf = vsum(vmul(m->u_e, tr)) / 3.f;
+        pdf = (pdf > 0.f) ? pdf : 1.f;
+        *beta = vdivs(vmul(tr, m->u_s), pdf);
+    }
+    *t_out = sample_t;
+    return is_mi;
+}
+/* bxdf/phase.py:21-31 */
+static float phase_hg(float cos_theta, float g) {
+    float g2 = g * g;
+    float denom = (1.f + g2) - (2.f * g) * cos_theta;
+    return (((1.f - g2) / (sqrtf(denom) * denom)) * 0.5f) * F_INV_2PI;
+}
+static float phase_rayleigh(float cos_theta) { return (float)(0.375 * ((1.0 / 3.14159265358979323846) * 0.5)) * (1.f + cos_theta * cos_theta); }
+/* sampler/phase_sampling.py:16-42 */
+static v3 sample_hg(rng_t* r, float g, float* cos_out) {
+    float cos_theta;
+    if (fabsf(g) < 1e-4f) cos_theta = 1.f - 2.f * rng_float(r);
+    else {
+        float g2 = g * g;
+        float sqr_term = (1.f - g2) / ((1.f + g) - (2.f * g) * rng_float(r));
+        cos_theta = ((1.f + g2) - sqr_term * sqr_term) / (2.f * g);
+    }
+    float sin_theta = sqrtf(fmaxf(0.f, 1.f - cos_theta * cos_theta));
+    float phi = F_PI2 * rng_float(r);
+    *cos_out = cos_theta;
+    return V(cosf(phi) * sin_theta, cos_theta, sinf(phi) * sin_theta);
+}
+static v3 sample_rayleigh(rng_t* r, float* cos_out) {
+    float rd = 2.f * rng_float(r) - 1.f;
+    float u = -powf(2.f * rd + sqrtf((4.f * rd) * rd + 1.f), (float)(1.0 / 3.0));
+    float cos_theta = fminf(fmaxf(u - 1.f / u, -1.f), 1.f);
+    float sin_theta = sqrtf(fmaxf(0.f, 1.f - cos_theta * cos_theta));
+    float phi = F_PI2 * rng_float(r);
+    *cos_out = cos_theta;
+    return V(cosf(phi) * sin_theta, cos_theta, sinf(phi) * sin_theta);
+}
+/* PhaseFunction.sample_p / eval_p, phase.py:39-84 */
+static v3 phase_sample_p(const medium_t* m, v3 incid, rng_t* r, float* p_out) {
+    v3 dir = incid; float p = 1.f, cos_t = 0.f;
+    if (m->type == 0) { float g = m->par.x; dir = sample_hg(r, g, &cos_t); p = phase_hg(cos_t, g); }
+    else if (m->type == 1) {
+        float eps = rng_float(r), g;
+        if (eps < m->pdf.x) g = m->par.x;
+        else if (eps < m->pdf.x + m->pdf.y) g = m->par.y;
+        else g = m->par.z;
+        dir = sample_hg(r, g, &cos_t); p = phase_hg(cos_t, g);
+    } else if (m->type == 2) { dir = sample_rayleigh(r, &cos_t); p = phase_rayleigh(cos_t); }
+    *p_out = p;
+    return dir;
+}
+static float phase_eval_p(const medium_t* m, v3 ray_in, v3 ray_out) {
+    float p = 1.f, cos_theta = -vdot(ray_in, ray_out);
+    if (m->type == 0) p = phase_hg(cos_theta, m->par.x);
+    else if (m->type == 1) {
+        p = phase_hg(cos_theta, m->par.x) * m->pdf.x + phase_hg(cos_theta, m->par.y) * m->pdf.y;
+        if (m->pdf.y > 1e-4f) p += phase_hg(cos_theta, m->par.z) * m->pdf.z;
+    } else if (m->type == 2) p = phase_rayleigh(cos_theta);
+    return p;
+}
+/* Medium.sample_new_rays, medium.py:112-121 */
+static v3 medium_sample_new_rays(const medium_t* m, v3 incid, rng_t* r, v3* spec, float* pdf) {
+    *spec = V(1.f, 1.f, 1.f); *pdf = 1.f;
+    if (m->type < 0) return incid;
+    float p; v3 local = phase_sample_p(m, incid, r, &p);
+    m3 R; v3 dir = delocalize_rotate(incid, local, &R);
+    *pdf = p; *spec = V(p, p, p);
+    return dir;
+}
+static inline int vpt_world_scattering(const ctx_t* c) { return c->sc->med[c->sc->n_objects].type >= 0; }
+static inline int vpt_is_scattering(const ctx_t* c, int idx) {                 /* path_tracer.py:528-535 */
+    return idx >= 0 && c->sc->bxdf[idx].is_bsdf && c->sc->med[idx].type >= 0;
+}
+static inline int vpt_non_null_surface(const ctx_t* c, int idx) {             /* vpt.py:64-70 */
+    return !(idx >= 0 && c->sc->bxdf[idx].is_bsdf) || c->sc->bxdf[idx].type >= 0;
+}
+static v3 vpt_get_transmittance(const ctx_t* c, int idx, int in_free_space, float depth) {     /* vpt.py:52-62 */
+    v3 tr = V(1.f, 1.f, 1.f);
+    int world_valid = in_free_space && vpt_world_scattering(c);
+    if (world_valid || vpt_is_scattering(c, idx)) {
+        if (world_valid) tr = medium_transmittance(&c->sc->med[c->sc->n_objects], depth);
+        else if (!in_free_space) tr = medium_transmittance(&c->sc->med[idx], depth);
+    }
+    return tr;
+}
+static int vpt_sample_mfp(const ctx_t* c, int idx, int in_free_space, float depth, rng_t* r, float* mfp, v3* beta) {   /* vpt.py:72-97 */
+    int is_mi = 0; *mfp = depth; *beta = V(1.f, 1.f, 1.f);
+    int world_valid = in_free_space && vpt_world_scattering(c);
+    if (world_valid || vpt_is_scattering(c, idx)) {
+        if (world_valid) is_mi = medium_sample_mfp(&c->sc->med[c->sc->n_objects], depth, r, mfp, beta);
+        else if (!in_free_space) is_mi = medium_sample_mfp(&c->sc->med[idx], depth, r, mfp, beta);
+    }
+    return is_mi;
+}
+static void vpt_ray_intersect(const ctx_t* c, v3 ray, v3 o, float min_depth, isect_t* it) {
+    if (c->cfg->use_bvh && c->sc->node_num > 0) ray_intersect_bvh(c->sc, ray, o, min_depth, it);
+    else ray_intersect_brute(c->sc, ray, o, min_depth, it);
+}
+/* VolumeRenderer.track_ray, vpt.py:99-138 (the accumulated optical length it also returns is unused by render) */
+static v3 vpt_track_ray(const ctx_t* c, v3 cur_ray, v3 cur_point, float depth, orc_stats* st) {
+    v3 tr = V(1.f, 1.f, 1.f);
+    int in_free_space = 1;
+    for (int k = 0; k < 7; k++) {
+        isect_t it; vpt_ray_intersect(c, cur_ray, cur_point, depth, &it);
+        st->n_track++;
+        if (it.obj_id < 0) {
+            if (!vpt_world_scattering(c)) break;
+            it.min_depth = depth; in_free_space = 1; it.obj_id = -1;
+        } else {
+            if (vpt_non_null_surface(c, it.obj_id)) { tr = ZERO3; break; }
+            in_free_space = vdot(it.n_g, cur_ray) < 0.f;
+        }
+        tr = vmul(tr, vpt_get_transmittance(c, it.obj_id, in_free_space, it.min_depth));
+        cur_point = vadd(cur_point, vscale(cur_ray, it.min_depth));
+        depth -= it.min_depth;
+        if (depth <= 5e-5f) break;
+    }
+    return tr;
+}
+static float vpt_world_bound_time(const scene_t* sc, v3 o, v3 d) {             /* vpt.py:140-143 */
+    v3 t_min = vdiv(vsub(sc->w_aabb_min, o), d), t_max = vdiv(vsub(sc->w_aabb_max, o), d);
+    v3 m = vmaxv(t_min, t_max);
+    float r = m.x;                       /* Vector.min(): NaN-propagating, like the fixture generator's */
+    if (!isnan(r) && (isnan(m.y) || m.y < r)) r = m.y;
+    if (!isnan(r) && (isnan(m.z) || m.z < r)) r = m.z;
+    return r;
+}
+/* PathTracer.eval / sample_new_ray with the medium-interaction flag, path_tracer.py:424-480 */
+static v3 vpt_eval(const ctx_t* c, isect_t* it, v3 incid, v3 out, int is_mi, int in_free_space) {
+    if (is_mi) {
+        const medium_t* m = in_free_space ? &c->sc->med[c->sc->n_objects] : &c->sc->med[it->obj_id];
+        float p = phase_eval_p(m, incid, out);
+        return V(p, p, p);
+    }
+    return pt_eval(c, it, incid, out);
+}
+static v3 vpt_sample_new_ray(const ctx_t* c, isect_t* it, v3 incid, int is_mi, int in_free_space, rng_t* r, v3* spec, float* pdf, int* is_specular) {
+    if (is_mi) {
+        const medium_t* m = in_free_space ? &c->sc->med[c->sc->n_objects] : &c->sc->med[it->obj_id];
+        *is_specular = 0;
+        return medium_sample_new_rays(m, incid, r, spec, pdf);
+    }
+    return pt_sample_new_ray(c, it, incid, r, spec, pdf, is_specular);
+}
+
+static v3 render_sample_vpt(const ctx_t* c, int i, int j, int cnt, rng_t* rng, orc_stats* st, trace_t* tr) {
+    const orc_cfg* g = c->cfg; const scene_t* sc = c->sc;
+    v3 ray_d = pix2ray(c, i, j, cnt, rng);
+    v3 ray_o = c->cam_t;
+    v3 color = ZERO3, throughput = V(1.f, 1.f, 1.f);
+    float emission_weight = 1.0f;
+    int in_free_space = 1, bounce = 0;
+    const int world_scat = vpt_world_scattering(c);
+    st->n_samples++;
+    for (;;) {
+        if (g->use_rr) {                                                        /* vpt.py:164-172 */
+            float max_value = vmax(throughput);
+            if (max_value < g->rr_threshold && bounce >= g->rr_bounce_th) {
+                if (rng_float(rng) > max_value) break;
+                else throughput = vscale(throughput, 1.f / (max_value + 1e-7f));
+            }
+        } else {
+            if (vmax(throughput) < 1e-5f) break;
+        }
+        isect_t it; vpt_ray_intersect(c, ray_d, ray_o, -1.0f, &it);
+        st->n_extend++;
+        if (it.obj_id < 0) {
+            if (!world_scat) break;
+            it.min_depth = vpt_world_bound_time(sc, ray_o, ray_d);
+            in_free_space = 1; it.obj_id = -1;
+        } else {
+            in_free_space = vdot(it.n_g, ray_d) < 0.f;
+        }
+        v3 path_beta; float mfp;
+        int is_mi = vpt_sample_mfp(c, it.obj_id, in_free_space, it.min_depth, rng, &mfp, &path_beta);
+        it.min_depth = mfp;
+        if (it.obj_id < 0 && !is_mi) break;
+        v3 hit_point = vadd(vscale(ray_d, it.min_depth), ray_o);
+        throughput = vmul(throughput, path_beta);
+        if (!is_mi && !vpt_non_null_surface(c, it.obj_id)) { ray_o = hit_point; continue; }
+        int hit_light = is_mi ? -1 : sc->emitter_id[it.obj_id];
+        st->n_shade++;
+        float direct_pdf = 1.0f, emitter_pdf = 1.0f;
+        int break_flag = 0;
+        v3 shadow_int = ZERO3, direct_int = ZERO3, direct_spec = V(1.f, 1.f, 1.f);
+        get_uv_item(sc, 0, &it, &it.tex);                                       /* vpt.py:199 */
+        for (int s = 0; s < g->num_shadow_ray; s++) {
+            int emitter_valid;
+            const src_t* emitter = pt_sample_light(c, hit_light, rng, &emitter_pdf, &emitter_valid);
+            v3 light_dir = ZERO3;
+            if (emitter_valid) {
+                v3 emit_pos = src_sample_hit(c, emitter, hit_point, rng, &shadow_int, &direct_pdf);
+                v3 to_emitter = vsub(emit_pos, hit_point);
+                float emitter_d = vnorm(to_emitter);
+                light_dir = vdivs(to_emitter, emitter_d);
+                st->n_shadow++;
+                v3 trn = vpt_track_ray(c, light_dir, hit_point, emitter_d, st);
+                if (trn.x != 0.f || trn.y != 0.f || trn.z != 0.f) st->n_lit++;
+                shadow_int = vmul(shadow_int, trn);
+                direct_spec = vpt_eval(c, &it, ray_d, light_dir, is_mi, in_free_space);
+            } else { break_flag = 1; break; }
+            float light_pdf = emitter_pdf * direct_pdf;
+            if (g->use_mis) {
+                float mis_w = 1.0f;
+                if (!(emitter->bool_bits & 0x01)) {
+                    float bsdf_pdf_v = is_mi ? direct_spec.x : pt_surface_pdf(c, &it, light_dir, ray_d);
+                    mis_w = balance_heuristic(light_pdf, bsdf_pdf_v);
+                }
+                direct_int = vadd(direct_int, vdivs(vscale(vmul(direct_spec, shadow_int), mis_w), emitter_pdf));
+            } else {
+                direct_int = vadd(direct_int, vdivs(vmul(direct_spec, shadow_int), emitter_pdf));
+            }
+        }
+        if (!break_flag) direct_int = vscale(direct_int, c->inv_num_shadow_ray);
+        v3 emit_int = ZERO3;
+        if (hit_light >= 0) emit_int = src_eval_le(&sc->src[hit_light], vsub(hit_point, ray_o), it.n_g);     /* n_g here, vpt.py:233 */
+        v3 indirect_spec; float ray_pdf; int is_specular;
+        v3 new_d = vpt_sample_new_ray(c, &it, ray_d, is_mi, in_free_space, rng, &indirect_spec, &ray_pdf, &is_specular);
+        if (tr && tr->n_events < tr->max_events) {
+            float* e = tr->ev + 18 * tr->n_events++;
+            v3 ew = vscale(emit_int, emission_weight);
+            e[0] = (float)it.obj_id; e[1] = is_mi ? -2.f : (float)it.prim_id; e[2] = it.min_depth;
+            e[3] = direct_int.x; e[4] = direct_int.y; e[5] = direct_int.z;
+            e[6] = ew.x; e[7] = ew.y; e[8] = ew.z;
+            e[9] = throughput.x; e[10] = throughput.y; e[11] = throughput.z;
+            e[12] = hit_point.x; e[13] = hit_point.y; e[14] = hit_point.z; e[15] = new_d.x; e[16] = new_d.y; e[17] = new_d.z;
+        }
+        ray_d = new_d;
+        ray_o = hit_point;
+        color = vadd(color, vmul(vadd(direct_int, vscale(emit_int, emission_weight)), throughput));
+        if (!is_mi) {
+            if (vmax(indirect_spec) == 0.f || ray_pdf == 0.f) break;
+            throughput = vmul(throughput, vdivs(indirect_spec, ray_pdf));
+        }
+        bounce++;
+        if (bounce >= g->max_bounce) break;
+        if (it.obj_id >= 0) {                                                   /* vpt.py:247-253: weights with THIS interaction */
+            hit_light = sc->emitter_id[it.obj_id];
+            if (g->use_mis) {
+                float e_pdf = 0.0f;
+                if (hit_light >= 0 && pt_is_delta(c, it.obj_id) == 0 && !is_specular)
+                    e_pdf = src_solid_angle_pdf(&sc->src[hit_light], &it, ray_d);
+                emission_weight = balance_heuristic(ray_pdf, e_pdf);
+            }
+        }
+    }
+    st->n_draws += rng->draw;
+    if (isnan(color.x)) color.x = 0.f;
+    if (isnan(color.y)) color.y = 0.f;
+    if (isnan(color.z)) color.z = 0.f;
+    return color;
+}
+
 static void make_ctx(ctx_t* c, const scene_t* sc, const orc_cfg* cfg) {
     c->sc = sc; c->cfg = cfg;
     c->inv_num_shadow_ray = (cfg->num_shadow_ray > 0) ? 1.f / (float)cfg->num_shadow_ray : 1.f;
@@ -1467,19 +1771,20 @@ ORC_API int orc_render(const scene_t* sc, const orc_cfg* cfg, float* accum, int*
 #ifdef _OPENMP
         if (n_threads > 0) omp_set_num_threads(n_threads);
 #endif
-        long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-#pragma omp parallel for schedule(dynamic, 64) reduction(+ : a0, a1, a2, a3, a4)
+        long long a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0;
+#pragma omp parallel for schedule(dynamic, 64) reduction(+ : a0, a1, a2, a3, a4, a5, a6)
         for (int p = 0; p < W * H; p++) {
             int i = p / H, j = p % H;
             if (cfg->do_crop && !(i >= cfg->start_x && i < cfg->end_x && j >= cfg->start_y && j < cfg->end_y)) continue;
             rng_t rng; rng_seed(&rng, (uint32_t)p, cfg->seed, (uint32_t)cur);
             orc_stats st; memset(&st, 0, sizeof(st));
-            v3 col = render_sample(&c, i, j, cur, &rng, &st, NULL);
+            v3 col = cfg->volumetric ? render_sample_vpt(&c, i, j, cur, &rng, &st, NULL) : render_sample(&c, i, j, cur, &rng, &st, NULL);
             float* px = accum + 3 * (size_t)p;
             px[0] += col.x; px[1] += col.y; px[2] += col.z;
-            a0 += st.n_samples; a1 += st.n_shade; a2 += st.n_shadow; a3 += st.n_lit; a4 += st.n_draws;
+            a0 += st.n_samples; a1 += st.n_shade; a2 += st.n_shadow; a3 += st.n_lit; a4 += st.n_draws; a5 += st.n_extend; a6 += st.n_track;
         }
         total.n_samples += a0; total.n_shade += a1; total.n_shadow += a2; total.n_lit += a3; total.n_draws += a4;
+        total.n_extend += a5; total.n_track += a6;
     }
     if (stats) *stats = total;
     (void)n_threads;
@@ -1494,7 +1799,8 @@ ORC_API int orc_trace_sample(const scene_t* sc, const orc_cfg* cfg, int i, int j
     if (script) { rng.mode = 1; rng.script = script; rng.script_n = script_n; }
     orc_stats st; memset(&st, 0, sizeof(st));
     trace_t tr = {max_events, 0, events};
-    v3 col = render_sample(&c, i, j, cnt, &rng, &st, events ? &tr : NULL);
+    v3 col = cfg->volumetric ? render_sample_vpt(&c, i, j, cnt, &rng, &st, events ? &tr : NULL)
+                             : render_sample(&c, i, j, cnt, &rng, &st, events ? &tr : NULL);
     color_out[0] = col.x; color_out[1] = col.y; color_out[2] = col.z;
     if (n_events) *n_events = tr.n_events;
     if (n_draws) *n_draws = (int)rng.draw;

@@ -104,6 +104,7 @@ def image_metrics(a, b):
 
 
 # ---- the reference's own bundled scenes, as arrays (tests/golden/refscene_*.npz; the XML files stay in /root/reference)
+VPT_SCENE_TAGS = sorted(f[len("vptscene_"):-4] for f in os.listdir(GOLDEN) if f.startswith("vptscene_") and f.endswith(".npz"))
 REF_SCENE_TAGS = sorted(f[len("refscene_"):-4] for f in os.listdir(GOLDEN) if f.startswith("refscene_") and f.endswith(".npz"))
 
 
@@ -126,15 +127,21 @@ class _World:
         ior = 1.0
 
 
-def scene_from_golden(tag):
-    """refscene_<tag>.npz -> the 4-tuple `scene_parsing` returns (emitters, array_info, objects, prop) + the fixture"""
-    g = golden(f"refscene_{tag}.npz")
+def scene_from_golden(tag, prefix="refscene"):
+    """refscene_<tag>.npz / vptscene_<tag>.npz -> the 4-tuple `scene_parsing` returns (emitters, array_info, objects, prop) + the fixture"""
+    g = golden(f"{prefix}_{tag}.npz")
     emitters = [_Packed(g["src_i"][k], g["src_f"][k]) for k in range(g["src_i"].shape[0])]
     objs = [_Obj(g["obj_info"][k, 1], g["obj_info"][k, 2], g["obj_aabb"][k], g["emitter_id"][k], _Packed(g["bxdf_i"][k], g["bxdf_f"][k]))
             for k in range(g["obj_info"].shape[0])]
     n = g["prims"].shape[0]
     arr = {"primitives": g["prims"], "n_g": g["normals"], "n_s": g["v_normals"], "uvs": np.zeros((n, 3, 2), np.float32), "indices": None}
     world = _World(); world.medium = type("M", (), {"ior": float(g["world_ior"])})()
+    if "med_i" in g:                            # participating media, already flat
+        n_obj = g["obj_info"].shape[0]
+        world.medium.packed_medium = (int(g["med_i"][n_obj]), np.float32(g["med_f"][n_obj]))
+        for k, o in enumerate(objs):
+            if int(g["bxdf_i"][k, 2]):
+                o.bsdf.medium = type("M", (), {"ior": float(g["med_f"][k, 0]), "packed_medium": (int(g["med_i"][k]), np.float32(g["med_f"][k]))})()
     prop = {"film": {"width": int(g["width"]), "height": int(g["height"])}, "fov": float(g["fov"]), "max_bounce": int(g["max_bounce"]),
             "num_shadow_ray": int(g["num_shadow_ray"]), "use_rr": bool(g["use_rr"]), "use_mis": bool(g["use_mis"]), "anti_alias": bool(g["anti_alias"]),
             "stratified_sampling": bool(g["stratified_sampling"]), "brdf_two_sides": bool(g["brdf_two_sides"]),

@@ -292,15 +292,15 @@ def gen_scene(scene_dir, xml, tag, w, h, spp, overrides, seed=0, n_rays=192):
 
 
 # ------------------------------------------------------------------ sweep over the reference's own bundled scenes
-def gen_refscene(scene_dir, xml, tag, w, h, spp, seed=0):
+def gen_refscene(scene_dir, xml, tag, w, h, spp, seed=0, volumetric=False, overrides=None):
     """Whole-kernel run of one of the reference's bundled scene files (its own parser, its own kernel) plus the parsed
     scene as flat arrays, so that the tests can render exactly that scene without the XML (which stays in /root/reference)."""
     sys.path.insert(0, refenv.REPO)
     from adapt_amd.scene_pack import pack_scene
     t0 = time.time()
-    rdr, (emitters, arr, objs, cfg) = refenv.make_renderer(scene_dir, xml, {"width": w, "height": h})
+    rdr, (emitters, arr, objs, cfg) = refenv.make_renderer(scene_dir, xml, dict({"width": w, "height": h}, **(overrides or {})), volumetric=volumetric)
     fs = pack_scene(emitters, arr, objs, cfg)          # reads the reference's host objects attribute by attribute
-    out = {"prims": fs.prims, "normals": fs.normals, "v_normals": fs.v_normals, "obj_info": fs.obj_info, "obj_aabb": fs.obj_aabb,
+    out = {"med_i": fs.med_i, "med_f": fs.med_f, "volumetric": np.int32(volumetric), "prims": fs.prims, "normals": fs.normals, "v_normals": fs.v_normals, "obj_info": fs.obj_info, "obj_aabb": fs.obj_aabb,
            "emitter_id": fs.emitter_id, "bxdf_i": fs.bxdf_i, "bxdf_f": fs.bxdf_f, "src_i": fs.src_i, "src_f": fs.src_f,
            "has_vertex_normal": np.int32(fs.has_vertex_normal), "world_ior": np.float32(fs.world_ior),
            "width": np.int32(w), "height": np.int32(h), "spp": np.int32(spp), "seed": np.int32(seed),
@@ -326,8 +326,8 @@ def gen_refscene(scene_dir, xml, tag, w, h, spp, seed=0):
         pi, pj = state["prev"]; draws[s_, pi, pj] = ti.RNG.draw
     ti.PIXEL_HOOK[0] = None
     out["accum"], out["draws"] = rdr.color.to_numpy(), draws
-    np.savez_compressed(os.path.join(OUT, f"refscene_{tag}.npz"), **out)
-    print(f"refscene_{tag}: {fs.n_prims} prims, {fs.n_objects} objects, {fs.n_sources} sources, {w}x{h}x{spp}spp, bounces {int(cfg['max_bounce'])}, "
+    np.savez_compressed(os.path.join(OUT, f"{'vptscene' if volumetric else 'refscene'}_{tag}.npz"), **out)
+    print(f"{'vptscene' if volumetric else 'refscene'}_{tag}: {fs.n_prims} prims, {fs.n_objects} objects, {fs.n_sources} sources, {w}x{h}x{spp}spp, bounces {int(cfg['max_bounce'])}, "
           f"{time.time() - t0:.1f}s, mean draws {draws.mean():.2f}, mean radiance {np.nanmean(out['accum']) / spp:.4f}")
 
 
@@ -359,6 +359,10 @@ if __name__ == "__main__":
                 gen_refscene(sdir, xml, tag, 32, 24, 2)
             except Exception as e:                      # missing mesh / texture / volume assets: not loadable here
                 print(f"refscene_{tag}: SKIPPED ({type(e).__name__}: {str(e)[:120]})")
+    if a.only in ("all", "vpt"):
+        # the reference's volumetric scenes (homogeneous media) through its own VolumeRenderer.render
+        for sdir, xml, ov in (("vpt", "cbox.xml", {}), ("vpt", "balls.xml", {"max_bounce": 12}), ("vpt", "volbox.xml", {})):
+            gen_refscene(sdir, xml, (sdir + "_" + xml[:-4]).replace("-", "_"), 32, 24, 2, volumetric=True, overrides=ov)
     if a.only in ("all", "image", "features"):
         # feature-coverage scenes authored in this repo (scenes/test/*.xml), run through the reference's own parser + kernel
         test_dir = os.path.join(refenv.REPO, "scenes", "test")

@@ -36,10 +36,13 @@ def f32_constants(obj):
             setattr(obj, k, np.float32(v))
 
 
-def make_renderer(scene_dir, xml, overrides=None):
-    """reference scene_parsing -> Renderer, with optional sensor overrides (width/height/max_bounce...)."""
+def make_renderer(scene_dir, xml, overrides=None, volumetric=False):
+    """reference scene_parsing -> Renderer (or VolumeRenderer), with optional sensor overrides (width/height/max_bounce...)."""
     from parsers.xml_parser import scene_parsing
-    from renderer.vanilla_renderer import Renderer
+    if volumetric:
+        from renderer.vpt import VolumeRenderer as Renderer
+    else:
+        from renderer.vanilla_renderer import Renderer
     base = scene_dir if os.path.isabs(scene_dir) else os.path.join(REFERENCE, "scenes", scene_dir)
     emitters, array_info, objs, cfg = scene_parsing(base, xml)
     for k, v in (overrides or {}).items():

@@ -108,7 +108,7 @@ def test_texture_query_bit_exact(oracle_scene):
 
 
 # ---- sweep over every pt-renderable scene file the reference bundles with its assets (tests/golden/refscene_*.npz)
-from conftest import REF_SCENE_TAGS, scene_from_golden  # noqa: E402
+from conftest import REF_SCENE_TAGS, VPT_SCENE_TAGS, scene_from_golden  # noqa: E402
 
 
 @pytest.mark.parametrize("tag", REF_SCENE_TAGS)
@@ -145,3 +145,25 @@ def test_own_parser_reads_the_reference_scene_files(tag):
     g = scene_from_golden(tag)[1]
     for k in ("prims", "normals", "v_normals", "obj_info", "obj_aabb", "emitter_id", "bxdf_i", "bxdf_f", "src_i", "src_f"):
         assert np.array_equal(np.asarray(getattr(fs, k)).view(np.uint32), np.asarray(g[k]).view(np.uint32)), (tag, k)
+
+
+# ---- volumetric path tracer (renderer/vpt.py, homogeneous media): the reference's own vpt scenes through ITS VolumeRenderer.render
+@pytest.mark.parametrize("tag", VPT_SCENE_TAGS)
+def test_volumetric_whole_kernel_matches_reference_run(tag):
+    """World medium (balls: spot light, volbox: area light) and an object medium behind a null surface (cbox): accumulated image
+    and per-sample draw counts of VolumeRenderer.render on the shared Philox stream, bit for bit."""
+    from adapt_amd.scene_pack import make_config, pack_scene
+    tup, g = scene_from_golden(tag, "vptscene")
+    fs = pack_scene(*tup)
+    assert np.array_equal(fs.med_i, g["med_i"]) and np.array_equal(fs.med_f.view(np.uint32), g["med_f"].view(np.uint32))
+    assert fs.has_scattering_media and int(g["volumetric"]) == 1
+    rc = make_config(tup[3], seed=int(g["seed"]), use_bvh=False, volumetric=True)
+    osc = ob.OracleScene(fs, rc.cam_t)
+    acc, cnt, st = osc.render(rc, int(g["spp"]))
+    ref = g["accum"]
+    same = (acc.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(acc) & np.isnan(ref))
+    assert same.all(), (tag, int((~same.all(axis=-1)).sum()))
+    assert st["n_draws"] == int(g["draws"].sum()) and st["n_track"] >= st["n_shadow"] > 0
+    # and the surface-only renderer on the same scene is a different estimator (media ignored): the flag matters
+    acc0 = osc.render(make_config(tup[3], seed=int(g["seed"]), use_bvh=False), int(g["spp"]))[0]
+    assert not np.array_equal(acc0, acc)
