@@ -9,7 +9,7 @@ The render path is hand-written HIP reached through the C-ABI in include/adapt_m
 """
 from .parsers.xml_parser import scene_parsing  # noqa: F401
 
-__all__ = ["scene_parsing", "Renderer", "load_renderer"]
+__all__ = ["scene_parsing", "Renderer", "VolumeRenderer", "load_renderer"]
 __version__ = "0.1.0"
 
 
@@ -17,6 +17,9 @@ def __getattr__(name):
     if name == "Renderer":
         from .renderer import Renderer
         return Renderer
+    if name == "VolumeRenderer":
+        from .renderer import VolumeRenderer
+        return VolumeRenderer
     raise AttributeError(name)
 
 

@@ -25,7 +25,8 @@ class SceneDesc(C.Structure):
                 ("prims", f32p), ("normals", f32p), ("v_normals", f32p), ("obj_info", i32p), ("obj_aabb", f32p),
                 ("emitter_id", i32p), ("bxdf_i", i32p), ("bxdf_f", f32p), ("src_i", i32p), ("src_f", f32p),
                 ("world_ior", C.c_float),
-                ("uvs", f32p), ("tex_i", i32p), ("tex_f", f32p), ("atlas", f32p * 3), ("atlas_w", C.c_int32 * 3), ("atlas_h", C.c_int32 * 3)]
+                ("uvs", f32p), ("tex_i", i32p), ("tex_f", f32p), ("atlas", f32p * 3), ("atlas_w", C.c_int32 * 3), ("atlas_h", C.c_int32 * 3),
+                ("med_i", i32p), ("med_f", f32p)]
 
 
 class RenderCfg(C.Structure):
@@ -37,16 +38,17 @@ class RenderCfg(C.Structure):
                 ("cam_r", C.c_float * 9), ("cam_t", C.c_float * 3),
                 ("inv_focal", C.c_float), ("half_w", C.c_float), ("half_h", C.c_float), ("seed", C.c_uint32),
                 ("band_width", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32),
-                ("spp_per_batch", C.c_int32), ("device", C.c_int32), ("profile", C.c_int32)]
+                ("spp_per_batch", C.c_int32), ("device", C.c_int32), ("profile", C.c_int32), ("volumetric", C.c_int32)]
 
 
 class Stats(C.Structure):
     _fields_ = [("n_samples", C.c_int64), ("n_extend", C.c_int64), ("n_shade", C.c_int64), ("n_shadow", C.c_int64),
                 ("n_shadow_traced", C.c_int64), ("n_lit", C.c_int64), ("n_draws", C.c_int64), ("n_poisoned", C.c_int64),
-                ("launches", C.c_int64 * APT_N_KERNELS), ("kernel_ms", C.c_double * APT_N_KERNELS), ("render_ms", C.c_double)]
+                ("launches", C.c_int64 * APT_N_KERNELS), ("kernel_ms", C.c_double * APT_N_KERNELS), ("render_ms", C.c_double),
+                ("n_track", C.c_int64)]
 
     def as_dict(self):
-        d = {k: int(getattr(self, k)) for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws", "n_poisoned")}
+        d = {k: int(getattr(self, k)) for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws", "n_poisoned", "n_track")}
         d["launches"] = dict(zip(KERNEL_NAMES, [int(x) for x in self.launches]))
         d["kernel_ms"] = dict(zip(KERNEL_NAMES, [float(x) for x in self.kernel_ms]))
         d["render_ms"] = float(self.render_ms)

@@ -17,6 +17,7 @@
 #include "../../include/adapt_mi.h"
 #include "bvh_build.hpp"
 #include "stages.hpp"
+#include "volumetric.hpp"
 
 #define APT_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -73,6 +74,7 @@ typedef void (*occluded_fn)(DevScene, uint32_t, const float*, const float*, cons
 static const extend_fn kExtend[3][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_extend<1, 0>, k_extend<1, 1>}, {k_extend<2, 0>, k_extend<2, 1>}};   // [mode][sorted]
 static const shadow_fn kShadow[3] = {k_shadow<0>, k_shadow<1>, k_shadow<2>};
 static const occluded_fn kOccluded[3] = {k_occluded<0>, k_occluded<1>, k_occluded<2>};
+static const shadow_fn kVShadow[3] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>};      // volumetric: transmittance walk (closest-hit queries)
 #define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
 
 // ============================================================== host side
@@ -96,6 +98,9 @@ struct apt_scene {
     apt::BvhData bvh;
     DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
     DevBuf uvs, tex_i, tex_f, atlas[3];      // image textures (empty when the scene has none)
+    DevBuf med;                          // participating media, n_objects + 1 rows (volumetric path tracer)
+    bool has_null_surface = false;       // some object carries a null BSDF (rays pass, vpt.py:189-191)
+    float box_min[3] = {1e3f, 1e3f, 1e3f}, box_max[3] = {-1e3f, -1e3f, -1e3f};    // union of the object boxes (path_tracer.py:130-134)
     int n_classes = 0;                   // material classes present (compact ids 0..n_classes-1)
     int class_def[APT_N_CLASS_DEFS] = {0, 0, 0, 0, 0, 0, 0, 0};   // compact id -> class definition
     int n_prims = 0, n_objects = 0, n_sources = 0, max_obj_prims = 0;
@@ -120,6 +125,7 @@ struct apt_renderer {
     int trace_mode = 0;           // 0 = BVH traversal, 1 = wave-uniform sweep, 2 = tiled sweep (small scenes)
     int trace_nt = BLOCK;         // workgroup size of the trace kernels
     int sorted = 0;               // 1 = material-sorted shading (>= 2 material classes in the scene)
+    int volumetric = 0;           // 1 = VolumeRenderer.render semantics (volumetric.hpp)
     shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string shade_name;
     LdsPlan plan{};
@@ -308,6 +314,27 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
             ds.atlas[m] = s->atlas[m].as<float>(); ds.atlas_w[m] = d->atlas_w[m];
         }
     }
+    {   // participating media: transparent everywhere unless the description carries the tables
+        std::vector<DevMedium> md((size_t)O + 1);
+        for (int o = 0; o <= O; o++) {
+            DevMedium& m = md[(size_t)o]; memset(&m, 0, sizeof(m));
+            if (d->med_i && d->med_f) {
+                const float* f = d->med_f + 16 * (size_t)o;
+                m.type = d->med_i[o]; m.ior = f[0];
+                m.u_s = mk3(f[1], f[2], f[3]); m.u_a = mk3(f[4], f[5], f[6]); m.u_e = mk3(f[7], f[8], f[9]);
+                m.par = mk3(f[10], f[11], f[12]); m.pdf = mk3(f[13], f[14], f[15]);
+                if (m.type < -1 || m.type > 3) { delete s; return fail(APT_E_INVALID, "apt_scene_create: unknown medium type"); }
+            } else { m.type = -1; m.ior = (o < O) ? bx[(size_t)o].ior : d->world_ior; m.pdf = mk3(1.f, 0.f, 0.f); }
+        }
+        UP(med, md);
+        ds.med = s->med.as<DevMedium>();
+        for (int o = 0; o < O; o++) {
+            if (bx[(size_t)o].is_bsdf && bx[(size_t)o].type < 0) s->has_null_surface = true;
+            if (d->obj_aabb) for (int a = 0; a < 3; a++) {
+                s->box_min[a] = std::min(s->box_min[a], d->obj_aabb[6 * o + a]); s->box_max[a] = std::max(s->box_max[a], d->obj_aabb[6 * o + 3 + a]);
+            }
+        }
+    }
 #undef UP
     *out = s;
     return APT_OK;
@@ -380,8 +407,17 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     r->sorted = (sc->n_classes >= 2) ? 1 : 0;
     if (const char* force = getenv("APT_SORTED")) r->sorted = (atoi(force) != 0 && sc->n_classes >= 1) ? 1 : 0;
     if (textured) r->sorted = 0;
+    r->volumetric = c.volumetric ? 1 : 0;
+    if (r->volumetric) {
+        if (c.max_bounce > 255) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer keeps the bounce count in 8 bits (max_bounce <= 255)"); }
+        if (!sc->has_aabb) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer needs the object boxes (world bound)"); }
+        r->sorted = 0;                                        // one generic kernel: media, null surfaces and every surface model
+        for (int a = 0; a < 3; a++) {                         // path_tracer.py:136-138
+            p.w_min[a] = std::min(c.cam_t[a], sc->box_min[a]) - 0.1f; p.w_max[a] = std::max(c.cam_t[a], sc->box_max[a]) + 0.1f;
+        }
+    }
     const int ncls = r->sorted ? sc->n_classes : 0;
-    r->shade_name = r->shade->name;
+    r->shade_name = r->volumetric ? "volumetric" : r->shade->name;
     if (r->sorted) {
         const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : 1;
         r->shade_name = "sorted:";
@@ -476,12 +512,14 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
                 HIP_TRY(hipFuncSetAttribute((const void*)kExtend[2][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
                 HIP_TRY(hipFuncSetAttribute((const void*)kShadow[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
                 HIP_TRY(hipFuncSetAttribute((const void*)kOccluded[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+                HIP_TRY(hipFuncSetAttribute((const void*)kVShadow[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             }
         } else if (r->lds_bytes > 64 * 1024) {
             HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kShadow[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kOccluded[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute((const void*)kVShadow[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         }
     }
     r->grid_small = cus * 8;       // streaming stages: up to 8 x 256-thread workgroups per CU
@@ -571,6 +609,30 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
         const int nq = r->nq;
         { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, p, q, cnt); }
         int cur = 0;
+        if (r->volumetric) {
+            // while-loop of vpt.py:161-253: an iteration ends a path or counts a bounce, except a null-surface pass-through.
+            // max_bounce iterations finish every path that met no null surface; then the live count decides (host read-back).
+            auto iterate = [&](int n_iter) -> int {
+                for (int b = 0; b < n_iter; b++) {
+                    { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(kExtend[r->trace_mode][0], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
+                    { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(k_vshade, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, cur); }
+                    if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kVShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, r->plan); }
+                    cur ^= 1;
+                }
+                return APT_OK;
+            };
+            iterate(p.max_bounce);
+            if (r->scene->has_null_surface) {
+                for (int round = 0; round < 4096; round++) {
+                    HIP_TRY(hipMemcpyAsync(r->host_counters.n_active[cur], cnt->n_active[cur], sizeof(cnt->n_active[cur]), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    unsigned long long live = 0;
+                    for (int k = 0; k < nq; k++) live += r->host_counters.n_active[cur][k * CNT_PAD];
+                    if (!live) break;
+                    iterate(2);
+                }
+            }
+        } else
         for (int b = 0; b < p.max_bounce; b++) {
             { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
             if (!r->sorted) {
@@ -661,7 +723,7 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
     auto sum = [&](int k) { unsigned long long a = 0; for (int q = 0; q < APT_MAX_NQ; q++) a += st[(size_t)q * 16 + k]; return (int64_t)a; };
     out->n_samples = sum(ST_SAMPLES); out->n_extend = sum(ST_EXTEND); out->n_shade = sum(ST_SHADE);
     out->n_shadow = sum(ST_SHADOW); out->n_shadow_traced = sum(ST_SHADOW_TRACED); out->n_lit = sum(ST_LIT);
-    out->n_draws = sum(ST_DRAWS); out->n_poisoned = sum(ST_POISON);
+    out->n_draws = sum(ST_DRAWS); out->n_poisoned = sum(ST_POISON); out->n_track = sum(ST_TRACK);
 #ifdef APT_SHADE_PROF
     {
         std::vector<unsigned long long> dbg(2 * 16384);

@@ -34,6 +34,11 @@
 #include "vec.hpp"
 
 // ------------------------------------------------------------- device views
+struct DevMedium {            // bxdf/medium.py:71-78 + bxdf/phase.py:33-37 (volumetric path tracer only)
+    int type;                 // -1 transparent, 0 hg, 1 multi-hg, 2 rayleigh, 3 mie (no phase function upstream)
+    float ior;
+    f3 u_s, u_a, u_e, par, pdf;
+};
 struct DevScene {
     DevBvh bvh;
     SweepScene sweep;         // small scenes: uniform brute-force sweep instead of the BVH
@@ -54,6 +59,7 @@ struct DevScene {
     const float* tex_f;       // n_objects*3*2: scale_u, scale_v
     const float* atlas[3];
     int atlas_w[3];
+    const DevMedium* med;     // n_objects + 1 rows (the last one is the world's), nullptr when the scene declares no media
 };
 
 struct Params {
@@ -76,6 +82,7 @@ struct Params {
     uint32_t pix_bits;
     const uint32_t* pix_key;  // local pixel -> global pixel index x * H + y = the RNG key (host-built; band mapping folded in)
     float inv_ns, inv_ns1;    // 1 / n_sources, 1 / (n_sources - 1): sample_light's pdfs (path_tracer.py:537-554)
+    float w_min[3], w_max[3]; // world box = (objects U camera) +- 0.1 (path_tracer.py:130-138); volumetric tracer only
 };
 
 // SoA queues; every array has `cap` (shadow: sh_cap) entries per component
@@ -105,7 +112,7 @@ struct ShadeIn {
 #define APT_MAX_NQ 32
 #endif
 #define CNT_PAD 32                               // one counter per 128-byte line
-enum { ST_SAMPLES = 0, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_SHADOW_TRACED, ST_LIT, ST_DRAWS, ST_POISON, ST_COUNT };
+enum { ST_SAMPLES = 0, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_SHADOW_TRACED, ST_LIT, ST_DRAWS, ST_POISON, ST_TRACK, ST_COUNT };
 struct Counters {
     uint32_t n_active[2][APT_MAX_NQ * CNT_PAD];
     uint32_t n_shadow[APT_MAX_NQ * CNT_PAD];

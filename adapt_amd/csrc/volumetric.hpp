@@ -1,0 +1,375 @@
+// Volumetric path tracer stages (homogeneous participating media).
+//
+// Replaces VolumeRenderer.render of the reference (renderer/vpt.py:145-258) on the same wavefront skeleton as the surface path
+// tracer: k_generate and k_extend are shared; k_vshade is the loop body between two closest-hit queries (Russian roulette, free
+// path sampling, null-surface pass-through, light sampling, emission, phase-function / surface scattering) and k_vshadow is
+// track_ray (vpt.py:99-138): the transmittance walk of a light sample through null surfaces and media, up to seven closest-hit
+// queries per sample.  Media: the world's and those attached to BSDF objects (bxdf/medium.py:71-125), phase functions H-G,
+// multi-H-G and Rayleigh (bxdf/phase.py, sampler/phase_sampling.py).  Grid volumes (bxdf/volume.py) are not supported; scenes
+// that declare one are refused by the host.
+#pragma once
+#include "stages.hpp"
+
+APT_D float med_random_rgb(Philox& r, f3 v) {                      // general_sampling.py:17-27
+    const int idx = pymod(rng_int(r), 3);
+    const float res = (idx == 0) ? v.x : ((idx == 1) ? v.y : v.z);
+    return fmaxf(res, 1e-5f);
+}
+APT_D f3 exp_neg(f3 u_e, float d) { return mk3(expf(-u_e.x * d), expf(-u_e.y * d), expf(-u_e.z * d)); }
+APT_D float sum3(f3 a) { return (a.x + a.y) + a.z; }
+// Medium.sample_mfp, medium.py:89-108
+APT_D bool medium_sample_mfp(const DevMedium& m, float max_depth, Philox& r, float& t, f3& beta) {
+    const float random_ue = med_random_rgb(r, m.u_e);
+    float sample_t = -logf(1.f - rng_float(r)) / random_ue;
+    bool is_mi = false;
+    if (sample_t >= max_depth) {
+        sample_t = max_depth;
+        const f3 tr = exp_neg(m.u_e, max_depth);
+        float pdf = sum3(tr) / 3.f;
+        pdf = (pdf > 0.f) ? pdf : 1.f;
+        beta = tr / pdf;
+    } else {
+        is_mi = true;
+        const f3 tr = exp_neg(m.u_e, sample_t);
+        float pdf = sum3(m.u_e * tr) / 3.f;
+        pdf = (pdf > 0.f) ? pdf : 1.f;
+        beta = (tr * m.u_s) / pdf;
+    }
+    t = sample_t;
+    return is_mi;
+}
+// bxdf/phase.py:21-31
+APT_D float phase_hg(float cos_theta, float g) {
+    const float g2 = g * g;
+    const float denom = (1.f + g2) - (2.f * g) * cos_theta;
+    return (((1.f - g2) / (sqrtf(denom) * denom)) * 0.5f) * APT_INV_2PI;
+}
+APT_D float phase_rayleigh(float cos_theta) { return (float)(0.375 * ((1.0 / 3.14159265358979323846) * 0.5)) * (1.f + cos_theta * cos_theta); }
+// sampler/phase_sampling.py:16-42
+APT_D f3 sample_hg(Philox& r, float g, float& cos_theta) {
+    if (fabsf(g) < 1e-4f) cos_theta = 1.f - 2.f * rng_float(r);
+    else {
+        const float g2 = g * g;
+        const float sqr_term = (1.f - g2) / ((1.f + g) - (2.f * g) * rng_float(r));
+        cos_theta = ((1.f + g2) - sqr_term * sqr_term) / (2.f * g);
+    }
+    const float sin_theta = sqrtf(fmaxf(0.f, 1.f - cos_theta * cos_theta));
+    const float phi = APT_2PI * rng_float(r);
+    return polar_dir(cos_theta, sin_theta, phi);
+}
+APT_D f3 sample_rayleigh(Philox& r, float& cos_theta) {
+    const float rd = 2.f * rng_float(r) - 1.f;
+    const float u = -apt_pow(2.f * rd + sqrtf((4.f * rd) * rd + 1.f), (float)(1.0 / 3.0));
+    cos_theta = fminf(fmaxf(u - 1.f / u, -1.f), 1.f);
+    const float sin_theta = sqrtf(fmaxf(0.f, 1.f - cos_theta * cos_theta));
+    const float phi = APT_2PI * rng_float(r);
+    return polar_dir(cos_theta, sin_theta, phi);
+}
+// PhaseFunction.sample_p / eval_p, phase.py:39-84
+APT_D f3 phase_sample_p(const DevMedium& m, f3 incid, Philox& r, float& p) {
+    f3 dir = incid; p = 1.f; float cos_t = 0.f;
+    if (m.type == 0) { dir = sample_hg(r, m.par.x, cos_t); p = phase_hg(cos_t, m.par.x); }
+    else if (m.type == 1) {
+        const float eps = rng_float(r);
+        const float g = (eps < m.pdf.x) ? m.par.x : ((eps < m.pdf.x + m.pdf.y) ? m.par.y : m.par.z);
+        dir = sample_hg(r, g, cos_t); p = phase_hg(cos_t, g);
+    } else if (m.type == 2) { dir = sample_rayleigh(r, cos_t); p = phase_rayleigh(cos_t); }
+    return dir;
+}
+APT_D float phase_eval_p(const DevMedium& m, f3 ray_in, f3 ray_out) {
+    float p = 1.f; const float cos_theta = -dot(ray_in, ray_out);
+    if (m.type == 0) p = phase_hg(cos_theta, m.par.x);
+    else if (m.type == 1) {
+        p = phase_hg(cos_theta, m.par.x) * m.pdf.x + phase_hg(cos_theta, m.par.y) * m.pdf.y;
+        if (m.pdf.y > 1e-4f) p += phase_hg(cos_theta, m.par.z) * m.pdf.z;
+    } else if (m.type == 2) p = phase_rayleigh(cos_theta);
+    return p;
+}
+APT_D bool vpt_is_scattering(const DevScene& sc, int idx) { return idx >= 0 && sc.bxdf[idx].is_bsdf && sc.med[idx].type >= 0; }    // path_tracer.py:528-535
+APT_D bool vpt_non_null(const DevScene& sc, int idx) { return !(idx >= 0 && sc.bxdf[idx].is_bsdf) || sc.bxdf[idx].type >= 0; }     // vpt.py:64-70
+// VolumeRenderer.world_bound_time, vpt.py:140-143 (max of the slab pairs ignores NaN, the min over the axes propagates it)
+APT_D float world_bound_time(const Params& p, f3 o, f3 d) {
+    const f3 lo = mk3(p.w_min[0], p.w_min[1], p.w_min[2]), hi = mk3(p.w_max[0], p.w_max[1], p.w_max[2]);
+    const f3 t_min = (lo - o) / d, t_max = (hi - o) / d;
+    const f3 m = mk3(fmaxf(t_min.x, t_max.x), fmaxf(t_min.y, t_max.y), fmaxf(t_min.z, t_max.z));
+    float r = m.x;
+    if (!isnan(r) && (isnan(m.y) || m.y < r)) r = m.y;
+    if (!isnan(r) && (isnan(m.z) || m.z < r)) r = m.z;
+    return r;
+}
+
+// ------------------------------------------------------------------- vshade
+// One iteration of the while-loop of vpt.py:161-253 for every path of ray queue `cur`, given its closest hit.  The bounce
+// counter lives in the path's meta word (a null-surface pass-through re-queues the path without counting a bounce) and the
+// float slot that carries ray_pdf in the surface tracer carries emission_weight here (vpt.py:247-253 computes it at the END of
+// an iteration, from the interaction being left).
+__global__ void __launch_bounds__(BLOCK) k_vshade(DevScene sc, Params p, Queues q, Counters* cnt, int cur) {
+    const int nxt = cur ^ 1;
+    const SubLoop sl = sub_loop(p.nq);
+    const uint32_t n = cnt->n_active[cur][sl.q * CNT_PAD];
+    const uint32_t qbase = (uint32_t)sl.q * p.subcap, sh_qbase = (uint32_t)sl.q * q.sh_subcap;
+    uint32_t* next_counter = &cnt->n_active[nxt][sl.q * CNT_PAD];
+    uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
+    const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
+    const DevMedium world = sc.med[sc.n_objects];
+    const bool world_scat = world.type >= 0;
+    uint32_t t_shade = 0, t_shadow = 0, t_poison = 0;
+    __shared__ uint32_t s_draws[BLOCK / 64];
+    if (lane_id() == 0) s_draws[threadIdx.x >> 6] = 0;
+    for (uint32_t base = sl.first; base < n; base += sl.stride) {
+        const uint32_t pos = base + threadIdx.x;
+        const uint32_t idx = qbase + pos;
+        bool alive = pos < n, shade = false, cont = false, is_mi = false, in_free = true;
+        f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), thr = splat3(0.f), hit_point = splat3(0.f);
+        uint32_t id = 0, draw0 = 0, l_off = 0, bounce = 0;
+        float emission_weight = 1.f;
+        Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
+        Hit it; it.obj_id = -1; it.prim_id = -1; it.n_s = it.n_g = mk3(1.f, 0.f, 0.f); it.min_depth = 0.f;
+        int hit_light = -1;
+        DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
+        DevMedium med = world;
+        if (alive) {
+            const uint32_t io = idx << 2;
+            o = ld3q(q.ray_o[cur], p.cap, io);
+            d = ld3q(q.ray_d[cur], p.cap, io);
+            thr = ld3q(q.thr[cur], p.cap, io);
+            id = ldq(q.id[cur], io);
+            const uint32_t meta = ldq(q.meta[cur], io);
+            emission_weight = ldq(q.pdf[cur], io);
+            bounce = (meta >> 16) & 0xffu; draw0 = meta & 0xffffu;
+            const uint32_t lp = id & ((1u << p.pix_bits) - 1u), s = id >> p.pix_bits;
+            l_off = (s * (uint32_t)p.npix + lp) << 2;
+            rng_init(rng, ldq(p.pix_key, lp << 2), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
+            // Step 1: Russian roulette / cut-off BEFORE the intersection is looked at (vpt.py:164-172)
+            if (p.use_rr) {
+                const float mx = max3(thr);
+                if (mx < p.rr_threshold && (int)bounce >= p.rr_bounce_th) {
+                    if (rng_float(rng) > mx) alive = false;
+                    else thr = thr * (1.f / (mx + 1e-7f));
+                }
+            } else if (max3(thr) < 1e-5f) alive = false;
+            if (alive) {
+                // Step 2: the hit, or the far side of the world box when the world itself scatters (vpt.py:173-181)
+                const int prim = ldq(q.hit_prim, io);
+                if (prim < 0) {
+                    if (!world_scat) alive = false;
+                    else { it.min_depth = world_bound_time(p, o, d); in_free = true; }
+                } else {
+                    build_hit(sc, prim, ldq(q.hit_t, io), ldq(q.hit_u, io), ldq(q.hit_v, io), o, d, it);
+                    in_free = dot(it.n_g, d) < 0.f;
+                    bx = sc.bxdf[it.obj_id];
+                }
+            }
+            if (alive) {
+                // Step 3: free-path sampling in the medium the segment crosses (vpt.py:72-97,184)
+                f3 beta = splat3(1.f);
+                const bool world_valid = in_free && world_scat;
+                if (world_valid || vpt_is_scattering(sc, it.obj_id)) {
+                    float mfp = it.min_depth;
+                    if (world_valid) { med = world; is_mi = medium_sample_mfp(med, it.min_depth, rng, mfp, beta); }
+                    else if (!in_free) { med = sc.med[it.obj_id]; is_mi = medium_sample_mfp(med, it.min_depth, rng, mfp, beta); }
+                    it.min_depth = mfp;
+                }
+                if (it.obj_id < 0 && !is_mi) alive = false;                 // left the world box
+                else {
+                    hit_point = d * it.min_depth + o;
+                    thr = thr * beta;
+                    if (!is_mi && !vpt_non_null(sc, it.obj_id)) cont = true;    // null surface: walk on, no bounce counted (vpt.py:189-191)
+                    else {
+                        shade = true;
+                        if (!is_mi) {
+                            hit_light = sc.emitter_id[it.obj_id];
+                            f3 tx;
+                            if (sc.tex_i != nullptr && get_uv_item(sc, 0, it.obj_id, it.prim_id, ldq(q.hit_u, io), ldq(q.hit_v, io), tx)) bx.k_d = tx;   // vpt.py:199
+                        }
+                    }
+                }
+            }
+        }
+        t_shade += wave_count(shade);
+
+        // ---- Step 4: light sampling; the transmittance along the sample is k_vshadow's job
+        bool break_flag = false;
+        for (int s = 0; s < p.S; s++) {
+            bool want = false, sampled = false, poisoned = false;
+            f3 light_dir = splat3(0.f), contrib = splat3(0.f);
+            float emitter_d = 0.f;
+            if (shade && !break_flag) {
+                const int ns = sc.n_sources;
+                int sidx = rng_int(rng);
+                sidx = (ns == 1) ? 0 : pymod(sidx, ns);
+                float emitter_pdf = p.inv_ns;
+                bool valid = true;
+                if (hit_light >= 0) {
+                    if (ns <= 1) valid = false;
+                    else {
+                        sidx = rng_int(rng);
+                        sidx = (ns == 2) ? 0 : pymod(sidx, ns - 1);
+                        if (sidx >= hit_light) sidx += 1;
+                        emitter_pdf = p.inv_ns1;
+                    }
+                }
+                if (!valid) break_flag = true;
+                else {
+                    const DevSrc src = sc.src[sidx];
+                    f3 shadow_int; float direct_pdf;
+                    const f3 emit_pos = emitter_sample_hit<APT_SRC_ALL>(src, geom, hit_point, rng, shadow_int, direct_pdf);
+                    const f3 to_emitter = emit_pos - hit_point;
+                    emitter_d = norm(to_emitter);
+                    light_dir = to_emitter / emitter_d;
+                    sampled = true;
+                    f3 direct_spec;
+                    if (is_mi) direct_spec = splat3(phase_eval_p(med, d, light_dir));
+                    else direct_spec = surface_eval<APT_BX_ALL>(bx, it, d, light_dir, sc.world_ior, p.two_sides);
+                    float mis_w = 1.0f;
+                    if (p.use_mis && !(src.bool_bits & 0x01)) {
+                        const float light_pdf = emitter_pdf * direct_pdf;
+                        const float bsdf_pdf_v = is_mi ? direct_spec.x : surface_pdf<APT_BX_ALL>(bx, it, light_dir, d, sc.world_ior, p.two_sides);
+                        mis_w = balance(light_pdf, bsdf_pdf_v);
+                    }
+                    if (isnan(mis_w)) { st3q(q.L, p.cap, l_off, splat3(mis_w)); poisoned = true; }     // as in k_shade: the sample is zeroed at the end
+                    else {
+                        f3 c = (direct_spec * shadow_int) * mis_w;
+                        if (ns != 1) c = c / emitter_pdf;
+                        contrib = (c * p.inv_S) * thr;
+                        want = !(contrib.x == 0.f && contrib.y == 0.f && contrib.z == 0.f);
+                    }
+                }
+            }
+            t_shadow += wave_count(sampled); t_poison += wave_count(poisoned);
+            const uint32_t spos = wave_append(want, shadow_counter);
+            if (want && spos < q.sh_subcap) {
+                const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
+                st3q(q.sh_o, sc_, so, hit_point);
+                st3q(q.sh_d, sc_, so, light_dir);
+                stq(q.sh_tmax, so, emitter_d);
+                st3q(q.sh_c, sc_, so, contrib);
+                stq(q.sh_id, so, l_off);
+            }
+        }
+
+        // ---- Steps 5-6: emission of the surface we are on, the next direction, the emission weight of the NEXT hit
+        f3 new_d = d;
+        bool is_spec = false;
+        if (shade) {
+            if (hit_light >= 0) {
+                const f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_g);      // geometric normal here (vpt.py:233)
+                if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
+                    const f3 add = (emit_int * emission_weight) * thr;
+                    const f3 cur_L = ld3q(q.L, p.cap, l_off);
+                    st3q(q.L, p.cap, l_off, mk3(cur_L.x + add.x, cur_L.y + add.y, cur_L.z + add.z));
+                }
+            }
+            float ray_pdf = 1.f;
+            if (is_mi) {                                                        // Medium.sample_new_rays, medium.py:112-121
+                if (med.type >= 0) {
+                    const f3 local = phase_sample_p(med, d, rng, ray_pdf);
+                    new_d = delocalize(d, local);
+                }
+                cont = true;                                                    // a medium event never ends the path by itself
+            } else {
+                f3 spec;
+                new_d = surface_sample<APT_BX_ALL>(bx, it, d, sc.world_ior, p.two_sides, rng, spec, ray_pdf, is_spec);
+                cont = !(max3(spec) == 0.f || ray_pdf == 0.f);                  // vpt.py:240-241
+                if (cont) thr = thr * (spec / ray_pdf);
+            }
+            bounce += 1;
+            if ((int)bounce >= p.max_bounce) cont = false;
+            if (cont && it.obj_id >= 0) {                                       // vpt.py:247-253, with THIS interaction
+                hit_light = sc.emitter_id[it.obj_id];
+                if (p.use_mis) {
+                    float e_pdf = 0.0f;
+                    if (hit_light >= 0 && bx.is_delta == 0 && !is_spec) e_pdf = emitter_solid_angle_pdf(sc.src[hit_light], it, new_d);
+                    emission_weight = balance(ray_pdf, e_pdf);
+                }
+            }
+        }
+        if (rng.draw != draw0) atomicAdd(&s_draws[threadIdx.x >> 6], rng.draw - draw0);
+        const uint32_t npos = wave_append(cont, next_counter);
+        if (cont) {
+            const uint32_t so = (qbase + npos) << 2;
+            st3q(q.ray_o[nxt], p.cap, so, hit_point);
+            st3q(q.ray_d[nxt], p.cap, so, new_d);
+            st3q(q.thr[nxt], p.cap, so, thr);
+            stq(q.id[nxt], so, id);
+            stq(q.meta[nxt], so, pack_meta(rng.draw, bounce, false));
+            stq(q.pdf[nxt], so, emission_weight);
+        }
+    }
+    flush_uniform(t_shade, &cnt->stats[sl.q][ST_SHADE]);
+    flush_uniform(t_shadow, &cnt->stats[sl.q][ST_SHADOW]);
+    if (lane_id() == 0 && s_draws[threadIdx.x >> 6]) atomicAdd(&cnt->stats[sl.q][ST_DRAWS], (unsigned long long)s_draws[threadIdx.x >> 6]);
+    flush_uniform(t_poison, &cnt->stats[sl.q][ST_POISON]);
+}
+
+// ------------------------------------------------------------------ vshadow
+// track_ray (vpt.py:99-138) for every queued light sample: closest hit within the remaining distance; a non-null surface blocks
+// the sample, a null surface or a miss in a scattering world attenuates it by the medium crossed and the walk goes on from there.
+template <int MODE>
+__global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 1)) k_vshadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
+    StagedBvh bvh;
+    int* my_stack = nullptr;
+    __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
+    if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
+    const SubLoop sl = sub_loop(p.nq, TRACE_NT(MODE));
+    const uint32_t n = min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
+    if (sl.first == 0 && threadIdx.x == 0) cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
+    const uint32_t qbase = (uint32_t)sl.q * q.sh_subcap, sc_ = q.sh_cap;
+    const f3 world_ue = sc.med[sc.n_objects].u_e;
+    const bool world_scat = sc.med[sc.n_objects].type >= 0;
+    uint32_t t_lit = 0, t_track = 0;
+    for (uint32_t base = sl.first; base < n; base += sl.stride) {
+        const uint32_t pos = base + threadIdx.x;
+        const bool valid = pos < n;
+        const uint32_t idx = qbase + (valid ? pos : n - 1);
+        const uint32_t io = idx << 2;
+        f3 o = ld3q(q.sh_o, sc_, io);
+        const f3 d = ld3q(q.sh_d, sc_, io);
+        float depth = ldq(q.sh_tmax, io);
+        f3 tr = splat3(1.f);
+        bool act = valid;
+        for (int k = 0; k < 7; k++) {
+            HitRec rec; rec.t = !act ? -1.f : ((depth > 0.0f) ? depth - 1e-4f : 1e7f); rec.prim = -1; rec.u = rec.v = 0.f;     // finished lanes: nothing is closer than -1
+            if (MODE == 0) traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
+            else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, act, s_sweep);
+            else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, act, reinterpret_cast<float*>(s_dyn));
+            if (act) {
+                t_track++;
+                int obj = -1; bool in_free = true; float seg = depth;
+                if (rec.prim < 0) { if (!world_scat) act = false; }
+                else {
+                    obj = sc.prim_obj[rec.prim];
+                    if (vpt_non_null(sc, obj)) { tr = splat3(0.f); act = false; }
+                    else {
+                        Hit it; build_hit(sc, rec.prim, rec.t, rec.u, rec.v, o, d, it);
+                        in_free = dot(it.n_g, d) < 0.f;
+                        seg = rec.t;
+                    }
+                }
+                if (act) {
+                    // get_transmittance, vpt.py:52-62
+                    if (in_free && world_scat) tr = tr * exp_neg(world_ue, seg);
+                    else if (!in_free && vpt_is_scattering(sc, obj)) tr = tr * exp_neg(sc.med[obj].u_e, seg);
+                    o = o + d * seg;
+                    depth -= seg;
+                    if (depth <= 5e-5f) act = false;
+                }
+            }
+            if (MODE == 0) { if (!__any(act)) break; }
+            else if (!__syncthreads_or(act)) break;
+        }
+        if (valid) {
+            const f3 c = ld3q(q.sh_c, sc_, io) * tr;           // a blocked sample is c * 0: NaN for a non-finite c, exactly as upstream
+            if (!(c.x == 0.f && c.y == 0.f && c.z == 0.f)) {
+                const uint32_t lo_ = ldq(q.sh_id, io);
+                char* Lb = reinterpret_cast<char*>(q.L);
+                atomicAdd(reinterpret_cast<float*>(Lb + lo_), c.x);
+                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 4 + lo_), c.y);
+                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 8 + lo_), c.z);
+            }
+            if (!(tr.x == 0.f && tr.y == 0.f && tr.z == 0.f)) t_lit++;
+        }
+    }
+    flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);
+    flush_stat(t_track, &cnt->stats[sl.q][ST_TRACK]);
+}

@@ -27,7 +27,7 @@ from . import _lib
 from .scene_pack import FlatScene, RenderConfig, make_config, pack_scene
 from .tiles import TilePlan
 
-__all__ = ["Renderer", "DeviceScene", "bxdf_probe", "rng_stream"]
+__all__ = ["Renderer", "VolumeRenderer", "DeviceScene", "bxdf_probe", "rng_stream"]
 
 
 def _fp(a):
@@ -78,6 +78,10 @@ class DeviceScene:
                 if img is not None:
                     img = np.ascontiguousarray(img, np.float32); keep.append(img)
                     desc.atlas[m] = _fp(img); desc.atlas_h[m], desc.atlas_w[m] = int(img.shape[0]), int(img.shape[1])
+        if fs.med_i is not None:                # participating media (read by the volumetric tracer only)
+            med = [np.ascontiguousarray(fs.med_i, np.int32), np.ascontiguousarray(fs.med_f, np.float32)]
+            keep += med
+            desc.med_i, desc.med_f = _ip(med[0]), _fp(med[1])
         h = C.c_void_p()
         _lib.check(lib.apt_scene_create(C.byref(desc), int(device), C.byref(h)), "apt_scene_create")
         self.handle = h
@@ -121,15 +125,22 @@ class _FieldView:
 
 
 class Renderer:
+    VOLUMETRIC = False          # subclass switch: VolumeRenderer renders with the reference's vpt semantics
+
     def __init__(self, emitters: List, array_info: dict, objects: List, prop: dict, *,
                  device: int = 0, rank: int = 0, world_size: int = 1, band_width: int = 32,
                  seed: int = 0, spp_per_batch: int = 0, profile: bool = False,
                  width: Optional[int] = None, height: Optional[int] = None,
-                 max_bounce: Optional[int] = None, num_shadow_ray: Optional[int] = None):
+                 max_bounce: Optional[int] = None, num_shadow_ray: Optional[int] = None, volumetric: Optional[bool] = None):
         self.lib = _lib.load()
+        if volumetric is None:
+            volumetric = self.VOLUMETRIC
+        if volumetric and prop.get("volume"):
+            raise NotImplementedError("grid volumes (bxdf/volume.py) are not supported; homogeneous media only")
         self.flat: FlatScene = pack_scene(emitters, array_info, objects, prop)
         self.rc: RenderConfig = make_config(prop, width=width, height=height, max_bounce=max_bounce,
-                                            num_shadow_ray=num_shadow_ray, seed=seed)
+                                            num_shadow_ray=num_shadow_ray, seed=seed, volumetric=bool(volumetric))
+        self.volumetric = bool(volumetric)
         rc = self.rc
         # attributes the reference's callers read (watermark.py:23-30, render.py:129, path_tracer.py:181-193)
         self.w, self.h = rc.width, rc.height
@@ -159,6 +170,7 @@ class Renderer:
         cfg.seed = int(rc.seed) & 0xffffffff
         cfg.band_width, cfg.rank, cfg.world_size = self.plan.band_width, self.rank, self.world_size
         cfg.spp_per_batch, cfg.device, cfg.profile = int(spp_per_batch), self.device, int(bool(profile))
+        cfg.volumetric = int(self.volumetric)
         h = C.c_void_p()
         _lib.check(self.lib.apt_renderer_create(self.scene.handle, C.byref(cfg), C.byref(h)), "apt_renderer_create")
         self.handle = h
@@ -289,7 +301,7 @@ class Renderer:
 
     def summary(self) -> str:
         self.synchronize()
-        msg = f"PT SPP = {self._cnt}. Rendering time: {time.time() - self._t0:.3f} s"
+        msg = f"{'VPT' if self.volumetric else 'PT'} SPP = {self._cnt}. Rendering time: {time.time() - self._t0:.3f} s"
         print(msg)
         return msg
 
@@ -305,3 +317,10 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+class VolumeRenderer(Renderer):
+    """Drop-in for the reference's `VolumeRenderer` (renderer/vpt.py:29-50,145-262; `--type vpt`, the reference's default): same
+    constructor and surface as `Renderer`, volumetric path tracing in homogeneous media (world medium, media attached to BSDF
+    objects, null surfaces, transmittance-tracked light samples).  Grid volumes are refused."""
+    VOLUMETRIC = True

@@ -63,6 +63,10 @@ typedef struct apt_scene_desc {
     const float*   tex_f;       /* n_objects*3*2 scale_u, scale_v */
     const float*   atlas[3];    /* per map: atlas_h * atlas_w * 3 floats, row-major [y][x][rgb], or NULL */
     int32_t        atlas_w[3], atlas_h[3];
+    /* Participating media for the volumetric path tracer (bxdf/medium.py:24-125, parsers/world.py): both NULL when the scene has
+     * none.  Row o < n_objects is the medium attached to object o's BSDF, row n_objects the world's. */
+    const int32_t* med_i;       /* (n_objects+1)    type: -1 transparent, 0 hg, 1 multi-hg, 2 rayleigh, 3 mie */
+    const float*   med_f;       /* (n_objects+1)*16 ior, u_s rgb, u_a rgb, u_e rgb, par[3], pdf[3] */
 } apt_scene_desc;
 
 /* Per-renderer configuration: film, camera, sampling flags, tile ownership, batching. */
@@ -82,6 +86,9 @@ typedef struct apt_render_cfg {
     int32_t spp_per_batch;                        /* samples per pixel in flight per wavefront batch (0 = auto) */
     int32_t device;                               /* HIP device ordinal */
     int32_t profile;                              /* 1 = time every kernel launch with HIP events */
+    int32_t volumetric;                           /* 0 = Renderer.render (renderer/vanilla_renderer.py:32-120); 1 = VolumeRenderer.render
+                                                     (renderer/vpt.py:145-258): free-path sampling in homogeneous media, null surfaces,
+                                                     transmittance-tracked light samples */
 } apt_render_cfg;
 
 #define APT_N_KERNELS 5   /* generate, extend, shade, shadow, finalize */
@@ -97,6 +104,7 @@ typedef struct apt_stats {
     int64_t launches[APT_N_KERNELS];
     double  kernel_ms[APT_N_KERNELS];   /* summed HIP-event time per kernel (profile=1 only) */
     double  render_ms;                  /* HIP-event time of all apt_render calls so far */
+    int64_t n_track;                    /* volumetric: closest-hit queries made by the transmittance walk of the light samples */
 } apt_stats;
 
 /* ---- BVH build (host, own layout; replaces bvh_cpp.bvh_build) */
