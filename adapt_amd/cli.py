@@ -103,11 +103,13 @@ def _folder(path: str) -> str:
 
 def main(argv=None) -> int:
     opts = get_options(argv)
-    if opts.type != "pt":
-        print(f"--type {opts.type}: only the `pt` renderer exists in this build (vpt/bdpt/ao are outside its scope)", file=sys.stderr)
+    if opts.type not in ("pt", "vpt"):
+        print(f"--type {opts.type}: only the `pt` and `vpt` renderers exist in this build (bdpt/ao are outside its scope)", file=sys.stderr)
         return 2
     from .parsers.xml_parser import scene_parsing
-    from .renderer import Renderer
+    from .renderer import Renderer, VolumeRenderer
+    if opts.type == "vpt":                      # render.py:33 rdr_mapping: "vpt" -> VolumeRenderer
+        Renderer = VolumeRenderer
     t0 = time.time()
     emitters, array_info, objs, cfg = scene_parsing(os.path.join(opts.input_path, opts.scene), opts.name)
     print(f"[adapt_amd] scene '{opts.scene}/{opts.name}': {array_info['primitives'].shape[0]} primitives, {len(objs)} objects, "

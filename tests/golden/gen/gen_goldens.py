@@ -363,6 +363,10 @@ if __name__ == "__main__":
         # the reference's volumetric scenes (homogeneous media) through its own VolumeRenderer.render
         for sdir, xml, ov in (("vpt", "cbox.xml", {}), ("vpt", "balls.xml", {"max_bounce": 12}), ("vpt", "volbox.xml", {})):
             gen_refscene(sdir, xml, (sdir + "_" + xml[:-4]).replace("-", "_"), 32, 24, 2, volumetric=True, overrides=ov)
+        # media coverage scenes authored in this repo (multi-H-G world, Rayleigh, media inside glass / frosted balls, several lights)
+        test_dir = os.path.join(refenv.REPO, "scenes", "test")
+        gen_refscene(test_dir, "media_a.xml", "media_a", 40, 30, 3, volumetric=True)
+        gen_refscene(test_dir, "media_b.xml", "media_b", 40, 30, 3, volumetric=True)
     if a.only in ("all", "image", "features"):
         # feature-coverage scenes authored in this repo (scenes/test/*.xml), run through the reference's own parser + kernel
         test_dir = os.path.join(refenv.REPO, "scenes", "test")

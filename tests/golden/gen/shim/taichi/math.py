@@ -9,3 +9,8 @@ vec3 = _TensorType((3,))
 vec4 = _TensorType((4,))
 mat3 = _TensorType((3, 3))
 ivec3 = _TensorType((3,), int)
+
+
+def clamp(x, xmin, xmax):
+    """taichi.math.clamp: min(xmax, max(xmin, x))"""
+    return min(xmax, max(xmin, x))

@@ -141,3 +141,31 @@ def test_bvh_on_subdivided_mesh():
     assert np.array_equal(nodes.view(np.int32), nodes2.view(np.int32)) and np.array_equal(order, order2)
     assert sorted(order.tolist()) == list(range(tris.shape[0]))
     assert depth <= 2.5 * np.log2(tris.shape[0]) and nodes.shape[0] < tris.shape[0]
+
+
+def test_struct_layouts_match_the_header():
+    """ctypes mirrors of the three C structs: same member order and count as include/adapt_mi.h (a silent mismatch would shift
+    every later field, e.g. the media tables or the `volumetric` switch)."""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "adapt_mi.h")).read(), flags=re.S)
+    def members(struct):
+        body = re.search(r"typedef struct " + struct + r"\s*\{(.*?)\}\s*" + struct + ";", text, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                names.append(re.sub(r"\[.*?\]", "", part.strip().split()[-1].lstrip("*")))
+        return names
+    assert members("apt_scene_desc") == [n for n, _ in _lib.SceneDesc._fields_]
+    assert members("apt_render_cfg") == [n for n, _ in _lib.RenderCfg._fields_]
+    assert members("apt_stats") == [n for n, _ in _lib.Stats._fields_]
+
+
+def test_volume_renderer_refuses_grid_volumes(parsed):
+    from adapt_amd.renderer import VolumeRenderer, Renderer
+    assert VolumeRenderer.VOLUMETRIC and not Renderer.VOLUMETRIC and issubclass(VolumeRenderer, Renderer)
+    tup = parsed("cbox")
+    prop = dict(tup[3]); prop["volume"] = ["smoke.vol"]
+    with pytest.raises(NotImplementedError):
+        VolumeRenderer(tup[0], tup[1], tup[2], prop)

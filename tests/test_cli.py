@@ -20,10 +20,11 @@ def test_reference_flags_are_accepted(tmp_path):
         get_options(["--type", "photon-map"])
 
 
-def test_only_pt_is_served(capsys):
+def test_only_pt_and_vpt_are_served(capsys):
     from adapt_amd.cli import main
     assert main(["--type", "bdpt"]) == 2
-    assert "only the `pt` renderer" in capsys.readouterr().err
+    assert "only the `pt` and `vpt` renderers" in capsys.readouterr().err
+    assert main(["--type", "ao"]) == 2
 
 
 def test_image_orientation_and_png(tmp_path):

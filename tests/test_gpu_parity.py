@@ -10,7 +10,7 @@ Tolerances (float32 path tracing):
 import numpy as np
 import pytest
 
-from conftest import SCENES, golden, image_metrics
+from conftest import SCENES, golden, image_metrics, scene_from_golden
 from adapt_amd.scene_pack import make_config
 
 pytestmark = pytest.mark.gpu
@@ -518,3 +518,100 @@ def test_texture_lookup_vs_reference_vectors_and_oracle(parsed, flat, oracle_sce
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     finally:
         sc.close()
+
+
+# ---- volumetric path tracer (VolumeRenderer, renderer/vpt.py): homogeneous media, null surfaces, tracked light samples
+from conftest import VPT_SCENE_TAGS  # noqa: E402
+
+
+@pytest.mark.parametrize("tag", VPT_SCENE_TAGS)
+def test_volumetric_hip_vs_reference_run_and_oracle(tag):
+    """The reference's three vpt scenes + the two media coverage scenes of this repo: (a) against the image the reference's own
+    VolumeRenderer.render produced on the same Philox stream (fixture), (b) against the oracle at more samples, where the path
+    structure has to agree too: vertices shaded, light samples taken and random numbers drawn."""
+    from adapt_amd.renderer import VolumeRenderer
+    from adapt_amd.scene_pack import make_config, pack_scene
+    from oracle import binding as ob
+    tup, g = scene_from_golden(tag, "vptscene")
+    w, h, spp = int(g["width"]), int(g["height"]), int(g["spp"])
+    r = VolumeRenderer(*tup, width=w, height=h)
+    try:
+        assert r.info()["shade_variant"] == "volumetric"
+        r.render(n_spp=spp)
+        m = image_metrics(r.color.to_numpy() / spp, g["accum"] / spp)
+        assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-3, (tag, m)
+        assert abs(r.stats()["n_draws"] - int(g["draws"].sum())) <= 2e-3 * int(g["draws"].sum())
+        r.clear(); r.render(n_spp=16)
+        rc = make_config(tup[3], width=w, height=h, volumetric=True)
+        ref, _, ost = ob.OracleScene(pack_scene(*tup), rc.cam_t).render(rc, 16)
+        m = image_metrics(r.color.to_numpy() / 16, ref / 16)
+        assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-3, (tag, m)
+        st = r.stats()
+        for k in ("n_shade", "n_shadow", "n_draws"):
+            assert abs(st[k] - ost[k]) <= 5e-4 * ost[k], (tag, k, st[k], ost[k])
+        assert st["n_samples"] == ost["n_samples"] == w * h * 16
+        # the walk only follows light samples that can contribute, the reference follows all of them
+        assert 0 < st["n_track"] <= ost["n_track"] and st["n_lit"] <= ost["n_lit"]
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("mode", ["bvh", "sweep", "tile"])
+def test_volumetric_every_traversal_mode(mode, monkeypatch):
+    """media_a (null fog cube, scattering glass ball, scattering world) under each closest-hit implementation: the transmittance walk
+    and the free-path sampling see the same surfaces whichever one finds them."""
+    from adapt_amd.renderer import VolumeRenderer
+    from adapt_amd.scene_pack import make_config, pack_scene
+    from oracle import binding as ob
+    monkeypatch.setenv("APT_TRAVERSAL", mode)
+    tup, g = scene_from_golden("media_a", "vptscene")
+    w, h, spp = 64, 48, 8
+    r = VolumeRenderer(*tup, width=w, height=h)
+    try:
+        assert r.info()["traversal"] == mode
+        r.render(n_spp=spp)
+        rc = make_config(tup[3], width=w, height=h, volumetric=True)
+        ref, _, ost = ob.OracleScene(pack_scene(*tup), rc.cam_t).render(rc, spp)
+        m = image_metrics(r.color.to_numpy() / spp, ref / spp)
+        assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-3, (mode, m)
+        st = r.stats()
+        for k in ("n_shade", "n_shadow", "n_draws"):
+            assert abs(st[k] - ost[k]) <= 1e-3 * ost[k], (mode, k, st[k], ost[k])
+    finally:
+        r.close()
+
+
+def test_volumetric_partition_and_batch_invariance():
+    """Two ranks' tiles side by side equal the single-rank image (RNG keyed by the global pixel), and one sample per batch equals
+    the automatic batching: vpt_cbox takes one light sample per vertex, so no two float atomics ever meet on a radiance slot."""
+    from adapt_amd.renderer import VolumeRenderer
+    tup, g = scene_from_golden("vpt_cbox", "vptscene")
+    w, h, spp = 64, 32, 6
+    full = VolumeRenderer(*tup, width=w, height=h)
+    full.render(n_spp=spp); ref = full.color.to_numpy(); full.close()
+    one = VolumeRenderer(*tup, width=w, height=h, spp_per_batch=1)
+    one.render(n_spp=spp); assert np.array_equal(one.color.to_numpy(), ref); one.close()
+    img = np.zeros_like(ref)
+    for rank in range(2):
+        r = VolumeRenderer(*tup, width=w, height=h, rank=rank, world_size=2, band_width=16)
+        r.render(n_spp=spp)
+        img[r.plan.columns(rank)] = r.tile_accum()
+        r.close()
+    assert np.array_equal(img, ref)
+
+
+def test_surface_tracer_ignores_media_like_the_reference():
+    """`--type pt` on a scene with media: Renderer.render never looks at them (vanilla_renderer.py), so the image equals the oracle's
+    surface-only render and differs from the volumetric one."""
+    from adapt_amd.renderer import Renderer, VolumeRenderer
+    from adapt_amd.scene_pack import make_config, pack_scene
+    from oracle import binding as ob
+    tup, g = scene_from_golden("vpt_volbox", "vptscene")
+    w, h, spp = 48, 36, 8
+    a = Renderer(*tup, width=w, height=h); a.render(n_spp=spp); pa = a.color.to_numpy(); a.close()
+    b = VolumeRenderer(*tup, width=w, height=h); b.render(n_spp=spp); pb = b.color.to_numpy(); b.close()
+    rc = make_config(tup[3], width=w, height=h)
+    ref = ob.OracleScene(pack_scene(*tup), rc.cam_t).render(rc, spp)[0]
+    m = image_metrics(pa / spp, ref / spp)
+    assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-3, m
+    assert float(np.abs(pa - pb).mean()) > 1e-2

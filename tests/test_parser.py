@@ -213,3 +213,38 @@ def test_reference_parser_objects_are_accepted(d, f, tag, flat):
     for name in ("prims", "normals", "v_normals", "obj_info", "obj_aabb", "emitter_id", "bxdf_i", "bxdf_f", "src_i", "src_f"):
         assert np.array_equal(getattr(fs, name), getattr(mine, name)), name
     assert fs.world_ior == mine.world_ior and fs.has_vertex_normal == mine.has_vertex_normal
+
+
+# ---- participating media (volumetric tracer inputs)
+@pytest.mark.parametrize("name", ["media_a", "media_b"])
+def test_media_scene_parse_matches_reference_parser_arrays(name):
+    """scenes/test/media_*.xml through this repo's front end = the arrays the reference's parser produced for the same file (stored
+    in the vptscene fixture): geometry, materials, emitters and the per-object / world medium tables, bit for bit."""
+    from conftest import golden
+    from adapt_amd.scene_pack import pack_scene, make_config
+    tup = scene_parsing(os.path.join(ROOT, "scenes", "test"), name + ".xml")
+    fs, g = pack_scene(*tup), golden(f"vptscene_{name}.npz")
+    for k in ("prims", "normals", "v_normals", "obj_info", "obj_aabb", "emitter_id", "bxdf_i", "bxdf_f", "src_i", "src_f", "med_i", "med_f"):
+        assert np.array_equal(np.asarray(getattr(fs, k)).view(np.uint32), np.asarray(g[k]).view(np.uint32)), (name, k)
+    assert fs.has_scattering_media
+    rc = make_config(tup[3], volumetric=True)
+    assert rc.volumetric and rc.max_bounce == int(g["max_bounce"]) and rc.num_shadow_ray == int(g["num_shadow_ray"])
+    assert np.array_equal(np.float32(rc.cam_t), g["cam_pos"])
+
+
+def test_medium_records():
+    """Medium_np (bxdf/medium.py:24-68): type ids, u_e = u_a + u_s, defaults of a missing <medium>, unknown types refused."""
+    import xml.etree.ElementTree as xet
+    from adapt_amd.materials import Medium_np
+    from adapt_amd.scene_pack import pack_medium
+    m = Medium_np(xet.fromstring('<medium type="multi-hg"><rgb name="u_a" value="0.25"/><rgb name="u_s" r="1" g="2" b="3"/>'
+                                 '<rgb name="par" r="0.5" g="-0.5" b="0"/><rgb name="pdf" r="0.25" g="0.5" b="0.25"/><float name="ior" value="1.25"/></medium>'))
+    kind, f = pack_medium(m)
+    assert kind == 1 and f.dtype == np.float32 and f.shape == (16,)
+    assert np.array_equal(f, np.float32([1.25, 1, 2, 3, .25, .25, .25, 1.25, 2.25, 3.25, .5, -.5, 0, .25, .5, .25]))
+    kind, f = pack_medium(Medium_np(None))
+    assert kind == -1 and f[0] == 1.0 and np.array_equal(f[1:13], np.zeros(12, np.float32)) and np.array_equal(f[13:], np.float32([1, 0, 0]))
+    assert [Medium_np(xet.fromstring(f'<medium type="{k}"/>')).type_id for k in ("hg", "multi-hg", "rayleigh", "mie", "transparent")] == [0, 1, 2, 3, -1]
+    with pytest.raises(NotImplementedError):
+        Medium_np(xet.fromstring('<medium type="smoke"/>'))
+    assert pack_medium(None)[0] == -1
