@@ -111,8 +111,8 @@ __global__ void __launch_bounds__(BLOCK) k_vshade(DevScene sc, Params p, Queues 
     uint32_t* next_counter = &cnt->n_active[nxt][sl.q * CNT_PAD];
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
     const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
-    const DevMedium world = sc.med[sc.n_objects];
-    const bool world_scat = world.type >= 0;
+    const DevMedium* world = sc.med + sc.n_objects;           // wave-uniform address: scalar loads
+    const bool world_scat = world->type >= 0;
     uint32_t t_shade = 0, t_shadow = 0, t_poison = 0;
     __shared__ uint32_t s_draws[BLOCK / 64];
     if (lane_id() == 0) s_draws[threadIdx.x >> 6] = 0;
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(BLOCK) k_vshade(DevScene sc, Params p, Queues 
         Hit it; it.obj_id = -1; it.prim_id = -1; it.n_s = it.n_g = mk3(1.f, 0.f, 0.f); it.min_depth = 0.f;
         int hit_light = -1;
         DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
-        DevMedium med = world;
+        const DevMedium* med = world;                         // the medium of a medium interaction (a pointer, not a 17-register copy)
         if (alive) {
             const uint32_t io = idx << 2;
             o = ld3q(q.ray_o[cur], p.cap, io);
@@ -166,8 +166,8 @@ __global__ void __launch_bounds__(BLOCK) k_vshade(DevScene sc, Params p, Queues 
                 const bool world_valid = in_free && world_scat;
                 if (world_valid || vpt_is_scattering(sc, it.obj_id)) {
                     float mfp = it.min_depth;
-                    if (world_valid) { med = world; is_mi = medium_sample_mfp(med, it.min_depth, rng, mfp, beta); }
-                    else if (!in_free) { med = sc.med[it.obj_id]; is_mi = medium_sample_mfp(med, it.min_depth, rng, mfp, beta); }
+                    if (world_valid) { med = world; is_mi = medium_sample_mfp(*med, it.min_depth, rng, mfp, beta); }
+                    else if (!in_free) { med = sc.med + it.obj_id; is_mi = medium_sample_mfp(*med, it.min_depth, rng, mfp, beta); }
                     it.min_depth = mfp;
                 }
                 if (it.obj_id < 0 && !is_mi) alive = false;                 // left the world box
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(BLOCK) k_vshade(DevScene sc, Params p, Queues 
                     light_dir = to_emitter / emitter_d;
                     sampled = true;
                     f3 direct_spec;
-                    if (is_mi) direct_spec = splat3(phase_eval_p(med, d, light_dir));
+                    if (is_mi) direct_spec = splat3(phase_eval_p(*med, d, light_dir));
                     else direct_spec = surface_eval<APT_BX_ALL>(bx, it, d, light_dir, sc.world_ior, p.two_sides);
                     float mis_w = 1.0f;
                     if (p.use_mis && !(src.bool_bits & 0x01)) {
@@ -262,8 +262,8 @@ __global__ void __launch_bounds__(BLOCK) k_vshade(DevScene sc, Params p, Queues 
             }
             float ray_pdf = 1.f;
             if (is_mi) {                                                        // Medium.sample_new_rays, medium.py:112-121
-                if (med.type >= 0) {
-                    const f3 local = phase_sample_p(med, d, rng, ray_pdf);
+                if (med->type >= 0) {
+                    const f3 local = phase_sample_p(*med, d, rng, ray_pdf);
                     new_d = delocalize(d, local);
                 }
                 cont = true;                                                    // a medium event never ends the path by itself

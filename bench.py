@@ -37,6 +37,9 @@ CONFIGS = {
     # synthetic stand-ins (adapt_amd/synth.py): the reference does not ship these scenes' assets
     "c4": ("synth", "three-bunnies", 800, 800, 512, 8, "three-bunnies stand-in, 95 050 tris, 800x800, 512 spp, 8 bounces (BASELINE configs[3])"),
     "c5": ("synth", "bunny-field", 1280, 720, 2048, 16, "sports-car stand-in (bunny field), 285 134 tris, 1280x720, 2048 spp, 16 bounces (BASELINE configs[4])"),
+    # volumetric path tracer (the reference's `--type vpt`): names starting with "v" render with VolumeRenderer
+    "v1": ("test", "media_a.xml", 512, 512, 256, 8, "media_a: Cornell box, fog cube behind a null surface, scattering glass ball, thin multi-H-G world medium, "
+                                                    "2 light samples per vertex; 512x512, 256 spp, 8 bounces, volumetric tracer"),
 }
 
 
@@ -102,8 +105,11 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from adapt_amd import scene_parsing
-    from adapt_amd.renderer import Renderer
+    from adapt_amd.renderer import Renderer, VolumeRenderer
     from adapt_amd.tiles import gather_image, gather_tiles
+    volumetric = args.config.startswith("v")
+    if volumetric:
+        Renderer = VolumeRenderer
 
     sdir, sfile, W, H, spp, bounces, label = CONFIGS[args.config]
     if args.lanes > 0:
@@ -214,7 +220,7 @@ def main():
         roofline["timed_region"] = {k: timed[k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches", "per_kernel", "sum_kernel_ms", "render_ms", "overlap")}
 
     out = {
-        "metric": "Msamples/s (W*H*spp/s), unidirectional MIS path tracing", "value": round(value, 3), "unit": "Msamples/s",
+        "metric": "Msamples/s (W*H*spp/s), " + ("volumetric path tracing (homogeneous media)" if volumetric else "unidirectional MIS path tracing"), "value": round(value, 3), "unit": "Msamples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": ("synthetic stand-in scene (adapt_amd/synth.py; the reference ships no assets for it)" if sdir == "synth" else "bundled Cornell scene file (same inputs as the reference's); no dataset involved"),
@@ -229,7 +235,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from adapt_amd.scene_pack import make_config, pack_scene
         from oracle import binding as ob
-        rc = make_config(parsed[3], width=W, height=H, max_bounce=bounces)
+        rc = make_config(parsed[3], width=W, height=H, max_bounce=bounces, volumetric=volumetric)
         osc = ob.OracleScene(pack_scene(*parsed), rc.cam_t, build_bvh=rc.use_bvh)
         cores = ob.num_threads()
         t = time.perf_counter(); osc.render(rc, 1, threads=cores); one = time.perf_counter() - t
