@@ -74,6 +74,13 @@ typedef void (*occluded_fn)(DevScene, uint32_t, const float*, const float*, cons
 static const extend_fn kExtend[3][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_extend<1, 0>, k_extend<1, 1>}, {k_extend<2, 0>, k_extend<2, 1>}};   // [mode][sorted]
 static const shadow_fn kShadow[3] = {k_shadow<0>, k_shadow<1>, k_shadow<2>};
 static const occluded_fn kOccluded[3] = {k_occluded<0>, k_occluded<1>, k_occluded<2>};
+typedef void (*vshade_fn)(DevScene, Params, Queues, Counters*, int);
+struct VShadeVariant { int bm, sm; vshade_fn fn; const char* name; };
+static const VShadeVariant kVShadeVariants[] = {          // first match wins; 0x400 = "other BSDF" = the null surface
+    {0x402, 0x03, k_vshade<0x402, 0x03>, "volumetric: lambertian+null/point+area"},
+    {0x503, 0x07, k_vshade<0x503, 0x07>, "volumetric: phong+lambertian+glass+null/point+area+spot"},
+    {APT_BX_ALL, APT_SRC_ALL, k_vshade<APT_BX_ALL, APT_SRC_ALL>, "volumetric: all models"},
+};
 static const shadow_fn kVShadow[3] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>};      // volumetric: transmittance walk (closest-hit queries)
 #define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
 
@@ -126,6 +133,7 @@ struct apt_renderer {
     int trace_nt = BLOCK;         // workgroup size of the trace kernels
     int sorted = 0;               // 1 = material-sorted shading (>= 2 material classes in the scene)
     int volumetric = 0;           // 1 = VolumeRenderer.render semantics (volumetric.hpp)
+    const VShadeVariant* vshade = nullptr;
     shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string shade_name;
     LdsPlan plan{};
@@ -411,13 +419,16 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (r->volumetric) {
         if (c.max_bounce > 255) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer keeps the bounce count in 8 bits (max_bounce <= 255)"); }
         if (!sc->has_aabb) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer needs the object boxes (world bound)"); }
-        r->sorted = 0;                                        // one generic kernel: media, null surfaces and every surface model
+        r->sorted = 0;
+        for (const VShadeVariant& v : kVShadeVariants)
+            if ((sc->bx_mask & ~v.bm) == 0 && (sc->src_mask & ~v.sm) == 0 && !(textured && v.bm != APT_BX_ALL)) { r->vshade = &v; break; }
+        if (!r->vshade) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: scene uses a material or emitter type the volumetric kernels do not know"); }
         for (int a = 0; a < 3; a++) {                         // path_tracer.py:136-138
             p.w_min[a] = std::min(c.cam_t[a], sc->box_min[a]) - 0.1f; p.w_max[a] = std::max(c.cam_t[a], sc->box_max[a]) + 0.1f;
         }
     }
     const int ncls = r->sorted ? sc->n_classes : 0;
-    r->shade_name = r->volumetric ? "volumetric" : r->shade->name;
+    r->shade_name = r->volumetric ? r->vshade->name : r->shade->name;
     if (r->sorted) {
         const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : 1;
         r->shade_name = "sorted:";
@@ -585,6 +596,69 @@ static int resolve_events(apt_renderer* r) {
     return APT_OK;
 }
 
+// Volumetric render (VolumeRenderer.render x n_spp).  Batches go round-robin over the render lanes like the surface tracer's, in
+// rounds: first every lane of the round gets its generate + max_bounce iterations (asynchronous), then, lane by lane, the
+// null-surface tail (live count read back, two more iterations while paths remain) and the ordered finalize.  While the host
+// waits on one lane's tail the other lanes are still busy with their main iterations.
+static int render_volumetric(apt_renderer* r, int32_t n_spp) {
+    const DevScene& sc = r->scene->dev;
+    const int nq = r->nq;
+    int done = 0;
+    hipEvent_t prev_fin = nullptr;
+    const int batch_cap = (r->cfg.spp_per_batch <= 0 && n_spp < r->n_lanes * r->spp_batch) ? std::max(1, (n_spp + r->n_lanes - 1) / r->n_lanes) : r->spp_batch;
+    struct Issued { int li, cur; Params p; size_t total; };
+    while (done < n_spp) {
+        std::vector<Issued> round;
+        for (int li = 0; li < r->n_lanes && done < n_spp; li++) {
+            const int B = (n_spp - done < batch_cap) ? (n_spp - done) : batch_cap;
+            hipStream_t st = li ? r->extra[(size_t)li - 1].stream : r->stream;
+            const Queues& q = li ? r->extra[(size_t)li - 1].q : r->q;
+            Counters* cnt = li ? r->extra[(size_t)li - 1].counters.as<Counters>() : r->counters.as<Counters>();
+            Issued is; is.li = li; is.cur = 0; is.p = r->par; is.p.cnt_base = r->cnt; is.p.spp_batch = B; is.total = (size_t)r->npix * (size_t)B;
+            HIP_TRY(hipMemsetAsync(cnt, 0, offsetof(Counters, stats), st));
+            { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate, dim3(grid_for(is.total, r->grid_small, 1)), dim3(BLOCK), 0, st, is.p, q, cnt); }
+            round.push_back(is);
+            r->cnt += B; done += B;
+        }
+        auto iterate = [&](Issued& is, int n_iter) {
+            hipStream_t st = is.li ? r->extra[(size_t)is.li - 1].stream : r->stream;
+            const Queues& q = is.li ? r->extra[(size_t)is.li - 1].q : r->q;
+            Counters* cnt = is.li ? r->extra[(size_t)is.li - 1].counters.as<Counters>() : r->counters.as<Counters>();
+            for (int b = 0; b < n_iter; b++) {
+                { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(kExtend[r->trace_mode][0], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], r->plan); }
+                { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vshade->fn, dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, is.cur); }
+                if (is.p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kVShadow[r->trace_mode], dim3(grid_for(is.total * (size_t)is.p.S, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, r->plan); }
+                is.cur ^= 1;
+            }
+        };
+        // an iteration ends a path or counts a bounce, except a null-surface pass-through: max_bounce iterations finish every
+        // path that met no null surface
+        for (Issued& is : round) iterate(is, is.p.max_bounce);
+        for (Issued& is : round) {
+            hipStream_t st = is.li ? r->extra[(size_t)is.li - 1].stream : r->stream;
+            const Queues& q = is.li ? r->extra[(size_t)is.li - 1].q : r->q;
+            Counters* cnt = is.li ? r->extra[(size_t)is.li - 1].counters.as<Counters>() : r->counters.as<Counters>();
+            hipEvent_t fin = is.li ? r->extra[(size_t)is.li - 1].fin : r->fin0;
+            if (r->scene->has_null_surface) {
+                for (int k = 0; k < 4096; k++) {
+                    HIP_TRY(hipMemcpyAsync(r->host_counters.n_active[is.cur], cnt->n_active[is.cur], sizeof(cnt->n_active[is.cur]), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    unsigned long long live = 0;
+                    for (int sq = 0; sq < nq; sq++) live += r->host_counters.n_active[is.cur][sq * CNT_PAD];
+                    if (!live) break;
+                    iterate(is, 2);
+                }
+            }
+            if (prev_fin && r->n_lanes > 1) HIP_TRY(hipStreamWaitEvent(st, prev_fin, 0));
+            { LaunchTimer t(r, 4, st); hipLaunchKernelGGL(k_finalize, dim3(grid_for((size_t)r->npix, r->grid_small, 1)), dim3(BLOCK), 0, st, is.p, q, r->accum.as<float>()); }
+            HIP_TRY(hipEventRecord(fin, st));
+            prev_fin = fin;
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return APT_OK;
+}
+
 APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
     if (!r || n_spp < 0) return fail(APT_E_INVALID, "apt_render: bad argument");
     HIP_TRY(hipSetDevice(r->cfg.device));
@@ -592,6 +666,13 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
     const DevScene& sc = r->scene->dev;
     HIP_TRY(hipEventRecord(r->ev_r0, r->stream));
     for (auto& ln : r->extra) HIP_TRY(hipStreamWaitEvent(ln.stream, r->ev_r0, 0));     // lanes start after whatever the main stream did before
+    if (r->volumetric) {
+        if (int rc = render_volumetric(r, n_spp)) return rc;
+        for (auto& ln : r->extra) { HIP_TRY(hipEventRecord(ln.fin, ln.stream)); HIP_TRY(hipStreamWaitEvent(r->stream, ln.fin, 0)); }
+        HIP_TRY(hipEventRecord(r->ev_r1, r->stream));
+        r->render_pending = true;
+        return APT_OK;
+    }
     int done = 0, batch = 0;
     hipEvent_t prev_fin = nullptr;
     // a call smaller than one full round of lane-batches is split evenly so that every lane has work
@@ -609,30 +690,6 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
         const int nq = r->nq;
         { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, p, q, cnt); }
         int cur = 0;
-        if (r->volumetric) {
-            // while-loop of vpt.py:161-253: an iteration ends a path or counts a bounce, except a null-surface pass-through.
-            // max_bounce iterations finish every path that met no null surface; then the live count decides (host read-back).
-            auto iterate = [&](int n_iter) -> int {
-                for (int b = 0; b < n_iter; b++) {
-                    { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(kExtend[r->trace_mode][0], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
-                    { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(k_vshade, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, cur); }
-                    if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kVShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, r->plan); }
-                    cur ^= 1;
-                }
-                return APT_OK;
-            };
-            iterate(p.max_bounce);
-            if (r->scene->has_null_surface) {
-                for (int round = 0; round < 4096; round++) {
-                    HIP_TRY(hipMemcpyAsync(r->host_counters.n_active[cur], cnt->n_active[cur], sizeof(cnt->n_active[cur]), hipMemcpyDeviceToHost, st));
-                    HIP_TRY(hipStreamSynchronize(st));
-                    unsigned long long live = 0;
-                    for (int k = 0; k < nq; k++) live += r->host_counters.n_active[cur][k * CNT_PAD];
-                    if (!live) break;
-                    iterate(2);
-                }
-            }
-        } else
         for (int b = 0; b < p.max_bounce; b++) {
             { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
             if (!r->sorted) {

@@ -9,6 +9,9 @@
 // that declare one are refused by the host.
 #pragma once
 #include "stages.hpp"
+#ifndef APT_VSHADE_LEAN_WAVES
+#define APT_VSHADE_LEAN_WAVES 3
+#endif
 
 APT_D float med_random_rgb(Philox& r, f3 v) {                      // general_sampling.py:17-27
     const int idx = pymod(rng_int(r), 3);
@@ -103,7 +106,11 @@ APT_D float world_bound_time(const Params& p, f3 o, f3 d) {
 // counter lives in the path's meta word (a null-surface pass-through re-queues the path without counting a bounce) and the
 // float slot that carries ray_pdf in the surface tracer carries emission_weight here (vpt.py:247-253 computes it at the END of
 // an iteration, from the interaction being left).
-__global__ void __launch_bounds__(BLOCK) k_vshade(DevScene sc, Params p, Queues q, Counters* cnt, int cur) {
+// BM / SM: material and emitter masks as in k_shade (code for absent models is compiled out); the all-models variant also carries
+// the image-texture lookup.
+template <int BM, int SM>
+__global__ void __launch_bounds__(BLOCK, (BM == 0x402 ? APT_VSHADE_LEAN_WAVES : 1)) k_vshade(DevScene sc, Params p, Queues q, Counters* cnt, int cur) {
+    constexpr bool TEX = (BM == APT_BX_ALL);
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
     const uint32_t n = cnt->n_active[cur][sl.q * CNT_PAD];
@@ -180,7 +187,7 @@ __global__ void __launch_bounds__(BLOCK) k_vshade(DevScene sc, Params p, Queues 
                         if (!is_mi) {
                             hit_light = sc.emitter_id[it.obj_id];
                             f3 tx;
-                            if (sc.tex_i != nullptr && get_uv_item(sc, 0, it.obj_id, it.prim_id, ldq(q.hit_u, io), ldq(q.hit_v, io), tx)) bx.k_d = tx;   // vpt.py:199
+                            if (TEX && sc.tex_i != nullptr && get_uv_item(sc, 0, it.obj_id, it.prim_id, ldq(q.hit_u, io), ldq(q.hit_v, io), tx)) bx.k_d = tx;   // vpt.py:199
                         }
                     }
                 }
@@ -213,18 +220,18 @@ __global__ void __launch_bounds__(BLOCK) k_vshade(DevScene sc, Params p, Queues 
                 else {
                     const DevSrc src = sc.src[sidx];
                     f3 shadow_int; float direct_pdf;
-                    const f3 emit_pos = emitter_sample_hit<APT_SRC_ALL>(src, geom, hit_point, rng, shadow_int, direct_pdf);
+                    const f3 emit_pos = emitter_sample_hit<SM>(src, geom, hit_point, rng, shadow_int, direct_pdf);
                     const f3 to_emitter = emit_pos - hit_point;
                     emitter_d = norm(to_emitter);
                     light_dir = to_emitter / emitter_d;
                     sampled = true;
                     f3 direct_spec;
                     if (is_mi) direct_spec = splat3(phase_eval_p(*med, d, light_dir));
-                    else direct_spec = surface_eval<APT_BX_ALL>(bx, it, d, light_dir, sc.world_ior, p.two_sides);
+                    else direct_spec = surface_eval<BM>(bx, it, d, light_dir, sc.world_ior, p.two_sides);
                     float mis_w = 1.0f;
                     if (p.use_mis && !(src.bool_bits & 0x01)) {
                         const float light_pdf = emitter_pdf * direct_pdf;
-                        const float bsdf_pdf_v = is_mi ? direct_spec.x : surface_pdf<APT_BX_ALL>(bx, it, light_dir, d, sc.world_ior, p.two_sides);
+                        const float bsdf_pdf_v = is_mi ? direct_spec.x : surface_pdf<BM>(bx, it, light_dir, d, sc.world_ior, p.two_sides);
                         mis_w = balance(light_pdf, bsdf_pdf_v);
                     }
                     if (isnan(mis_w)) { st3q(q.L, p.cap, l_off, splat3(mis_w)); poisoned = true; }     // as in k_shade: the sample is zeroed at the end
@@ -252,7 +259,7 @@ __global__ void __launch_bounds__(BLOCK) k_vshade(DevScene sc, Params p, Queues 
         f3 new_d = d;
         bool is_spec = false;
         if (shade) {
-            if (hit_light >= 0) {
+            if ((SM & 2) && hit_light >= 0) {
                 const f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_g);      // geometric normal here (vpt.py:233)
                 if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
                     const f3 add = (emit_int * emission_weight) * thr;
@@ -269,7 +276,7 @@ __global__ void __launch_bounds__(BLOCK) k_vshade(DevScene sc, Params p, Queues 
                 cont = true;                                                    // a medium event never ends the path by itself
             } else {
                 f3 spec;
-                new_d = surface_sample<APT_BX_ALL>(bx, it, d, sc.world_ior, p.two_sides, rng, spec, ray_pdf, is_spec);
+                new_d = surface_sample<BM>(bx, it, d, sc.world_ior, p.two_sides, rng, spec, ray_pdf, is_spec);
                 cont = !(max3(spec) == 0.f || ray_pdf == 0.f);                  // vpt.py:240-241
                 if (cont) thr = thr * (spec / ray_pdf);
             }

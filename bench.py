@@ -38,8 +38,10 @@ CONFIGS = {
     "c4": ("synth", "three-bunnies", 800, 800, 512, 8, "three-bunnies stand-in, 95 050 tris, 800x800, 512 spp, 8 bounces (BASELINE configs[3])"),
     "c5": ("synth", "bunny-field", 1280, 720, 2048, 16, "sports-car stand-in (bunny field), 285 134 tris, 1280x720, 2048 spp, 16 bounces (BASELINE configs[4])"),
     # volumetric path tracer (the reference's `--type vpt`): names starting with "v" render with VolumeRenderer
-    "v1": ("test", "media_a.xml", 512, 512, 256, 8, "media_a: Cornell box, fog cube behind a null surface, scattering glass ball, thin multi-H-G world medium, "
-                                                    "2 light samples per vertex; 512x512, 256 spp, 8 bounces, volumetric tracer"),
+    "v1": ("vpt", "cbox_fog.xml", 512, 512, 256, 16, "vpt Cornell box (the reference's scenes/vpt/cbox.xml set-up: Lambertian box, quad light, fog cube = null surface + H-G medium); "
+                                                    "512x512, 256 spp, 16 bounces, 1 light sample per vertex, volumetric tracer"),
+    "v2": ("test", "media_a.xml", 512, 512, 256, 8, "media_a: Cornell box, fog cube behind a null surface, scattering glass ball, thin multi-H-G world medium, "
+                                                    "2 light samples per vertex; 512x512, 256 spp, 8 bounces, volumetric tracer (all-models kernel)"),
 }
 
 
