@@ -81,7 +81,8 @@ static const VShadeVariant kVShadeVariants[] = {          // first match wins; 0
     {0x503, 0x07, k_vshade<0x503, 0x07>, "volumetric: phong+lambertian+glass+null/point+area+spot"},
     {APT_BX_ALL, APT_SRC_ALL, k_vshade<APT_BX_ALL, APT_SRC_ALL>, "volumetric: all models"},
 };
-static const shadow_fn kVShadow[3] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>};      // volumetric: transmittance walk (closest-hit queries)
+typedef void (*vshadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan, int);
+static const vshadow_fn kVShadow[3] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>};     // volumetric: transmittance walk (one closest-hit query per pass)
 #define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
 
 // ============================================================== host side
@@ -139,6 +140,7 @@ struct apt_renderer {
     LdsPlan plan{};
     size_t lds_bytes = 0, lds_bytes_any = 0;     // dynamic LDS of the closest-hit / any-hit trace kernels
     int grid_shadow = 0;
+    int grid_vshadow = 0;         // volumetric transmittance walk (closest-hit LDS footprint, its own register budget)
     std::vector<EventPair> pending;
     std::vector<EventPair> free_events;
     double kernel_ms[APT_N_KERNELS] = {0, 0, 0, 0, 0};
@@ -437,7 +439,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     // the kernels address queue slots with 32-bit byte offsets (stages.hpp "Queue addressing")
     if (cap >= ((size_t)1 << 30) || sh_cap >= ((size_t)1 << 30)) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: batch too large (queue capacity must stay below 2^30 slots)"); }
     // one pool per lane, carved into the SoA arrays (all 4-byte lanes)
-    const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 3) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls;
+    const bool walk_lists = r->volumetric && sc->has_null_surface;      // light samples that cross null surfaces are re-queued by slot
+    const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 3) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
         hipError_t e_ = pool.alloc(words * 4);
         if (e_ != hipSuccess) return e_;
@@ -449,6 +452,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         q.L = take(3 * cap);
         q.sh_o = take(3 * sh_cap); q.sh_d = take(3 * sh_cap); q.sh_tmax = take(sh_cap); q.sh_c = take(3 * sh_cap); q.sh_id = (uint32_t*)take(sh_cap);
         q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
+        q.sh_walk[0] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr; q.sh_walk[1] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr;
         q.n_classes = ncls;
         for (int c = 0; c < ncls; c++) {
             Queues::ClassQ& k = q.cls[c];
@@ -538,6 +542,10 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (const char* g = getenv("APT_GRID_TRACE")) r->grid_trace = cus * std::max(1, atoi(g));
     if (r->trace_mode != 2) { r->lds_bytes_any = r->lds_bytes; r->grid_shadow = r->grid_trace; }
     if (const char* g = getenv("APT_GRID_SHADOW")) r->grid_shadow = cus * std::max(1, atoi(g));
+    r->grid_vshadow = r->grid_trace;
+    if (r->trace_mode == 2) r->grid_vshadow = cus * std::max(1, std::min((int)((160 * 1024) / r->lds_bytes), (APT_VSHADOW_WAVES * 4) / (APT_TILE_NT / 64)));
+    if (const char* g = getenv("APT_GRID_VSHADOW")) r->grid_vshadow = cus * std::max(1, atoi(g));
+    r->grid_vshadow = ((r->grid_vshadow + nq - 1) / nq) * nq;
     r->grid_trace = ((r->grid_trace + nq - 1) / nq) * nq;          // persistent grids are multiples of nq
     r->grid_shadow = ((r->grid_shadow + nq - 1) / nq) * nq;
     r->grid_small = ((r->grid_small + nq - 1) / nq) * nq;
@@ -627,7 +635,13 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
             for (int b = 0; b < n_iter; b++) {
                 { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(kExtend[r->trace_mode][0], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], r->plan); }
                 { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vshade->fn, dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, is.cur); }
-                if (is.p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kVShadow[r->trace_mode], dim3(grid_for(is.total * (size_t)is.p.S, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, r->plan); }
+                if (is.p.S > 0) {
+                    const int n_pass = r->scene->has_null_surface ? 7 : 1;       // track_ray walks at most seven segments (vpt.py:113)
+                    for (int pass = 0; pass < n_pass; pass++) {
+                        LaunchTimer t(r, 3, st);
+                        hipLaunchKernelGGL(kVShadow[r->trace_mode], dim3(grid_for(is.total * (size_t)is.p.S, r->grid_vshadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, r->plan, pass);
+                    }
+                }
                 is.cur ^= 1;
             }
         };

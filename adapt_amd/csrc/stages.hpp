@@ -91,6 +91,7 @@ struct Queues {
     float* hit_t; int* hit_prim; float* hit_u; float* hit_v;
     float* thr[2]; uint32_t* id[2]; uint32_t* meta[2]; float* pdf[2];
     float* sh_o; float* sh_d; float* sh_tmax; float* sh_c; uint32_t* sh_id;
+    uint32_t* sh_walk[2];                        // volumetric, scenes with null surfaces: slot lists of the samples that walk on (ping-pong)
     float* L;                                    // 3 components, indexed by path id
     uint32_t sh_cap, sh_subcap;
     // Material-sorted shading (scenes with >= 2 material classes): extend drops misses and appends each hit
@@ -116,6 +117,7 @@ enum { ST_SAMPLES = 0, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_SHADOW_TRACED, ST_LIT,
 struct Counters {
     uint32_t n_active[2][APT_MAX_NQ * CNT_PAD];
     uint32_t n_shadow[APT_MAX_NQ * CNT_PAD];
+    uint32_t n_walk[8][APT_MAX_NQ * CNT_PAD];     // volumetric: light samples still walking after pass p-1 (pass p reads list p, fills list p + 1)
     uint32_t n_cls[8][APT_MAX_NQ * CNT_PAD];
     unsigned long long stats[APT_MAX_NQ][16];    // [q][ST_*], 128 bytes per sub-queue
 #ifdef APT_SHADE_PROF
@@ -281,6 +283,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
     const uint32_t n = n_src[sl.q * CNT_PAD];
     if (cnt && sl.first == 0 && threadIdx.x == 0) {
         cnt->n_shadow[sl.q * CNT_PAD] = 0; cnt->n_active[cur ^ 1][sl.q * CNT_PAD] = 0;
+        for (int w = 0; w < 8; w++) cnt->n_walk[w][sl.q * CNT_PAD] = 0;
         cnt->stats[sl.q][ST_EXTEND] += n;
     }
     const float* ro = q.ray_o[cur]; const float* rd = q.ray_d[cur];

@@ -12,6 +12,9 @@
 #ifndef APT_VSHADE_LEAN_WAVES
 #define APT_VSHADE_LEAN_WAVES 3
 #endif
+#ifndef APT_VSHADOW_WAVES
+#define APT_VSHADOW_WAVES 5
+#endif
 
 APT_D float med_random_rgb(Philox& r, f3 v) {                      // general_sampling.py:17-27
     const int idx = pymod(rng_int(r), 3);
@@ -310,71 +313,83 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x402 ? APT_VSHADE_LEAN_WAVES : 
 }
 
 // ------------------------------------------------------------------ vshadow
-// track_ray (vpt.py:99-138) for every queued light sample: closest hit within the remaining distance; a non-null surface blocks
-// the sample, a null surface or a miss in a scattering world attenuates it by the medium crossed and the walk goes on from there.
+// track_ray (vpt.py:99-138), one closest-hit query per pass.  Pass 0 reads every queued light sample; a sample that is blocked by
+// a non-null surface is dropped, one that reaches its light adds contribution x transmittance to the path's radiance, and one
+// that crossed a null surface (or a stretch of scattering world) is written back in place - origin moved to the crossing point,
+// remaining distance shortened, transmittance folded into the contribution - and its slot is appended to the list the next pass
+// reads.  The reference walks at most seven segments; the host launches pass p + 1 only where null surfaces exist.
 template <int MODE>
-__global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 1)) k_vshadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
+__global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAVES : 1)) k_vshadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan, int pass) {
     StagedBvh bvh;
     int* my_stack = nullptr;
     __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
     if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
     const SubLoop sl = sub_loop(p.nq, TRACE_NT(MODE));
-    const uint32_t n = min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
-    if (sl.first == 0 && threadIdx.x == 0) cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
+    const uint32_t n = min(pass == 0 ? cnt->n_shadow[sl.q * CNT_PAD] : cnt->n_walk[pass][sl.q * CNT_PAD], q.sh_subcap);
+    if (pass == 0 && sl.first == 0 && threadIdx.x == 0) cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
     const uint32_t qbase = (uint32_t)sl.q * q.sh_subcap, sc_ = q.sh_cap;
+    const uint32_t* list_in = q.sh_walk[pass & 1];
+    uint32_t* list_out = q.sh_walk[(pass + 1) & 1];
+    uint32_t* next_counter = &cnt->n_walk[pass + 1][sl.q * CNT_PAD];
     const f3 world_ue = sc.med[sc.n_objects].u_e;
     const bool world_scat = sc.med[sc.n_objects].type >= 0;
     uint32_t t_lit = 0, t_track = 0;
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
         const uint32_t pos = base + threadIdx.x;
         const bool valid = pos < n;
-        const uint32_t idx = qbase + (valid ? pos : n - 1);
+        uint32_t idx = qbase + (valid ? pos : n - 1);
+        if (pass > 0) idx = ldq(list_in, idx << 2);                         // slot of a sample that is still walking
         const uint32_t io = idx << 2;
         f3 o = ld3q(q.sh_o, sc_, io);
         const f3 d = ld3q(q.sh_d, sc_, io);
         float depth = ldq(q.sh_tmax, io);
-        f3 tr = splat3(1.f);
-        bool act = valid;
-        for (int k = 0; k < 7; k++) {
-            HitRec rec; rec.t = !act ? -1.f : ((depth > 0.0f) ? depth - 1e-4f : 1e7f); rec.prim = -1; rec.u = rec.v = 0.f;     // finished lanes: nothing is closer than -1
-            if (MODE == 0) traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
-            else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, act, s_sweep);
-            else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, act, reinterpret_cast<float*>(s_dyn));
-            if (act) {
-                t_track++;
-                int obj = -1; bool in_free = true; float seg = depth;
-                if (rec.prim < 0) { if (!world_scat) act = false; }
-                else {
-                    obj = sc.prim_obj[rec.prim];
-                    if (vpt_non_null(sc, obj)) { tr = splat3(0.f); act = false; }
-                    else {
-                        Hit it; build_hit(sc, rec.prim, rec.t, rec.u, rec.v, o, d, it);
-                        in_free = dot(it.n_g, d) < 0.f;
-                        seg = rec.t;
-                    }
-                }
-                if (act) {
-                    // get_transmittance, vpt.py:52-62
-                    if (in_free && world_scat) tr = tr * exp_neg(world_ue, seg);
-                    else if (!in_free && vpt_is_scattering(sc, obj)) tr = tr * exp_neg(sc.med[obj].u_e, seg);
-                    o = o + d * seg;
-                    depth -= seg;
-                    if (depth <= 5e-5f) act = false;
-                }
-            }
-            if (MODE == 0) { if (!__any(act)) break; }
-            else if (!__syncthreads_or(act)) break;
-        }
+        HitRec rec; rec.t = (depth > 0.0f) ? depth - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
+        if (MODE == 0) traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
+        else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
+        else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
+        bool arrived = false, walk_on = false;
+        f3 c = splat3(0.f);
         if (valid) {
-            const f3 c = ld3q(q.sh_c, sc_, io) * tr;           // a blocked sample is c * 0: NaN for a non-finite c, exactly as upstream
-            if (!(c.x == 0.f && c.y == 0.f && c.z == 0.f)) {
-                const uint32_t lo_ = ldq(q.sh_id, io);
-                char* Lb = reinterpret_cast<char*>(q.L);
-                atomicAdd(reinterpret_cast<float*>(Lb + lo_), c.x);
-                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 4 + lo_), c.y);
-                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 8 + lo_), c.z);
+            t_track++;
+            c = ld3q(q.sh_c, sc_, io);
+            int obj = -1; bool in_free = true, blocked = false; float seg = depth;
+            if (rec.prim < 0) { if (!world_scat) arrived = true; }         // nothing in the way and nothing to attenuate: done
+            else {
+                obj = sc.prim_obj[rec.prim];
+                if (vpt_non_null(sc, obj)) blocked = true;
+                else {
+                    Hit it; build_hit(sc, rec.prim, rec.t, rec.u, rec.v, o, d, it);
+                    in_free = dot(it.n_g, d) < 0.f;
+                    seg = rec.t;
+                }
             }
-            if (!(tr.x == 0.f && tr.y == 0.f && tr.z == 0.f)) t_lit++;
+            if (blocked) c = c * 0.f;                                       // NaN for a non-finite c, exactly as upstream's 0 * x
+            else if (!arrived) {
+                // get_transmittance, vpt.py:52-62
+                if (in_free && world_scat) c = c * exp_neg(world_ue, seg);
+                else if (!in_free && vpt_is_scattering(sc, obj)) c = c * exp_neg(sc.med[obj].u_e, seg);
+                o = o + d * seg;
+                depth -= seg;
+                if (depth <= 5e-5f || pass >= 6) arrived = true;            // at the light, or the seventh segment (vpt.py:113)
+                else walk_on = true;
+            }
+            if (arrived || blocked) {
+                if (!(c.x == 0.f && c.y == 0.f && c.z == 0.f)) {
+                    const uint32_t lo_ = ldq(q.sh_id, io);
+                    char* Lb = reinterpret_cast<char*>(q.L);
+                    atomicAdd(reinterpret_cast<float*>(Lb + lo_), c.x);
+                    atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 4 + lo_), c.y);
+                    atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 8 + lo_), c.z);
+                }
+                if (arrived) t_lit++;
+            }
+        }
+        if (list_out != nullptr) {
+            const uint32_t wpos = wave_append(walk_on, next_counter);
+            if (walk_on && wpos < q.sh_subcap) {
+                st3q(q.sh_o, sc_, io, o); stq(q.sh_tmax, io, depth); st3q(q.sh_c, sc_, io, c);
+                stq(list_out, (qbase + wpos) << 2, idx);
+            }
         }
     }
     flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);

@@ -13,10 +13,15 @@ out = sys.argv[1]
 
 
 def short(name):
-    for k in ("k_generate", "k_extend", "k_shade", "k_shadow", "k_finalize", "k_divide"):
+    for k in ("k_generate", "k_extend", "k_vshade", "k_vshadow", "k_shade", "k_shadow", "k_finalize", "k_divide"):
         if k in name:
             tag = k
-            if k in ("k_extend", "k_shadow"):
+            if k == "k_vshade":
+                import re
+                m = re.search(r"k_vshadeILi(\d+)ELi(\d+)E", name)
+                if m:
+                    tag += f"<bx=0x{int(m.group(1)):x},src=0x{int(m.group(2)):x}>"
+            if k in ("k_extend", "k_shadow", "k_vshadow"):
                 tag += "<sweep>" if "ILi1E" in name else ("<tile>" if "ILi2E" in name else "<bvh>")
             if k == "k_shade":
                 import re
