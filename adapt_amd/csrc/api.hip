@@ -509,6 +509,9 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         pl.lds_prims = ((size_t)n_prims * 48 <= budget / 2) ? n_prims : 0;
         size_t left = budget - (size_t)pl.lds_prims * 48;
         pl.lds_nodes = (int)std::min<size_t>((size_t)n_nodes, left / 64);
+#if !APT_BVH_STAGING
+        pl.lds_prims = 0; pl.lds_nodes = 0;                  // staging is compiled out of the walk (traverse.hpp)
+#endif
         r->plan = pl;
         r->lds_bytes = (size_t)pl.lds_nodes * 64 + (size_t)pl.lds_prims * 48 + stack_b;
         if (r->lds_bytes > 160 * 1024) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: BVH too deep for the LDS traversal stack"); }
