@@ -79,6 +79,7 @@ SYMBOLS = {
     "apt_occluded": (C.c_int, [C.c_void_p, C.c_int32, f32p, f32p, f32p, i32p]),
     "apt_rng_stream": (C.c_int, [C.c_int32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, u32p]),
     "apt_bxdf_probe": (C.c_int, [C.c_int32, C.c_int32, i32p, f32p, f32p, C.c_float, C.c_int32, C.c_uint32, f32p]),
+    "apt_medium_probe": (C.c_int, [C.c_int32, C.c_int32, i32p, f32p, C.c_int32, f32p, C.c_uint32, f32p]),
     "apt_emitter_probe": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_uint32, f32p]),
     "apt_texture_probe": (C.c_int, [C.c_void_p, C.c_int32, i32p, f32p, f32p]),
     "apt_renderer_info": (C.c_int, [C.c_void_p, i32p, i32p, C.POINTER(C.c_int64), i32p, C.POINTER(C.c_char_p), i32p]),

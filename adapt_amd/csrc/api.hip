@@ -923,6 +923,27 @@ APT_EXPORT int apt_bxdf_probe(int32_t device, int32_t n, const int32_t* bxdf_i, 
     HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * per * 4, hipMemcpyDeviceToHost));
     return APT_OK;
 }
+APT_EXPORT int apt_medium_probe(int32_t device, int32_t n, const int32_t* med_i, const float* med_f, int32_t mode, const float* in7, uint32_t seed, float* out8) {
+    if (n <= 0 || !med_i || !med_f || !in7 || !out8 || mode < 0 || mode > 2) return fail(APT_E_INVALID, "apt_medium_probe: bad argument");
+    int ndev = 0;
+    if (int rc = count_device(&ndev)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    std::vector<DevMedium> md((size_t)n);
+    for (int k = 0; k < n; k++) {
+        const float* f = med_f + 16 * (size_t)k; DevMedium& m = md[(size_t)k]; memset(&m, 0, sizeof(m));
+        m.type = med_i[k]; m.ior = f[0]; m.u_s = mk3(f[1], f[2], f[3]); m.u_a = mk3(f[4], f[5], f[6]); m.u_e = mk3(f[7], f[8], f[9]);
+        m.par = mk3(f[10], f[11], f[12]); m.pdf = mk3(f[13], f[14], f[15]);
+    }
+    std::vector<float> in(in7, in7 + (size_t)n * 7);
+    DevBuf dmed, din, dout;
+    HIP_TRY(upload(dmed, md)); HIP_TRY(upload(din, in)); HIP_TRY(dout.alloc((size_t)n * 32));
+    HIP_TRY(hipMemset(dout.p, 0, (size_t)n * 32));
+    hipLaunchKernelGGL(k_medium_probe, dim3((n + 63) / 64), dim3(64), 0, 0, n, dmed.as<DevMedium>(), mode, din.as<float>(), seed, dout.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out8, dout.p, (size_t)n * 32, hipMemcpyDeviceToHost));
+    return APT_OK;
+}
 APT_EXPORT int apt_emitter_probe(const apt_scene* sc, int32_t n, const float* in11, uint32_t seed, float* out12) {
     if (!sc || n <= 0 || !in11 || !out12) return fail(APT_E_INVALID, "apt_emitter_probe: bad argument");
     HIP_TRY(hipSetDevice(sc->device));

@@ -395,3 +395,26 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAVES
     flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);
     flush_stat(t_track, &cnt->stats[sl.q][ST_TRACK]);
 }
+
+// ------------------------------------------------------- unit entry kernel
+// Medium functions on explicit inputs (parity probe): one medium row and 7 input floats per test, 8 output floats; RNG = Philox
+// stream keyed by (test index, seed, 1).  mode 0 sample_mfp, 1 sample_new_rays, 2 phase value + transmittance.
+__global__ void k_medium_probe(int n, const DevMedium* med, int mode, const float* in7, uint32_t seed, float* out8) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const DevMedium m = med[k];
+    const float* x = in7 + 7 * k; float* y = out8 + 8 * k;
+    Philox r; rng_init(r, (uint32_t)k, seed, 1u, 0u);
+    if (mode == 0) {
+        float t; f3 beta; const bool is_mi = medium_sample_mfp(m, x[0], r, t, beta);
+        y[0] = is_mi ? 1.f : 0.f; y[1] = t; y[2] = beta.x; y[3] = beta.y; y[4] = beta.z; y[5] = (float)r.draw;
+    } else if (mode == 1) {
+        const f3 incid = ld3(x); f3 d = incid; float p = 1.f;
+        if (m.type >= 0) { const f3 local = phase_sample_p(m, incid, r, p); d = delocalize(incid, local); }
+        y[0] = d.x; y[1] = d.y; y[2] = d.z; y[3] = p; y[4] = p; y[5] = p; y[6] = p; y[7] = (float)r.draw;
+    } else {
+        y[0] = (m.type >= 0) ? phase_eval_p(m, ld3(x), ld3(x + 3)) : 1.f;
+        const f3 tr = exp_neg(m.u_e, x[6]);
+        y[1] = tr.x; y[2] = tr.y; y[3] = tr.z;
+    }
+}

@@ -27,7 +27,7 @@ from . import _lib
 from .scene_pack import FlatScene, RenderConfig, make_config, pack_scene
 from .tiles import TilePlan
 
-__all__ = ["Renderer", "VolumeRenderer", "DeviceScene", "bxdf_probe", "rng_stream"]
+__all__ = ["Renderer", "VolumeRenderer", "DeviceScene", "bxdf_probe", "medium_probe", "rng_stream"]
 
 
 def _fp(a):
@@ -48,6 +48,16 @@ def bxdf_probe(bxdf_i, bxdf_f, dirs12, world_ior: float = 1.0, sample: bool = Fa
     out = np.zeros((n, 9 if sample else 4), np.float32)
     _lib.check(lib.apt_bxdf_probe(int(device), n, _ip(bi), _fp(bf), _fp(dd), float(world_ior), int(bool(sample)), int(seed) & 0xffffffff, _fp(out)),
                "apt_bxdf_probe")
+    return out
+
+
+def medium_probe(med_i, med_f, mode: int, in7, seed: int = 0, device: int = 0) -> np.ndarray:
+    """apt_medium_probe: per test a medium row (type, 16 floats) and 7 inputs -> (n, 8); mode 0 sample_mfp, 1 sample_new_rays, 2 eval + transmittance"""
+    lib = _lib.load()
+    mi = np.ascontiguousarray(med_i, np.int32).reshape(-1); mf = np.ascontiguousarray(med_f, np.float32).reshape(-1, 16)
+    x = np.ascontiguousarray(in7, np.float32).reshape(-1, 7)
+    out = np.zeros((x.shape[0], 8), np.float32)
+    _lib.check(lib.apt_medium_probe(int(device), x.shape[0], _ip(mi), _fp(mf), int(mode), _fp(x), int(seed) & 0xffffffff, _fp(out)), "apt_medium_probe")
     return out
 
 

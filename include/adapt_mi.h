@@ -145,6 +145,12 @@ int apt_bxdf_probe(int32_t device, int32_t n, const int32_t* bxdf_i, const float
                    float world_ior, int32_t do_sample, uint32_t seed, float* out);
 /* Texture probe: map_obj[2k..] = map (0 albedo, 1 normal, 2 bump), object; uv[2k..]; out3[3k..] = Texture.query. */
 int apt_texture_probe(const apt_scene*, int32_t n, const int32_t* map_obj, const float* uv, float* out3);
+/* Medium probe (volumetric tracer; bxdf/medium.py:84-125, bxdf/phase.py): test k uses medium (med_i[k], med_f[16k..]) and in7[7k..].
+ * mode 0: Medium.sample_mfp, in = max_depth            -> out8[8k..] = is_mi, t, beta rgb, draws
+ * mode 1: Medium.sample_new_rays, in = incid xyz       -> dir xyz, phase value x3, pdf, draws
+ * mode 2: Medium.eval + transmittance, in = incid xyz, out xyz, depth -> phase value, transmittance rgb.  RNG as above. */
+int apt_medium_probe(int32_t device, int32_t n, const int32_t* med_i, const float* med_f, int32_t mode, const float* in7,
+                     uint32_t seed, float* out8);
 /* Emitter probe: in11[11k..] = source index, hit_pos, normal, ray_d, min_depth;
  * out12[12k..] = sampled pos, intensity (/pdf), pdf, draws, eval_le rgb, solid_angle_pdf; RNG as above. */
 int apt_emitter_probe(const apt_scene*, int32_t n, const float* in11, uint32_t seed, float* out12);

@@ -269,3 +269,15 @@ def philox(counter4, key2):
     out = (C.c_uint32 * 4)()
     lib().orc_philox(c, k, out)
     return [int(x) for x in out]
+
+
+def medium_probe(med_type, med_f16, mode, vec, key=0, seed=0):
+    """orc_medium_probe: mode 0 sample_mfp (vec = [max_depth]) -> 6 floats; 1 sample_new_rays (vec = incid) -> 8; 2 eval + transmittance
+    (vec = incid, out, depth) -> 4"""
+    L = lib()
+    L.orc_medium_probe.argtypes = [C.c_int, f32p, C.c_int, f32p, C.c_uint32, C.c_uint32, f32p]
+    L.orc_medium_probe.restype = None
+    f = np.ascontiguousarray(med_f16, np.float32); x = np.ascontiguousarray(vec, np.float32)
+    out = np.zeros((6, 8, 4)[mode], np.float32)
+    L.orc_medium_probe(int(med_type), _fp(f), int(mode), _fp(x), C.c_uint32(key), C.c_uint32(seed), _fp(out))
+    return out

@@ -1852,6 +1852,25 @@ ORC_API void orc_bxdf_sample(const int bi[4], const float bf[13], float world_io
     }
     st3(dir_out, dir); st3(spec_out, spec); *pdf_out = pdf; *is_specular = sp; *n_draws = (int)r.draw;
 }
+/* Medium functions on explicit inputs (bxdf/medium.py:84-125); RNG = Philox stream (key, seed), sample 1.
+ * mode 0  sample_mfp       in = max_depth                  out = is_mi, t, beta rgb, draws
+ * mode 1  sample_new_rays  in = incid xyz                  out = dir xyz, spec rgb, pdf, draws
+ * mode 2  eval + transmit  in = incid xyz, out xyz, depth  out = phase value, transmittance rgb */
+ORC_API void orc_medium_probe(int type, const float f[16], int mode, const float* in, uint32_t key, uint32_t seed, float* out) {
+    medium_t m; m.type = type; m.ior = f[0];
+    m.u_s = LD3(f + 1); m.u_a = LD3(f + 4); m.u_e = LD3(f + 7); m.par = LD3(f + 10); m.pdf = LD3(f + 13);
+    rng_t r; unit_rng(&r, NULL, 0, key, seed);
+    if (mode == 0) {
+        float t; v3 beta; int is_mi = medium_sample_mfp(&m, in[0], &r, &t, &beta);
+        out[0] = (float)is_mi; out[1] = t; st3(out + 2, beta); out[5] = (float)r.draw;
+    } else if (mode == 1) {
+        v3 spec; float pdf; v3 d = medium_sample_new_rays(&m, LD3(in), &r, &spec, &pdf);
+        st3(out, d); st3(out + 3, spec); out[6] = pdf; out[7] = (float)r.draw;
+    } else {
+        out[0] = (m.type >= 0) ? phase_eval_p(&m, LD3(in), LD3(in + 3)) : 1.f;
+        st3(out + 1, medium_transmittance(&m, in[6]));
+    }
+}
 ORC_API void orc_rotation_between(const float a[3], const float b[3], float R_out[9]) {
     m3 R; rotation_between(LD3(a), LD3(b), &R);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R_out[3 * i + j] = R.m[i][j];

@@ -196,6 +196,54 @@ def gen_functions():
 
 
 # ---------------------------------------------- scene-bound functions + images
+
+def gen_media_functions():
+    """Medium.sample_mfp / transmittance / sample_new_rays / eval (bxdf/medium.py:84-125) and the phase functions behind them
+    (bxdf/phase.py, sampler/phase_sampling.py) on the shared Philox stream: key = test index, seeds 779 (free path) / 780 (scatter)."""
+    from bxdf.medium import Medium
+    from bxdf.phase import PhaseFunction
+    media = [   # type, ior, u_s, u_a, par, pdf
+        (0, 1.0, [1.2, 1.0, 0.8], [0.15] * 3, [0.6] * 3, [1, 0, 0]),                    # forward H-G, coloured
+        (0, 1.0, [1.5] * 3, [0.2] * 3, [0.0] * 3, [1, 0, 0]),                           # isotropic branch of sample_hg (|g| < 1e-4)
+        (0, 1.33, [0.05, 2.5, 0.4], [0.0, 0.1, 1.0], [-0.75] * 3, [1, 0, 0]),           # back-scattering, very different channels
+        (1, 1.0, [0.05, 0.06, 0.08], [0.01] * 3, [0.7, -0.3, 0.1], [0.5, 0.3, 0.2]),    # three lobes
+        (1, 1.0, [0.9] * 3, [0.1] * 3, [0.8, -0.2, 0.0], [0.7, 0.3, 0.0]),              # two lobes (third weight 0; pdf[1] > 1e-4 still adds lobe 3)
+        (1, 1.0, [0.9] * 3, [0.1] * 3, [0.5, 0.2, 0.9], [1.0, 0.0, 0.0]),               # pdf[1] = 0: the third lobe is skipped in eval
+        (2, 1.5, [0.6, 0.9, 1.4], [0.05] * 3, [0] * 3, [1, 0, 0]),                      # Rayleigh
+        (3, 1.0, [1.0] * 3, [0.1] * 3, [0] * 3, [1, 0, 0]),                             # mie: no phase function upstream
+        (-1, 1.5, [0] * 3, [0] * 3, [0] * 3, [1, 0, 0]),                                # transparent
+        (0, 1.0, [0.0, 0.0, 2.0], [0.0] * 3, [0.3] * 3, [1, 0, 0]),                     # u_e = 0 in two channels: the 1e-5 floor of random_rgb
+    ]
+    med_i, med_f, objs = [], [], []
+    for t, ior, us, ua, par, pdf in media:
+        us, ua, par, pdf = np.float32(us), np.float32(ua), np.float32(par), np.float32(pdf)
+        ue = us + ua
+        med_i.append(t); med_f.append(np.concatenate([[ior], us, ua, ue, par, pdf]))
+        objs.append(Medium(_type=t, ior=ior, u_a=vec3(ua), u_s=vec3(us), u_e=vec3(ue), ph=PhaseFunction(_type=t, par=vec3(par), pdf=vec3(pdf))))
+    mfp_in, mfp_out, sc_in, sc_out, ev_in, ev_out = [], [], [], [], [], []
+    for mi, m in enumerate(objs):
+        for k in range(24):
+            depth = np.float32(10.0 ** RS.uniform(-2, 1.3))
+            ti.RNG.set_philox(len(mfp_in), 779, 1)
+            is_mi, t, beta = m.sample_mfp(depth)
+            mfp_in.append([mi, depth]); mfp_out.append(np.concatenate([[float(bool(is_mi)), t], np.float32(beta.to_numpy()), [ti.RNG.draw]]))
+            incid, outd = rand_dir(), rand_dir()
+            if k % 6 == 0:
+                outd = incid.copy()                       # straight on (cos = -1 for eval_p)
+            if k % 6 == 1:
+                outd = -incid
+            ti.RNG.set_philox(len(sc_in), 780, 1)
+            d, s, pdf = m.sample_new_rays(vec3(incid))
+            sc_in.append(np.concatenate([[mi], incid])); sc_out.append(np.concatenate([np.float32(d.to_numpy()), np.float32(s.to_numpy()), [pdf, ti.RNG.draw]]))
+            p = m.eval(vec3(incid), vec3(outd)) if m.is_scattering() else np.float32(1.0)
+            tr = m.transmittance(depth)
+            ev_in.append(np.concatenate([[mi], incid, outd, [depth]])); ev_out.append(np.concatenate([[p], np.float32(tr.to_numpy())]))
+    np.savez_compressed(os.path.join(OUT, "media_functions.npz"), med_i=np.int32(med_i), med_f=np.float32(med_f),
+                        mfp_in=np.float32(mfp_in), mfp_out=np.float32(mfp_out), scat_in=np.float32(sc_in), scat_out=np.float32(sc_out),
+                        eval_in=np.float32(ev_in), eval_out=np.float32(ev_out))
+    print(f"media_functions: {len(objs)} media, {len(mfp_in)} vectors each; medium events {int(np.float32(mfp_out)[:, 0].sum())}")
+
+
 def gen_scene(scene_dir, xml, tag, w, h, spp, overrides, seed=0, n_rays=192):
     ov = dict(overrides); ov.update(width=w, height=h)
     t0 = time.time()
@@ -359,6 +407,8 @@ if __name__ == "__main__":
                 gen_refscene(sdir, xml, tag, 32, 24, 2)
             except Exception as e:                      # missing mesh / texture / volume assets: not loadable here
                 print(f"refscene_{tag}: SKIPPED ({type(e).__name__}: {str(e)[:120]})")
+    if a.only in ("all", "func", "media"):
+        gen_media_functions()
     if a.only in ("all", "vpt"):
         # the reference's volumetric scenes (homogeneous media) through its own VolumeRenderer.render
         for sdir, xml, ov in (("vpt", "cbox.xml", {}), ("vpt", "balls.xml", {"max_bounce": 12}), ("vpt", "volbox.xml", {})):

@@ -615,3 +615,27 @@ def test_surface_tracer_ignores_media_like_the_reference():
     m = image_metrics(pa / spp, ref / spp)
     assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-3, m
     assert float(np.abs(pa - pb).mean()) > 1e-2
+
+
+def test_medium_functions_vs_reference_vectors():
+    """Free-path sampling, phase sampling / evaluation and transmittance on the device against the reference-run vectors: decisions
+    (medium event or not, draws consumed) exact, floats to the per-call tolerance (device expf / logf / double-precision sincos
+    against glibc's float functions)."""
+    from adapt_amd.renderer import medium_probe
+    g = golden("media_functions.npz")
+    mi, mf = g["med_i"], g["med_f"]
+    x = g["mfp_in"]; m = np.int32(x[:, 0])
+    in7 = np.zeros((x.shape[0], 7), np.float32); in7[:, 0] = x[:, 1]
+    out = medium_probe(mi[m], mf[m], 0, in7, seed=779)
+    y = g["mfp_out"]
+    assert np.array_equal(out[:, 0], y[:, 0]) and np.array_equal(out[:, 5], y[:, 5])          # same events, same number of draws
+    assert close(out[:, 1:5], y[:, 1:5], rel=2e-5)     # a free path is -log(1 - eps) / u_e: relative error of logf near eps -> 0 is amplified
+    x = g["scat_in"]; m = np.int32(x[:, 0])
+    in7 = np.zeros((x.shape[0], 7), np.float32); in7[:, :3] = x[:, 1:4]
+    out = medium_probe(mi[m], mf[m], 1, in7, seed=780)
+    y = g["scat_out"]
+    assert np.array_equal(out[:, 7], y[:, 7])
+    assert close(out[:, :3], y[:, :3], rel=1e-5, abs_=2e-6) and close(out[:, 3:7], y[:, 3:7], rel=1e-5)
+    x = g["eval_in"]; m = np.int32(x[:, 0])
+    out = medium_probe(mi[m], mf[m], 2, x[:, 1:8])
+    assert close(out[:, :4], g["eval_out"], rel=1e-5)

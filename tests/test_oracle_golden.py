@@ -167,3 +167,26 @@ def test_volumetric_whole_kernel_matches_reference_run(tag):
     # and the surface-only renderer on the same scene is a different estimator (media ignored): the flag matters
     acc0 = osc.render(make_config(tup[3], seed=int(g["seed"]), use_bvh=False), int(g["spp"]))[0]
     assert not np.array_equal(acc0, acc)
+
+
+def test_medium_functions_bit_exact():
+    """Medium.sample_mfp / sample_new_rays / eval / transmittance of the reference (ten media: H-G forward, isotropic and backward,
+    three multi-H-G weightings, Rayleigh, mie, transparent, zero extinction in two channels) on the shared Philox stream."""
+    g = golden("media_functions.npz")
+    mi, mf = g["med_i"], g["med_f"]
+    assert set(mi.tolist()) == {-1, 0, 1, 2, 3}
+    events = 0
+    for k, (x, y) in enumerate(zip(g["mfp_in"], g["mfp_out"])):
+        m = int(x[0])
+        out = ob.medium_probe(mi[m], mf[m], 0, [x[1]], key=k, seed=779)
+        assert np.array_equal(out.view(np.uint32), y.view(np.uint32)), (m, k, out, y)
+        events += int(y[0])
+    assert 40 < events < 200                           # both outcomes of the free-path draw are exercised
+    for k, (x, y) in enumerate(zip(g["scat_in"], g["scat_out"])):
+        m = int(x[0])
+        out = ob.medium_probe(mi[m], mf[m], 1, x[1:4], key=k, seed=780)
+        assert np.array_equal(out.view(np.uint32), y.view(np.uint32)), (m, k, out, y)
+    for k, (x, y) in enumerate(zip(g["eval_in"], g["eval_out"])):
+        m = int(x[0])
+        out = ob.medium_probe(mi[m], mf[m], 2, x[1:8])
+        assert np.array_equal(out.view(np.uint32), y.view(np.uint32)), (m, k, out, y)
