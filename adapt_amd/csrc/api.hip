@@ -24,6 +24,7 @@
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY_VOID(expr) do { hipError_t e__ = (expr); (void)e__; } while (0)
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -72,6 +73,7 @@ typedef void (*extend_fn)(DevScene, Params, Queues, Counters*, int, const uint32
 typedef void (*shadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan);
 typedef void (*occluded_fn)(DevScene, uint32_t, const float*, const float*, const float*, int*, LdsPlan);
 static const extend_fn kExtend[3][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_extend<1, 0>, k_extend<1, 1>}, {k_extend<2, 0>, k_extend<2, 1>}};   // [mode][sorted]
+static const extend_fn kExtendDyn[2] = {k_extend_dyn<0>, k_extend_dyn<1>};      // BVH walk with dynamic ray fetch [sorted]
 static const shadow_fn kShadow[3] = {k_shadow<0>, k_shadow<1>, k_shadow<2>};
 static const occluded_fn kOccluded[3] = {k_occluded<0>, k_occluded<1>, k_occluded<2>};
 typedef void (*vshade_fn)(DevScene, Params, Queues, Counters*, int);
@@ -134,6 +136,7 @@ struct apt_renderer {
     int trace_nt = BLOCK;         // workgroup size of the trace kernels
     int sorted = 0;               // 1 = material-sorted shading (>= 2 material classes in the scene)
     int volumetric = 0;           // 1 = VolumeRenderer.render semantics (volumetric.hpp)
+    int dyn_fetch = 0;            // BVH mode: closest-hit walk with dynamic ray fetch (k_extend_dyn)
     const VShadeVariant* vshade = nullptr;
     shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string shade_name;
@@ -540,6 +543,12 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
             HIP_TRY(hipFuncSetAttribute((const void*)kVShadow[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         }
     }
+    r->dyn_fetch = (r->trace_mode == 0) ? 1 : 0;         // BVH scenes: closest-hit walk with dynamic ray fetch
+    if (const char* f = getenv("APT_DYN_FETCH")) r->dyn_fetch = (atoi(f) != 0 && r->trace_mode == 0) ? 1 : 0;
+    if (r->dyn_fetch && r->lds_bytes > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+    }
     r->grid_small = cus * 8;       // streaming stages: up to 8 x 256-thread workgroups per CU
     if (const char* g = getenv("APT_GRID_SMALL")) r->grid_small = cus * std::max(1, atoi(g));       // tuning knobs: workgroups per CU
     if (const char* g = getenv("APT_GRID_TRACE")) r->grid_trace = cus * std::max(1, atoi(g));
@@ -636,7 +645,8 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
             const Queues& q = is.li ? r->extra[(size_t)is.li - 1].q : r->q;
             Counters* cnt = is.li ? r->extra[(size_t)is.li - 1].counters.as<Counters>() : r->counters.as<Counters>();
             for (int b = 0; b < n_iter; b++) {
-                { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(kExtend[r->trace_mode][0], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], r->plan); }
+                if (r->dyn_fetch) HIP_TRY_VOID(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st));
+                { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[0] : kExtend[r->trace_mode][0], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], r->plan); }
                 { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vshade->fn, dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, is.cur); }
                 if (is.p.S > 0) {
                     const int n_pass = r->scene->has_null_surface ? 7 : 1;       // track_ray walks at most seven segments (vpt.py:113)
@@ -708,7 +718,8 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
         { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, p, q, cnt); }
         int cur = 0;
         for (int b = 0; b < p.max_bounce; b++) {
-            { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
+            if (r->dyn_fetch) HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st));
+            { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
             if (!r->sorted) {
                 ShadeIn in = {q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.id[cur], q.meta[cur], q.pdf[cur],
                               q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur]};

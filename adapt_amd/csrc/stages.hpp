@@ -119,6 +119,7 @@ struct Counters {
     uint32_t n_shadow[APT_MAX_NQ * CNT_PAD];
     uint32_t n_walk[8][APT_MAX_NQ * CNT_PAD];     // volumetric: light samples still walking after pass p-1 (pass p reads list p, fills list p + 1)
     uint32_t n_cls[8][APT_MAX_NQ * CNT_PAD];
+    uint32_t n_work[2][APT_MAX_NQ * CNT_PAD];     // BVH walk with dynamic fetch: next unclaimed queue position (0 extend, 1 shadow); zeroed by the host before the launch
     unsigned long long stats[APT_MAX_NQ][16];    // [q][ST_*], 128 bytes per sub-queue
 #ifdef APT_SHADE_PROF
     unsigned long long dbg[2 * 16384];           // per-wave (start, end) of the last k_shade launch, 100 MHz ticks
@@ -340,6 +341,113 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 }
 
 
+
+// ------------------------------------------------------- extend, BVH walk with dynamic ray fetch
+// Incoherent rays need very different numbers of traversal steps, and in the plain persistent loop a wave is as slow as its slowest
+// ray: lanes that have finished idle until the last one is done.  Here a wave keeps walking only while at least APT_DYN_MIN_ACTIVE
+// of its lanes still hold a ray; when fewer do, the finished lanes hand in their results and claim fresh rays from the sub-queue's
+// work counter (one atomic per wave), so the walk loops always run with a mostly full wave (Aila & Laine's "persistent threads with
+// dynamic fetch", re-cut for 64-wide waves and an LDS stack).  Per-ray arithmetic and the visiting order inside a ray are those of
+// traverse<false>; only the assignment of rays to lanes changes, and hits are written to the ray's own slot.
+#ifndef APT_DYN_MIN_ACTIVE
+#define APT_DYN_MIN_ACTIVE 40
+#endif
+template <int SORTED>
+__global__ void __launch_bounds__(BLOCK) k_extend_dyn(DevScene sc, Params p, Queues q, Counters* cnt, int cur_q, const uint32_t* n_src, LdsPlan plan) {
+    StagedBvh bvh;
+    int* stack = carve_lds(sc.bvh, plan, bvh);
+    const int stride = BLOCK;
+    const int sq = (int)(blockIdx.x % (uint32_t)p.nq);
+    const uint32_t n = n_src[sq * CNT_PAD];
+    if (blockIdx.x / (uint32_t)p.nq == 0 && threadIdx.x == 0) {
+        cnt->n_shadow[sq * CNT_PAD] = 0; cnt->n_active[cur_q ^ 1][sq * CNT_PAD] = 0;
+        for (int w = 0; w < 8; w++) cnt->n_walk[w][sq * CNT_PAD] = 0;
+        cnt->stats[sq][ST_EXTEND] += n;
+    }
+    uint32_t* work = &cnt->n_work[0][sq * CNT_PAD];
+    const float* ro = q.ray_o[cur_q]; const float* rd = q.ray_d[cur_q];
+    const uint32_t qbase = (uint32_t)sq * p.subcap;
+    // per-lane ray state
+    int state = 0;                              // 0 no ray, 1 walking, 2 finished (result not yet handed in)
+    uint32_t io = 0;
+    f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), inv_d = splat3(1.f);
+    HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
+    int sp = 0, cur = APT_TRAV_DONE;
+    bool exhausted = false;                     // wave-uniform: the work counter has run past the queue
+    for (;;) {
+        // ---- hand in finished rays (all lanes take part: the class appends are ballot-compacted)
+        const bool fin = state == 2;
+        if (!SORTED) {
+            if (fin) { stq(q.hit_t, io, rec.t); stq(q.hit_prim, io, rec.prim); stq(q.hit_u, io, rec.u); stq(q.hit_v, io, rec.v); }
+        } else if (__any(fin)) {
+            const int cls = (fin && rec.prim >= 0) ? sc.prim_class[rec.prim] : -1;
+            for (int c = 0; c < q.n_classes; c++) {
+                const bool mine = cls == c;
+                const uint32_t cpos = wave_append(mine, &cnt->n_cls[c][sq * CNT_PAD]);
+                if (mine) {
+                    const Queues::ClassQ& k = q.cls[c];
+                    const uint32_t so = (qbase + cpos) << 2;
+                    st3q(k.ray_o, p.cap, so, o);
+                    st3q(k.ray_d, p.cap, so, d);
+                    st3q(k.thr, p.cap, so, ld3q(q.thr[cur_q], p.cap, io));
+                    stq(k.id, so, ldq(q.id[cur_q], io)); stq(k.meta, so, ldq(q.meta[cur_q], io)); stq(k.pdf, so, ldq(q.pdf[cur_q], io));
+                    stq(k.t, so, rec.t); stq(k.prim, so, rec.prim); stq(k.u, so, rec.u); stq(k.v, so, rec.v);
+                }
+            }
+        }
+        if (fin) state = 0;
+        // ---- claim fresh rays for the idle lanes
+        if (!exhausted) {
+            const bool need = state == 0;
+            const unsigned long long m = __ballot(need);
+            uint32_t base = 0;
+            if (lane_id() == 0 && m) base = atomicAdd(work, (uint32_t)__popcll(m));
+            base = __shfl(base, 0);
+            const uint32_t pos = base + rank_in(m);
+            if (need && pos < n) {
+                io = (qbase + pos) << 2;
+                o = ld3q(ro, p.cap, io); d = ld3q(rd, p.cap, io);
+                inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
+                sp = 0; cur = 0; state = 1;
+            }
+            if (base + (uint32_t)__popcll(m) >= n) exhausted = true;
+        }
+        if (!__any(state == 1)) break;
+        // ---- walk: the while-while loop of traverse<false>, left as soon as too few lanes still hold a ray
+        const uint32_t min_active = exhausted ? 1u : (uint32_t)APT_DYN_MIN_ACTIVE;
+        do {
+            while (cur >= 0) {
+                float4 q0 = bvh.node(cur, 0), q1 = bvh.node(cur, 1), q2 = bvh.node(cur, 2), q3 = bvh.node(cur, 3);
+                float tl = box_entry(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, inv_d, rec.t);
+                float tr = box_entry(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, inv_d, rec.t);
+                int l = __float_as_int(q3.x), r = __float_as_int(q3.y);
+                bool hl = tl >= 0.f, hr = tr >= 0.f;
+                if (hl && hr) {
+                    bool swap = tr < tl;
+                    stack[sp * stride] = swap ? l : r; sp++;
+                    cur = swap ? r : l;
+                } else if (hl) cur = l;
+                else if (hr) cur = r;
+                else if (sp > 0) { sp--; cur = stack[sp * stride]; }
+                else cur = APT_TRAV_DONE;
+            }
+            while (cur < 0 && cur != APT_TRAV_DONE) {
+                int code = ~cur;
+                int first = code >> 4, count = code & 15;
+                for (int k = 0; k < count; k++) {
+                    float4 p0 = bvh.prim(first + k, 0), p1 = bvh.prim(first + k, 1), p2 = bvh.prim(first + k, 2);
+                    float u, v;
+                    float t = prim_test(p0, p1, p2, o, d, u, v);
+                    if (t > 1e-4f && t < rec.t) { rec.t = t; rec.prim = __float_as_int(p2.y); rec.u = u; rec.v = v; }
+                }
+                if (sp > 0) { sp--; cur = stack[sp * stride]; }
+                else cur = APT_TRAV_DONE;
+            }
+            if (state == 1 && cur == APT_TRAV_DONE) state = 2;
+        } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
+    }
+}
 
 // ----------------------------------------------------------------- textures
 // Taichi's float `a % b` is a - b * floor(a / b) (python/taichi/lang/ops.py, mod)
