@@ -548,6 +548,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (r->dyn_fetch && r->lds_bytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_shadow_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
     }
     r->grid_small = cus * 8;       // streaming stages: up to 8 x 256-thread workgroups per CU
     if (const char* g = getenv("APT_GRID_SMALL")) r->grid_small = cus * std::max(1, atoi(g));       // tuning knobs: workgroups per CU
@@ -732,7 +733,10 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
                 }
                 if (p.S <= 0) HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st));      // normally k_shadow recycles these
             }
-            if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, r->plan); }
+            if (p.S > 0 && r->dyn_fetch) {
+                HIP_TRY(hipMemsetAsync(cnt->n_work[1], 0, sizeof(cnt->n_work[1]), st));
+                LaunchTimer t(r, 3, st); hipLaunchKernelGGL(k_shadow_dyn, dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, r->plan);
+            } else if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, r->plan); }
             cur ^= 1;
         }
         // the framebuffer is shared: batch k's samples are added after batch k-1's, whichever lanes they ran on

@@ -750,6 +750,97 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
     flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);
 }
 
+// ------------------------------------------------------- shadow, BVH walk with dynamic ray fetch
+// Any-hit twin of k_extend_dyn: a lane leaves the walk at its first occluder or when its stack runs empty, adds its contribution if
+// unoccluded, and claims the next shadow ray as soon as the wave runs low on walking lanes.
+__global__ void __launch_bounds__(BLOCK) k_shadow_dyn(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
+    StagedBvh bvh;
+    int* stack = carve_lds(sc.bvh, plan, bvh);
+    const int stride = BLOCK;
+    const int sq = (int)(blockIdx.x % (uint32_t)p.nq);
+    const uint32_t n = min(cnt->n_shadow[sq * CNT_PAD], q.sh_subcap);
+    if (blockIdx.x / (uint32_t)p.nq == 0 && threadIdx.x == 0) {
+        cnt->stats[sq][ST_SHADOW_TRACED] += n;
+        for (int c = 0; c < q.n_classes; c++) cnt->n_cls[c][sq * CNT_PAD] = 0;      // every shade of this bounce is done
+    }
+    uint32_t* work = &cnt->n_work[1][sq * CNT_PAD];
+    const uint32_t qbase = (uint32_t)sq * q.sh_subcap, sc_ = q.sh_cap;
+    int state = 0;                              // 0 no ray, 1 walking, 2 finished
+    bool occluded = false;
+    uint32_t io = 0;
+    f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), inv_d = splat3(1.f);
+    float tmax = 0.f;
+    int sp = 0, cur = APT_TRAV_DONE;
+    bool exhausted = false;
+    uint32_t t_lit = 0;
+    for (;;) {
+        if (state == 2) {
+            f3 c = ld3q(q.sh_c, sc_, io);
+            const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));       // see k_shadow
+            if (occluded && weird) c = c * 0.f;
+            if (!occluded || weird) {
+                const uint32_t lo_ = ldq(q.sh_id, io);
+                char* Lb = reinterpret_cast<char*>(q.L);
+                atomicAdd(reinterpret_cast<float*>(Lb + lo_), c.x);
+                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 4 + lo_), c.y);
+                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 8 + lo_), c.z);
+            }
+            if (!occluded) t_lit++;
+            state = 0;
+        }
+        if (!exhausted) {
+            const bool need = state == 0;
+            const unsigned long long m = __ballot(need);
+            uint32_t base = 0;
+            if (lane_id() == 0 && m) base = atomicAdd(work, (uint32_t)__popcll(m));
+            base = __shfl(base, 0);
+            const uint32_t pos = base + rank_in(m);
+            if (need && pos < n) {
+                io = (qbase + pos) << 2;
+                o = ld3q(q.sh_o, sc_, io); d = ld3q(q.sh_d, sc_, io);
+                const float dist = ldq(q.sh_tmax, io);
+                tmax = (dist > 0.0f) ? dist - 1e-4f : 1e7f;
+                inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                occluded = false; sp = 0; cur = 0; state = 1;
+            }
+            if (base + (uint32_t)__popcll(m) >= n) exhausted = true;
+        }
+        if (!__any(state == 1)) break;
+        const uint32_t min_active = exhausted ? 1u : (uint32_t)APT_DYN_MIN_ACTIVE;
+        do {
+            while (cur >= 0) {
+                float4 q0 = bvh.node(cur, 0), q1 = bvh.node(cur, 1), q2 = bvh.node(cur, 2), q3 = bvh.node(cur, 3);
+                float tl = box_entry(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, inv_d, tmax);
+                float tr = box_entry(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, inv_d, tmax);
+                int l = __float_as_int(q3.x), r = __float_as_int(q3.y);
+                bool hl = tl >= 0.f, hr = tr >= 0.f;
+                if (hl && hr) {
+                    bool swap = tr < tl;
+                    stack[sp * stride] = swap ? l : r; sp++;
+                    cur = swap ? r : l;
+                } else if (hl) cur = l;
+                else if (hr) cur = r;
+                else if (sp > 0) { sp--; cur = stack[sp * stride]; }
+                else cur = APT_TRAV_DONE;
+            }
+            while (cur < 0 && cur != APT_TRAV_DONE) {
+                int code = ~cur;
+                int first = code >> 4, count = code & 15;
+                for (int k = 0; k < count; k++) {
+                    float4 p0 = bvh.prim(first + k, 0), p1 = bvh.prim(first + k, 1), p2 = bvh.prim(first + k, 2);
+                    float u, v;
+                    float t = prim_test(p0, p1, p2, o, d, u, v);
+                    if (t > 1e-4f && t < tmax) { occluded = true; sp = 0; break; }      // first occluder ends the walk
+                }
+                if (sp > 0) { sp--; cur = stack[sp * stride]; }
+                else cur = APT_TRAV_DONE;
+            }
+            if (state == 1 && cur == APT_TRAV_DONE) state = 2;
+        } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
+    }
+    flush_stat(t_lit, &cnt->stats[sq][ST_LIT]);
+}
+
 // ----------------------------------------------------------------- finalize
 // one thread per owned pixel: samples summed in sample order -> bit-reproducible, no atomics
 __global__ void __launch_bounds__(BLOCK) k_finalize(Params p, Queues q, float* accum) {
