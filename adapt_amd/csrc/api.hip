@@ -290,6 +290,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         s->src_mask |= 1 << (e.type & 7);
         e.intensity = mk3(sf[0], sf[1], sf[2]); e.dir = mk3(sf[3], sf[4], sf[5]); e.pos = mk3(sf[6], sf[7], sf[8]); e.inv_area = sf[9]; e.r = sf[10];
         if (e.type == 1 && (e.obj_ref_id < 0 || e.obj_ref_id >= O)) { delete s; return fail(APT_E_INVALID, "apt_scene_create: area emitter is not attached to an object"); }
+        if (e.type == 1) { e.prim_first = d->obj_info[3 * e.obj_ref_id]; e.prim_count = d->obj_info[3 * e.obj_ref_id + 2] ? -1 : d->obj_info[3 * e.obj_ref_id + 1]; }
     }
     std::vector<float> nrm(d->normals, d->normals + (size_t)N * 3);
     std::vector<float> vn((size_t)N * 9, 0.f);

@@ -22,9 +22,11 @@ struct DevBxdf {          // one per object: bxdf/brdf.py:152-158 | bxdf/bsdf.py
     float _pad2[3];
 };
 struct DevSrc {           // emitters/abtract_source.py:44-54
-    int type, bool_bits, obj_ref_id, _pad;
-    f3 intensity, dir, pos;
-    float inv_area, r, _pad2;
+    int type, bool_bits, obj_ref_id;
+    int prim_first;       // area emitters: first primitive of the attached object (copied from obj_info at scene creation, so that
+    f3 intensity, dir, pos;   // sampling the emitter does not chase obj_info -> primitive through two dependent loads)
+    float inv_area, r;
+    int prim_count;       // area emitters: triangles of the attached mesh, or -1 for a sphere
 };
 struct Hit {              // tracer/interaction.py:11-39 minus texture/uv members
     int obj_id, prim_id;
@@ -537,9 +539,8 @@ APT_D f3 emitter_sample_hit(const DevSrc& s, const EmitterGeom& g, f3 hit_pos, P
     } else if (BXHAS(SM, 1) && s.type == 1) {
         pdf = s.inv_area;
         f3 normal;
-        const int* oi = g.obj_info + 3 * s.obj_ref_id;
-        if (oi[2]) {
-            const float* pc = g.precom + 9 * oi[0];
+        if (s.prim_count < 0) {
+            const float* pc = g.precom + 9 * s.prim_first;
             f3 center = ld3(pc);
             float radius = pc[3];
             f3 to_hit = normalize(hit_pos - center);
@@ -549,7 +550,7 @@ APT_D f3 emitter_sample_hit(const DevSrc& s, const EmitterGeom& g, f3 hit_pos, P
             pos = center + normal * radius;
             pdf = p / (radius * radius);
         } else {
-            int tri = pymod(rng_int(r), oi[1]) + oi[0];
+            int tri = pymod(rng_int(r), s.prim_count) + s.prim_first;
             normal = ld3(g.normals + 3 * tri);
             const float* pc = g.precom + 9 * tri;
             pos = sample_on_triangle(r, ld3(pc), ld3(pc + 3)) + ld3(pc + 6);

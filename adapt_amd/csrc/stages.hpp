@@ -173,6 +173,16 @@ APT_D void flush_stat(uint32_t v, unsigned long long* counter) {
     if (lane_id() == 0 && v) atomicAdd(counter, (unsigned long long)v);
 }
 
+// An emitter record through the constant address space: with a wave-uniform address (scenes with one light) the backend emits
+// scalar loads into SGPRs, outside the light-sample loop, instead of a 64-byte per-lane fetch at the head of every sample's
+// dependent chain (record -> triangle pick -> vertices).
+APT_D DevSrc ld_src_uniform(const DevSrc* p) {
+    const ci_ptr w = (ci_ptr)reinterpret_cast<const int*>(p);
+    DevSrc s; int* dst = reinterpret_cast<int*>(&s);
+    for (int k = 0; k < (int)(sizeof(DevSrc) / 4); k++) dst[k] = w[k];
+    return s;
+}
+
 // local pixel -> (global column, row)
 APT_D void local_to_global(const Params& p, uint32_t lp, int& i, int& j) {
     int lc = (int)(lp / (uint32_t)p.H);
@@ -501,7 +511,7 @@ APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3
 // it): inlined into the specialised kernels the lookup costs e.g. the mod-Phong class kernel its fourth wave per SIMD
 // (126 -> 129 VGPRs) in every scene WITHOUT textures, and out of line it costs a call frame in scratch.
 template <int BM, int SM, int TEX = 0>
-__global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
+__global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
     const uint32_t n = in.counts[sl.q * CNT_PAD];
@@ -592,6 +602,8 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
 
         // ---- next-event estimation: one shadow-queue entry per useful light sample
         bool break_flag = false;
+        DevSrc src_only;                                      // the scene's only light, read once through the scalar path
+        if (sc.n_sources == 1) src_only = ld_src_uniform(sc.src);
         for (int s = 0; s < p.S; s++) {
             bool want = false, sampled = false, poisoned = false;
             f3 light_dir = splat3(0.f), contrib = splat3(0.f);
@@ -614,7 +626,7 @@ __global__ void __launch_bounds__(BLOCK, APT_SHADE_WAVES) k_shade(DevScene sc, P
                 }
                 if (!valid) break_flag = true;
                 else {
-                    const DevSrc src = sc.src[sidx];
+                    const DevSrc src = (ns == 1) ? src_only : sc.src[sidx];
                     f3 shadow_int; float direct_pdf;
                     f3 emit_pos = emitter_sample_hit<SM>(src, geom, hit_point, rng, shadow_int, direct_pdf);
                     f3 to_emitter = emit_pos - hit_point;

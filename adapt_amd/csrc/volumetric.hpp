@@ -200,6 +200,8 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x402 ? APT_VSHADE_LEAN_WAVES : 
 
         // ---- Step 4: light sampling; the transmittance along the sample is k_vshadow's job
         bool break_flag = false;
+        DevSrc src_only;
+        if (sc.n_sources == 1) src_only = ld_src_uniform(sc.src);
         for (int s = 0; s < p.S; s++) {
             bool want = false, sampled = false, poisoned = false;
             f3 light_dir = splat3(0.f), contrib = splat3(0.f);
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x402 ? APT_VSHADE_LEAN_WAVES : 
                 }
                 if (!valid) break_flag = true;
                 else {
-                    const DevSrc src = sc.src[sidx];
+                    const DevSrc src = (ns == 1) ? src_only : sc.src[sidx];
                     f3 shadow_int; float direct_pdf;
                     const f3 emit_pos = emitter_sample_hit<SM>(src, geom, hit_point, rng, shadow_int, direct_pdf);
                     const f3 to_emitter = emit_pos - hit_point;
