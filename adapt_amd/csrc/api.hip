@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -64,6 +65,8 @@ static const shade_fn kClassShade[APT_N_CLASS_DEFS][2] = {
     {k_shade<0x010, 0x03>, k_shade<0x010, APT_SRC_ALL>}, {k_shade<0x020, 0x03>, k_shade<0x020, APT_SRC_ALL>},
     {k_shade<0x080, 0x03>, k_shade<0x080, APT_SRC_ALL>}, {k_shade<0x200, 0x03>, k_shade<0x200, APT_SRC_ALL>},
 };
+// Blinn-Phong class in scenes where none of its materials has a specular lobe (shading.hpp, mask bit 11)
+static const shade_fn kPhongDiffuseShade[2] = {k_shade<0x801, 0x03>, k_shade<0x801, APT_SRC_ALL>};
 static int class_of(int is_bsdf, int type) {
     const int bit = is_bsdf ? (type == 0 ? 8 : (type == 1 ? 9 : 10)) : (type & 7);
     for (int c = 0; c < APT_N_CLASS_DEFS; c++) if ((kClassMask[c] >> bit) & 1) return c;
@@ -110,6 +113,7 @@ struct apt_scene {
     DevBuf uvs, tex_i, tex_f, atlas[3];      // image textures (empty when the scene has none)
     DevBuf med;                          // participating media, n_objects + 1 rows (volumetric path tracer)
     bool has_null_surface = false;       // some object carries a null BSDF (rays pass, vpt.py:189-191)
+    bool phong_no_lobe = true;           // every Blinn-Phong material has k_s = 0 and finite k_g >= 0
     float box_min[3] = {1e3f, 1e3f, 1e3f}, box_max[3] = {-1e3f, -1e3f, -1e3f};    // union of the object boxes (path_tracer.py:130-134)
     int n_classes = 0;                   // material classes present (compact ids 0..n_classes-1)
     int class_def[APT_N_CLASS_DEFS] = {0, 0, 0, 0, 0, 0, 0, 0};   // compact id -> class definition
@@ -267,6 +271,8 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         b.type = bi[0]; b.is_delta = bi[1]; b.is_bsdf = bi[2];
         s->bx_mask |= b.is_bsdf ? (b.type == 0 ? 0x100 : (b.type == 1 ? 0x200 : 0x400)) : (1 << (b.type & 7));
         b.k_d = mk3(bf[0], bf[1], bf[2]); b.k_s = mk3(bf[3], bf[4], bf[5]); b.k_g = mk3(bf[6], bf[7], bf[8]); b.mean = mk3(bf[9], bf[10], bf[11]); b.ior = bf[12];
+        if (!b.is_bsdf && b.type == 0)
+            for (int a = 0; a < 3; a++) if (!(bf[3 + a] == 0.f && !std::signbit(bf[3 + a]) && bf[6 + a] >= 0.f && std::isfinite(bf[6 + a]))) s->phong_no_lobe = false;
     }
     // material classes present in this scene -> compact ids; per-primitive class table for the sorting extend
     {
@@ -438,7 +444,11 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (r->sorted) {
         const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : 1;
         r->shade_name = "sorted:";
-        for (int c = 0; c < ncls; c++) { r->class_fn[c] = kClassShade[sc->class_def[c]][smi]; r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]]; }
+        for (int c = 0; c < ncls; c++) {
+            const bool lean_phong = sc->class_def[c] == 1 && sc->phong_no_lobe;
+            r->class_fn[c] = lean_phong ? kPhongDiffuseShade[smi] : kClassShade[sc->class_def[c]][smi];
+            r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]] + (lean_phong ? "(no lobe)" : "");
+        }
     }
     // the kernels address queue slots with 32-bit byte offsets (stages.hpp "Queue addressing")
     if (cap >= ((size_t)1 << 30) || sh_cap >= ((size_t)1 << 30)) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: batch too large (queue capacity must stay below 2^30 slots)"); }
