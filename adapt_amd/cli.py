@@ -1,12 +1,12 @@
-"""`render.py`-compatible command line for the `pt` renderer on MI355X.
+"""`render.py`-compatible command line for the `pt` and `vpt` renderers on MI355X.
 
-Mirrors the reference driver's flags and control flow for `--type pt --no_gui`
+Mirrors the reference driver's flags and control flow for `--type pt|vpt --no_gui`
 (`render.py:65-166`, `parsers/opts.py:15-44`): scene parsing, optional checkpoint load,
 `iter_num + 1` samples (the reference's `--no_gui` loop runs `range(iter_num + 1)`,
 render.py:80-81,118), periodic checkpoint saves, summary, optional quantile normalisation
 (`utils/watermark.py:28-29`), image file `<output_path><img_name>-<scene file stem>-pt.<ext>`.
 Differences: there is no GUI and no Taichi (`--arch` is accepted and ignored unless it is not
-one of the known names), only `--type pt` exists, the "RENDERED WITH AdaPT" watermark is not
+one of the known names), only `--type pt` and `--type vpt` exist (homogeneous media), the "RENDERED WITH AdaPT" watermark is not
 stamped (`--no_watermark` is accepted), PNG/BMP are written by a small built-in encoder.
 """
 from __future__ import annotations
