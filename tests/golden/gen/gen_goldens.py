@@ -379,6 +379,31 @@ def gen_refscene(scene_dir, xml, tag, w, h, spp, seed=0, volumetric=False, overr
           f"{time.time() - t0:.1f}s, mean draws {draws.mean():.2f}, mean radiance {np.nanmean(out['accum']) / spp:.4f}")
 
 
+def gen_vptrun(scene_dir, xml, tag, w, h, spp, seed=0):
+    """VolumeRenderer.render of the reference on a scene file of this repo that the tests parse themselves: only the accumulated
+    image and the per-sample draw counts are stored."""
+    rdr, (emitters, arr, objs, cfg) = refenv.make_renderer(scene_dir, xml, {"width": w, "height": h}, volumetric=True)
+    draws = np.zeros((spp, w, h), np.int32)
+    state = {"prev": None}
+
+    def hook(i, j):
+        if state["prev"] is not None:
+            pi, pj = state["prev"]; draws[state["s"], pi, pj] = ti.RNG.draw
+        ti.RNG.set_philox(i * h + j, seed, rdr.cnt[None])
+        state["prev"] = (i, j)
+
+    ti.PIXEL_HOOK[0] = hook
+    t0 = time.time()
+    for s_ in range(spp):
+        state["s"], state["prev"] = s_, None
+        rdr.render(0, 0, 0, 0, 0, 0)
+        pi, pj = state["prev"]; draws[s_, pi, pj] = ti.RNG.draw
+    ti.PIXEL_HOOK[0] = None
+    np.savez_compressed(os.path.join(OUT, f"vptrun_{tag}.npz"), accum=rdr.color.to_numpy(), draws=draws, width=np.int32(w), height=np.int32(h),
+                        spp=np.int32(spp), seed=np.int32(seed), max_bounce=np.int32(cfg["max_bounce"]))
+    print(f"vptrun_{tag}: {w}x{h}x{spp}spp, {time.time() - t0:.1f}s, mean draws {draws.mean():.2f}, mean radiance {np.nanmean(rdr.color.to_numpy()) / spp:.4f}")
+
+
 REF_SCENES = [("cbox", "cbox-point.xml"), ("cbox", "cbox-vn.xml"), ("cbox", "smaller.xml"), ("cbox", "single-orb.xml"), ("cbox", "ite-orb.xml"),
               ("cbox", "skeleton.xml"), ("cbox", "vader.xml"), ("cbox", "venus.xml"), ("cbox", "bvh-benchmark.xml"),
               ("csphere", "balls-glossy.xml"), ("csphere", "balls-multi.xml"), ("csphere", "big.xml"), ("csphere", "mix-balls.xml"),
@@ -417,6 +442,11 @@ if __name__ == "__main__":
         test_dir = os.path.join(refenv.REPO, "scenes", "test")
         gen_refscene(test_dir, "media_a.xml", "media_a", 40, 30, 3, volumetric=True)
         gen_refscene(test_dir, "media_b.xml", "media_b", 40, 30, 3, volumetric=True)
+        # surface-only scenes through the volumetric loop (the reference's default renderer type): every BRDF / BSDF / emitter type,
+        # and image textures (vpt.py looks up the albedo map only)
+        os.chdir(refenv.REPO)                           # texture paths in textured.xml are relative to the repository root
+        for name in ("features_a", "features_b", "textured"):
+            gen_vptrun(test_dir, name + ".xml", name, 40, 30, 2)
     if a.only in ("all", "image", "features"):
         # feature-coverage scenes authored in this repo (scenes/test/*.xml), run through the reference's own parser + kernel
         test_dir = os.path.join(refenv.REPO, "scenes", "test")

@@ -639,3 +639,25 @@ def test_medium_functions_vs_reference_vectors():
     x = g["eval_in"]; m = np.int32(x[:, 0])
     out = medium_probe(mi[m], mf[m], 2, x[:, 1:8])
     assert close(out[:, :4], g["eval_out"], rel=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "textured", "features_a"])
+def test_volumetric_tracer_on_scenes_without_media(tag, renderer, parsed, oracle_scene):
+    """`--type vpt` on surface-only scenes (the reference's default renderer type): no medium ever scatters, but the loop differs from
+    the surface tracer's - roulette before the hit, emission against the geometric normal, no normal / bump maps (vpt.py never calls
+    process_ns), albedo textures on every vertex - so it is checked against the oracle's volumetric loop, not against `pt`."""
+    from adapt_amd.renderer import VolumeRenderer
+    w, h, spp = 48, 36, 8
+    tup = parsed(tag)
+    r = VolumeRenderer(*tup, width=w, height=h)
+    try:
+        r.render(n_spp=spp)
+        rc = make_config(tup[3], width=w, height=h, volumetric=True)
+        ref, _, ost = oracle_scene(tag).render(rc, spp)
+        m = image_metrics(r.color.to_numpy() / spp, ref / spp)
+        assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-3, (tag, m)
+        st = r.stats()
+        for k in ("n_shade", "n_shadow", "n_draws"):
+            assert abs(st[k] - ost[k]) <= 1e-3 * ost[k], (tag, k, st[k], ost[k])
+    finally:
+        r.close()
