@@ -59,12 +59,19 @@ class FlatScene:
     # participating media for the volumetric path tracer: row o < n = medium attached to object o's BSDF, row n = the world's
     med_i: Optional[np.ndarray] = None      # (n+1,)   i32   type: -1 transparent, 0 hg, 1 multi-hg, 2 rayleigh, 3 mie
     med_f: Optional[np.ndarray] = None      # (n+1,16) f32   ior, u_s, u_a, u_e, par, pdf
+    # grid volume of the volumetric tracer (None when the scene declares none): adapt_amd/volumes.py
+    vol_i: Optional[np.ndarray] = None      # (5,)     i32   type (2 = RGB), xres, yres, zres, phase type
+    vol_f: Optional[np.ndarray] = None      # (33,)    f32   albedo, inv_T, trans, mini, maxi, majorant, majorant pdf, phase par, lobe weights
+    vol_grid: Optional[np.ndarray] = None   # (z,y,x,3) f32  extinction per channel
 
     @property
     def has_textures(self): return self.tex_i is not None
 
     @property
     def has_scattering_media(self): return self.med_i is not None and bool((self.med_i >= 0).any())
+
+    @property
+    def has_volume(self): return self.vol_i is not None
 
     @property
     def n_prims(self): return int(self.prims.shape[0])
@@ -197,6 +204,12 @@ def pack_scene(emitters: List, array_info: dict, objects: List, prop: dict) -> F
     for i, obj in enumerate(objects):
         med_i[i], med_f[i] = pack_medium(getattr(obj.bsdf, "medium", None))
     med_i[n_obj], med_f[n_obj] = pack_medium(prop["world"].medium)
+    vol = {}
+    if prop.get("volume"):
+        from .volumes import GridVolume_np
+        gv = prop["volume"][0]
+        vi, vf, vg = (gv if isinstance(gv, GridVolume_np) else GridVolume_np(gv)).pack()
+        vol = dict(vol_i=vi, vol_f=vf, vol_grid=vg)
     tex = {}
     images = prop.get("packed_textures")
     if images is not None and any(images.get(m) is not None for m in _TEX_MAPS):
@@ -213,7 +226,7 @@ def pack_scene(emitters: List, array_info: dict, objects: List, prop: dict) -> F
     return FlatScene(prims=prims, normals=n_g, v_normals=n_s, obj_info=obj_info, obj_aabb=obj_aabb,
                      emitter_id=emitter_id, bxdf_i=bxdf_i, bxdf_f=bxdf_f, src_i=src_i, src_f=src_f,
                      has_vertex_normal=bool(prop["has_vertex_normal"]),
-                     world_ior=float(prop["world"].medium.ior), med_i=med_i, med_f=med_f, **tex)
+                     world_ior=float(prop["world"].medium.ior), med_i=med_i, med_f=med_f, **vol, **tex)
 
 
 def make_config(prop: dict, *, width: Optional[int] = None, height: Optional[int] = None,

@@ -26,7 +26,7 @@ class SceneDesc(C.Structure):
                 ("emitter_id", i32p), ("bxdf_i", i32p), ("bxdf_f", f32p), ("src_i", i32p), ("src_f", f32p),
                 ("world_ior", C.c_float),
                 ("uvs", f32p), ("tex_i", i32p), ("tex_f", f32p), ("atlas", f32p * 3), ("atlas_w", C.c_int * 3), ("atlas_h", C.c_int * 3),
-                ("med_i", i32p), ("med_f", f32p)]
+                ("med_i", i32p), ("med_f", f32p), ("vol_i", i32p), ("vol_f", f32p), ("vol_grid", f32p)]
 
 
 class Cfg(C.Structure):
@@ -124,6 +124,10 @@ class OracleScene:
             med = [np.ascontiguousarray(fs.med_i, np.int32), np.ascontiguousarray(fs.med_f, np.float32)]
             self._keep += med
             d.med_i, d.med_f = _ip(med[0]), _fp(med[1])
+        if getattr(fs, "vol_i", None) is not None:                  # grid volume (volumetric path tracer)
+            vol = [np.ascontiguousarray(fs.vol_i, np.int32), np.ascontiguousarray(fs.vol_f, np.float32), np.ascontiguousarray(fs.vol_grid, np.float32)]
+            self._keep += vol
+            d.vol_i, d.vol_f, d.vol_grid = _ip(vol[0]), _fp(vol[1]), _fp(vol[2])
         ct = _f3(cam_t)
         self.handle = C.c_void_p(L.orc_scene_create(C.byref(d), _fp(ct), int(build_bvh)))
         self.fs = fs

@@ -206,6 +206,10 @@ typedef struct {
        object o's BSDF; row n_objects: the world medium */
     const int*   med_i;       /* (n_objects+1): type  -1 transparent, 0 hg, 1 multi-hg, 2 rayleigh, 3 mie */
     const float* med_f;       /* (n_objects+1)*16: ior, u_s[3], u_a[3], u_e[3], par[3], pdf[3] */
+    /* grid volume (volumetric path tracer; all NULL when the scene declares none): bxdf/volume.py:36-218 */
+    const int*   vol_i;       /* 5: type (2 = RGB), xres, yres, zres, phase type */
+    const float* vol_f;       /* 33: albedo, inv_T (row-major), trans, mini, maxi, majorant, majorant pdf, phase par, phase lobe weights */
+    const float* vol_grid;    /* zres*yres*xres*3 extinction per channel, [z][y][x][c] */
 } orc_scene_desc;
 
 typedef struct {
@@ -245,6 +249,12 @@ typedef struct {
     src_t* src;
     float world_ior;
     medium_t* med;            /* n_objects + 1 rows, the last one is the world's */
+    /* grid volume, bxdf/volume.py:221-246 */
+    int vol_type, vol_res[3];
+    v3 vol_albedo, vol_trans, vol_mini, vol_maxi, vol_majorant, vol_pdf;
+    m3 vol_inv_T;
+    medium_t vol_ph;          /* phase function of the volume (type, par, pdf) */
+    float* vol_grid;
     v3 w_aabb_min, w_aabb_max;    /* path_tracer.py:130-138 */
     /* textures: bxdf/texture.py:99-139, path_tracer.py:84-126,261-266 */
     float (*uvs)[3][2];
@@ -1219,6 +1229,7 @@ static void build_reference_bvh(scene_t* sc, v3 wmin, v3 wmax) {
 
 /* ----------------------------------------------------- scene construction */
 static const v3* as_v3(const float* p) { return (const v3*)p; }
+#define LD3(p) V((p)[0], (p)[1], (p)[2])
 
 ORC_API scene_t* orc_scene_create(const orc_scene_desc* d, const float cam_t[3], int build_bvh) {
     scene_t* sc = (scene_t*)calloc(1, sizeof(scene_t));
@@ -1278,6 +1289,18 @@ ORC_API scene_t* orc_scene_create(const orc_scene_desc* d, const float cam_t[3],
             m->type = -1; m->ior = (o < O) ? sc->bxdf[o].ior : sc->world_ior; m->pdf = V(1.f, 0.f, 0.f);
         }
     }
+    if (d->vol_i && d->vol_f && d->vol_grid && d->vol_i[0] > 0) {
+        const float* f = d->vol_f;
+        sc->vol_type = d->vol_i[0]; sc->vol_res[0] = d->vol_i[1]; sc->vol_res[1] = d->vol_i[2]; sc->vol_res[2] = d->vol_i[3];
+        sc->vol_albedo = LD3(f);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) sc->vol_inv_T.m[i][j] = f[3 + 3 * i + j];
+        sc->vol_trans = LD3(f + 12); sc->vol_mini = LD3(f + 15); sc->vol_maxi = LD3(f + 18);
+        sc->vol_majorant = LD3(f + 21); sc->vol_pdf = LD3(f + 24);
+        memset(&sc->vol_ph, 0, sizeof(sc->vol_ph));
+        sc->vol_ph.type = d->vol_i[4]; sc->vol_ph.par = LD3(f + 27); sc->vol_ph.pdf = LD3(f + 30);
+        size_t n = (size_t)d->vol_i[1] * (size_t)d->vol_i[2] * (size_t)d->vol_i[3] * 3;
+        sc->vol_grid = malloc(sizeof(float) * n); memcpy(sc->vol_grid, d->vol_grid, sizeof(float) * n);
+    }
     {   /* world AABB, path_tracer.py:130-138 */
         v3 lo = V(1e3f, 1e3f, 1e3f), hi = V(-1e3f, -1e3f, -1e3f);
         for (int o = 0; o < O; o++) { lo = vminv(lo, sc->aabbs[o][0]); hi = vmaxv(hi, sc->aabbs[o][1]); }
@@ -1290,7 +1313,7 @@ ORC_API scene_t* orc_scene_create(const orc_scene_desc* d, const float cam_t[3],
 ORC_API void orc_scene_destroy(scene_t* sc) {
     if (!sc) return;
     free(sc->prims); free(sc->precom); free(sc->vnorm); free(sc->normals); free(sc->obj_info); free(sc->aabbs);
-    free(sc->emitter_id); free(sc->bxdf); free(sc->src); free(sc->med); free(sc->nodes); free(sc->bvhs);
+    free(sc->emitter_id); free(sc->bxdf); free(sc->src); free(sc->med); free(sc->vol_grid); free(sc->nodes); free(sc->bvhs);
     free(sc->uvs); free(sc->tex_i); free(sc->tex_f); for (int m = 0; m < 3; m++) free(sc->atlas[m]);
     free(sc);
 }
@@ -1585,12 +1608,88 @@ static v3 vpt_get_transmittance(const ctx_t* c, int idx, int in_free_space, floa
     }
     return tr;
 }
-static int vpt_sample_mfp(const ctx_t* c, int idx, int in_free_space, float depth, rng_t* r, float* mfp, v3* beta) {   /* vpt.py:72-97 */
+/* ------------------------------------------------------------------ grid volume, bxdf/volume.py:248-463 (RGB volumes) */
+static float vmax_np(v3 a) { if (isnan(a.x) || isnan(a.y) || isnan(a.z)) return NAN; return vmax(a); }      /* Vector.max() / .min(): NaN-propagating */
+static float vmin_np(v3 a) { if (isnan(a.x) || isnan(a.y) || isnan(a.z)) return NAN; return vmin(a); }
+static int vol_intersect(const scene_t* sc, v3 o, v3 d, float max_t, float* near_t, float* far_t) {             /* volume.py:271-285 */
+    v3 inv_dir = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    v3 t1s = vmul(vsub(sc->vol_mini, o), inv_dir), t2s = vmul(vsub(sc->vol_maxi, o), inv_dir);
+    v3 tmin = vminv(t1s, t2s), tmax = vmaxv(t1s, t2s);
+    *near_t = fmaxf(0.f, vmax_np(tmin)) + 1e-5f;
+    *far_t = fminf(max_t, vmin_np(tmax)) - 1e-5f;
+    return *near_t < *far_t && *far_t > 0.f;
+}
+static v3 vol_density_lookup(const scene_t* sc, v3 index, v3 u_offset) {                                       /* volume.py:307-314 */
+    v3 f = V(floorf(index.x + (u_offset.x - 0.5f)), floorf(index.y + (u_offset.y - 0.5f)), floorf(index.z + (u_offset.z - 0.5f)));
+    int ix = (int)f.x, iy = (int)f.y, iz = (int)f.z;
+    if (ix >= 0 && iy >= 0 && iz >= 0 && ix <= sc->vol_res[0] - 1 && iy <= sc->vol_res[1] - 1 && iz <= sc->vol_res[2] - 1) {
+        const float* p = sc->vol_grid + 3 * (((size_t)iz * sc->vol_res[1] + iy) * sc->vol_res[0] + ix);
+        return V(p[0], p[1], p[2]);
+    }
+    return ZERO3;
+}
+static inline float rgb_select(v3 a, int ch) { return ch == 0 ? a.x : (ch == 1 ? a.y : a.z); }
+/* wavelength channel by throughput x majorant pdf (volume.py:352-377, 410-432) */
+static int vol_pick_channel(const scene_t* sc, v3 thp, rng_t* r, float* pdf) {
+    v3 pdfs = vmul(thp, sc->vol_pdf);
+    pdfs = vdivs(pdfs, vsum(pdfs));
+    float val = rng_float(r);
+    if (val <= pdfs.x) { *pdf = pdfs.x; return 0; }
+    if (val <= pdfs.x + pdfs.y) { *pdf = pdfs.y; return 1; }
+    *pdf = pdfs.z; return 2;
+}
+static inline v3 vol_channel_vec(int ch, float v) { return ch == 0 ? V(v, 0.f, 0.f) : (ch == 1 ? V(0.f, v, 0.f) : V(0.f, 0.f, v)); }
+/* GridVolume.sample_mfp -> delta tracking (volume.py:295-305, 346-397): returns the collision distance or -1, beta in *out */
+static float vol_sample_mfp(const scene_t* sc, v3 ray_o, v3 ray_d, v3 thp, float max_t, rng_t* r, v3* out) {
+    *out = V(1.f, 1.f, 1.f);
+    float near_t, far_t;
+    if (!sc->vol_type || !vol_intersect(sc, ray_o, ray_d, max_t, &near_t, &far_t)) return -1.f;
+    v3 ol = m3mulv(&sc->vol_inv_T, vsub(ray_o, sc->vol_trans)), dl = m3mulv(&sc->vol_inv_T, ray_d);
+    float pdf; int ch = vol_pick_channel(sc, thp, r, &pdf);
+    float albedo = rgb_select(sc->vol_albedo, ch), inv_maj = 1.0f / rgb_select(sc->vol_majorant, ch);
+    float Tr = 1.0f, hit_t = -1.f;
+    float t = near_t - logf(1.0f - rng_float(r)) * inv_maj;
+    while (t < far_t) {
+        float u0 = rng_float(r), u1 = rng_float(r), u2 = rng_float(r);
+        v3 dns = vol_density_lookup(sc, vadd(ol, vscale(dl, t)), V(u0, u1, u2));
+        float n_t = rgb_select(dns, ch);
+        if (rng_float(r) < n_t * inv_maj) { Tr *= albedo; hit_t = t; break; }
+        t -= logf(1.0f - rng_float(r)) * inv_maj;
+    }
+    *out = (sc->vol_type == 2) ? vol_channel_vec(ch, Tr / pdf) : V(Tr, Tr, Tr);
+    return hit_t;
+}
+/* GridVolume.transmittance -> ratio tracking with roulette (volume.py:283-293, 399-463) */
+static v3 vol_transmittance(const scene_t* sc, v3 ray_o, v3 ray_d, v3 thp, float max_t, rng_t* r) {
+    float near_t, far_t;
+    if (!sc->vol_type || !vol_intersect(sc, ray_o, ray_d, max_t, &near_t, &far_t)) return V(1.f, 1.f, 1.f);
+    v3 ol = m3mulv(&sc->vol_inv_T, vsub(ray_o, sc->vol_trans)), dl = m3mulv(&sc->vol_inv_T, ray_d);
+    float pdf; int ch = vol_pick_channel(sc, thp, r, &pdf);
+    float inv_maj = 1.0f / rgb_select(sc->vol_majorant, ch);
+    float Tr = 1.0f, t = near_t;
+    for (;;) {
+        t -= logf(1.0f - rng_float(r)) * inv_maj;
+        if (t >= far_t) break;
+        float u0 = rng_float(r), u1 = rng_float(r), u2 = rng_float(r);
+        v3 dns = vol_density_lookup(sc, vadd(ol, vscale(dl, t)), V(u0, u1, u2));
+        Tr *= fmaxf(0.0f, 1.0f - rgb_select(dns, ch) * inv_maj);
+        if (Tr < 0.1f) {
+            if (rng_float(r) >= Tr) { Tr = 0.0f; break; }
+            Tr = 1.0f;
+        }
+    }
+    return (sc->vol_type == 2) ? vol_channel_vec(ch, Tr / pdf) : V(Tr, Tr, Tr);
+}
+static int vpt_sample_mfp(const ctx_t* c, v3 ray_o, v3 ray_d, v3 thp, int idx, int in_free_space, float depth, rng_t* r, float* mfp, v3* beta) {   /* vpt.py:72-97 */
     int is_mi = 0; *mfp = depth; *beta = V(1.f, 1.f, 1.f);
     int world_valid = in_free_space && vpt_world_scattering(c);
     if (world_valid || vpt_is_scattering(c, idx)) {
         if (world_valid) is_mi = medium_sample_mfp(&c->sc->med[c->sc->n_objects], depth, r, mfp, beta);
         else if (!in_free_space) is_mi = medium_sample_mfp(&c->sc->med[idx], depth, r, mfp, beta);
+    }
+    if (c->sc->vol_type) {                  /* a grid-volume event overrides the homogeneous one (vpt.py:91-96) */
+        v3 vb; float vt = vol_sample_mfp(c->sc, ray_o, ray_d, thp, depth, r, &vb);
+        if (vt > 0.f) { is_mi = 2; *mfp = vt; *beta = vb; }
     }
     return is_mi;
 }
@@ -1599,8 +1698,9 @@ static void vpt_ray_intersect(const ctx_t* c, v3 ray, v3 o, float min_depth, ise
     else ray_intersect_brute(c->sc, ray, o, min_depth, it);
 }
 /* VolumeRenderer.track_ray, vpt.py:99-138 (the accumulated optical length it also returns is unused by render) */
-static v3 vpt_track_ray(const ctx_t* c, v3 cur_ray, v3 cur_point, float depth, orc_stats* st) {
+static v3 vpt_track_ray(const ctx_t* c, v3 cur_ray, v3 cur_point, v3 thp, float depth, rng_t* r, orc_stats* st) {
     v3 tr = V(1.f, 1.f, 1.f);
+    if (c->sc->vol_type) tr = vol_transmittance(c->sc, cur_point, cur_ray, thp, depth, r);      /* vpt.py:107-108: draws from the path's stream */
     int in_free_space = 1;
     for (int k = 0; k < 7; k++) {
         isect_t it; vpt_ray_intersect(c, cur_ray, cur_point, depth, &it);
@@ -1638,8 +1738,17 @@ static v3 vpt_eval(const ctx_t* c, isect_t* it, v3 incid, v3 out, int is_mi, int
 }
 static v3 vpt_sample_new_ray(const ctx_t* c, isect_t* it, v3 incid, int is_mi, int in_free_space, rng_t* r, v3* spec, float* pdf, int* is_specular) {
     if (is_mi) {
-        const medium_t* m = in_free_space ? &c->sc->med[c->sc->n_objects] : &c->sc->med[it->obj_id];
+        /* is_mi == 2: the grid volume's own phase function (path_tracer.py:440-441); eval above keeps using the medium the
+           flags point at, as upstream */
+        const medium_t* m = (is_mi > 1) ? &c->sc->vol_ph : (in_free_space ? &c->sc->med[c->sc->n_objects] : &c->sc->med[it->obj_id]);
         *is_specular = 0;
+        if (is_mi > 1) {                    /* GridVolume.sample_new_rays: scattering iff _type >= 1, whatever the phase type */
+            *spec = V(1.f, 1.f, 1.f); *pdf = 1.f;
+            float p; v3 local = phase_sample_p(m, incid, r, &p);
+            m3 R; v3 dir = delocalize_rotate(incid, local, &R);
+            *pdf = p; *spec = V(p, p, p);
+            return dir;
+        }
         return medium_sample_new_rays(m, incid, r, spec, pdf);
     }
     return pt_sample_new_ray(c, it, incid, r, spec, pdf, is_specular);
@@ -1667,14 +1776,14 @@ static v3 render_sample_vpt(const ctx_t* c, int i, int j, int cnt, rng_t* rng, o
         isect_t it; vpt_ray_intersect(c, ray_d, ray_o, -1.0f, &it);
         st->n_extend++;
         if (it.obj_id < 0) {
-            if (!world_scat) break;
+            if (!world_scat && !sc->vol_type) break;
             it.min_depth = vpt_world_bound_time(sc, ray_o, ray_d);
             in_free_space = 1; it.obj_id = -1;
         } else {
             in_free_space = vdot(it.n_g, ray_d) < 0.f;
         }
         v3 path_beta; float mfp;
-        int is_mi = vpt_sample_mfp(c, it.obj_id, in_free_space, it.min_depth, rng, &mfp, &path_beta);
+        int is_mi = vpt_sample_mfp(c, ray_o, ray_d, throughput, it.obj_id, in_free_space, it.min_depth, rng, &mfp, &path_beta);
         it.min_depth = mfp;
         if (it.obj_id < 0 && !is_mi) break;
         v3 hit_point = vadd(vscale(ray_d, it.min_depth), ray_o);
@@ -1696,7 +1805,7 @@ static v3 render_sample_vpt(const ctx_t* c, int i, int j, int cnt, rng_t* rng, o
                 float emitter_d = vnorm(to_emitter);
                 light_dir = vdivs(to_emitter, emitter_d);
                 st->n_shadow++;
-                v3 trn = vpt_track_ray(c, light_dir, hit_point, emitter_d, st);
+                v3 trn = vpt_track_ray(c, light_dir, hit_point, throughput, emitter_d, rng, st);
                 if (trn.x != 0.f || trn.y != 0.f || trn.z != 0.f) st->n_lit++;
                 shadow_int = vmul(shadow_int, trn);
                 direct_spec = vpt_eval(c, &it, ray_d, light_dir, is_mi, in_free_space);
@@ -1818,7 +1927,6 @@ static void load_bxdf(bxdf_t* b, const int bi[4], const float bf[13]) {
     b->k_d = as_v3(bf)[0]; b->k_s = as_v3(bf)[1]; b->k_g = as_v3(bf)[2]; b->mean = as_v3(bf)[3]; b->ior = bf[12];
 }
 static void st3(float* o, v3 a) { o[0] = a.x; o[1] = a.y; o[2] = a.z; }
-#define LD3(p) V((p)[0], (p)[1], (p)[2])
 
 /* eval (f*cos), pdf for given directions; BRDF or BSDF by bi[2] */
 ORC_API void orc_bxdf_eval_pdf(const int bi[4], const float bf[13], float world_ior, const float n_s[3], const float n_g[3],

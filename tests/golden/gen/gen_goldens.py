@@ -399,8 +399,16 @@ def gen_vptrun(scene_dir, xml, tag, w, h, spp, seed=0):
         rdr.render(0, 0, 0, 0, 0, 0)
         pi, pj = state["prev"]; draws[s_, pi, pj] = ti.RNG.draw
     ti.PIXEL_HOOK[0] = None
+    extra = {}
+    if getattr(rdr, "has_volume", False):               # the reference's exported grid-volume record and density grid
+        v = rdr.volume
+        tn = lambda x: np.float32(x.to_numpy() if hasattr(x, "to_numpy") else x)
+        extra["vol_f"] = np.concatenate([tn(v.albedo), tn(v.inv_T).reshape(-1), tn(v.trans), tn(v.mini), tn(v.maxi), tn(v.majorant), tn(v.pdf),
+                                         tn(v.ph.par), tn(v.ph.pdf)]).astype(np.float32)
+        extra["vol_i"] = np.int32([int(v._type), int(v.max_idxs[0]) + 1, int(v.max_idxs[1]) + 1, int(v.max_idxs[2]) + 1, int(v.ph._type)])
+        extra["vol_grid"] = np.float32(rdr.density_grid.to_numpy())
     np.savez_compressed(os.path.join(OUT, f"vptrun_{tag}.npz"), accum=rdr.color.to_numpy(), draws=draws, width=np.int32(w), height=np.int32(h),
-                        spp=np.int32(spp), seed=np.int32(seed), max_bounce=np.int32(cfg["max_bounce"]))
+                        spp=np.int32(spp), seed=np.int32(seed), max_bounce=np.int32(cfg["max_bounce"]), **extra)
     print(f"vptrun_{tag}: {w}x{h}x{spp}spp, {time.time() - t0:.1f}s, mean draws {draws.mean():.2f}, mean radiance {np.nanmean(rdr.color.to_numpy()) / spp:.4f}")
 
 
@@ -447,6 +455,11 @@ if __name__ == "__main__":
         os.chdir(refenv.REPO)                           # texture paths in textured.xml are relative to the repository root
         for name in ("features_a", "features_b", "textured"):
             gen_vptrun(test_dir, name + ".xml", name, 40, 30, 2)
+    if a.only in ("all", "vpt", "volgrid"):
+        os.chdir(refenv.REPO)                           # the .vol paths in the scene files are relative to the repository root
+        test_dir = os.path.join(refenv.REPO, "scenes", "test")
+        for name in ("volgrid_a", "volgrid_b"):
+            gen_vptrun(test_dir, name + ".xml", name, 40, 30, 3)
     if a.only in ("all", "image", "features"):
         # feature-coverage scenes authored in this repo (scenes/test/*.xml), run through the reference's own parser + kernel
         test_dir = os.path.join(refenv.REPO, "scenes", "test")

@@ -270,7 +270,17 @@ def pow(x, y):
 
 
 def floor(x, dtype=None):
+    if isinstance(x, Tensor):
+        return type(x)._wrap(_np.floor(x.a).astype(f32))
     return f32(_np.floor(f32(x)))
+
+
+def cast(x, dtype):
+    """ti.cast: float -> int truncates toward zero (C semantics), int -> float converts to f32"""
+    to_int = dtype in (int, i32)
+    if isinstance(x, Tensor):
+        return type(x)._wrap(_np.trunc(x.a).astype(_np.int32) if to_int else x.a.astype(f32))
+    return int(x) if to_int else f32(x)
 
 
 def abs(x):

@@ -248,3 +248,29 @@ def test_medium_records():
     with pytest.raises(NotImplementedError):
         Medium_np(xet.fromstring('<medium type="smoke"/>'))
     assert pack_medium(None)[0] == -1
+
+
+def test_vol_reader_and_refusals(tmp_path):
+    """Own .vol reader (Mitsuba v3 layout, vol2numpy.cpp:35-73) and the configurations that fail upstream are refused with a reason."""
+    import struct
+    import xml.etree.ElementTree as xet
+    from adapt_amd.volumes import GridVolume_np, read_vol
+    grid = np.arange(2 * 3 * 4, dtype=np.float32).reshape(2, 3, 4)          # [z][y][x]
+    path = tmp_path / "g.vol"
+    path.write_bytes(b"VOL\x03" + struct.pack("<5i", 1, 4, 3, 2, 1) + struct.pack("<6f", 0, 0, 0, 1, 1, 1) + grid.tobytes())
+    data, shape = read_vol(str(path))
+    assert shape == (4, 3, 2, 1) and data.shape == (2, 3, 4, 1) and np.array_equal(data[..., 0], grid)
+    (tmp_path / "bad.vol").write_bytes(b"VOX\x03" + bytes(60))
+    with pytest.raises(ValueError):
+        read_vol(str(tmp_path / "bad.vol"))
+    mk = lambda body, kind="mono": xet.fromstring(f'<volume name="v" type="{kind}" phase_type="hg"><string name="density_grid" path="{path}"/>{body}</volume>')
+    v = GridVolume_np(mk('<bool name="mono2rgb" value="true"/><rgb name="density_scaling" r="2" g="3" b="4"/>'))
+    ints, floats, g3 = v.pack()
+    assert ints.tolist() == [2, 4, 3, 2, 0] and floats.shape == (33,) and g3.shape == (2, 3, 4, 3)
+    assert np.array_equal(g3[1, :, :, 1], grid[1] * np.float32(3))           # z = 1 lies in the second part of the ramp: green untouched
+    with pytest.raises(NotImplementedError):                                  # mono without mono2rgb: upstream fails exporting the majorant
+        GridVolume_np(mk(""))
+    with pytest.raises(NotImplementedError):
+        GridVolume_np(mk("", kind="smoke"))
+    with pytest.raises(RuntimeError):
+        GridVolume_np(xet.fromstring('<volume name="v" type="mono" phase_type="hg"><string name="density_grid" path="/nonexistent.vol"/></volume>'))
