@@ -26,7 +26,7 @@ class SceneDesc(C.Structure):
                 ("emitter_id", i32p), ("bxdf_i", i32p), ("bxdf_f", f32p), ("src_i", i32p), ("src_f", f32p),
                 ("world_ior", C.c_float),
                 ("uvs", f32p), ("tex_i", i32p), ("tex_f", f32p), ("atlas", f32p * 3), ("atlas_w", C.c_int32 * 3), ("atlas_h", C.c_int32 * 3),
-                ("med_i", i32p), ("med_f", f32p)]
+                ("med_i", i32p), ("med_f", f32p), ("vol_i", i32p), ("vol_f", f32p), ("vol_grid", f32p)]
 
 
 class RenderCfg(C.Structure):

@@ -86,6 +86,10 @@ static const VShadeVariant kVShadeVariants[] = {          // first match wins; 0
     {0x503, 0x07, k_vshade<0x503, 0x07>, "volumetric: phong+lambertian+glass+null/point+area+spot"},
     {APT_BX_ALL, APT_SRC_ALL, k_vshade<APT_BX_ALL, APT_SRC_ALL>, "volumetric: all models"},
 };
+static const VShadeVariant kVShadeVolVariants[] = {       // scenes with a grid volume
+    {0x402, 0x03, k_vshade<0x402, 0x03, 1>, "volumetric + grid volume: lambertian+null/point+area"},
+    {APT_BX_ALL, APT_SRC_ALL, k_vshade<APT_BX_ALL, APT_SRC_ALL, 1>, "volumetric + grid volume: all models"},
+};
 typedef void (*vshadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan, int);
 static const vshadow_fn kVShadow[3] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>};     // volumetric: transmittance walk (one closest-hit query per pass)
 #define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
@@ -112,6 +116,8 @@ struct apt_scene {
     DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
     DevBuf uvs, tex_i, tex_f, atlas[3];      // image textures (empty when the scene has none)
     DevBuf med;                          // participating media, n_objects + 1 rows (volumetric path tracer)
+    DevBuf vol_grid;                     // grid volume densities
+    bool has_volume = false;
     bool has_null_surface = false;       // some object carries a null BSDF (rays pass, vpt.py:189-191)
     bool phong_no_lobe = true;           // every Blinn-Phong material has k_s = 0 and finite k_g >= 0
     float box_min[3] = {1e3f, 1e3f, 1e3f}, box_max[3] = {-1e3f, -1e3f, -1e3f};    // union of the object boxes (path_tracer.py:130-134)
@@ -355,6 +361,24 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
             }
         }
     }
+    memset(&ds.vol, 0, sizeof(ds.vol));
+    if (d->vol_i && d->vol_f && d->vol_grid && d->vol_i[0] != 0) {
+        const int32_t* vi = d->vol_i; const float* f = d->vol_f;
+        if (vi[0] != 2) { delete s; return fail(APT_E_INVALID, "apt_scene_create: only RGB grid volumes (type 2) exist upstream"); }
+        if (vi[1] <= 0 || vi[2] <= 0 || vi[3] <= 0 || vi[4] < -1 || vi[4] > 3) { delete s; return fail(APT_E_INVALID, "apt_scene_create: bad grid volume shape or phase type"); }
+        if (!(f[21] > 0.f && f[22] > 0.f && f[23] > 0.f)) { delete s; return fail(APT_E_INVALID, "apt_scene_create: grid volume majorants must be positive"); }
+        std::vector<float> grid(d->vol_grid, d->vol_grid + (size_t)vi[1] * (size_t)vi[2] * (size_t)vi[3] * 3);
+        UP(vol_grid, grid);
+        DevVolume& vo = ds.vol;
+        vo.type = vi[0]; vo.xres = vi[1]; vo.yres = vi[2]; vo.zres = vi[3];
+        vo.albedo = mk3(f[0], f[1], f[2]);
+        vo.inv_r0 = mk3(f[3], f[4], f[5]); vo.inv_r1 = mk3(f[6], f[7], f[8]); vo.inv_r2 = mk3(f[9], f[10], f[11]);
+        vo.trans = mk3(f[12], f[13], f[14]); vo.mini = mk3(f[15], f[16], f[17]); vo.maxi = mk3(f[18], f[19], f[20]);
+        vo.majorant = mk3(f[21], f[22], f[23]); vo.pdf = mk3(f[24], f[25], f[26]);
+        vo.ph.type = vi[4]; vo.ph.par = mk3(f[27], f[28], f[29]); vo.ph.pdf = mk3(f[30], f[31], f[32]);
+        vo.grid = s->vol_grid.as<float>();
+        s->has_volume = true;
+    }
 #undef UP
     *out = s;
     return APT_OK;
@@ -432,6 +456,10 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         if (c.max_bounce > 255) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer keeps the bounce count in 8 bits (max_bounce <= 255)"); }
         if (!sc->has_aabb) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer needs the object boxes (world bound)"); }
         r->sorted = 0;
+        if (sc->has_volume) {
+            for (const VShadeVariant& v : kVShadeVolVariants)
+                if ((sc->bx_mask & ~v.bm) == 0 && (sc->src_mask & ~v.sm) == 0 && !(textured && v.bm != APT_BX_ALL)) { r->vshade = &v; break; }
+        } else
         for (const VShadeVariant& v : kVShadeVariants)
             if ((sc->bx_mask & ~v.bm) == 0 && (sc->src_mask & ~v.sm) == 0 && !(textured && v.bm != APT_BX_ALL)) { r->vshade = &v; break; }
         if (!r->vshade) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: scene uses a material or emitter type the volumetric kernels do not know"); }

@@ -39,6 +39,13 @@ struct DevMedium {            // bxdf/medium.py:71-78 + bxdf/phase.py:33-37 (vol
     float ior;
     f3 u_s, u_a, u_e, par, pdf;
 };
+struct DevVolume {            // bxdf/volume.py:221-246 (grid volume of the volumetric tracer; type 0 = none, 2 = RGB)
+    int type, xres, yres, zres;
+    f3 albedo, trans, mini, maxi, majorant, pdf;
+    f3 inv_r0, inv_r1, inv_r2; // rows of (rotation @ scale)^-1: world -> voxel coordinates
+    DevMedium ph;             // phase function (type, par, pdf)
+    const float* grid;        // zres*yres*xres*3 extinction per channel, [z][y][x][c]
+};
 struct DevScene {
     DevBvh bvh;
     SweepScene sweep;         // small scenes: uniform brute-force sweep instead of the BVH
@@ -60,6 +67,7 @@ struct DevScene {
     const float* atlas[3];
     int atlas_w[3];
     const DevMedium* med;     // n_objects + 1 rows (the last one is the world's), nullptr when the scene declares no media
+    DevVolume vol;
 };
 
 struct Params {

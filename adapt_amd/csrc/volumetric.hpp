@@ -1,12 +1,12 @@
-// Volumetric path tracer stages (homogeneous participating media).
+// Volumetric path tracer stages (homogeneous participating media and grid volumes).
 //
 // Replaces VolumeRenderer.render of the reference (renderer/vpt.py:145-258) on the same wavefront skeleton as the surface path
 // tracer: k_generate and k_extend are shared; k_vshade is the loop body between two closest-hit queries (Russian roulette, free
 // path sampling, null-surface pass-through, light sampling, emission, phase-function / surface scattering) and k_vshadow is
 // track_ray (vpt.py:99-138): the transmittance walk of a light sample through null surfaces and media, up to seven closest-hit
 // queries per sample.  Media: the world's and those attached to BSDF objects (bxdf/medium.py:71-125), phase functions H-G,
-// multi-H-G and Rayleigh (bxdf/phase.py, sampler/phase_sampling.py).  Grid volumes (bxdf/volume.py) are not supported; scenes
-// that declare one are refused by the host.
+// multi-H-G and Rayleigh (bxdf/phase.py, sampler/phase_sampling.py), and one RGB grid volume (bxdf/volume.py: delta tracking for
+// free paths, ratio tracking for light samples).
 #pragma once
 #include "stages.hpp"
 #ifndef APT_VSHADE_LEAN_WAVES
@@ -104,6 +104,75 @@ APT_D float world_bound_time(const Params& p, f3 o, f3 d) {
     return r;
 }
 
+// ------------------------------------------------------------- grid volume, bxdf/volume.py:248-463 (RGB volumes)
+APT_D float max_np(f3 a) { return (isnan(a.x) || isnan(a.y) || isnan(a.z)) ? NAN : max3(a); }       // Vector.max() / .min() propagate NaN
+APT_D float min_np(f3 a) { return (isnan(a.x) || isnan(a.y) || isnan(a.z)) ? NAN : min3(a); }
+APT_D bool vol_intersect(const DevVolume& vo, f3 o, f3 d, float max_t, float& near_t, float& far_t) {        // volume.py:271-285
+    const f3 inv_dir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const f3 t1s = (vo.mini - o) * inv_dir, t2s = (vo.maxi - o) * inv_dir;
+    near_t = fmaxf(0.f, max_np(min3v(t1s, t2s))) + 1e-5f;
+    far_t = fminf(max_t, min_np(max3v(t1s, t2s))) - 1e-5f;
+    return near_t < far_t && far_t > 0.f;
+}
+APT_D f3 vol_to_local(const DevVolume& vo, f3 p) { return mk3(dot(vo.inv_r0, p), dot(vo.inv_r1, p), dot(vo.inv_r2, p)); }
+APT_D float pick3(f3 a, int ch) { return (ch == 0) ? a.x : ((ch == 1) ? a.y : a.z); }
+// stochastic nearest-voxel lookup of one channel (volume.py:307-314 + rgb_select)
+APT_D float vol_density(const DevVolume& vo, f3 index, f3 u, int ch) {
+    const int ix = (int)floorf(index.x + (u.x - 0.5f)), iy = (int)floorf(index.y + (u.y - 0.5f)), iz = (int)floorf(index.z + (u.z - 0.5f));
+    if (ix >= 0 && iy >= 0 && iz >= 0 && ix < vo.xres && iy < vo.yres && iz < vo.zres)
+        return vo.grid[3 * (((size_t)iz * vo.yres + iy) * vo.xres + ix) + ch];
+    return 0.f;
+}
+// wavelength channel by throughput x majorant pdf (volume.py:352-377, 410-432)
+APT_D int vol_pick_channel(const DevVolume& vo, f3 thp, Philox& r, float& pdf) {
+    f3 pdfs = thp * vo.pdf;
+    pdfs = pdfs / sum3(pdfs);
+    const float val = rng_float(r);
+    if (val <= pdfs.x) { pdf = pdfs.x; return 0; }
+    if (val <= pdfs.x + pdfs.y) { pdf = pdfs.y; return 1; }
+    pdf = pdfs.z; return 2;
+}
+APT_D f3 channel_vec(int ch, float v) { return mk3(ch == 0 ? v : 0.f, ch == 1 ? v : 0.f, ch == 2 ? v : 0.f); }
+// GridVolume.sample_mfp: delta tracking (volume.py:295-305, 346-397); returns the collision distance or -1
+APT_D float vol_sample_mfp(const DevVolume& vo, f3 ray_o, f3 ray_d, f3 thp, float max_t, Philox& r, f3& beta) {
+    beta = splat3(1.f);
+    float near_t, far_t;
+    if (!vol_intersect(vo, ray_o, ray_d, max_t, near_t, far_t)) return -1.f;
+    const f3 ol = vol_to_local(vo, ray_o - vo.trans), dl = vol_to_local(vo, ray_d);
+    float pdf; const int ch = vol_pick_channel(vo, thp, r, pdf);
+    const float albedo = pick3(vo.albedo, ch), inv_maj = 1.0f / pick3(vo.majorant, ch);
+    float Tr = 1.0f, hit_t = -1.f;
+    float t = near_t - logf(1.0f - rng_float(r)) * inv_maj;
+    while (t < far_t) {
+        const float u0 = rng_float(r), u1 = rng_float(r), u2 = rng_float(r);
+        const float n_t = vol_density(vo, ol + dl * t, mk3(u0, u1, u2), ch);
+        if (rng_float(r) < n_t * inv_maj) { Tr *= albedo; hit_t = t; break; }
+        t -= logf(1.0f - rng_float(r)) * inv_maj;
+    }
+    beta = (vo.type == 2) ? channel_vec(ch, Tr / pdf) : splat3(Tr);
+    return hit_t;
+}
+// GridVolume.transmittance: ratio tracking with roulette (volume.py:283-293, 399-463)
+APT_D f3 vol_transmittance(const DevVolume& vo, f3 ray_o, f3 ray_d, f3 thp, float max_t, Philox& r) {
+    float near_t, far_t;
+    if (!vol_intersect(vo, ray_o, ray_d, max_t, near_t, far_t)) return splat3(1.f);
+    const f3 ol = vol_to_local(vo, ray_o - vo.trans), dl = vol_to_local(vo, ray_d);
+    float pdf; const int ch = vol_pick_channel(vo, thp, r, pdf);
+    const float inv_maj = 1.0f / pick3(vo.majorant, ch);
+    float Tr = 1.0f, t = near_t;
+    for (;;) {
+        t -= logf(1.0f - rng_float(r)) * inv_maj;
+        if (t >= far_t) break;
+        const float u0 = rng_float(r), u1 = rng_float(r), u2 = rng_float(r);
+        Tr *= fmaxf(0.0f, 1.0f - vol_density(vo, ol + dl * t, mk3(u0, u1, u2), ch) * inv_maj);
+        if (Tr < 0.1f) {
+            if (rng_float(r) >= Tr) { Tr = 0.0f; break; }
+            Tr = 1.0f;
+        }
+    }
+    return (vo.type == 2) ? channel_vec(ch, Tr / pdf) : splat3(Tr);
+}
+
 // ------------------------------------------------------------------- vshade
 // One iteration of the while-loop of vpt.py:161-253 for every path of ray queue `cur`, given its closest hit.  The bounce
 // counter lives in the path's meta word (a null-surface pass-through re-queues the path without counting a bounce) and the
@@ -111,8 +180,9 @@ APT_D float world_bound_time(const Params& p, f3 o, f3 d) {
 // an iteration, from the interaction being left).
 // BM / SM: material and emitter masks as in k_shade (code for absent models is compiled out); the all-models variant also carries
 // the image-texture lookup.
-template <int BM, int SM>
-__global__ void __launch_bounds__(BLOCK, (BM == 0x402 ? APT_VSHADE_LEAN_WAVES : 1)) k_vshade(DevScene sc, Params p, Queues q, Counters* cnt, int cur) {
+// VOL: the scene holds a grid volume (delta tracking in the free-path step, ratio tracking inside the light sampling).
+template <int BM, int SM, int VOL = 0>
+__global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEAN_WAVES : 1)) k_vshade(DevScene sc, Params p, Queues q, Counters* cnt, int cur) {
     constexpr bool TEX = (BM == APT_BX_ALL);
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
@@ -129,7 +199,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x402 ? APT_VSHADE_LEAN_WAVES : 
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
         const uint32_t pos = base + threadIdx.x;
         const uint32_t idx = qbase + pos;
-        bool alive = pos < n, shade = false, cont = false, is_mi = false, in_free = true;
+        bool alive = pos < n, shade = false, cont = false, is_mi = false, vol_event = false, in_free = true;
         f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), thr = splat3(0.f), hit_point = splat3(0.f);
         uint32_t id = 0, draw0 = 0, l_off = 0, bounce = 0;
         float emission_weight = 1.f;
@@ -162,7 +232,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x402 ? APT_VSHADE_LEAN_WAVES : 
                 // Step 2: the hit, or the far side of the world box when the world itself scatters (vpt.py:173-181)
                 const int prim = ldq(q.hit_prim, io);
                 if (prim < 0) {
-                    if (!world_scat) alive = false;
+                    if (!world_scat && !VOL) alive = false;
                     else { it.min_depth = world_bound_time(p, o, d); in_free = true; }
                 } else {
                     build_hit(sc, prim, ldq(q.hit_t, io), ldq(q.hit_u, io), ldq(q.hit_v, io), o, d, it);
@@ -174,11 +244,19 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x402 ? APT_VSHADE_LEAN_WAVES : 
                 // Step 3: free-path sampling in the medium the segment crosses (vpt.py:72-97,184)
                 f3 beta = splat3(1.f);
                 const bool world_valid = in_free && world_scat;
+                const float depth0 = it.min_depth;
                 if (world_valid || vpt_is_scattering(sc, it.obj_id)) {
                     float mfp = it.min_depth;
                     if (world_valid) { med = world; is_mi = medium_sample_mfp(*med, it.min_depth, rng, mfp, beta); }
                     else if (!in_free) { med = sc.med + it.obj_id; is_mi = medium_sample_mfp(*med, it.min_depth, rng, mfp, beta); }
                     it.min_depth = mfp;
+                }
+                if (VOL) {                                                  // a grid-volume event overrides the homogeneous one (vpt.py:91-96)
+                    f3 vb; const float vt = vol_sample_mfp(sc.vol, o, d, thr, depth0, rng, vb);
+                    if (vt > 0.f) {
+                        is_mi = true; vol_event = true; it.min_depth = vt; beta = vb;
+                        med = in_free ? world : sc.med + it.obj_id;         // what eval() looks at for such an event (path_tracer.py:466-470)
+                    }
                 }
                 if (it.obj_id < 0 && !is_mi) alive = false;                 // left the world box
                 else {
@@ -230,6 +308,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x402 ? APT_VSHADE_LEAN_WAVES : 
                     emitter_d = norm(to_emitter);
                     light_dir = to_emitter / emitter_d;
                     sampled = true;
+                    if (VOL) shadow_int = shadow_int * vol_transmittance(sc.vol, hit_point, light_dir, thr, emitter_d, rng);    // track_ray's first step (vpt.py:107-108): draws from the path's stream, here and now
                     f3 direct_spec;
                     if (is_mi) direct_spec = splat3(phase_eval_p(*med, d, light_dir));
                     else direct_spec = surface_eval<BM>(bx, it, d, light_dir, sc.world_ior, p.two_sides);
@@ -274,7 +353,10 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x402 ? APT_VSHADE_LEAN_WAVES : 
             }
             float ray_pdf = 1.f;
             if (is_mi) {                                                        // Medium.sample_new_rays, medium.py:112-121
-                if (med->type >= 0) {
+                if (VOL && vol_event) {                                         // GridVolume.sample_new_rays: its own phase function
+                    const f3 local = phase_sample_p(sc.vol.ph, d, rng, ray_pdf);
+                    new_d = delocalize(d, local);
+                } else if (med->type >= 0) {
                     const f3 local = phase_sample_p(*med, d, rng, ray_pdf);
                     new_d = delocalize(d, local);
                 }

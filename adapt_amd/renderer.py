@@ -92,6 +92,10 @@ class DeviceScene:
             med = [np.ascontiguousarray(fs.med_i, np.int32), np.ascontiguousarray(fs.med_f, np.float32)]
             keep += med
             desc.med_i, desc.med_f = _ip(med[0]), _fp(med[1])
+        if fs.vol_i is not None:                # grid volume (read by the volumetric tracer only)
+            vol = [np.ascontiguousarray(fs.vol_i, np.int32), np.ascontiguousarray(fs.vol_f, np.float32), np.ascontiguousarray(fs.vol_grid, np.float32)]
+            keep += vol
+            desc.vol_i, desc.vol_f, desc.vol_grid = _ip(vol[0]), _fp(vol[1]), _fp(vol[2])
         h = C.c_void_p()
         _lib.check(lib.apt_scene_create(C.byref(desc), int(device), C.byref(h)), "apt_scene_create")
         self.handle = h
@@ -145,8 +149,6 @@ class Renderer:
         self.lib = _lib.load()
         if volumetric is None:
             volumetric = self.VOLUMETRIC
-        if volumetric and prop.get("volume"):
-            raise NotImplementedError("grid volumes (bxdf/volume.py) are not supported; homogeneous media only")
         self.flat: FlatScene = pack_scene(emitters, array_info, objects, prop)
         self.rc: RenderConfig = make_config(prop, width=width, height=height, max_bounce=max_bounce,
                                             num_shadow_ray=num_shadow_ray, seed=seed, volumetric=bool(volumetric))
@@ -332,5 +334,5 @@ class Renderer:
 class VolumeRenderer(Renderer):
     """Drop-in for the reference's `VolumeRenderer` (renderer/vpt.py:29-50,145-262; `--type vpt`, the reference's default): same
     constructor and surface as `Renderer`, volumetric path tracing in homogeneous media (world medium, media attached to BSDF
-    objects, null surfaces, transmittance-tracked light samples).  Grid volumes are refused."""
+    objects, null surfaces, transmittance-tracked light samples) and in one grid volume (`<volume>`, adapt_amd/volumes.py)."""
     VOLUMETRIC = True

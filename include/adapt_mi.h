@@ -67,6 +67,11 @@ typedef struct apt_scene_desc {
      * none.  Row o < n_objects is the medium attached to object o's BSDF, row n_objects the world's. */
     const int32_t* med_i;       /* (n_objects+1)    type: -1 transparent, 0 hg, 1 multi-hg, 2 rayleigh, 3 mie */
     const float*   med_f;       /* (n_objects+1)*16 ior, u_s rgb, u_a rgb, u_e rgb, par[3], pdf[3] */
+    /* Grid volume for the volumetric path tracer (bxdf/volume.py:36-246; what GridVolume_np.export() hands to the kernels): all NULL
+     * when the scene declares none. */
+    const int32_t* vol_i;       /* 5   type (2 = RGB; the only kind the reference can export), xres, yres, zres, phase-function type */
+    const float*   vol_f;       /* 33  albedo rgb, inv_T[9] row-major, trans, mini, maxi (world box), majorant rgb, majorant pdf rgb, phase par[3], lobe weights[3] */
+    const float*   vol_grid;    /* zres*yres*xres*3 extinction per channel, [z][y][x][rgb] */
 } apt_scene_desc;
 
 /* Per-renderer configuration: film, camera, sampling flags, tile ownership, batching. */

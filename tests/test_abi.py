@@ -162,10 +162,6 @@ def test_struct_layouts_match_the_header():
     assert members("apt_stats") == [n for n, _ in _lib.Stats._fields_]
 
 
-def test_volume_renderer_refuses_grid_volumes(parsed):
+def test_volume_renderer_class():
     from adapt_amd.renderer import VolumeRenderer, Renderer
     assert VolumeRenderer.VOLUMETRIC and not Renderer.VOLUMETRIC and issubclass(VolumeRenderer, Renderer)
-    tup = parsed("cbox")
-    prop = dict(tup[3]); prop["volume"] = ["smoke.vol"]
-    with pytest.raises(NotImplementedError):
-        VolumeRenderer(tup[0], tup[1], tup[2], prop)

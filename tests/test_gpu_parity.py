@@ -661,3 +661,41 @@ def test_volumetric_tracer_on_scenes_without_media(tag, renderer, parsed, oracle
             assert abs(st[k] - ost[k]) <= 1e-3 * ost[k], (tag, k, st[k], ost[k])
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("name", ["volgrid_a", "volgrid_b"])
+def test_grid_volume_hip_vs_reference_run_and_oracle(name):
+    """Grid volumes on the device: delta tracking in the free-path step and ratio tracking inside the light sampling draw from the
+    path's own Philox stream in the reference's order, so image, vertices shaded, light samples and draw counts follow the oracle
+    (and the reference-run fixture) like every other scene."""
+    import os
+    from conftest import ROOT
+    from adapt_amd.parsers.xml_parser import scene_parsing
+    from adapt_amd.renderer import VolumeRenderer
+    from adapt_amd.scene_pack import pack_scene
+    from oracle import binding as ob
+    g = golden(f"vptrun_{name}.npz")
+    cwd = os.getcwd(); os.chdir(ROOT)
+    try:
+        tup = scene_parsing(os.path.join(ROOT, "scenes", "test"), name + ".xml")
+        w, h, spp = int(g["width"]), int(g["height"]), int(g["spp"])
+        r = VolumeRenderer(*tup, width=w, height=h)
+        fs = pack_scene(*tup)
+    finally:
+        os.chdir(cwd)
+    try:
+        assert "grid volume" in r.info()["shade_variant"]
+        r.render(n_spp=spp)
+        m = image_metrics(r.color.to_numpy() / spp, g["accum"] / spp)
+        assert m["frac_within"] >= 0.985 and m["relMSE"] <= 2e-3, (name, m)
+        assert abs(r.stats()["n_draws"] - int(g["draws"].sum())) <= 3e-3 * int(g["draws"].sum())
+        r.clear(); r.render(n_spp=16)
+        rc = make_config(tup[3], width=w, height=h, volumetric=True)
+        ref, _, ost = ob.OracleScene(fs, rc.cam_t).render(rc, 16)
+        m = image_metrics(r.color.to_numpy() / 16, ref / 16)
+        assert m["frac_within"] >= 0.985 and m["relMSE"] <= 2e-3, (name, m)
+        st = r.stats()
+        for k in ("n_shade", "n_shadow", "n_draws"):
+            assert abs(st[k] - ost[k]) <= 2e-3 * ost[k], (name, k, st[k], ost[k])
+    finally:
+        r.close()
