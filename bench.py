@@ -40,6 +40,8 @@ CONFIGS = {
     # volumetric path tracer (the reference's `--type vpt`): names starting with "v" render with VolumeRenderer
     "v1": ("vpt", "cbox_fog.xml", 512, 512, 256, 16, "vpt Cornell box (the reference's scenes/vpt/cbox.xml set-up: Lambertian box, quad light, fog cube = null surface + H-G medium); "
                                                     "512x512, 256 spp, 16 bounces, 1 light sample per vertex, volumetric tracer"),
+    "v3": ("test", "volgrid_a.xml", 512, 512, 128, 8, "volgrid_a: Cornell box with a 20x16x12 RGB grid volume (delta / ratio tracking), mirror ball, quad + point light, "
+                                                      "2 light samples per vertex; 512x512, 128 spp, 8 bounces, volumetric tracer"),
     "v2": ("test", "media_a.xml", 512, 512, 256, 8, "media_a: Cornell box, fog cube behind a null surface, scattering glass ball, thin multi-H-G world medium, "
                                                     "2 light samples per vertex; 512x512, 256 spp, 8 bounces, volumetric tracer (all-models kernel)"),
 }
@@ -50,7 +52,12 @@ def load_scene(sdir, sfile):
         from adapt_amd.synth import SYNTH_SCENES
         return SYNTH_SCENES[sfile]()
     from adapt_amd import scene_parsing
-    return scene_parsing(os.path.join(ROOT, "scenes", sdir), sfile)
+    cwd = os.getcwd()
+    os.chdir(ROOT)                  # texture / .vol paths inside scene files are relative to the repository root
+    try:
+        return scene_parsing(os.path.join(ROOT, "scenes", sdir), sfile)
+    finally:
+        os.chdir(cwd)
 
 
 def kernel_bytes(st):
