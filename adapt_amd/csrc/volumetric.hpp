@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEA
             id = ldq(q.id[cur], io);
             const uint32_t meta = ldq(q.meta[cur], io);
             emission_weight = ldq(q.pdf[cur], io);
-            bounce = (meta >> 16) & 0xffu; draw0 = meta & 0xffffu;
+            bounce = (meta >> 23) & 0xffu; draw0 = meta & 0x7fffffu;           // volumetric meta word: draw index [0,23) | bounce [23,31)
             const uint32_t lp = id & ((1u << p.pix_bits) - 1u), s = id >> p.pix_bits;
             l_off = (s * (uint32_t)p.npix + lp) << 2;
             rng_init(rng, ldq(p.pix_key, lp << 2), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEA
             st3q(q.ray_d[nxt], p.cap, so, new_d);
             st3q(q.thr[nxt], p.cap, so, thr);
             stq(q.id[nxt], so, id);
-            stq(q.meta[nxt], so, pack_meta(rng.draw, bounce, false));
+            stq(q.meta[nxt], so, (rng.draw & 0x7fffffu) | (bounce << 23));      // tracking loops draw thousands of numbers per path: 16 bits would wrap
             stq(q.pdf[nxt], so, emission_weight);
         }
     }
