@@ -135,7 +135,7 @@ struct Counters {
 };
 
 // meta word: draw index [0,16) | bounce [16,24) | is_specular bit 24
-APT_D uint32_t pack_meta(uint32_t draw, uint32_t bounce, bool spec) { return (draw & 0xffffu) | (bounce << 16) | (spec ? (1u << 24) : 0u); }
+APT_D uint32_t pack_meta(uint32_t draw, uint32_t bounce, bool spec) { return (draw & 0xffffu) | ((bounce & 0xffu) << 16) | (spec ? (1u << 24) : 0u); }
 
 #define BLOCK 256
 
