@@ -397,7 +397,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     apt_render_cfg c = *cfg;
     if (c.width <= 0 || c.height <= 0 || c.max_bounce < 0 || c.num_shadow_ray < 0) return fail(APT_E_INVALID, "apt_renderer_create: bad film / bounce settings");
     // a path's position in its random stream travels in 16 bits of the meta word (23 in the volumetric tracer): bound the draws a path can make
-    if (!c.volumetric && (int64_t)(4 * (int64_t)c.num_shadow_ray + 8) * (int64_t)c.max_bounce + 4 >= 65536)
+    if (!c.volumetric && (int64_t)(5 * (int64_t)c.num_shadow_ray + 8) * (int64_t)c.max_bounce + 4 >= 65536)
         return fail(APT_E_INVALID, "apt_renderer_create: num_shadow_ray x max_bounce too large for the 16-bit draw index of a path");
     if (c.world_size <= 0) { c.world_size = 1; c.rank = 0; }
     if (c.band_width <= 0) c.band_width = c.width;
