@@ -115,6 +115,7 @@ struct apt_scene {
     apt::BvhData bvh;
     DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
     DevBuf uvs, tex_i, tex_f, atlas[3];      // image textures (empty when the scene has none)
+    DevBuf prim_shade;                   // per-primitive shading records (stages.hpp DevScene::prim_shade)
     DevBuf med;                          // participating media, n_objects + 1 rows (volumetric path tracer)
     DevBuf vol_grid;                     // grid volume densities
     bool has_volume = false;
@@ -339,6 +340,20 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
             UP(atlas[m], img);
             ds.atlas[m] = s->atlas[m].as<float>(); ds.atlas_w[m] = d->atlas_w[m];
         }
+    }
+    {   // per-primitive shading records
+        std::vector<float> ps((size_t)N * 8, 0.f);
+        for (int k = 0; k < N; k++) {
+            float* r = ps.data() + 8 * (size_t)k;
+            const int o = prim_obj[(size_t)k];
+            int32_t code = sphere[(size_t)k] ? ~o : o, light = d->emitter_id[o];
+            const float* src3 = sphere[(size_t)k] ? prec.data() + 9 * (size_t)k : d->normals + 3 * (size_t)k;      // centre | n_g
+            r[0] = src3[0]; r[1] = src3[1]; r[2] = src3[2];
+            memcpy(&r[3], &code, 4); memcpy(&r[4], &light, 4);
+            r[5] = d->bxdf_f[13 * o]; r[6] = d->bxdf_f[13 * o + 1]; r[7] = d->bxdf_f[13 * o + 2];
+        }
+        UP(prim_shade, ps);
+        ds.prim_shade = s->prim_shade.as<float4>();
     }
     {   // participating media: transparent everywhere unless the description carries the tables
         std::vector<DevMedium> md((size_t)O + 1);

@@ -66,6 +66,10 @@ struct DevScene {
     const float* tex_f;       // n_objects*3*2: scale_u, scale_v
     const float* atlas[3];
     int atlas_w[3];
+    // per-primitive shading record, 32 B: (n_g | sphere centre, object code = id or ~id for a sphere), (emitter id, k_d of the object's
+    // material).  One fetch after the hit primitive is known replaces the chain primitive -> object -> {is-sphere flag -> normal,
+    // emitter id, material}; the Lambertian-only kernel needs nothing else from the scene tables.
+    const float4* prim_shade;
     const DevMedium* med;     // n_objects + 1 rows (the last one is the world's), nullptr when the scene declares no media
     DevVolume vol;
 };
@@ -496,22 +500,28 @@ APT_D bool get_uv_item(const DevScene& sc, int map, int obj, int prim, float bu,
 }
 
 // -------------------------------------------------------------------- shade
-APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3 o, f3 d, Hit& it) {
+APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3 o, f3 d, Hit& it, int& hit_light, f3& k_d) {
+    const float4 ra = sc.prim_shade[2 * prim], rb = sc.prim_shade[2 * prim + 1];
+    const int code = __float_as_int(ra.w);
     it.prim_id = prim; it.min_depth = t;
-    it.obj_id = sc.prim_obj[prim];
-    if (sc.obj_info[3 * it.obj_id + 2]) {
-        // sphere: precom row 0 = centre; normal from the hit point (tracer_base.py:217-223)
-        f3 c = ld3(sc.precom + 9 * prim);
-        it.n_g = normalize((o + d * t) - c);
+    it.obj_id = (code < 0) ? ~code : code;
+    hit_light = __float_as_int(rb.x);
+    k_d = mk3(rb.y, rb.z, rb.w);
+    if (code < 0) {
+        // sphere: the record holds the centre; normal from the hit point (tracer_base.py:217-223)
+        it.n_g = normalize((o + d * t) - mk3(ra.x, ra.y, ra.z));
         it.n_s = it.n_g;
     } else {
-        it.n_g = ld3(sc.normals + 3 * prim);
+        it.n_g = mk3(ra.x, ra.y, ra.z);
         if (sc.has_vn) {
             const float* vn = sc.vnormals + 9 * prim;
             // interpolated vertex normal, NOT re-normalised (tracer_base.py:228-230)
             it.n_s = (ld3(vn) * (1.f - u - v) + ld3(vn + 3) * u) + ld3(vn + 6) * v;
         } else it.n_s = it.n_g;
     }
+}
+APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3 o, f3 d, Hit& it) {
+    int light; f3 kd; build_hit(sc, prim, t, u, v, o, d, it, light, kd);
 }
 
 // BM / SM: material and emitter masks of the scene (shading.hpp); code for absent models is compiled out.
@@ -567,9 +577,10 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_
                 uint32_t meta = ldq(in.meta, io);
                 ray_pdf = ldq(in.pdf, io);
                 was_spec = (meta >> 24) & 1u;
-                build_hit(sc, prim, ldq(in.t, io), ldq(in.u, io), ldq(in.v, io), o, d, it);
-                bx = sc.bxdf[it.obj_id];
-                hit_light = sc.emitter_id[it.obj_id];
+                f3 rec_kd;
+                build_hit(sc, prim, ldq(in.t, io), ldq(in.u, io), ldq(in.v, io), o, d, it, hit_light, rec_kd);
+                if (BM == 0x002) bx.k_d = rec_kd;               // Lambertian-only scenes: type 1, not delta, not a BSDF (the defaults above), colour from the record
+                else bx = sc.bxdf[it.obj_id];
                 if (TEX && sc.tex_i != nullptr) {                // the scene declares image textures (TEX kernels only, see below)
                     const float bu = ldq(in.u, io), bv = ldq(in.v, io);
                     f3 tx;

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEA
         float emission_weight = 1.f;
         Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
         Hit it; it.obj_id = -1; it.prim_id = -1; it.n_s = it.n_g = mk3(1.f, 0.f, 0.f); it.min_depth = 0.f;
-        int hit_light = -1;
+        int hit_light = -1, rec_light = -1;
         DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
         const DevMedium* med = world;                         // the medium of a medium interaction (a pointer, not a 17-register copy)
         if (alive) {
@@ -235,7 +235,8 @@ __global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEA
                     if (!world_scat && !VOL) alive = false;
                     else { it.min_depth = world_bound_time(p, o, d); in_free = true; }
                 } else {
-                    build_hit(sc, prim, ldq(q.hit_t, io), ldq(q.hit_u, io), ldq(q.hit_v, io), o, d, it);
+                    f3 rec_kd;
+                    build_hit(sc, prim, ldq(q.hit_t, io), ldq(q.hit_u, io), ldq(q.hit_v, io), o, d, it, rec_light, rec_kd);
                     in_free = dot(it.n_g, d) < 0.f;
                     bx = sc.bxdf[it.obj_id];
                 }
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEA
                     else {
                         shade = true;
                         if (!is_mi) {
-                            hit_light = sc.emitter_id[it.obj_id];
+                            hit_light = rec_light;
                             f3 tx;
                             if (TEX && sc.tex_i != nullptr && get_uv_item(sc, 0, it.obj_id, it.prim_id, ldq(q.hit_u, io), ldq(q.hit_v, io), tx)) bx.k_d = tx;   // vpt.py:199
                         }
@@ -370,7 +371,7 @@ __global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEA
             bounce += 1;
             if ((int)bounce >= p.max_bounce) cont = false;
             if (cont && it.obj_id >= 0) {                                       // vpt.py:247-253, with THIS interaction
-                hit_light = sc.emitter_id[it.obj_id];
+                hit_light = rec_light;
                 if (p.use_mis) {
                     float e_pdf = 0.0f;
                     if (hit_light >= 0 && bx.is_delta == 0 && !is_spec) e_pdf = emitter_solid_angle_pdf(sc.src[hit_light], it, new_d);
