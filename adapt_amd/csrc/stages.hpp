@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_
                 const uint32_t lp = id & ((1u << p.pix_bits) - 1u), s = id >> p.pix_bits;
                 l_off = (s * (uint32_t)p.npix + lp) << 2;
                 draw0 = meta & 0xffffu;
-                rng_init(rng, ldq(p.pix_key, lp << 2), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
+                rng_init(rng, (p.world == 1) ? lp : ldq(p.pix_key, lp << 2), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
                 // tail of the previous iteration: emission MIS weight for this hit (vanilla_renderer.py:111-117)
                 if (bounce > 0 && p.use_mis) {
                     float e_pdf = 0.0f;

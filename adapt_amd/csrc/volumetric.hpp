@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEA
             bounce = (meta >> 23) & 0xffu; draw0 = meta & 0x7fffffu;           // volumetric meta word: draw index [0,23) | bounce [23,31)
             const uint32_t lp = id & ((1u << p.pix_bits) - 1u), s = id >> p.pix_bits;
             l_off = (s * (uint32_t)p.npix + lp) << 2;
-            rng_init(rng, ldq(p.pix_key, lp << 2), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
+            rng_init(rng, (p.world == 1) ? lp : ldq(p.pix_key, lp << 2), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
             // Step 1: Russian roulette / cut-off BEFORE the intersection is looked at (vpt.py:164-172)
             if (p.use_rr) {
                 const float mx = max3(thr);
