@@ -148,6 +148,7 @@ struct apt_renderer {
     int sorted = 0;               // 1 = material-sorted shading (>= 2 material classes in the scene)
     int volumetric = 0;           // 1 = VolumeRenderer.render semantics (volumetric.hpp)
     int dyn_fetch = 0;            // BVH mode: closest-hit walk with dynamic ray fetch (k_extend_dyn)
+    int ovf_levels = 0;           // traversal-stack levels beyond the LDS part
     const VShadeVariant* vshade = nullptr;
     shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string shade_name;
@@ -166,7 +167,8 @@ struct apt_renderer {
     // one lane's latency-bound shade runs beside another lane's VALU-bound extend.  Lane 0 is {stream, pool, counters, q}
     // above; the framebuffer is shared and the finalize kernels are chained by events so that samples are still added to
     // a pixel in sample order (bit-identical to the single-lane result).
-    struct Lane { hipStream_t stream = nullptr; DevBuf pool, counters; Queues q{}; hipEvent_t fin = nullptr; };
+    struct Lane { hipStream_t stream = nullptr; DevBuf pool, counters, ovf; Queues q{}; hipEvent_t fin = nullptr; LdsPlan plan{}; };
+    DevBuf ovf;                   // lane 0: global spill columns of the BVH traversal stack
     std::vector<Lane> extra;      // lanes 1..n-1
     hipEvent_t fin0 = nullptr;    // lane 0's "finalize done" event
     int n_lanes = 1;
@@ -558,7 +560,12 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     {
         const apt::BvhData& bd = sc->bvh;
         LdsPlan pl;
-        pl.stack_depth = bd.max_depth + 2;
+        const int full_depth = bd.max_depth + 2;
+        int lds_levels = 20;                                 // 20 KiB per workgroup: eight workgroups (8 waves per SIMD, the VGPR limit) per CU; measured: 27 -> 20 levels = -8 % walk time
+        if (const char* sd = getenv("APT_BVH_LDS_LEVELS")) lds_levels = std::max(4, atoi(sd));
+        pl.stack_depth = std::min(full_depth, lds_levels);   // deeper levels spill to per-lane global columns (traverse.hpp TravStack)
+        r->ovf_levels = full_depth - pl.stack_depth;
+        pl.ovf = nullptr; pl.ovf_stride = 0;
         size_t stack_b = (size_t)pl.stack_depth * BLOCK * 4;
         size_t lds_target = 8 * 1024;                        // per-workgroup LDS target of the BVH walk beyond which nothing is staged: the stack alone is ~27 KiB on the 95 k / 285 k-triangle scenes
         if (const char* kb = getenv("APT_BVH_LDS_KB")) lds_target = (size_t)std::max(8, atoi(kb)) * 1024;
@@ -619,6 +626,17 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     r->grid_trace = ((r->grid_trace + nq - 1) / nq) * nq;          // persistent grids are multiples of nq
     r->grid_shadow = ((r->grid_shadow + nq - 1) / nq) * nq;
     r->grid_small = ((r->grid_small + nq - 1) / nq) * nq;
+    for (auto& ln : r->extra) ln.plan = r->plan;
+    if (r->trace_mode == 0 && r->ovf_levels > 0) {
+        const int max_grid = std::max(r->grid_trace, std::max(r->grid_shadow, r->grid_vshadow));
+        const size_t stride = (size_t)max_grid * BLOCK, bytes = stride * (size_t)r->ovf_levels * 4;
+        if ((e = r->ovf.alloc(bytes)) != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("traversal stack spill: ") + hipGetErrorString(e)); }
+        r->plan.ovf = r->ovf.as<int>(); r->plan.ovf_stride = (int)stride;
+        for (auto& ln : r->extra) {
+            if ((e = ln.ovf.alloc(bytes)) != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("traversal stack spill (lane): ") + hipGetErrorString(e)); }
+            ln.plan = r->plan; ln.plan.ovf = ln.ovf.as<int>();
+        }
+    }
     HIP_TRY(hipStreamSynchronize(r->stream));
     *out = r;
     return APT_OK;
@@ -702,15 +720,16 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
             hipStream_t st = is.li ? r->extra[(size_t)is.li - 1].stream : r->stream;
             const Queues& q = is.li ? r->extra[(size_t)is.li - 1].q : r->q;
             Counters* cnt = is.li ? r->extra[(size_t)is.li - 1].counters.as<Counters>() : r->counters.as<Counters>();
+            const LdsPlan& lane_plan = is.li ? r->extra[(size_t)is.li - 1].plan : r->plan;
             for (int b = 0; b < n_iter; b++) {
                 if (r->dyn_fetch) HIP_TRY_VOID(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st));
-                { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[0] : kExtend[r->trace_mode][0], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], r->plan); }
+                { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[0] : kExtend[r->trace_mode][0], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
                 { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vshade->fn, dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, is.cur); }
                 if (is.p.S > 0) {
                     const int n_pass = r->scene->has_null_surface ? 7 : 1;       // track_ray walks at most seven segments (vpt.py:113)
                     for (int pass = 0; pass < n_pass; pass++) {
                         LaunchTimer t(r, 3, st);
-                        hipLaunchKernelGGL(kVShadow[r->trace_mode], dim3(grid_for(is.total * (size_t)is.p.S, r->grid_vshadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, r->plan, pass);
+                        hipLaunchKernelGGL(kVShadow[r->trace_mode], dim3(grid_for(is.total * (size_t)is.p.S, r->grid_vshadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, lane_plan, pass);
                     }
                 }
                 is.cur ^= 1;
@@ -769,6 +788,7 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
         const Queues& q = li ? r->extra[(size_t)li - 1].q : r->q;
         Counters* cnt = li ? r->extra[(size_t)li - 1].counters.as<Counters>() : r->counters.as<Counters>();
         hipEvent_t fin = li ? r->extra[(size_t)li - 1].fin : r->fin0;
+        const LdsPlan& lane_plan = li ? r->extra[(size_t)li - 1].plan : r->plan;
         Params p = r->par; p.cnt_base = r->cnt; p.spp_batch = B;
         const size_t total = (size_t)r->npix * (size_t)B;
         HIP_TRY(hipMemsetAsync(cnt, 0, offsetof(Counters, stats), st));   // queue counters only; statistics keep accumulating
@@ -777,7 +797,7 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
         int cur = 0;
         for (int b = 0; b < p.max_bounce; b++) {
             if (r->dyn_fetch) HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st));
-            { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], r->plan); }
+            { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
             if (!r->sorted) {
                 ShadeIn in = {q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.id[cur], q.meta[cur], q.pdf[cur],
                               q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur]};
@@ -792,8 +812,8 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
             }
             if (p.S > 0 && r->dyn_fetch) {
                 HIP_TRY(hipMemsetAsync(cnt->n_work[1], 0, sizeof(cnt->n_work[1]), st));
-                LaunchTimer t(r, 3, st); hipLaunchKernelGGL(k_shadow_dyn, dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, r->plan);
-            } else if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, r->plan); }
+                LaunchTimer t(r, 3, st); hipLaunchKernelGGL(k_shadow_dyn, dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan);
+            } else if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan); }
             cur ^= 1;
         }
         // the framebuffer is shared: batch k's samples are added after batch k-1's, whichever lanes they ran on

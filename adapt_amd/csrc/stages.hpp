@@ -145,7 +145,7 @@ APT_D uint32_t pack_meta(uint32_t draw, uint32_t bounce, bool spec) { return (dr
 
 // LDS carve for the traversal stages (dynamic, sized per scene by the host):
 //   [ lds_nodes * 64 B node records | lds_prims * 48 B primitive records | stack_depth * BLOCK ints ]
-struct LdsPlan { int lds_nodes, lds_prims, stack_depth; };
+struct LdsPlan { int lds_nodes, lds_prims, stack_depth; int* ovf; int ovf_stride; };     // stack_depth: levels kept in LDS; ovf: global spill columns (one per thread of the largest grid)
 extern __shared__ float4 s_dyn[];
 APT_D int* carve_lds(const DevBvh& b, const LdsPlan& plan, StagedBvh& out) {
     float4* s_nodes = s_dyn;
@@ -153,6 +153,12 @@ APT_D int* carve_lds(const DevBvh& b, const LdsPlan& plan, StagedBvh& out) {
     stage_bvh(b, s_nodes, plan.lds_nodes, s_prims, plan.lds_prims, out);
     __syncthreads();
     return reinterpret_cast<int*>(s_prims + 3 * plan.lds_prims) + threadIdx.x;
+}
+APT_D TravStack make_stack(int* lds_column, const LdsPlan& plan) {
+    TravStack ts;
+    ts.lds = lds_column; ts.stride = BLOCK; ts.k = plan.stack_depth; ts.ovf_stride = plan.ovf_stride;
+    ts.ovf = plan.ovf ? plan.ovf + (blockIdx.x * blockDim.x + threadIdx.x) : nullptr;
+    return ts;
 }
 
 APT_D uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -325,7 +331,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
         const f3 o = ld3q(ro, p.cap, io);
         const f3 d = ld3q(rd, p.cap, io);
         HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
-        if (MODE == 0) traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
+        if (MODE == 0) traverse<false>(bvh, make_stack(my_stack, plan), o, d, rec);
         else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
 #ifdef APT_TILE_PROF
         else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn), tile_prof);
@@ -377,8 +383,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 template <int SORTED>
 __global__ void __launch_bounds__(BLOCK) k_extend_dyn(DevScene sc, Params p, Queues q, Counters* cnt, int cur_q, const uint32_t* n_src, LdsPlan plan) {
     StagedBvh bvh;
-    int* stack = carve_lds(sc.bvh, plan, bvh);
-    const int stride = BLOCK;
+    const TravStack ts = make_stack(carve_lds(sc.bvh, plan, bvh), plan);
     const int sq = (int)(blockIdx.x % (uint32_t)p.nq);
     const uint32_t n = n_src[sq * CNT_PAD];
     if (blockIdx.x / (uint32_t)p.nq == 0 && threadIdx.x == 0) {
@@ -447,11 +452,11 @@ __global__ void __launch_bounds__(BLOCK) k_extend_dyn(DevScene sc, Params p, Que
                 bool hl = tl >= 0.f, hr = tr >= 0.f;
                 if (hl && hr) {
                     bool swap = tr < tl;
-                    stack[sp * stride] = swap ? l : r; sp++;
+                    tpush(ts, sp, swap ? l : r);
                     cur = swap ? r : l;
                 } else if (hl) cur = l;
                 else if (hr) cur = r;
-                else if (sp > 0) { sp--; cur = stack[sp * stride]; }
+                else if (sp > 0) cur = tpop(ts, sp);
                 else cur = APT_TRAV_DONE;
             }
             while (cur < 0 && cur != APT_TRAV_DONE) {
@@ -463,7 +468,7 @@ __global__ void __launch_bounds__(BLOCK) k_extend_dyn(DevScene sc, Params p, Que
                     float t = prim_test(p0, p1, p2, o, d, u, v);
                     if (t > 1e-4f && t < rec.t) { rec.t = t; rec.prim = __float_as_int(p2.y); rec.u = u; rec.v = v; }
                 }
-                if (sp > 0) { sp--; cur = stack[sp * stride]; }
+                if (sp > 0) cur = tpop(ts, sp);
                 else cur = APT_TRAV_DONE;
             }
             if (state == 1 && cur == APT_TRAV_DONE) state = 2;
@@ -758,7 +763,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
         const f3 d = ld3q(q.sh_d, sc_, io);
         const float dist = ldq(q.sh_tmax, io);
         HitRec rec; rec.t = (dist > 0.0f) ? dist - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        const bool occluded = (MODE == 0) ? traverse<true>(bvh, my_stack, BLOCK, o, d, rec)
+        const bool occluded = (MODE == 0) ? traverse<true>(bvh, make_stack(my_stack, plan), o, d, rec)
                             : (MODE == 1) ? sweep_wg<true, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep)
                                           : sweep_tile<true, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         if (valid) {
@@ -786,8 +791,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 // unoccluded, and claims the next shadow ray as soon as the wave runs low on walking lanes.
 __global__ void __launch_bounds__(BLOCK) k_shadow_dyn(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
     StagedBvh bvh;
-    int* stack = carve_lds(sc.bvh, plan, bvh);
-    const int stride = BLOCK;
+    const TravStack ts = make_stack(carve_lds(sc.bvh, plan, bvh), plan);
     const int sq = (int)(blockIdx.x % (uint32_t)p.nq);
     const uint32_t n = min(cnt->n_shadow[sq * CNT_PAD], q.sh_subcap);
     if (blockIdx.x / (uint32_t)p.nq == 0 && threadIdx.x == 0) {
@@ -847,11 +851,11 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_dyn(DevScene sc, Params p, Que
                 bool hl = tl >= 0.f, hr = tr >= 0.f;
                 if (hl && hr) {
                     bool swap = tr < tl;
-                    stack[sp * stride] = swap ? l : r; sp++;
+                    tpush(ts, sp, swap ? l : r);
                     cur = swap ? r : l;
                 } else if (hl) cur = l;
                 else if (hr) cur = r;
-                else if (sp > 0) { sp--; cur = stack[sp * stride]; }
+                else if (sp > 0) cur = tpop(ts, sp);
                 else cur = APT_TRAV_DONE;
             }
             while (cur < 0 && cur != APT_TRAV_DONE) {
@@ -863,7 +867,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_dyn(DevScene sc, Params p, Que
                     float t = prim_test(p0, p1, p2, o, d, u, v);
                     if (t > 1e-4f && t < tmax) { occluded = true; sp = 0; break; }      // first occluder ends the walk
                 }
-                if (sp > 0) { sp--; cur = stack[sp * stride]; }
+                if (sp > 0) cur = tpop(ts, sp);
                 else cur = APT_TRAV_DONE;
             }
             if (state == 1 && cur == APT_TRAV_DONE) state = 2;
@@ -905,7 +909,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE)) k_occluded(DevScene sc, uint32
         const uint32_t idx = valid ? pos : n - 1;
         f3 o = mk3(o_[idx], o_[n + idx], o_[2 * n + idx]), d = mk3(d_[idx], d_[n + idx], d_[2 * n + idx]);
         HitRec rec; rec.t = (tmax[idx] > 0.0f) ? tmax[idx] - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        const bool hit = (MODE == 0) ? traverse<true>(bvh, my_stack, BLOCK, o, d, rec)
+        const bool hit = (MODE == 0) ? traverse<true>(bvh, make_stack(my_stack, plan), o, d, rec)
                        : (MODE == 1) ? sweep_any(sc.sweep, o, d, rec)
                                      : sweep_tile<true, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         if (valid) occ[idx] = hit ? 1 : 0;

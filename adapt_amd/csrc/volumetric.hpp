@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAVES
         const f3 d = ld3q(q.sh_d, sc_, io);
         float depth = ldq(q.sh_tmax, io);
         HitRec rec; rec.t = (depth > 0.0f) ? depth - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        if (MODE == 0) traverse<false>(bvh, my_stack, BLOCK, o, d, rec);
+        if (MODE == 0) traverse<false>(bvh, make_stack(my_stack, plan), o, d, rec);
         else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
         else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         bool arrived = false, walk_on = false;

@@ -354,6 +354,34 @@ def bunnies_small():
     return three_bunnies(levels=1)                 # 5 950 triangles: the oracle's brute force still finishes in seconds
 
 
+@pytest.mark.parametrize("levels,dyn", [(4, "1"), (4, "0"), (64, "1")])
+def test_bvh_stack_spill_and_fetch_modes_agree(levels, dyn, bunnies_small, monkeypatch):
+    """The traversal stack keeps its first levels in LDS and spills deeper ones to global columns; with only 4 LDS levels nearly every
+    ray spills.  Closest hits, occlusion flags and the image must not depend on where the stack lives nor on whether rays are assigned
+    to lanes statically or fetched dynamically (same per-ray arithmetic): compared with the default configuration bit for bit."""
+    from adapt_amd.renderer import Renderer
+    rs = np.random.RandomState(5)
+    n = 4000
+    o = rs.uniform([0.3, 0.2, 0.3], [5.2, 5.2, 5.2], size=(n, 3)).astype(np.float32)
+    d = rs.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tmax = rs.uniform(0.2, 6.0, n).astype(np.float32)
+    ref = Renderer(*bunnies_small, width=64, height=64)
+    ref_hit, ref_occ = ref.intersect(o, d), ref.occluded(o, d, tmax)
+    ref.render(n_spp=3); ref_img = ref.color.to_numpy(); ref.close()
+    monkeypatch.setenv("APT_BVH_LDS_LEVELS", str(levels)); monkeypatch.setenv("APT_DYN_FETCH", dyn)
+    r = Renderer(*bunnies_small, width=64, height=64)
+    try:
+        prim, t, uv = r.intersect(o, d)
+        assert np.array_equal(prim, ref_hit[0]) and np.array_equal(t, ref_hit[1]) and np.array_equal(uv, ref_hit[2])
+        assert np.array_equal(r.occluded(o, d, tmax), ref_occ)
+        r.render(n_spp=3)
+        a, b = r.color.to_numpy(), ref_img
+        # three-bunnies takes two light samples per vertex: their float atomics may land in either order, nothing else may differ
+        assert np.mean(np.all(np.abs(a - b) <= 1e-5 * (1 + np.abs(b)), axis=2)) >= 0.999
+    finally:
+        r.close()
+
+
 def test_bvh_mode_matches_oracle_on_mesh_scene(bunnies_small):
     """> 96 primitives => BVH traversal (own tree).  Against the oracle's BRUTE-FORCE intersector: same closest hits,
     same occlusion, same image, spot lights + glass + fresnel-blend."""
