@@ -1,6 +1,7 @@
 /*
  * adapt_mi.h — C-ABI of libadapt_mi.so: the MI355X (gfx950) wavefront path tracer that
- * stands in for AdaPT's Taichi `pt` renderer.
+ * stands in for AdaPT's Taichi `pt` renderer (Renderer, renderer/vanilla_renderer.py) and, with apt_render_cfg.volumetric = 1,
+ * for its `vpt` renderer (VolumeRenderer, renderer/vpt.py: homogeneous media, null surfaces, one grid volume).
  *
  * What each entry point replaces in the reference (paths under /root/reference):
  *   apt_bvh_build / apt_bvh_*      tracer/bvh/bvh.cpp:274-296  bvh_cpp.bvh_build(...) (pybind11 module),
@@ -9,8 +10,8 @@
  *                                   tracer/path_tracer.py:245-274 (initialze): numpy -> device fields
  *   apt_renderer_create            renderer/vanilla_renderer.py:26-30 / tracer_base.py:36-102 (film, crop, camera,
  *                                   sampling flags) — the constructor half that is not scene data
- *   apt_render                     renderer/vanilla_renderer.py:32-120  Renderer.render (one launch == one spp
- *                                   there; here `n_spp` samples per call, cnt += n_spp)
+ *   apt_render                     renderer/vanilla_renderer.py:32-120  Renderer.render, or renderer/vpt.py:145-258
+ *                                   VolumeRenderer.render (one launch == one spp there; here `n_spp` samples per call, cnt += n_spp)
  *   apt_read_pixels                `rdr.pixels.to_numpy()` (utils/watermark.py:23): color / cnt, layout [x][y][rgb]
  *   apt_get_accum / apt_set_accum  tracer/path_tracer.py:181-211  get_check_point / load_check_point
  *   apt_get_stats                  (none; the reference only has ti.profiler, render.py:154-160)
