@@ -79,12 +79,22 @@ static const extend_fn kExtend[3][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_ext
 static const extend_fn kExtendDyn[2] = {k_extend_dyn<0>, k_extend_dyn<1>};      // BVH walk with dynamic ray fetch [sorted]
 static const shadow_fn kShadow[3] = {k_shadow<0>, k_shadow<1>, k_shadow<2>};
 static const occluded_fn kOccluded[3] = {k_occluded<0>, k_occluded<1>, k_occluded<2>};
-typedef void (*vshade_fn)(DevScene, Params, Queues, Counters*, int);
+typedef void (*vshade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int);
 struct VShadeVariant { int bm, sm; vshade_fn fn; const char* name; };
 static const VShadeVariant kVShadeVariants[] = {          // first match wins; 0x400 = "other BSDF" = the null surface
     {0x402, 0x03, k_vshade<0x402, 0x03>, "volumetric: lambertian+null/point+area"},
     {0x503, 0x07, k_vshade<0x503, 0x07>, "volumetric: phong+lambertian+glass+null/point+area+spot"},
     {APT_BX_ALL, APT_SRC_ALL, k_vshade<APT_BX_ALL, APT_SRC_ALL>, "volumetric: all models"},
+};
+// sorted volumetric shading: one kernel per surface class (kClassMask order) plus the class of rays that hit nothing (index
+// APT_N_CLASS_DEFS: media only), without / with a grid volume.  Every class kernel carries the medium code; what it sheds is the
+// other surface models, i.e. most of the all-models kernel's 256 VGPRs + AGPR spills.
+static const vshade_fn kVClassShade[APT_N_CLASS_DEFS + 1][2] = {
+    {k_vshade<0x00a, APT_SRC_ALL>, k_vshade<0x00a, APT_SRC_ALL, 1>}, {k_vshade<0x001, APT_SRC_ALL>, k_vshade<0x001, APT_SRC_ALL, 1>},
+    {k_vshade<0x040, APT_SRC_ALL>, k_vshade<0x040, APT_SRC_ALL, 1>}, {k_vshade<0x504, APT_SRC_ALL>, k_vshade<0x504, APT_SRC_ALL, 1>},
+    {k_vshade<0x010, APT_SRC_ALL>, k_vshade<0x010, APT_SRC_ALL, 1>}, {k_vshade<0x020, APT_SRC_ALL>, k_vshade<0x020, APT_SRC_ALL, 1>},
+    {k_vshade<0x080, APT_SRC_ALL>, k_vshade<0x080, APT_SRC_ALL, 1>}, {k_vshade<0x200, APT_SRC_ALL>, k_vshade<0x200, APT_SRC_ALL, 1>},
+    {k_vshade<0x000, APT_SRC_ALL>, k_vshade<0x000, APT_SRC_ALL, 1>},
 };
 static const VShadeVariant kVShadeVolVariants[] = {       // scenes with a grid volume
     {0x402, 0x03, k_vshade<0x402, 0x03, 1>, "volumetric + grid volume: lambertian+null/point+area"},
@@ -119,6 +129,7 @@ struct apt_scene {
     DevBuf med;                          // participating media, n_objects + 1 rows (volumetric path tracer)
     DevBuf vol_grid;                     // grid volume densities
     bool has_volume = false;
+    bool world_scattering = false;       // the world medium scatters (rays that hit nothing still take part, vpt.py:176-181)
     bool has_null_surface = false;       // some object carries a null BSDF (rays pass, vpt.py:189-191)
     bool phong_no_lobe = true;           // every Blinn-Phong material has k_s = 0 and finite k_g >= 0
     float box_min[3] = {1e3f, 1e3f, 1e3f}, box_max[3] = {-1e3f, -1e3f, -1e3f};    // union of the object boxes (path_tracer.py:130-134)
@@ -150,6 +161,8 @@ struct apt_renderer {
     int dyn_fetch = 0;            // BVH mode: closest-hit walk with dynamic ray fetch (k_extend_dyn)
     int ovf_levels = 0;           // traversal-stack levels beyond the LDS part
     const VShadeVariant* vshade = nullptr;
+    vshade_fn vclass_fn[APT_N_CLASS_DEFS + 1] = {};     // sorted volumetric shading: kernel per class queue (the miss class last)
+    int v_ncls = 0;               // class queues in use (surface classes + the miss class when misses matter)
     shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string shade_name;
     LdsPlan plan{};
@@ -371,6 +384,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         }
         UP(med, md);
         ds.med = s->med.as<DevMedium>();
+        s->world_scattering = md[(size_t)O].type >= 0;
         for (int o = 0; o < O; o++) {
             if (bx[(size_t)o].is_bsdf && bx[(size_t)o].type < 0) s->has_null_surface = true;
             if (d->obj_aabb) for (int a = 0; a < 3; a++) {
@@ -483,13 +497,27 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         for (const VShadeVariant& v : kVShadeVariants)
             if ((sc->bx_mask & ~v.bm) == 0 && (sc->src_mask & ~v.sm) == 0 && !(textured && v.bm != APT_BX_ALL)) { r->vshade = &v; break; }
         if (!r->vshade) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: scene uses a material or emitter type the volumetric kernels do not know"); }
+        // event-class sorting pays when the all-models kernel would be needed for a scene of several material classes
+        const bool keep_miss = sc->world_scattering || sc->has_volume;
+        int vs = (!textured && r->vshade->bm == APT_BX_ALL && sc->n_classes >= 2 && sc->n_classes + (keep_miss ? 1 : 0) <= APT_MAX_CLASSES) ? 1 : 0;
+        if (const char* force = getenv("APT_SORTED")) vs = (atoi(force) != 0 && !textured && sc->n_classes + (keep_miss ? 1 : 0) <= APT_MAX_CLASSES) ? 1 : 0;
+        if (vs) {
+            r->sorted = 1;
+            r->v_ncls = sc->n_classes + (keep_miss ? 1 : 0);
+            for (int c = 0; c < sc->n_classes; c++) r->vclass_fn[c] = kVClassShade[sc->class_def[c]][sc->has_volume ? 1 : 0];
+            if (keep_miss) r->vclass_fn[sc->n_classes] = kVClassShade[APT_N_CLASS_DEFS][sc->has_volume ? 1 : 0];
+        }
         for (int a = 0; a < 3; a++) {                         // path_tracer.py:136-138
             p.w_min[a] = std::min(c.cam_t[a], sc->box_min[a]) - 0.1f; p.w_max[a] = std::max(c.cam_t[a], sc->box_max[a]) + 0.1f;
         }
     }
-    const int ncls = r->sorted ? sc->n_classes : 0;
+    const int ncls = r->volumetric ? r->v_ncls : (r->sorted ? sc->n_classes : 0);
     r->shade_name = r->volumetric ? r->vshade->name : r->shade->name;
-    if (r->sorted) {
+    if (r->sorted && r->volumetric) {
+        r->shade_name = std::string(sc->has_volume ? "volumetric + grid volume, sorted:" : "volumetric, sorted:");
+        for (int c = 0; c < sc->n_classes; c++) r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
+        if (r->v_ncls > sc->n_classes) r->shade_name += "+miss";
+    } else if (r->sorted) {
         const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : 1;
         r->shade_name = "sorted:";
         for (int c = 0; c < ncls; c++) {
@@ -516,6 +544,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
         q.sh_walk[0] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr; q.sh_walk[1] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr;
         q.n_classes = ncls;
+        q.miss_class = (r->volumetric && r->v_ncls > sc->n_classes) ? sc->n_classes : -1;
         for (int c = 0; c < ncls; c++) {
             Queues::ClassQ& k = q.cls[c];
             k.ray_o = take(3 * cap); k.ray_d = take(3 * cap); k.thr = take(3 * cap); k.id = (uint32_t*)take(cap); k.meta = (uint32_t*)take(cap);
@@ -723,8 +752,19 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
             const LdsPlan& lane_plan = is.li ? r->extra[(size_t)is.li - 1].plan : r->plan;
             for (int b = 0; b < n_iter; b++) {
                 if (r->dyn_fetch) HIP_TRY_VOID(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st));
-                { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[0] : kExtend[r->trace_mode][0], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
-                { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vshade->fn, dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, is.cur); }
+                { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
+                if (!r->sorted) {
+                    ShadeIn in = {q.ray_o[is.cur], q.ray_d[is.cur], q.thr[is.cur], q.id[is.cur], q.meta[is.cur], q.pdf[is.cur],
+                                  q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[is.cur]};
+                    LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vshade->fn, dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, in, is.cur);
+                } else {
+                    for (int c = 0; c < q.n_classes; c++) {
+                        const Queues::ClassQ& k = q.cls[c];
+                        ShadeIn in = {k.ray_o, k.ray_d, k.thr, k.id, k.meta, k.pdf, k.t, k.prim, k.u, k.v, (const uint32_t*)cnt->n_cls[c]};
+                        LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vclass_fn[c], dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, in, is.cur);
+                    }
+                    if (is.p.S <= 0) HIP_TRY_VOID(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st));     // normally k_vshadow's first pass recycles these
+                }
                 if (is.p.S > 0) {
                     const int n_pass = r->scene->has_null_surface ? 7 : 1;       // track_ray walks at most seven segments (vpt.py:113)
                     for (int pass = 0; pass < n_pass; pass++) {

@@ -112,6 +112,7 @@ struct Queues {
     struct ClassQ { float* ray_o; float* ray_d; float* thr; uint32_t* id; uint32_t* meta; float* pdf; float* t; int* prim; float* u; float* v; };
     ClassQ cls[8];
     int n_classes;
+    int miss_class;                              // volumetric, sorted: class queue that receives the rays that hit nothing (-1: misses are dropped)
 };
 #define APT_MAX_CLASSES 8
 // what one shade launch reads: either ray queue `cur` + the hit arrays (unsorted) or one class queue (sorted)
@@ -344,7 +345,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
             if (valid) { stq(q.hit_t, io, rec.t); stq(q.hit_prim, io, rec.prim); stq(q.hit_u, io, rec.u); stq(q.hit_v, io, rec.v); }
         } else {
             // sort by material class: one ballot-compacted append per class present in the scene; misses vanish here
-            const int cls = (valid && rec.prim >= 0) ? sc.prim_class[rec.prim] : -1;
+            const int cls = !valid ? -1 : ((rec.prim >= 0) ? sc.prim_class[rec.prim] : q.miss_class);
             for (int c = 0; c < q.n_classes; c++) {
                 const bool mine = cls == c;
                 const uint32_t cpos = wave_append(mine, &cnt->n_cls[c][sl.q * CNT_PAD]);
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(BLOCK) k_extend_dyn(DevScene sc, Params p, Que
         if (!SORTED) {
             if (fin) { stq(q.hit_t, io, rec.t); stq(q.hit_prim, io, rec.prim); stq(q.hit_u, io, rec.u); stq(q.hit_v, io, rec.v); }
         } else if (__any(fin)) {
-            const int cls = (fin && rec.prim >= 0) ? sc.prim_class[rec.prim] : -1;
+            const int cls = !fin ? -1 : ((rec.prim >= 0) ? sc.prim_class[rec.prim] : q.miss_class);
             for (int c = 0; c < q.n_classes; c++) {
                 const bool mine = cls == c;
                 const uint32_t cpos = wave_append(mine, &cnt->n_cls[c][sq * CNT_PAD]);

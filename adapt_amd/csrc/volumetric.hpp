@@ -174,7 +174,8 @@ APT_D f3 vol_transmittance(const DevVolume& vo, f3 ray_o, f3 ray_d, f3 thp, floa
 }
 
 // ------------------------------------------------------------------- vshade
-// One iteration of the while-loop of vpt.py:161-253 for every path of ray queue `cur`, given its closest hit.  The bounce
+// One iteration of the while-loop of vpt.py:161-253 for every path of ray queue `cur` (unsorted) or of one event-class queue
+// (sorted: k_extend appended every ray to the queue of the surface class it hit, or to the miss class), given its closest hit.  The bounce
 // counter lives in the path's meta word (a null-surface pass-through re-queues the path without counting a bounce) and the
 // float slot that carries ray_pdf in the surface tracer carries emission_weight here (vpt.py:247-253 computes it at the END of
 // an iteration, from the interaction being left).
@@ -182,11 +183,11 @@ APT_D f3 vol_transmittance(const DevVolume& vo, f3 ray_o, f3 ray_d, f3 thp, floa
 // the image-texture lookup.
 // VOL: the scene holds a grid volume (delta tracking in the free-path step, ratio tracking inside the light sampling).
 template <int BM, int SM, int VOL = 0>
-__global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEAN_WAVES : 1)) k_vshade(DevScene sc, Params p, Queues q, Counters* cnt, int cur) {
+__global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEAN_WAVES : 1)) k_vshade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur) {
     constexpr bool TEX = (BM == APT_BX_ALL);
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
-    const uint32_t n = cnt->n_active[cur][sl.q * CNT_PAD];
+    const uint32_t n = in.counts[sl.q * CNT_PAD];
     const uint32_t qbase = (uint32_t)sl.q * p.subcap, sh_qbase = (uint32_t)sl.q * q.sh_subcap;
     uint32_t* next_counter = &cnt->n_active[nxt][sl.q * CNT_PAD];
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
@@ -210,12 +211,12 @@ __global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEA
         const DevMedium* med = world;                         // the medium of a medium interaction (a pointer, not a 17-register copy)
         if (alive) {
             const uint32_t io = idx << 2;
-            o = ld3q(q.ray_o[cur], p.cap, io);
-            d = ld3q(q.ray_d[cur], p.cap, io);
-            thr = ld3q(q.thr[cur], p.cap, io);
-            id = ldq(q.id[cur], io);
-            const uint32_t meta = ldq(q.meta[cur], io);
-            emission_weight = ldq(q.pdf[cur], io);
+            o = ld3q(in.ray_o, p.cap, io);
+            d = ld3q(in.ray_d, p.cap, io);
+            thr = ld3q(in.thr, p.cap, io);
+            id = ldq(in.id, io);
+            const uint32_t meta = ldq(in.meta, io);
+            emission_weight = ldq(in.pdf, io);
             bounce = (meta >> 23) & 0xffu; draw0 = meta & 0x7fffffu;           // volumetric meta word: draw index [0,23) | bounce [23,31)
             const uint32_t lp = id & ((1u << p.pix_bits) - 1u), s = id >> p.pix_bits;
             l_off = (s * (uint32_t)p.npix + lp) << 2;
@@ -230,13 +231,13 @@ __global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEA
             } else if (max3(thr) < 1e-5f) alive = false;
             if (alive) {
                 // Step 2: the hit, or the far side of the world box when the world itself scatters (vpt.py:173-181)
-                const int prim = ldq(q.hit_prim, io);
+                const int prim = ldq(in.prim, io);
                 if (prim < 0) {
                     if (!world_scat && !VOL) alive = false;
                     else { it.min_depth = world_bound_time(p, o, d); in_free = true; }
                 } else {
                     f3 rec_kd;
-                    build_hit(sc, prim, ldq(q.hit_t, io), ldq(q.hit_u, io), ldq(q.hit_v, io), o, d, it, rec_light, rec_kd);
+                    build_hit(sc, prim, ldq(in.t, io), ldq(in.u, io), ldq(in.v, io), o, d, it, rec_light, rec_kd);
                     in_free = dot(it.n_g, d) < 0.f;
                     bx = sc.bxdf[it.obj_id];
                 }
@@ -269,7 +270,7 @@ __global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEA
                         if (!is_mi) {
                             hit_light = rec_light;
                             f3 tx;
-                            if (TEX && sc.tex_i != nullptr && get_uv_item(sc, 0, it.obj_id, it.prim_id, ldq(q.hit_u, io), ldq(q.hit_v, io), tx)) bx.k_d = tx;   // vpt.py:199
+                            if (TEX && sc.tex_i != nullptr && get_uv_item(sc, 0, it.obj_id, it.prim_id, ldq(in.u, io), ldq(in.v, io), tx)) bx.k_d = tx;   // vpt.py:199
                         }
                     }
                 }
@@ -411,7 +412,10 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAVES
     if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
     const SubLoop sl = sub_loop(p.nq, TRACE_NT(MODE));
     const uint32_t n = min(pass == 0 ? cnt->n_shadow[sl.q * CNT_PAD] : cnt->n_walk[pass][sl.q * CNT_PAD], q.sh_subcap);
-    if (pass == 0 && sl.first == 0 && threadIdx.x == 0) cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
+    if (pass == 0 && sl.first == 0 && threadIdx.x == 0) {
+        cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
+        for (int c = 0; c < q.n_classes; c++) cnt->n_cls[c][sl.q * CNT_PAD] = 0;      // every shade of this iteration is done
+    }
     const uint32_t qbase = (uint32_t)sl.q * q.sh_subcap, sc_ = q.sh_cap;
     const uint32_t* list_in = q.sh_walk[pass & 1];
     uint32_t* list_out = q.sh_walk[(pass + 1) & 1];
