@@ -183,7 +183,7 @@ APT_D f3 vol_transmittance(const DevVolume& vo, f3 ray_o, f3 ray_d, f3 thp, floa
 // the image-texture lookup.
 // VOL: the scene holds a grid volume (delta tracking in the free-path step, ratio tracking inside the light sampling).
 template <int BM, int SM, int VOL = 0>
-__global__ void __launch_bounds__(BLOCK, ((BM == 0x402 && !VOL) ? APT_VSHADE_LEAN_WAVES : 1)) k_vshade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur) {
+__global__ void __launch_bounds__(BLOCK, (((BM == 0x402 || BM == 0x00a || BM == 0x000 || BM == 0x504 || BM == 0x200) && !VOL) ? APT_VSHADE_LEAN_WAVES : 1)) k_vshade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur) {
     constexpr bool TEX = (BM == APT_BX_ALL);
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
