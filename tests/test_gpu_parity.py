@@ -727,3 +727,38 @@ def test_grid_volume_hip_vs_reference_run_and_oracle(name):
             assert abs(st[k] - ost[k]) <= 2e-3 * ost[k], (name, k, st[k], ost[k])
     finally:
         r.close()
+
+
+def test_full_size_properties_volumetric_fog_box():
+    """The volumetric bench workload (`bench.py --config v1`: fog Cornell box, 512x512, 16 bounces) at a reduced sample count, through
+    properties that need no oracle at this size: sample additivity across calls and lanes (bit-exact: one light sample per vertex),
+    statistics identities of the loop, the fog's visible effect, and a crop window that equals the same window of the full render."""
+    import os
+    from conftest import ROOT
+    from adapt_amd.parsers.xml_parser import scene_parsing
+    from adapt_amd.renderer import Renderer, VolumeRenderer
+    tup = scene_parsing(os.path.join(ROOT, "scenes", "vpt"), "cbox_fog.xml")
+    r = VolumeRenderer(*tup)
+    assert (r.w, r.h, r.max_bounce, r.num_shadow_ray) == (512, 512, 16, 1) and r.info()["shade_variant"].startswith("volumetric: lambertian+null")
+    r.render(n_spp=24)
+    st, img = r.stats(), r.color.to_numpy()
+    n = 512 * 512 * 24
+    assert st["n_samples"] == n and st["n_shade"] < st["n_extend"] and st["n_shadow"] <= st["n_shade"]       # null crossings extend without shading
+    assert st["n_lit"] <= st["n_shadow_traced"] <= st["n_shadow"] and st["n_track"] >= st["n_shadow_traced"] and st["n_poisoned"] == 0
+    assert np.isfinite(img).all() and img.min() >= 0
+    two = VolumeRenderer(*tup)
+    two.render(n_spp=10); two.render(n_spp=14)
+    assert np.array_equal(two.color.to_numpy(), img) and two.cnt[None] == 24                               # 10 + 14 samples == 24 samples
+    two.close()
+    # the fog cube is where the small box stands: the surface tracer sees through the null surface's object as if it were black
+    # (a null BSDF scatters nothing there), the volumetric tracer sees light scattered inside it
+    s = Renderer(*tup); s.render(n_spp=24); simg = s.color.to_numpy(); s.close()
+    assert float(np.abs(simg - img).mean()) > 0.05 * float(img.mean())
+    # crop window: same pixels as in the full frame (RNG keyed by the global pixel)
+    prop = dict(tup[3]); prop["film"] = dict(prop["film"], crop_x=256, crop_y=200, crop_rx=40, crop_ry=30)
+    c = VolumeRenderer(tup[0], tup[1], tup[2], prop)
+    c.render(n_spp=24)
+    cimg = c.color.to_numpy()
+    assert np.array_equal(cimg[c.start_x:c.end_x, c.start_y:c.end_y], img[c.start_x:c.end_x, c.start_y:c.end_y])
+    assert not cimg[:c.start_x].any() and not cimg[c.end_x:].any()
+    c.close(); r.close()
