@@ -8,7 +8,8 @@ python bench.py --config c4 --steps 1 --warmup 1 --spp 128 --cpu-seconds 10 > gp
 python bench.py --config c5 --steps 1 --warmup 1 --spp 64 --cpu-seconds 10 > gpurun_out/bench/c5.json 2> gpurun_out/bench/c5.err
 python bench.py --config v1 --steps 2 --warmup 1 --cpu-seconds 10 > gpurun_out/bench/v1.json 2> gpurun_out/bench/v1.err
 python bench.py --config v3 --steps 2 --warmup 1 --cpu-seconds 10 > gpurun_out/bench/v3.json 2> gpurun_out/bench/v3.err
-for c in c1 c2 c3 c4 c5 v1 v3; do python - <<PY
+python bench.py --config v2 --steps 2 --warmup 1 --cpu-seconds 10 > gpurun_out/bench/v2.json 2> gpurun_out/bench/v2.err
+for c in c1 c2 c3 c4 c5 v1 v2 v3; do python - <<PY
 import json
 try:
     d = json.load(open("gpurun_out/bench/$c.json"))
