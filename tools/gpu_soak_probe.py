@@ -1,0 +1,38 @@
+"""GPU soak: repeated renderer create / render / destroy (surface and volumetric, every traversal mode) with the free device memory
+watched, then a longer C2 run.  Prints one line per phase."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from adapt_amd import scene_parsing
+from adapt_amd.renderer import Renderer, VolumeRenderer
+
+def free_gb():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0] / 2 ** 30
+
+os.chdir(ROOT)
+base = free_gb()
+scenes = [("cbox", "c2_cbox.xml", Renderer), ("csphere", "c3_balls_mono.xml", Renderer), ("vpt", "cbox_fog.xml", VolumeRenderer),
+          ("test", "media_a.xml", VolumeRenderer), ("test", "volgrid_b.xml", VolumeRenderer), ("test", "textured.xml", Renderer)]
+parsed = [(scene_parsing(os.path.join(ROOT, "scenes", d), f), cls) for d, f, cls in scenes]
+t0 = time.time()
+for it in range(8):
+    for tup, cls in parsed:
+        for mode in ("", "bvh"):
+            if mode: os.environ["APT_TRAVERSAL"] = mode
+            else: os.environ.pop("APT_TRAVERSAL", None)
+            r = cls(*tup, width=96, height=64)
+            r.render(n_spp=3); r.pixels.to_numpy(); r.stats(); r.close()
+os.environ.pop("APT_TRAVERSAL", None)
+print("create/destroy x", 8 * len(parsed) * 2, "in %.1fs; free memory drift %.3f GiB" % (time.time() - t0, base - free_gb()), flush=True)
+r = Renderer(*parsed[0][0])
+t0 = time.time()
+for k in range(12):
+    r.render(n_spp=1024)
+r.synchronize()
+dt = time.time() - t0
+img = r.pixels.to_numpy()
+print("C2 x 12288 spp: %.2fs = %.0f Msamples/s, finite %s, mean %.4f, cnt %d" % (dt, 512 * 512 * 12288 / dt / 1e6, bool((img == img).all()), float(img.mean()), r.cnt[None]), flush=True)
+r.close()
+print("free memory drift after close %.3f GiB" % (base - free_gb()))
