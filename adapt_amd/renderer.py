@@ -142,7 +142,7 @@ class Renderer:
     VOLUMETRIC = False          # subclass switch: VolumeRenderer renders with the reference's vpt semantics
 
     def __init__(self, emitters: List, array_info: dict, objects: List, prop: dict, *,
-                 device: int = 0, rank: int = 0, world_size: int = 1, band_width: int = 32,
+                 device: int = 0, rank: int = 0, world_size: int = 1, band_width: int = 4,
                  seed: int = 0, spp_per_batch: int = 0, profile: bool = False,
                  width: Optional[int] = None, height: Optional[int] = None,
                  max_bounce: Optional[int] = None, num_shadow_ray: Optional[int] = None, volumetric: Optional[bool] = None):

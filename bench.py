@@ -27,6 +27,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# film sharding for N > 1: interleaved column bands.  Measured on C2 (every rank of an 8-rank step rendered in turn on one GPU,
+# tools/gpu_rank_probe.py): slowest / mean rank time 1.196 with 32-column bands (the lit centre of the image is dearer than its dark
+# edges), 1.032 with 16, 1.016 with 4; the per-rank rate itself does not depend on the band width.
+BAND_WIDTH = 4
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 CONFIGS = {
@@ -129,7 +133,7 @@ def main():
     spp_step = spp * world                  # weak scaling: per-GPU samples stay at the N = 1 amount
     parsed = load_scene(sdir, sfile)
     rdr = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world,
-                   band_width=32, profile=True, spp_per_batch=args.spp_per_batch)
+                   band_width=BAND_WIDTH, profile=True, spp_per_batch=args.spp_per_batch)
     info = rdr.info()
 
     def step():
@@ -206,7 +210,7 @@ def main():
     measured, source = timed, "timed region (one render lane: kernels do not overlap)"
     if lanes > 1 and not args.no_exclusive_pass:
         os.environ["APT_LANES"] = "1"
-        r1 = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world, band_width=32, profile=True,
+        r1 = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world, band_width=BAND_WIDTH, profile=True,
                       spp_per_batch=args.spp_per_batch)
         os.environ["APT_LANES"] = str(lanes)
         n1 = max(1, min(spp_step, 256))
@@ -234,7 +238,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": ("synthetic stand-in scene (adapt_amd/synth.py; the reference ships no assets for it)" if sdir == "synth" else "bundled Cornell scene file (same inputs as the reference's); no dataset involved"),
         "config": {"workload": label, "scene": f"scenes/{sdir}/{sfile}", "width": W, "height": H, "spp_per_step": spp_step,
-                   "max_bounce": bounces, "num_shadow_ray": rdr.num_shadow_ray, "tiling": f"{world} x interleaved 32-column bands",
+                   "max_bounce": bounces, "num_shadow_ray": rdr.num_shadow_ray, "tiling": f"{world} x interleaved {BAND_WIDTH}-column bands",
                    "spp_per_batch": info["spp_per_batch"], "sub_queues": info["n_subqueues"], "shade_variant": info["shade_variant"],
                    "queue_MiB": round(info["queue_bytes"] / 2 ** 20, 1), "render_lanes": lanes, "seed": 0},
         "per_sample": {k: round(st[k] / max(1, st["n_samples"]), 4) for k in ("n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws")},
