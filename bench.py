@@ -151,6 +151,12 @@ def main():
         rdr.synchronize()
         torch.cuda.synchronize()
 
+    # one-off initialisation that is not a step: load every kernel of the pipeline (1 spp) and, for N > 1, create the RCCL
+    # communicator with a first gather - so that `--warmup 0` does not time module loading or communicator set-up
+    rdr.render(n_spp=1)
+    if world > 1 and args.backend == "nccl":
+        gather_image(rdr, normalised=False)
+    rdr.synchronize()
     for _ in range(args.warmup):
         step()
     rdr.clear()                              # zero accumulation + statistics + event timers: the timed region starts clean
