@@ -13,6 +13,10 @@ out = sys.argv[1]
 
 
 def short(name):
+    if "k_extend_dyn" in name:
+        return "k_extend_dyn<bvh, dynamic fetch" + (", sorted>" if "ILi1E" in name else ">")
+    if "k_shadow_dyn" in name:
+        return "k_shadow_dyn<bvh, dynamic fetch>"
     for k in ("k_generate", "k_extend", "k_vshade", "k_vshadow", "k_shade", "k_shadow", "k_finalize", "k_divide"):
         if k in name:
             tag = k
