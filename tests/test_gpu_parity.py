@@ -762,3 +762,17 @@ def test_full_size_properties_volumetric_fog_box():
     assert np.array_equal(cimg[c.start_x:c.end_x, c.start_y:c.end_y], img[c.start_x:c.end_x, c.start_y:c.end_y])
     assert not cimg[:c.start_x].any() and not cimg[c.end_x:].any()
     c.close(); r.close()
+
+
+def test_both_tracers_estimate_the_same_image_without_media(parsed):
+    """Independent check of the two loops against each other: on a scene without media the surface tracer and the volumetric tracer
+    are different estimators (roulette placement, emission weighting, draw order) of the same integral, so their converged images must
+    agree within Monte-Carlo noise.  Cornell box, 48x48, 4096 spp each: region means within 2 %."""
+    from adapt_amd.renderer import Renderer, VolumeRenderer
+    tup = parsed("cbox")
+    a = Renderer(*tup, width=48, height=48); a.render(n_spp=4096); ia = a.pixels.to_numpy().astype(np.float64); a.close()
+    b = VolumeRenderer(*tup, width=48, height=48, seed=7); b.render(n_spp=4096); ib = b.pixels.to_numpy().astype(np.float64); b.close()
+    assert np.isfinite(ia).all() and np.isfinite(ib).all()
+    for (x0, x1, y0, y1) in ((0, 48, 0, 48), (0, 16, 8, 40), (32, 48, 8, 40), (12, 36, 0, 12), (12, 36, 30, 48)):
+        ma, mb = ia[x0:x1, y0:y1].mean(axis=(0, 1)), ib[x0:x1, y0:y1].mean(axis=(0, 1))
+        assert np.all(np.abs(ma - mb) <= 0.02 * np.maximum(ma, mb) + 1e-4), ((x0, x1, y0, y1), ma, mb)
