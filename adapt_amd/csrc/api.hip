@@ -169,6 +169,8 @@ struct apt_renderer {
     size_t lds_bytes = 0, lds_bytes_any = 0;     // dynamic LDS of the closest-hit / any-hit trace kernels
     int grid_shadow = 0;
     int grid_vshadow = 0;         // volumetric transmittance walk (closest-hit LDS footprint, its own register budget)
+    int vshadow_nt = BLOCK;       // its workgroup size and dynamic LDS
+    size_t vshadow_lds = 0;
     std::vector<EventPair> pending;
     std::vector<EventPair> free_events;
     double kernel_ms[APT_N_KERNELS] = {0, 0, 0, 0, 0};
@@ -648,8 +650,12 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (const char* g = getenv("APT_GRID_TRACE")) r->grid_trace = cus * std::max(1, atoi(g));
     if (r->trace_mode != 2) { r->lds_bytes_any = r->lds_bytes; r->grid_shadow = r->grid_trace; }
     if (const char* g = getenv("APT_GRID_SHADOW")) r->grid_shadow = cus * std::max(1, atoi(g));
-    r->grid_vshadow = r->grid_trace;
-    if (r->trace_mode == 2) r->grid_vshadow = cus * std::max(1, std::min((int)((160 * 1024) / r->lds_bytes), (APT_VSHADOW_WAVES * 4) / (APT_TILE_NT / 64)));
+    r->grid_vshadow = r->grid_trace; r->vshadow_nt = r->trace_nt; r->vshadow_lds = r->lds_bytes;
+    if (r->trace_mode == 2) {
+        r->vshadow_nt = APT_VSHADOW_NT;
+        r->vshadow_lds = APT_TILE_LDS_BYTES(APT_VSHADOW_NT, sc->n_objects);
+        r->grid_vshadow = cus * std::max(1, std::min((int)((160 * 1024) / r->vshadow_lds), (APT_VSHADOW_WAVES * 4) / (APT_VSHADOW_NT / 64)));
+    }
     if (const char* g = getenv("APT_GRID_VSHADOW")) r->grid_vshadow = cus * std::max(1, atoi(g));
     r->grid_vshadow = ((r->grid_vshadow + nq - 1) / nq) * nq;
     r->grid_trace = ((r->grid_trace + nq - 1) / nq) * nq;          // persistent grids are multiples of nq
@@ -769,7 +775,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
                     const int n_pass = r->scene->has_null_surface ? 7 : 1;       // track_ray walks at most seven segments (vpt.py:113)
                     for (int pass = 0; pass < n_pass; pass++) {
                         LaunchTimer t(r, 3, st);
-                        hipLaunchKernelGGL(kVShadow[r->trace_mode], dim3(grid_for(is.total * (size_t)is.p.S, r->grid_vshadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, lane_plan, pass);
+                        hipLaunchKernelGGL(kVShadow[r->trace_mode], dim3(grid_for(is.total * (size_t)is.p.S, r->grid_vshadow, nq, r->vshadow_nt)), dim3(r->vshadow_nt), r->vshadow_lds, st, sc, is.p, q, cnt, lane_plan, pass);
                     }
                 }
                 is.cur ^= 1;

@@ -15,6 +15,12 @@
 #ifndef APT_VSHADOW_WAVES
 #define APT_VSHADOW_WAVES 5
 #endif
+// workgroup size of the tiled transmittance walk: its closest-hit lists cost 8 B per thread and object in LDS, so on scenes of 8-9
+// objects a 512-thread tile leaves room for two workgroups per CU only; 256-thread tiles: V1 walk 38.2 -> 35.3 ms, V2 52.7 -> 50.4 ms
+#ifndef APT_VSHADOW_NT
+#define APT_VSHADOW_NT 256
+#endif
+#define VSHADOW_NT(MODE) ((MODE) == 2 ? APT_VSHADOW_NT : BLOCK)
 
 APT_D float med_random_rgb(Philox& r, f3 v) {                      // general_sampling.py:17-27
     const int idx = pymod(rng_int(r), 3);
@@ -405,12 +411,12 @@ __global__ void __launch_bounds__(BLOCK, (((BM == 0x402 || BM == 0x00a || BM == 
 // remaining distance shortened, transmittance folded into the contribution - and its slot is appended to the list the next pass
 // reads.  The reference walks at most seven segments; the host launches pass p + 1 only where null surfaces exist.
 template <int MODE>
-__global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAVES : 1)) k_vshadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan, int pass) {
+__global__ void __launch_bounds__(VSHADOW_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAVES : 1)) k_vshadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan, int pass) {
     StagedBvh bvh;
     int* my_stack = nullptr;
     __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
     if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
-    const SubLoop sl = sub_loop(p.nq, TRACE_NT(MODE));
+    const SubLoop sl = sub_loop(p.nq, VSHADOW_NT(MODE));
     const uint32_t n = min(pass == 0 ? cnt->n_shadow[sl.q * CNT_PAD] : cnt->n_walk[pass][sl.q * CNT_PAD], q.sh_subcap);
     if (pass == 0 && sl.first == 0 && threadIdx.x == 0) {
         cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
@@ -435,7 +441,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAVES
         HitRec rec; rec.t = (depth > 0.0f) ? depth - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
         if (MODE == 0) traverse<false>(bvh, make_stack(my_stack, plan), o, d, rec);
         else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
-        else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
+        else sweep_tile<false, APT_VSHADOW_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         bool arrived = false, walk_on = false;
         f3 c = splat3(0.f);
         if (valid) {
