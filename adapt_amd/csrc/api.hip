@@ -579,7 +579,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     // traversal mode: small scenes sweep all primitives wave-uniformly in the reference's brute-force order
     // the tiled sweep pays off once some object has enough primitives that skipping it per ray matters;
     // scenes of spheres and quads only are as fast in the plain wave sweep
-    const bool tile_ok = sc->has_aabb && sc->n_objects <= APT_TILE_MAX_OBJECTS && sc->n_prims < 65536;
+    const bool tile_ok = sc->has_aabb && sc->n_objects <= APT_TILE_MAX_OBJECTS && sc->n_prims < 65536 &&
+                         APT_TILE_LDS_BYTES(APT_TILE_NT, sc->n_objects) <= 160 * 1024;      // the per-object lists of a tile must fit the CU's LDS (34 objects at 512 threads)
     r->trace_mode = (sc->n_prims <= APT_SWEEP_MAX_PRIMS && sc->has_aabb) ? ((tile_ok && sc->max_obj_prims >= APT_SWEEP_LIST_MIN) ? 2 : 1) : 0;
     if (const char* force = getenv("APT_TRAVERSAL")) {
         if (!strcmp(force, "bvh")) r->trace_mode = 0;

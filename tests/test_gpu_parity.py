@@ -776,3 +776,44 @@ def test_both_tracers_estimate_the_same_image_without_media(parsed):
     for (x0, x1, y0, y1) in ((0, 48, 0, 48), (0, 16, 8, 40), (32, 48, 8, 40), (12, 36, 0, 12), (12, 36, 30, 48)):
         ma, mb = ia[x0:x1, y0:y1].mean(axis=(0, 1)), ib[x0:x1, y0:y1].mean(axis=(0, 1))
         assert np.all(np.abs(ma - mb) <= 0.02 * np.maximum(ma, mb) + 1e-4), ((x0, x1, y0, y1), ma, mb)
+
+
+def test_many_small_objects_fall_back_to_the_wave_sweep(parsed, monkeypatch):
+    """The tiled sweep keeps a list per object in LDS; beyond 34 objects those lists no longer fit a CU and the renderer has to pick
+    the plain wave sweep instead of failing at launch.  Cornell box with its five wall quads repeated to 38 objects / 96 primitives
+    (coincident copies: the sweep resolves ties in the reference's object order, so the oracle image is matched exactly as usual)."""
+    import copy
+    from adapt_amd.renderer import Renderer
+    from adapt_amd.scene_pack import pack_scene
+    from oracle import binding as ob
+    em, arr, objs, prop = parsed("cbox")
+    arr = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in arr.items()}
+    objs = list(objs)
+    first = np.cumsum([0] + [o.tri_num for o in objs])
+    quads = [k for k, o in enumerate(objs) if o.tri_num == 2 and o.type == 0]
+    assert len(quads) >= 5
+    extra = []
+    while len(objs) + len(extra) < 38:
+        extra.append(quads[len(extra) % len(quads)])
+    for k in extra:
+        sl = slice(first[k], first[k] + 2)
+        for key in ("primitives", "n_g", "n_s", "uvs"):
+            arr[key] = np.concatenate([arr[key], arr[key][sl]], axis=0)
+        objs.append(copy.copy(objs[k]))
+    tup = (em, arr, objs, prop)
+    assert len(objs) == 38 and arr["primitives"].shape[0] == 34 + 2 * len(extra) <= 96
+    r = Renderer(*tup, width=48, height=48)
+    try:
+        assert r.info()["traversal"] == "sweep"
+        r.render(n_spp=8)
+        rc = make_config(prop, width=48, height=48)
+        ref, cnt, ost = ob.OracleScene(pack_scene(*tup), rc.cam_t).render(rc, 8)
+        m = image_metrics(r.pixels.to_numpy(), ref / np.float32(cnt))
+        assert m["frac_within"] >= 0.995 and m["relMSE"] <= 1e-4, m
+        assert abs(r.stats()["n_draws"] - ost["n_draws"]) <= 2e-4 * ost["n_draws"]
+    finally:
+        r.close()
+    monkeypatch.setenv("APT_TRAVERSAL", "tile")          # asking for the tiled sweep explicitly must not select it either
+    r2 = Renderer(*tup, width=32, height=32)
+    assert r2.info()["traversal"] == "sweep"
+    r2.render(n_spp=1); r2.synchronize(); r2.close()
