@@ -817,3 +817,25 @@ def test_many_small_objects_fall_back_to_the_wave_sweep(parsed, monkeypatch):
     r2 = Renderer(*tup, width=32, height=32)
     assert r2.info()["traversal"] == "sweep"
     r2.render(n_spp=1); r2.synchronize(); r2.close()
+
+
+@pytest.mark.parametrize("tag,vol", [("cbox", False), ("balls_mono", False), ("balls_mono", True)])
+def test_no_light_samples_at_all(tag, vol, parsed, oracle_scene):
+    """num_shadow_ray = 0 (no next-event estimation: only paths that run into an emitter carry light; upstream then uses a sample
+    weight of 1, path_tracer.py:71-74).  Queues, class counters and the walk passes must cope with a shadow stage that never runs,
+    sorted and unsorted, in both tracers."""
+    from adapt_amd.renderer import Renderer, VolumeRenderer
+    tup = parsed(tag)
+    cls = VolumeRenderer if vol else Renderer
+    r = cls(*tup, width=40, height=40, num_shadow_ray=0)
+    try:
+        r.render(n_spp=16)
+        st = r.stats()
+        assert st["n_shadow"] == 0 and st["n_shadow_traced"] == 0 and st["n_samples"] == 40 * 40 * 16
+        rc = make_config(tup[3], width=40, height=40, num_shadow_ray=0, volumetric=vol)
+        ref, cnt, ost = oracle_scene(tag).render(rc, 16)
+        m = image_metrics(r.pixels.to_numpy(), ref / np.float32(cnt))
+        assert m["frac_within"] >= 0.995 and m["relMSE"] <= 1e-4, (tag, vol, m)
+        assert abs(st["n_shade"] - ost["n_shade"]) <= 2e-4 * ost["n_shade"] + 2
+    finally:
+        r.close()
