@@ -784,7 +784,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
         };
         // an iteration ends a path or counts a bounce, except a null-surface pass-through: max_bounce iterations finish every
         // path that met no null surface
-        for (Issued& is : round) iterate(is, is.p.max_bounce);
+        for (Issued& is : round) iterate(is, std::max(1, is.p.max_bounce));      // the loop body runs once even with max_bounce = 0 (vpt.py:161-245)
         for (Issued& is : round) {
             hipStream_t st = is.li ? r->extra[(size_t)is.li - 1].stream : r->stream;
             const Queues& q = is.li ? r->extra[(size_t)is.li - 1].q : r->q;

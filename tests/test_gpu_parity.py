@@ -839,3 +839,24 @@ def test_no_light_samples_at_all(tag, vol, parsed, oracle_scene):
         assert abs(st["n_shade"] - ost["n_shade"]) <= 2e-4 * ost["n_shade"] + 2
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("vol", [False, True])
+def test_degenerate_bounce_limits(vol, parsed, oracle_scene):
+    """max_bounce = 0 and 1: the surface tracer's for-loop does not run at all with 0 (black image), the volumetric tracer's while-loop
+    always runs its body once (vpt.py:161-245) - both as the oracle."""
+    from adapt_amd.renderer import Renderer, VolumeRenderer
+    tup = parsed("balls_mono")
+    for mb in (0, 1):
+        r = (VolumeRenderer if vol else Renderer)(*tup, width=32, height=32, max_bounce=mb)
+        try:
+            r.render(n_spp=8)
+            rc = make_config(tup[3], width=32, height=32, max_bounce=mb, volumetric=vol)
+            ref, cnt, ost = oracle_scene("balls_mono").render(rc, 8)
+            m = image_metrics(r.pixels.to_numpy(), ref / np.float32(cnt))
+            assert m["frac_within"] >= 0.995, (vol, mb, m)
+            assert abs(r.stats()["n_shade"] - ost["n_shade"]) <= 2
+            if not vol and mb == 0:
+                assert not r.color.to_numpy().any()
+        finally:
+            r.close()
