@@ -860,3 +860,23 @@ def test_degenerate_bounce_limits(vol, parsed, oracle_scene):
                 assert not r.color.to_numpy().any()
         finally:
             r.close()
+
+
+@pytest.mark.parametrize("w,h,world,bw", [(50, 30, 3, 4), (37, 20, 8, 4), (64, 17, 5, 7)])
+def test_ragged_film_partitions(w, h, world, bw, renderer):
+    """Widths that are not a multiple of band x ranks: the last band is short, ranks own different numbers of columns (some of the
+    8 ranks of a 37-pixel film own a single band) - the assembled tiles still equal the single-renderer image, bit for bit."""
+    from adapt_amd.tiles import TilePlan, assemble
+    full = renderer("cbox", width=w, height=h)
+    full.render(n_spp=4)
+    ref = full.color.to_numpy()
+    plan = TilePlan(w, h, bw, world)
+    tiles = []
+    for rank in range(world):
+        if len(plan.columns(rank)) == 0:
+            tiles.append(np.zeros((0, h, 3), np.float32)); continue
+        r = renderer("cbox", width=w, height=h, rank=rank, world_size=world, band_width=bw)
+        r.render(n_spp=4)
+        tiles.append(r.tile_accum())
+        assert tiles[-1].shape == (len(plan.columns(rank)), h, 3)
+    assert np.array_equal(assemble(plan, tiles), ref)
