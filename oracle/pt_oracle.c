@@ -1342,6 +1342,25 @@ ORC_API int orc_bvh_export(const scene_t* sc, float* node_minmax, int* node_info
     return 0;
 }
 
+/* The restated builder on bare arrays, with bvh_cpp.bvh_build's own signature (bvh.cpp:274-296): prims[N*9], the (2, n_obj) table of
+ * primitive counts and sphere flags, the world box.  Two calls: with the output pointers NULL it only returns the node count.
+ * Used by the golden generator's `bvh_cpp` stand-in so that the reference's own traversal code walks this tree. */
+ORC_API int orc_bvh_build_raw(const float* prims, int n_prims, const int* obj_cnt, const int* obj_flag, int n_obj, const float wmin[3], const float wmax[3],
+                              float* bvh_minmax, float* node_minmax, int* bvh_info, int* node_info) {
+    scene_t tmp; memset(&tmp, 0, sizeof(tmp));
+    tmp.n_prims = n_prims; tmp.n_objects = n_obj;
+    tmp.prims = (v3(*)[3])prims;
+    tmp.obj_info = malloc(sizeof(int) * 3 * (size_t)n_obj);
+    int start = 0;
+    for (int o = 0; o < n_obj; o++) { tmp.obj_info[o][0] = start; tmp.obj_info[o][1] = obj_cnt[o]; tmp.obj_info[o][2] = obj_flag[o]; start += obj_cnt[o]; }
+    if (start != n_prims) { free(tmp.obj_info); return -1; }
+    build_reference_bvh(&tmp, V(wmin[0], wmin[1], wmin[2]), V(wmax[0], wmax[1], wmax[2]));
+    const int n = tmp.node_num;
+    if (bvh_minmax && node_minmax && bvh_info && node_info) orc_bvh_export(&tmp, node_minmax, node_info, bvh_minmax, bvh_info);
+    free(tmp.nodes); free(tmp.bvhs); free(tmp.obj_info);
+    return n;
+}
+
 /* ------------------------------------- TracerBase.pix2ray, tracer_base.py:136-157 */
 static v3 pix2ray(const ctx_t* c, int i, int j, int cnt, rng_t* r) {
     const orc_cfg* g = c->cfg;

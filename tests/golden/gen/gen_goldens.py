@@ -412,6 +412,179 @@ def gen_vptrun(scene_dir, xml, tag, w, h, spp, seed=0):
     print(f"vptrun_{tag}: {w}x{h}x{spp}spp, {time.time() - t0:.1f}s, mean draws {draws.mean():.2f}, mean radiance {np.nanmean(rdr.color.to_numpy()) / spp:.4f}")
 
 
+# ------------------------------------------------------------------ the reference's BVH path (accelerator = bvh)
+def _write_obj(path, tris, flat_normals):
+    """(n,3,3) float32 triangles -> OBJ with per-face `vn` (like meshes/cornell/bunny.obj); %.9g round-trips float32 exactly"""
+    with open(path, "w") as f:
+        for t in tris.reshape(-1, 3):
+            f.write("v %.9g %.9g %.9g\n" % tuple(float(x) for x in t))
+        for n in flat_normals:
+            f.write("vn %.9g %.9g %.9g\n" % tuple(float(x) for x in n))
+        for k in range(tris.shape[0]):
+            f.write("f %d//%d %d//%d %d//%d\n" % (3 * k + 1, k + 1, 3 * k + 2, k + 1, 3 * k + 3, k + 1))
+
+
+def write_three_bunnies(tmp, levels):
+    """adapt_amd.synth.three_bunnies(levels) as a scene directory the REFERENCE parser can load (temporary files, not committed):
+    the placed bunnies as OBJ files + an XML with the same materials / lights / sensor.  Returns (dir, xml, synth 4-tuple)."""
+    import shutil
+    from adapt_amd import synth
+    em, arr, objs, cfg = synth.three_bunnies(levels)
+    os.makedirs(os.path.join(tmp, "meshes"), exist_ok=True)
+    mesh_dir = os.path.join(refenv.REPO, "scenes", "meshes", "cornell")
+    for name in ("floor", "ceiling", "back", "greenwall", "redwall"):
+        shutil.copy(os.path.join(mesh_dir, f"cbox_{name}.obj"), os.path.join(tmp, "meshes"))
+    start = 10
+    for k in range(3):
+        n = objs[5 + k].tri_num
+        tris = arr["primitives"][start:start + n]
+        _write_obj(os.path.join(tmp, "meshes", f"bunny{k}.obj"), tris, arr["n_g"][start:start + n])
+        start += n
+    spots = ((("6.0, 4.0, 4.0", "245.0", (3.779, 5.2, 2.745), (-0.2, -1.5, -0.3), 20.0)), ("6.0, 6.0, 4.0", "200.0", (1.2, 4.8, 3.2), (0.6, -1.5, -0.05), 15.0),
+             ("4.0, 4.0, 6.0", "200.0", (4.9, 2.5, 3.8), (-1.6, -0.6, -0.4), 15.0))
+    x = ['<?xml version="1.0" encoding="utf-8"?>', '<scene version="1.1">', '<sensor type="perspective">', '<float name="fov" value="39.3077"/>',
+         '<integer name="max_bounce" value="8"/>', '<integer name="num_shadow_ray" value="2"/>', '<boolean name="use_rr" value="true"/>',
+         '<boolean name="anti_alias" value="true"/>', '<boolean name="stratified_sampling" value="true"/>', '<boolean name="use_mis" value="true"/>',
+         '<string name="accelerator" value="bvh"/>',
+         '<transform name="toWorld"><lookat target="2.78, 2.73, -7.0" origin="2.78, 2.73, -8.0" up="0, 1, 0"/></transform>',
+         '<film type="film"><integer name="width" value="800"/><integer name="height" value="800"/></film>', '</sensor>']
+    for ident, kd in (("white", "#BDBDBD"), ("left", "#DD2525"), ("right", "#25DD25"), ("lava", "#FFFFFF")):
+        x.append(f'<brdf type="lambertian" id="{ident}"><rgb name="k_d" value="{kd}"/><rgb name="k_g" value="1.0"/><rgb name="k_s" value="0.0"/></brdf>')
+    x.append('<bsdf type="det-refraction" id="glass"><rgb name="k_d" value="#FFFFFF"/><medium type="transparent"><float name="ior" value="1.5"/></medium></bsdf>')
+    x.append('<brdf type="fresnel-blend" id="fresnel"><rgb name="k_d" value="#CACACA"/><rgb name="k_s" value="#333333"/><rgb name="k_g" r="10" g="1000"/></brdf>')
+    for k, (e, sc, pos, d, ha) in enumerate(spots):
+        x.append(f'<emitter type="spot" id="source{k + 1}"><rgb name="emission" value="{e}"/><rgb name="scaler" value="{sc}"/>'
+                 f'<point name="pos" x="{pos[0]}" y="{pos[1]}" z="{pos[2]}"/><point name="dir" x="{d[0]}" y="{d[1]}" z="{d[2]}"/><float name="half-angle" value="{ha}"/></emitter>')
+    for name, mat in (("floor", "white"), ("ceiling", "white"), ("back", "white"), ("greenwall", "right"), ("redwall", "left")):
+        x.append(f'<shape type="obj"><string name="filename" value="meshes/cbox_{name}.obj"/><ref type="material" id="{mat}"/></shape>')
+    for k, mat in enumerate(("lava", "glass", "fresnel")):
+        x.append(f'<shape type="obj"><string name="filename" value="meshes/bunny{k}.obj"/><ref type="material" id="{mat}"/></shape>')
+    x += ['<world name="w"><medium type="transparent"><float name="ior" value="1.0"/></medium></world>', '</scene>']
+    with open(os.path.join(tmp, "three_bunnies.xml"), "w") as f:
+        f.write("\n".join(x))
+    return tmp, "three_bunnies.xml", (em, arr, objs, cfg)
+
+
+def _ray_batch(rs, rdr, n, w, h, lo=(0.3, 0.2, 0.3), hi=(5.2, 5.2, 5.2)):
+    O, D, TM = [], [], []
+    for k in range(n):
+        if k % 3 == 0:
+            ti.RNG.set_script(rs.rand(2)); rdr.cnt[None] = 1
+            O.append(rdr.cam_t.to_numpy()); D.append(rdr.pix2ray(int(rs.randint(w)), int(rs.randint(h))).to_numpy())
+        else:
+            d = np.float32(rs.normal(size=3)); d /= np.float32(np.linalg.norm(d))
+            O.append(np.float32(rs.uniform(lo, hi))); D.append(np.float32(d))
+        TM.append(np.float32(rs.uniform(0.3, 6.0)))
+    rdr.cnt[None] = 0
+    return np.float32(O), np.float32(D), np.float32(TM)
+
+
+def _trace_batch(rdr, O, D, TM, closest, anyhit):
+    hits, occ = [], []
+    for o, d, tm in zip(O, D, TM):
+        it = closest(vec3(d), vec3(o))
+        hits.append(np.concatenate([[it.obj_id, it.prim_id, it.min_depth], it.uv.to_numpy(), it.n_s.to_numpy(), it.n_g.to_numpy()]))
+        occ.append(int(bool(anyhit(vec3(d), vec3(o), tm))))
+    return np.float32(hits), np.int32(occ)
+
+
+def gen_bvhref(tag, scene_dir, xml, w, h, spp, n_rays, seed=0, synth_check=None, extra_rays=None, brute_rays=0, store_scene=True, overrides=None):
+    """The reference's BVH path pinned with the reference's own traversal code: `PathTracer.bvh_process` imports `bvh_cpp` (the
+    stand-in in shim/: tree from the builder restated in the oracle, reference layout), `convert_bvh_info` fills the LinearNode /
+    LinearBVH fields, and `ray_intersect_bvh` / `does_intersect_bvh` (path_tracer.py:338-422, ti_bvh.py) answer a ray batch and render
+    the image.  Stored: the rays, the hits, the occlusion flags, the image + draw counts, the tree's node count (the four arrays
+    themselves for small scenes), and for `brute_rays` of the rays also the answer of the reference's brute-force intersector
+    (tracer_base.py:168-278) - which is what decides whether the reference's two intersectors agree on a scene."""
+    sys.path.insert(0, refenv.REPO)
+    import hashlib
+    import bvh_cpp
+    from adapt_amd.scene_pack import pack_scene
+    from tracer.tracer_base import TracerBase
+    rs = np.random.RandomState({"cbox": 411, "bunnies1": 412, "bunnies3": 413}.get(tag, 499))      # own stream: `--only bvh` reproduces the committed files
+    t0 = time.time()
+    ov = dict({"width": w, "height": h, "accelerator": "bvh"}, **(overrides or {}))
+    rdr, (emitters, arr, objs, cfg) = refenv.make_renderer(scene_dir, xml, ov)
+    assert getattr(rdr, "node_num", 0) > 0 and rdr.ray_intersect.__func__ is type(rdr).ray_intersect_bvh, "the BVH path is not active"
+    fs = pack_scene(emitters, arr, objs, cfg)
+    if synth_check is not None:                       # the temporary scene directory reproduces the synthetic scene array for array
+        from adapt_amd.scene_pack import pack_scene as ps
+        fs2 = ps(*synth_check)
+        for name in ("prims", "normals", "v_normals", "obj_info", "obj_aabb", "emitter_id", "bxdf_i", "bxdf_f", "src_i", "src_f"):
+            assert np.array_equal(getattr(fs, name), getattr(fs2, name)), f"reference parser vs synth: {name} differs"
+    bvh_mm, node_mm, bvh_info, node_info = [np.asarray(a) for a in bvh_cpp.LAST["arrays"]]
+    out = {"tree_source": np.array(bvh_cpp.LAST["source"]), "node_num": np.int32(rdr.node_num), "bvh_num": np.int32(rdr.bvh_num),
+           "prims_sha256": np.array(hashlib.sha256(np.ascontiguousarray(fs.prims).tobytes()).hexdigest()),
+           "width": np.int32(w), "height": np.int32(h), "spp": np.int32(spp), "seed": np.int32(seed),
+           "max_bounce": np.int32(cfg["max_bounce"]), "num_shadow_ray": np.int32(cfg["num_shadow_ray"])}
+    if rdr.node_num <= 20000:
+        out.update(bvh_minmax=bvh_mm.reshape(-1, 2, 3), node_minmax=node_mm.reshape(-1, 2, 3), bvh_info=bvh_info.reshape(-1, 2), node_info=node_info.reshape(-1, 3))
+    if store_scene:
+        out.update({"prims": fs.prims, "normals": fs.normals, "v_normals": fs.v_normals, "obj_info": fs.obj_info, "obj_aabb": fs.obj_aabb,
+                    "emitter_id": fs.emitter_id, "bxdf_i": fs.bxdf_i, "bxdf_f": fs.bxdf_f, "src_i": fs.src_i, "src_f": fs.src_f,
+                    "has_vertex_normal": np.int32(fs.has_vertex_normal), "world_ior": np.float32(fs.world_ior), "fov": np.float64(cfg["fov"]),
+                    "use_rr": np.int32(cfg["use_rr"]), "use_mis": np.int32(cfg["use_mis"]), "anti_alias": np.int32(cfg["anti_alias"]),
+                    "stratified_sampling": np.int32(cfg["stratified_sampling"]), "brdf_two_sides": np.int32(cfg.get("brdf_two_sides", False)),
+                    "accelerator_bvh": np.int32(1), "rr_bounce_th": np.int32(cfg.get("rr_bounce_th", 4)), "rr_threshold": np.float64(cfg.get("rr_threshold", 0.1)),
+                    "cam_dir": np.float32(cfg["transform"][0]), "cam_pos": np.float32(cfg["transform"][1])})
+    O, D, TM = _ray_batch(rs, rdr, n_rays, w, h)
+    if extra_rays is not None:
+        eo, ed, etm = extra_rays(fs, cfg)
+        O, D, TM = np.concatenate([eo, O]), np.concatenate([ed, D]), np.concatenate([etm, TM])
+    out["ray_o"], out["ray_d"], out["ray_tmax"] = O, D, TM
+    out["bvh_hit"], out["bvh_occ"] = _trace_batch(rdr, O, D, TM, rdr.ray_intersect, rdr.does_intersect)
+    print(f"bvhref_{tag}: {rdr.node_num} nodes / {rdr.bvh_num} prims, {len(O)} rays traced through the BVH in {time.time() - t0:.1f}s", flush=True)
+    if brute_rays:
+        nb = min(brute_rays if brute_rays > 0 else getattr(disputed_rays_95k, 'count', 0), len(O))
+        out["brute_hit"], out["brute_occ"] = _trace_batch(rdr, O[:nb], D[:nb], TM[:nb], lambda d, o: TracerBase.ray_intersect(rdr, d, o),
+                                                          lambda d, o, tm: TracerBase.does_intersect(rdr, d, o, tm))
+        nd = int((out["brute_hit"][:, 1] != out["bvh_hit"][:nb, 1]).sum()); no = int((out["brute_occ"] != out["bvh_occ"][:nb]).sum())
+        print(f"bvhref_{tag}: brute force on the first {nb} rays in {time.time() - t0:.1f}s: {nd} closest hits and {no} occlusion flags differ from the BVH path", flush=True)
+    if spp > 0:
+        draws = np.zeros((spp, w, h), np.int32)
+        state = {"prev": None}
+
+        def hook(i, j):
+            if state["prev"] is not None:
+                pi, pj = state["prev"]; draws[state["s"], pi, pj] = ti.RNG.draw
+            ti.RNG.set_philox(i * h + j, seed, rdr.cnt[None])
+            state["prev"] = (i, j)
+
+        ti.PIXEL_HOOK[0] = hook
+        for s_ in range(spp):
+            state["s"], state["prev"] = s_, None
+            rdr.render(0, 0, 0, 0, 0, 0)
+            pi, pj = state["prev"]; draws[s_, pi, pj] = ti.RNG.draw
+        ti.PIXEL_HOOK[0] = None
+        out["accum"], out["draws"] = rdr.color.to_numpy(), draws
+    np.savez_compressed(os.path.join(OUT, f"bvhref_{tag}.npz"), **out)
+    print(f"bvhref_{tag}: done in {time.time() - t0:.1f}s" + (f", mean draws {out['draws'].mean():.2f}, mean radiance {np.nanmean(out['accum']) / spp:.4f}" if spp > 0 else ""), flush=True)
+
+
+def disputed_rays_95k(fs, cfg):
+    """Rays of the 95 050-triangle scene on which the oracle's two intersectors (brute force vs reference-layout BVH) disagree, found
+    among 300 000 random rays, plus as many rays on which they agree: the reference's own two intersectors then answer exactly these."""
+    from adapt_amd.scene_pack import make_config
+    from oracle import binding as ob
+    rs = np.random.RandomState(414)
+    rc = make_config(cfg)
+    sc = ob.OracleScene(fs, rc.cam_t, build_bvh=True)
+    n = 300000
+    o = rs.uniform([0.3, 0.2, 0.3], [5.2, 5.2, 5.2], size=(n, 3)).astype(np.float32)
+    d = rs.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    tm = rs.uniform(0.3, 6.0, n).astype(np.float32)
+    _, p0, t0, _, _ = sc.intersect(o, d, use_bvh=False)
+    _, p1, t1, _, _ = sc.intersect(o, d, use_bvh=True)
+    bad = np.nonzero((p0 != p1) | (t0 != t1))[0]
+    occ_bad = np.nonzero(sc.occluded(o, d, tm, use_bvh=False) != sc.occluded(o, d, tm, use_bvh=True))[0]
+    pick = np.unique(np.concatenate([bad[:40], occ_bad[:8]]))
+    good = np.setdiff1d(np.arange(n), np.concatenate([bad, occ_bad]))[:len(pick)]
+    idx = np.concatenate([pick, good])
+    print(f"95k scene: oracle brute force vs oracle reference-layout BVH on {n} rays: {len(bad)} closest hits differ, {len(occ_bad)} occlusion flags differ; "
+          f"{len(pick)} disputed + {len(good)} undisputed rays go to the reference", flush=True)
+    disputed_rays_95k.count = len(idx)
+    return o[idx], d[idx], tm[idx]
+
+
 REF_SCENES = [("cbox", "cbox-point.xml"), ("cbox", "cbox-vn.xml"), ("cbox", "smaller.xml"), ("cbox", "single-orb.xml"), ("cbox", "ite-orb.xml"),
               ("cbox", "skeleton.xml"), ("cbox", "vader.xml"), ("cbox", "venus.xml"), ("cbox", "bvh-benchmark.xml"),
               ("csphere", "balls-glossy.xml"), ("csphere", "balls-multi.xml"), ("csphere", "big.xml"), ("csphere", "mix-balls.xml"),
@@ -440,6 +613,15 @@ if __name__ == "__main__":
                 gen_refscene(sdir, xml, tag, 32, 24, 2)
             except Exception as e:                      # missing mesh / texture / volume assets: not loadable here
                 print(f"refscene_{tag}: SKIPPED ({type(e).__name__}: {str(e)[:120]})")
+    if a.only in ("all", "bvh"):
+        import tempfile
+        gen_bvhref("cbox", "cbox", "cbox.xml", 32, 32, 4, 256, brute_rays=256, overrides={"max_bounce": 8})
+        with tempfile.TemporaryDirectory() as tmp:
+            sdir, xml, synth4 = write_three_bunnies(tmp, 1)
+            gen_bvhref("bunnies1", sdir, xml, 24, 24, 2, 384, synth_check=synth4, brute_rays=48, store_scene=False)
+        with tempfile.TemporaryDirectory() as tmp:
+            sdir, xml, synth4 = write_three_bunnies(tmp, 3)
+            gen_bvhref("bunnies3", sdir, xml, 800, 800, 0, 600, synth_check=synth4, extra_rays=disputed_rays_95k, brute_rays=-1, store_scene=False)
     if a.only in ("all", "func", "media"):
         gen_media_functions()
     if a.only in ("all", "vpt"):

@@ -24,8 +24,9 @@ def close(a, b, rel=3e-6, abs_=1e-7):
     return bool(np.all(both_nan | (np.abs(a - b) <= abs_ + rel * np.abs(b))))
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def renderer(parsed):
+    """factory; every renderer a test makes is closed when that test ends (a renderer holds several GiB of queues per render lane)"""
     from adapt_amd.renderer import Renderer
     made = []
 
@@ -492,6 +493,130 @@ def test_full_size_c4_crop_matches_brute_force_oracle():
     mb = image_metrics(img / 2, ref_bvh[310:350, 236:264] / 2)
     assert mb["frac_within"] >= 0.97, mb
     r.close()
+
+
+def test_full_size_c5_scene_properties():
+    """BASELINE configs[4] stand-in at full geometry (285 134 triangles, 1280x720, 16 bounces, S = 1, every live surface model,
+    two area lights) with few samples: the checks that need no CPU at this size - statistics identities, NaN-free image, and a
+    cropped window that equals the same window of the full render (the RNG is keyed by the global pixel)."""
+    from adapt_amd.renderer import Renderer
+    from adapt_amd.synth import bunny_field
+    em, arr, objs, cfg = bunny_field()
+    r = Renderer(em, arr, objs, cfg)
+    assert (r.w, r.h, r.num_prims, r.max_bounce, r.num_shadow_ray) == (1280, 720, 285134, 16, 1) and r.info()["traversal"] == "bvh"
+    r.render(n_spp=2)
+    st, img = r.stats(), r.pixels.to_numpy()
+    n = 1280 * 720 * 2
+    assert st["n_samples"] == n and st["n_lit"] <= st["n_shadow_traced"] <= st["n_shadow"] <= st["n_shade"]      # S = 1; no light sample on an emitter hit
+    assert n < st["n_extend"] <= n + st["n_shade"] and 2.0 < st["n_shade"] / n < 8.0
+    # upstream zeroes NaN samples and lets +-inf through (vanilla_renderer.py:119): no NaN ever, inf only as a rare pdf = 0 path
+    assert not np.isnan(img).any() and np.isinf(img).any(axis=2).mean() < 1e-4
+    fin = img[np.isfinite(img).all(axis=2)]
+    assert 0.05 < fin.mean() < 5.0
+    r.close()                                     # 8 class queues x 3 lanes: ~30 GiB of queues per renderer at this film size
+    cfg2 = dict(cfg); cfg2["film"] = {"width": 1280, "height": 720, "crop_x": 640, "crop_y": 300, "crop_rx": 56, "crop_ry": 36}
+    c = Renderer(em, arr, objs, cfg2)
+    c.render(n_spp=2)
+    win, full = c.pixels.to_numpy()[584:696, 264:336], img[584:696, 264:336]
+    assert c.stats()["n_samples"] == 2 * 112 * 72
+    assert np.array_equal(win, full)              # one light sample per vertex: no two float atomics meet on a radiance slot
+    c.close()
+
+
+@pytest.mark.parametrize("cx,cy", [(640, 360), (330, 250), (930, 200)])
+def test_full_size_c5_crop_matches_brute_force_oracle(cx, cy):
+    """Full 285 134-triangle scene, cropped windows of 96 x 64 pixels x 4 spp, 16 bounces: HIP (own BVH) vs the oracle's BRUTE-FORCE
+    intersector on the same Philox stream - per pixel, plus exact sample counts and path statistics to 2e-3."""
+    from adapt_amd.renderer import Renderer
+    from adapt_amd.scene_pack import pack_scene
+    from adapt_amd.synth import bunny_field
+    from oracle import binding as ob
+    em, arr, objs, cfg = bunny_field()
+    cfg = dict(cfg); cfg["film"] = {"width": 1280, "height": 720, "crop_x": cx, "crop_y": cy, "crop_rx": 48, "crop_ry": 32}
+    r = Renderer(em, arr, objs, cfg)
+    r.render(n_spp=4)
+    rc = make_config(cfg)
+    assert rc.do_crop and rc.use_bvh and (rc.end_x - rc.start_x, rc.end_y - rc.start_y) == (96, 64)
+    win = (slice(rc.start_x, rc.end_x), slice(rc.start_y, rc.end_y))
+    img = r.color.to_numpy()[win]
+    sc = ob.OracleScene(pack_scene(em, arr, objs, cfg), rc.cam_t, build_bvh=False)
+    rc.use_bvh = False
+    ref, _, ost = sc.render(rc, 4)
+    m = image_metrics(img / 4, ref[win] / 4)
+    st = r.stats()
+    assert st["n_samples"] == ost["n_samples"] == 4 * 96 * 64
+    assert m["frac_within"] >= 0.99 and m["relMSE"] <= 2e-4, m
+    for k in ("n_shade", "n_shadow", "n_draws"):
+        assert abs(st[k] - ost[k]) <= 2e-3 * ost[k], (k, st[k], ost[k])
+    r.close()
+
+
+def test_full_size_properties_c3(renderer):
+    """BASELINE configs[2] shape (csphere balls-mono, 512x512, 16 bounces, S = 4 light samples per vertex, area light, spheres,
+    glass, mirror, Fresnel blend) at a reduced sample count: statistics identities, energy bounds, NaN-free image, and a cropped
+    window vs the same window of the full render."""
+    r = renderer("balls_mono")
+    assert (r.w, r.h, r.max_bounce, r.num_shadow_ray) == (512, 512, 16, 4)
+    r.render(n_spp=16)
+    st, img = r.stats(), r.pixels.to_numpy()
+    n = 512 * 512 * 16
+    assert st["n_samples"] == n and st["n_poisoned"] * 1000 < st["n_shadow"]
+    # four light samples per shaded vertex, except on the emitter itself (single light: break_flag, vanilla_renderer.py:84-86)
+    assert st["n_shadow"] <= 4 * st["n_shade"] and st["n_shadow"] > 3.5 * st["n_shade"]
+    assert st["n_lit"] <= st["n_shadow_traced"] <= st["n_shadow"] and n < st["n_extend"] <= n + st["n_shade"]
+    assert 3.5 < st["n_shade"] / n < 5.0 and 60.0 < st["n_draws"] / n < 95.0            # SURVEY 8(d): 4.21 shades, 77 draws per sample
+    assert not np.isnan(img).any() and np.isinf(img).any(axis=2).mean() < 1e-4
+    fin = img[np.isfinite(img).all(axis=2)]
+    assert fin.min() > -1e-3 and 0.1 < fin.mean() < 2.0
+
+
+def test_full_size_c3_crop_matches_oracle(parsed, oracle_scene):
+    """C3 at full film size, a 128 x 96 window x 16 spp, all 16 bounces and S = 4: HIP (wave sweep) vs the oracle, same stream."""
+    from adapt_amd.renderer import Renderer
+    em, arr, objs, cfg = parsed("balls_mono")
+    cfg = dict(cfg); cfg["film"] = {"width": 512, "height": 512, "crop_x": 250, "crop_y": 200, "crop_rx": 64, "crop_ry": 48}
+    r = Renderer(em, arr, objs, cfg)
+    r.render(n_spp=16)
+    rc = make_config(cfg)
+    win = (slice(rc.start_x, rc.end_x), slice(rc.start_y, rc.end_y))
+    ref, cnt, ost = oracle_scene("balls_mono").render(rc, 16)
+    m = image_metrics(r.pixels.to_numpy()[win], (ref / np.float32(cnt))[win])
+    st = r.stats()
+    assert st["n_samples"] == ost["n_samples"] == 16 * 128 * 96
+    assert m["frac_within"] >= 0.995 and m["relMSE"] <= 1e-4, m
+    for k in ("n_shade", "n_shadow", "n_draws"):
+        assert abs(st[k] - ost[k]) <= 5e-4 * ost[k], (k, st[k], ost[k])
+    r.close()
+
+
+@pytest.mark.parametrize("tag", ["cbox", "bunnies1", "bunnies3"])
+def test_hip_vs_the_reference_intersectors_on_recorded_rays(tag):
+    """tests/golden/bvhref_*.npz: rays answered by the reference's own BVH walk and (the first ones) by its own brute force.
+    HIP returns the brute-force answer on every ray: equal to both reference intersectors where those agree, and on the rays of
+    the 95 050-triangle scene where the reference's BVH walk loses a hit (DESIGN "the reference's BVH path") HIP has the nearer hit
+    its brute force finds."""
+    from test_oracle_golden import bvhref_scene
+    from adapt_amd.renderer import Renderer
+    tup, fs, g = bvhref_scene(tag)
+    r = Renderer(*tup, width=64, height=64)
+    try:
+        O, D, TM = g["ray_o"], g["ray_d"], g["ray_tmax"]
+        prim, t, uv = r.intersect(O, D)
+        occ = r.occluded(O, D, TM)
+        hb, hv = g["brute_hit"], g["bvh_hit"]
+        n = hb.shape[0]
+        miss = hb[:, 1] < 0
+        assert np.array_equal(prim[:n][~miss], np.int32(hb[:, 1][~miss])) and np.array_equal(t[:n][~miss], hb[:, 2][~miss]) and (prim[:n][miss] < 0).all()
+        assert np.array_equal(uv[:n][~miss], hb[:, 3:5][~miss]) and np.array_equal(occ[:n], g["brute_occ"])
+        # the rest of the batch was answered by the reference's BVH walk only
+        hit = hv[:, 1] >= 0
+        same = (prim == np.int32(hv[:, 1])) & hit & (t == hv[:, 2]) | (~hit & (prim < 0))
+        nearer = hit & (prim >= 0) & (t < hv[:, 2]) | (~hit & (prim >= 0))
+        assert (same | nearer).all()
+        assert nearer.sum() <= (45 if tag == "bunnies3" else 0)         # 41 of the 682 rays were picked for being lost by the walk
+        assert ((occ == g["bvh_occ"]) | (occ == 1)).all() and (occ != g["bvh_occ"]).sum() <= (10 if tag == "bunnies3" else 0)
+    finally:
+        r.close()
 
 
 # ---- the reference's own bundled scene files (arrays from its parser, tests/golden/refscene_*.npz)

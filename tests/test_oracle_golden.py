@@ -236,3 +236,75 @@ def test_grid_volume_matches_reference_run(name):
     fs.vol_i = None
     acc0 = ob.OracleScene(fs, rc.cam_t).render(rc, int(g["spp"]))[0]
     assert not np.array_equal(acc0, acc)
+
+
+# ---- the reference's BVH path (accelerator = bvh), tests/golden/bvhref_*.npz: the reference's OWN traversal code
+# (PathTracer.bvh_process -> convert_bvh_info -> ray_intersect_bvh / does_intersect_bvh, tracer/path_tracer.py:143-179,338-422,
+# tracer/ti_bvh.py) run on a reference-layout tree handed over by the `bvh_cpp` stand-in of the generator
+def bvhref_scene(tag):
+    """(scene 4-tuple, fixture): cbox carries its arrays; the bunny scenes are rebuilt by adapt_amd.synth and checked by hash"""
+    import hashlib
+    from adapt_amd.scene_pack import pack_scene
+    g = golden(f"bvhref_{tag}.npz")
+    if "prims" in g:
+        tup, _ = scene_from_golden(tag, prefix="bvhref")
+    else:
+        from adapt_amd.synth import three_bunnies
+        tup = three_bunnies({"bunnies1": 1, "bunnies3": 3}[tag])
+    fs = pack_scene(*tup)
+    assert hashlib.sha256(np.ascontiguousarray(fs.prims).tobytes()).hexdigest() == str(g["prims_sha256"]), "the fixture was recorded on other geometry"
+    return tup, fs, g
+
+
+@pytest.mark.parametrize("tag", ["cbox", "bunnies1", "bunnies3"])
+def test_reference_bvh_traversal_bit_exact(tag):
+    """Oracle's restatement of the reference's BVH walk == the reference's own walk on the same tree: closest hits (object,
+    primitive, t, barycentrics, normals), occlusion flags, and - where recorded - the image and every sample's draw count."""
+    tup, fs, g = bvhref_scene(tag)
+    rc = make_config(tup[3], width=int(g["width"]), height=int(g["height"]), max_bounce=int(g["max_bounce"]), seed=int(g["seed"]))
+    assert rc.use_bvh or tag == "cbox"
+    sc = ob.OracleScene(fs, rc.cam_t, build_bvh=True)
+    bvh_mm, node_mm, bvh_info, node_info = sc.bvh_arrays()
+    assert str(g["tree_source"]) == "oracle" and node_info.shape[0] == int(g["node_num"]) and bvh_info.shape[0] == int(g["bvh_num"])
+    if "node_info" in g:                        # small trees travel in the fixture: the tree the reference walked is this tree
+        assert np.array_equal(node_info, g["node_info"]) and np.array_equal(bvh_info, g["bvh_info"])
+        assert np.array_equal(node_mm, g["node_minmax"]) and np.array_equal(bvh_mm, g["bvh_minmax"])
+    O, D, TM, h = g["ray_o"], g["ray_d"], g["ray_tmax"], g["bvh_hit"]
+    obj, prim, t, uv, ns = sc.intersect(O, D, use_bvh=True)
+    assert np.array_equal(obj, h[:, 0]) and np.array_equal(prim, h[:, 1]) and np.array_equal(t, h[:, 2])
+    assert np.array_equal(uv, h[:, 3:5]) and np.array_equal(ns, h[:, 5:8])
+    assert np.array_equal(sc.occluded(O, D, TM, use_bvh=True), g["bvh_occ"])
+    assert (obj >= 0).sum() > 0.5 * len(O)
+    if "accum" in g:
+        rc.use_bvh = True
+        img, cnt, st = sc.render(rc, int(g["spp"]))
+        assert cnt == int(g["spp"]) and st["n_draws"] == int(g["draws"].sum())
+        bad = (img.view(np.uint32) != g["accum"].view(np.uint32)).any(axis=2) & ~(np.isnan(img) & np.isnan(g["accum"])).all(axis=2)
+        assert bad.sum() <= 2, int(bad.sum())         # <= 2 pixels: the generator's np.float32 ** 2 (see test_whole_kernel_matches_reference_run)
+
+
+@pytest.mark.parametrize("tag", ["cbox", "bunnies1", "bunnies3"])
+def test_reference_brute_force_on_the_bvh_rays(tag):
+    """The reference's brute-force intersector (tracer_base.py:168-278) on the first rays of the same batch, vs the oracle's
+    brute force: bit-exact.  On the Cornell box and the 5 950-triangle scene the reference's two intersectors agree on every
+    ray.  On the 95 050-triangle scene the batch starts with rays picked because the ORACLE's two intersectors disagree on
+    them - and the reference's own two intersectors disagree on exactly those rays, in exactly the same way: its BVH walk
+    (strict slab test on unpadded node boxes, ti_bvh.py:16-22, bvh_helper.h:30-45) loses hits its brute force finds."""
+    tup, fs, g = bvhref_scene(tag)
+    rc = make_config(tup[3])
+    sc = ob.OracleScene(fs, rc.cam_t, build_bvh=True)
+    hb, ob_ = g["brute_hit"], g["brute_occ"]
+    n = hb.shape[0]
+    O, D, TM = g["ray_o"][:n], g["ray_d"][:n], g["ray_tmax"][:n]
+    obj, prim, t, uv, ns = sc.intersect(O, D, use_bvh=False)
+    assert np.array_equal(obj, hb[:, 0]) and np.array_equal(prim, hb[:, 1]) and np.array_equal(t, hb[:, 2]) and np.array_equal(uv, hb[:, 3:5])
+    assert np.array_equal(sc.occluded(O, D, TM, use_bvh=False), ob_)
+    differ = (g["bvh_hit"][:n, 1] != hb[:, 1]) | (g["bvh_hit"][:n, 2] != hb[:, 2])
+    occ_differ = g["bvh_occ"][:n] != ob_
+    if tag != "bunnies3":
+        assert not differ.any() and not occ_differ.any()
+    else:
+        # every lost closest hit is a hit the brute force finds NEARER (or at all); never the other way round
+        assert differ.sum() >= 30 and (g["bvh_hit"][:n, 2][differ] > hb[:, 2][differ]).all()
+        assert occ_differ.sum() >= 4 and (ob_[occ_differ] == 1).all()
+        assert not differ[n // 2:].any()              # the second half of the picked rays are the undisputed controls
