@@ -221,6 +221,36 @@ APT_EXPORT int apt_bvh_export(const apt_bvh* b, float* nodes, int32_t* prim_orde
 }
 APT_EXPORT void apt_bvh_free(apt_bvh* b) { delete b; }
 
+// ---- `bvh_cpp.bvh_build`-compatible export (host only): the reference-layout tree for AdaPT's own traversal kernels
+struct apt_linear_bvh { apt::LinearBvhData data; };
+APT_EXPORT int apt_bvh_build_linear(const float* prims, int32_t n_prims, const int32_t* obj_prim_cnt, const int32_t* obj_is_sphere, int32_t n_objects,
+                                    const float* world_min, const float* world_max, apt_linear_bvh** out) {
+    if (!prims || !obj_prim_cnt || !obj_is_sphere || !world_min || !world_max || !out || n_prims <= 0 || n_objects <= 0)
+        return fail(APT_E_INVALID, "apt_bvh_build_linear: bad argument");
+    apt_linear_bvh* b = new apt_linear_bvh();
+    if (apt::build_linear_bvh(prims, n_prims, obj_prim_cnt, obj_is_sphere, n_objects, world_min, world_max, b->data) != 0) {
+        delete b;
+        return fail(APT_E_INVALID, "apt_bvh_build_linear: the per-object primitive counts must be non-negative and sum to n_prims");
+    }
+    *out = b;
+    return APT_OK;
+}
+APT_EXPORT int apt_linear_bvh_counts(const apt_linear_bvh* b, int32_t* n_nodes, int32_t* n_prims) {
+    if (!b) return fail(APT_E_INVALID, "apt_linear_bvh_counts: null handle");
+    if (n_nodes) *n_nodes = b->data.n_nodes();
+    if (n_prims) *n_prims = b->data.n_prims();
+    return APT_OK;
+}
+APT_EXPORT int apt_linear_bvh_export(const apt_linear_bvh* b, float* bvh_minmax, float* node_minmax, int32_t* bvh_info, int32_t* node_info) {
+    if (!b || !bvh_minmax || !node_minmax || !bvh_info || !node_info) return fail(APT_E_INVALID, "apt_linear_bvh_export: bad argument");
+    memcpy(bvh_minmax, b->data.bvh_minmax.data(), b->data.bvh_minmax.size() * sizeof(float));
+    memcpy(node_minmax, b->data.node_minmax.data(), b->data.node_minmax.size() * sizeof(float));
+    memcpy(bvh_info, b->data.bvh_info.data(), b->data.bvh_info.size() * sizeof(int32_t));
+    memcpy(node_info, b->data.node_info.data(), b->data.node_info.size() * sizeof(int32_t));
+    return APT_OK;
+}
+APT_EXPORT void apt_linear_bvh_free(apt_linear_bvh* b) { delete b; }
+
 // ---- scene
 APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_scene** out) {
     if (!d || !out) return fail(APT_E_INVALID, "apt_scene_create: null argument");

@@ -12,4 +12,16 @@ struct BvhData {
 };
 // prims: n_prims*9 (triangle v0 v1 v2 | sphere centre, r r r, -); obj_info: n_objects*3 (first, count, is_sphere)
 int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, BvhData& out);
+
+// bvh_linear.cpp: the four arrays `bvh_cpp.bvh_build` returns (tracer/bvh/bvh.cpp:274-296), preorder with subtree-skip offsets
+struct LinearBvhData {
+    std::vector<float> bvh_minmax;     // n_prims * 6, tree order
+    std::vector<float> node_minmax;    // n_nodes * 6
+    std::vector<int32_t> bvh_info;     // n_prims * 2: object, original primitive
+    std::vector<int32_t> node_info;    // n_nodes * 3: first primitive, count, subtree size
+    int n_nodes() const { return (int)(node_info.size() / 3); }
+    int n_prims() const { return (int)(bvh_info.size() / 2); }
+};
+int build_linear_bvh(const float* prims, int n_prims, const int32_t* obj_prim_cnt, const int32_t* obj_is_sphere, int n_objects,
+                     const float world_min[3], const float world_max[3], LinearBvhData& out);
 }  // namespace apt

@@ -121,6 +121,22 @@ int apt_bvh_counts(const apt_bvh*, int32_t* n_nodes, int32_t* n_leaf_prims, int3
 int apt_bvh_export(const apt_bvh*, float* nodes, int32_t* prim_order);
 void apt_bvh_free(apt_bvh*);
 
+/* ---- BVH build, reference layout: the drop-in for the pybind11 module itself.
+ * Replaces bvh_cpp.bvh_build(obj_array, obj_info, world_min, world_max) (tracer/bvh/bvh.cpp:274-296), whose four flat arrays
+ * PathTracer.bvh_process reshapes and loads into the LinearBVH / LinearNode fields (tracer/path_tracer.py:155-170,
+ * tracer/ti_bvh.py:10-53) for AdaPT's own stackless preorder walk.  obj_prim_cnt / obj_is_sphere are the two rows of the
+ * reference's (2, n_obj) obj_info table (tracer/path_tracer.py:222-230).  Outputs of apt_linear_bvh_export, caller-allocated:
+ *   bvh_minmax  n_prims*6  per-primitive box (min xyz, max xyz) in tree order      node_minmax n_nodes*6  per-node box
+ *   bvh_info    n_prims*2  (object, original primitive)                            node_info   n_nodes*3  (first, count, subtree size)
+ * Nodes are in preorder; node 0 is the root with box = the world box and subtree size = n_nodes; a leaf has subtree size 1.
+ * Host only (no device needed).  adapt_amd/bvh_cpp.py wraps these three calls as a module named like the reference's. */
+typedef struct apt_linear_bvh apt_linear_bvh;
+int apt_bvh_build_linear(const float* prims /* n_prims*9 */, int32_t n_prims, const int32_t* obj_prim_cnt, const int32_t* obj_is_sphere,
+                         int32_t n_objects, const float* world_min /* 3 */, const float* world_max /* 3 */, apt_linear_bvh** out);
+int apt_linear_bvh_counts(const apt_linear_bvh*, int32_t* n_nodes, int32_t* n_prims);
+int apt_linear_bvh_export(const apt_linear_bvh*, float* bvh_minmax, float* node_minmax, int32_t* bvh_info, int32_t* node_info);
+void apt_linear_bvh_free(apt_linear_bvh*);
+
 /* ---- scene / renderer lifetime */
 int apt_scene_create(const apt_scene_desc* desc, int32_t device, apt_scene** out);
 void apt_scene_destroy(apt_scene*);

@@ -1111,14 +1111,60 @@ static void prim_bound(const v3 p[3], int is_sphere, bvh_info_t* out) {     /* b
         float* l = &lo.x; float* h = &hi.x;
         for (int i = 0; i < 3; i++) if (h[i] - l[i] < 1e-4f) { l[i] -= 1e-4f; h[i] += 1e-4f; }
         out->bound.mini = lo; out->bound.maxi = hi;
-        /* Eigen rowwise().mean(): (a+b+c)/3 */
-        out->centroid = V(((p[0].x + p[1].x) + p[2].x) / 3.f, ((p[0].y + p[1].y) + p[2].y) / 3.f, ((p[0].z + p[1].z) + p[2].z) / 3.f);
+        /* Eigen 3.4 rowwise().mean() = sum() / 3 (VectorwiseOp.h), and a fixed-size sum of three coefficients is unrolled as
+         * x0 + (x1 + x2) (Redux.h, redux_novec_unroller: the range is halved recursively, 3 -> 1 + 2) */
+        out->centroid = V((p[0].x + (p[1].x + p[2].x)) / 3.f, (p[0].y + (p[1].y + p[2].y)) / 3.f, (p[0].z + (p[1].z + p[2].z)) / 3.f);
     }
 }
-static int g_sort_axis;
-static int cmp_centroid(const void* a, const void* b) {
-    float ca = comp(((const bvh_info_t*)a)->centroid, g_sort_axis), cb = comp(((const bvh_info_t*)b)->centroid, g_sort_axis);
-    return (ca < cb) ? -1 : (ca > cb);
+/* The reference is built against libstdc++ (tracer/setup.py: g++ -O3), and the standard leaves the element order that
+ * std::partition / std::nth_element produce unspecified - but that order decides later splits wherever centroids tie, which is
+ * everywhere in axis-aligned geometry (the Cornell box comes out with 61 nodes, not 57 as with a stable partition + sort).
+ * So both are restated from libstdc++'s published algorithms (bits/stl_algo.h):
+ *   std::partition, bidirectional iterators: Hoare scheme - advance `first` over elements satisfying the predicate, retreat `last`
+ *     over elements that do not, swap, repeat;
+ *   std::nth_element = introselect: while the range is longer than 3, median-of-three (first+1, middle, last-1) moved to the front,
+ *     unguarded Hoare partition about it, continue in the half that holds nth; then insertion sort of the rest.  Ranges here
+ *     have at most 4 elements (bvh.cpp:153-158): at most one partition round, so the depth limit never triggers. */
+static void info_swap(bvh_info_t* a, bvh_info_t* b) { bvh_info_t t = *a; *a = *b; *b = t; }
+static void stl_partition_lt(bvh_info_t* first, bvh_info_t* last, int axis, float pivot) {
+    for (;;) {
+        for (;;) { if (first == last) return; else if (comp(first->centroid, axis) < pivot) ++first; else break; }
+        --last;
+        for (;;) { if (first == last) return; else if (!(comp(last->centroid, axis) < pivot)) --last; else break; }
+        info_swap(first, last);
+        ++first;
+    }
+}
+static void stl_insertion_sort(bvh_info_t* first, bvh_info_t* last, int axis) {
+    if (first == last) return;
+    for (bvh_info_t* i = first + 1; i != last; ++i) {
+        bvh_info_t val = *i;
+        bvh_info_t* j = i;
+        while (j != first && comp(val.centroid, axis) < comp((j - 1)->centroid, axis)) { *j = *(j - 1); --j; }
+        *j = val;
+    }
+}
+static void stl_nth_element(bvh_info_t* first, bvh_info_t* nth, bvh_info_t* last, int axis) {
+#define LT(a, b) (comp((a)->centroid, axis) < comp((b)->centroid, axis))
+    while (last - first > 3) {
+        bvh_info_t *mid = first + (last - first) / 2, *a = first + 1, *b = mid, *c = last - 1;
+        if (LT(a, b)) { if (LT(b, c)) info_swap(first, b); else if (LT(a, c)) info_swap(first, c); else info_swap(first, a); }
+        else if (LT(a, c)) info_swap(first, a);
+        else if (LT(b, c)) info_swap(first, c);
+        else info_swap(first, b);
+        bvh_info_t *lo = first + 1, *hi = last;
+        for (;;) {
+            while (LT(lo, first)) ++lo;
+            --hi;
+            while (LT(first, hi)) --hi;
+            if (!(lo < hi)) break;
+            info_swap(lo, hi);
+            ++lo;
+        }
+        if (lo <= nth) first = lo; else last = lo;
+    }
+#undef LT
+    stl_insertion_sort(first, last, axis);
 }
 static int build_sah(bnode_t* cur, bvh_info_t* infos) {
     aabb_t fwd, bwd; aabb_clear(&fwd); aabb_clear(&bwd);
@@ -1159,14 +1205,7 @@ static int build_sah(bnode_t* cur, bvh_info_t* infos) {
             if (cost < min_cost) { min_cost = cost; seg = i; }
         }
         if (min_cost < node_prim_cnt) {
-            /* std::partition by centroid < pivot; a stable partition yields the same two sets */
-            float pivot = bins[seg];
-            bvh_info_t* tmp = (bvh_info_t*)malloc(sizeof(bvh_info_t) * (size_t)prim_num);
-            int k = 0;
-            for (int i = base; i < max_pos; i++) if (comp(infos[i].centroid, axis) < pivot) tmp[k++] = infos[i];
-            for (int i = base; i < max_pos; i++) if (!(comp(infos[i].centroid, axis) < pivot)) tmp[k++] = infos[i];
-            memcpy(infos + base, tmp, sizeof(bvh_info_t) * (size_t)prim_num);
-            free(tmp);
+            stl_partition_lt(infos + base, infos + max_pos, axis, bins[seg]);      /* bvh.cpp:138-141 */
             child_cnt = prim_cnts[seg];
         }
         aabb_clear(&fwd); aabb_clear(&bwd);
@@ -1174,8 +1213,7 @@ static int build_sah(bnode_t* cur, bvh_info_t* infos) {
         for (int i = NUM_BINS - 1; i > seg; i--) aabb_grow(&bwd, &bin_bound[i]);
     } else {
         int seg_idx = (base + max_pos) >> 1;
-        g_sort_axis = axis;                  /* nth_element -> full sort of <= 4 items: same split sets */
-        qsort(infos + base, (size_t)prim_num, sizeof(bvh_info_t), cmp_centroid);
+        stl_nth_element(infos + base, infos + seg_idx, infos + max_pos, axis);       /* bvh.cpp:153-158 */
         for (int i = base; i < seg_idx; i++) aabb_grow(&fwd, &infos[i].bound);
         for (int i = seg_idx; i < max_pos; i++) aabb_grow(&bwd, &infos[i].bound);
         child_cnt = seg_idx - base;

@@ -165,3 +165,110 @@ def test_struct_layouts_match_the_header():
 def test_volume_renderer_class():
     from adapt_amd.renderer import VolumeRenderer, Renderer
     assert VolumeRenderer.VOLUMETRIC and not Renderer.VOLUMETRIC and issubclass(VolumeRenderer, Renderer)
+
+
+# ---- the bvh_cpp.bvh_build drop-in (apt_bvh_build_linear, adapt_amd/bvh_cpp.py): reference layout, host only
+def _world_box(fs, cam_t):
+    """PathTracer.__init__, tracer/path_tracer.py:130-138: (objects U camera) -+ 0.1, seeded with +-1e3"""
+    ab = np.asarray(fs.obj_aabb, np.float32).reshape(-1, 2, 3)
+    lo = np.minimum(np.float32(cam_t), np.minimum(ab[:, 0].min(axis=0), np.float32(1e3)))
+    hi = np.maximum(np.float32(cam_t), np.maximum(ab[:, 1].max(axis=0), np.float32(-1e3)))
+    return np.float32(lo - np.float32(0.1)), np.float32(hi + np.float32(0.1))
+
+
+def _linear(fs, cam_t):
+    from adapt_amd.bvh_cpp import bvh_build
+    info = np.stack([fs.obj_info[:, 1], fs.obj_info[:, 2]]).astype(np.int32)          # PathTracer.prepare_for_bvh: (2, n_obj)
+    out = bvh_build(np.asarray(fs.prims, np.float32).reshape(-1, 3, 3), info, *_world_box(fs, cam_t))
+    assert [a.ndim for a in out] == [1, 1, 1, 1] and [a.dtype for a in out] == [np.float32, np.float32, np.int32, np.int32]     # flat, as bvh.cpp:215-251 returns them
+    return out[0].reshape(-1, 2, 3), out[1].reshape(-1, 2, 3), out[2].reshape(-1, 2), out[3].reshape(-1, 3)     # the reshapes of path_tracer.py:157-160
+
+
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a"])
+def test_bvh_cpp_drop_in_structure(tag, flat, parsed):
+    """What AdaPT's stackless walk relies on (tracer/path_tracer.py:338-394): preorder, subtree-skip offsets, leaf <=> offset 1,
+    leaves partition the primitives, boxes nest, (object, primitive) pairs consistent with the scene."""
+    from adapt_amd.scene_pack import make_config
+    fs = flat(tag)
+    bvh_mm, node_mm, bvh_info, node_info = _linear(fs, make_config(parsed(tag)[3]).cam_t)
+    M, N = node_info.shape[0], bvh_info.shape[0]
+    assert N == fs.n_prims and tuple(node_info[0]) == (0, N, M)
+    wlo, whi = _world_box(fs, make_config(parsed(tag)[3]).cam_t)
+    assert np.array_equal(node_mm[0, 0], wlo) and np.array_equal(node_mm[0, 1], whi)         # the root carries the world box
+    assert sorted(bvh_info[:, 1].tolist()) == list(range(N))
+    leaf = node_info[:, 2] == 1
+    assert node_info[leaf, 1].sum() == N and node_info[leaf, 1].min() >= 1
+    for i in range(M):
+        base, cnt, off = node_info[i]
+        if off > 1:
+            l = i + 1; r = l + node_info[l, 2]
+            assert node_info[l, 2] + node_info[r, 2] + 1 == off and r + node_info[r, 2] == i + off
+            assert node_info[l, 0] == base and node_info[r, 0] == base + node_info[l, 1] and node_info[l, 1] + node_info[r, 1] == cnt
+            if i > 0:
+                for c in (l, r):
+                    assert np.all(node_mm[c, 0] >= node_mm[i, 0]) and np.all(node_mm[c, 1] <= node_mm[i, 1])
+        else:
+            assert np.all(bvh_mm[base:base + cnt, 0] >= node_mm[i, 0]) and np.all(bvh_mm[base:base + cnt, 1] <= node_mm[i, 1])
+    obj_of_prim = np.repeat(np.arange(fs.n_objects), fs.obj_info[:, 1])
+    assert np.array_equal(bvh_info[:, 0], obj_of_prim[bvh_info[:, 1]])
+    # primitive boxes: vertex min / max, axes thinner than 1e-4 widened by 1e-4 (bvh_helper.h:30-45); spheres centre -+ radius
+    sphere = np.repeat(fs.obj_info[:, 2], fs.obj_info[:, 1]).astype(bool)
+    for slot in range(N):
+        lo, hi = prim_bounds(fs, bvh_info[slot, 1], sphere[bvh_info[slot, 1]])
+        if not sphere[bvh_info[slot, 1]]:
+            thin = (hi - lo) < np.float32(1e-4)
+            lo, hi = np.where(thin, lo - np.float32(1e-4), lo), np.where(thin, hi + np.float32(1e-4), hi)
+        assert np.array_equal(bvh_mm[slot, 0], np.float32(lo)) and np.array_equal(bvh_mm[slot, 1], np.float32(hi))
+
+
+def test_bvh_cpp_drop_in_known_answers(flat, parsed):
+    """Node counts recorded from the reference's own bvh.cpp (probe (4)): the Cornell box's 34 primitives give 61 nodes
+    (31 leaves, at most 2 primitives per leaf, root (0, 34, 61)); bunny.obj's 495 triangles give 975 nodes (488 leaves: 481 of one
+    primitive, 7 of two).  Both depend on how libstdc++'s std::partition / std::nth_element order tied centroids."""
+    import os
+    from adapt_amd.bvh_cpp import bvh_build
+    from adapt_amd.parsers.obj_loader import extract_obj_info
+    from adapt_amd.scene_pack import make_config
+    _, _, _, ni = _linear(flat("cbox"), make_config(parsed("cbox")[3]).cam_t)
+    leaves = ni[ni[:, 2] == 1]
+    assert tuple(ni[0]) == (0, 34, 61) and leaves.shape[0] == 31 and leaves[:, 1].max() == 2
+    m, _, _, _ = extract_obj_info(os.path.join(ROOT, "scenes", "meshes", "cornell", "bunny.obj"))
+    out = bvh_build(m, np.int32([[m.shape[0]], [0]]), m.min(axis=(0, 1)) - np.float32(0.1), m.max(axis=(0, 1)) + np.float32(0.1))
+    ni = out[3].reshape(-1, 3)
+    leaves = ni[ni[:, 2] == 1]
+    assert ni.shape[0] == 975 and leaves.shape[0] == 488 and np.bincount(leaves[:, 1]).tolist() == [0, 481, 7]
+
+
+def test_bvh_cpp_drop_in_matches_the_fixture_tree_and_rejects_bad_input(flat, parsed):
+    """The tree the reference's own traversal walked when tests/golden/bvhref_cbox.npz was recorded (it came from the oracle's
+    restated builder) is, array for array, the tree this entry point returns."""
+    from adapt_amd.bvh_cpp import bvh_build
+    from adapt_amd import _lib
+    from conftest import golden, scene_from_golden
+    from adapt_amd.scene_pack import make_config, pack_scene
+    tup, g = scene_from_golden("cbox", prefix="bvhref")
+    bvh_mm, node_mm, bvh_info, node_info = _linear(pack_scene(*tup), make_config(tup[3]).cam_t)
+    assert np.array_equal(node_info, g["node_info"]) and np.array_equal(bvh_info, g["bvh_info"])
+    assert np.array_equal(node_mm, g["node_minmax"]) and np.array_equal(bvh_mm, g["bvh_minmax"])
+    tri = np.zeros((2, 3, 3), np.float32)
+    with pytest.raises(_lib.AptError):
+        bvh_build(tri, np.int32([[3], [0]]), np.zeros(3, np.float32), np.ones(3, np.float32))     # counts do not sum to N
+    with pytest.raises(ValueError):
+        bvh_build(tri.reshape(-1, 9), np.int32([[2], [0]]), np.zeros(3, np.float32), np.ones(3, np.float32))
+
+
+@pytest.mark.parametrize("levels", [1, 3])
+def test_bvh_cpp_drop_in_equals_the_oracle_builder_on_mesh_scenes(levels):
+    """Two independent writings of the reference's builder - the product's C++ (real std::partition / std::nth_element) and the
+    oracle's C (those algorithms restated) - return the same four arrays on the 5 950- and the 95 050-triangle scene."""
+    from adapt_amd.scene_pack import make_config, pack_scene
+    from adapt_amd.synth import three_bunnies
+    from oracle import binding as ob
+    tup = three_bunnies(levels)
+    fs, rc = pack_scene(*tup), make_config(tup[3])
+    mine = _linear(fs, rc.cam_t)
+    theirs = ob.OracleScene(fs, rc.cam_t, build_bvh=True).bvh_arrays()
+    for a, b in zip(mine, theirs):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    ni = mine[3]
+    assert ni[ni[:, 2] == 1, 1].max() <= 4          # a rejected split happens only in the <= 4 branch or when SAH says so

@@ -306,5 +306,5 @@ def test_reference_brute_force_on_the_bvh_rays(tag):
     else:
         # every lost closest hit is a hit the brute force finds NEARER (or at all); never the other way round
         assert differ.sum() >= 30 and (g["bvh_hit"][:n, 2][differ] > hb[:, 2][differ]).all()
-        assert occ_differ.sum() >= 4 and (ob_[occ_differ] == 1).all()
+        assert occ_differ.sum() >= 1 and (ob_[occ_differ] == 1).all()
         assert not differ[n // 2:].any()              # the second half of the picked rays are the undisputed controls
