@@ -117,12 +117,13 @@ template <class T> static hipError_t upload(DevBuf& b, const std::vector<T>& v) 
     return v.empty() ? hipSuccess : hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
 }
 
-struct apt_bvh { apt::BvhData data; };
+struct apt_bvh { apt::BvhData data; apt::BvhData bin3; apt::WideBvhData wide; };     // data: the exported binary tree (leaves <= 4); bin3 -> wide: what the kernels walk
 
 struct apt_scene {
     int device = 0;
     DevScene dev{};
-    apt::BvhData bvh;
+    apt::BvhData bvh;                    // binary SAH tree (leaves of <= 3 primitives): the intermediate of the build
+    apt::WideBvhData wide;               // 8-wide quantised tree: what the kernels walk
     DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
     DevBuf uvs, tex_i, tex_f, atlas[3];      // image textures (empty when the scene has none)
     DevBuf prim_shade;                   // per-primitive shading records (stages.hpp DevScene::prim_shade)
@@ -202,7 +203,8 @@ APT_EXPORT const char* apt_version(void) { return "adapt_mi 0.1 (gfx950 wavefron
 APT_EXPORT int apt_bvh_build(const float* prims, int32_t n_prims, const int32_t* obj_info, int32_t n_objects, apt_bvh** out) {
     if (!prims || !obj_info || !out || n_prims <= 0 || n_objects <= 0) return fail(APT_E_INVALID, "apt_bvh_build: bad argument");
     apt_bvh* b = new apt_bvh();
-    if (apt::build_bvh(prims, n_prims, obj_info, n_objects, b->data) != 0) { delete b; return fail(APT_E_INVALID, "apt_bvh_build: build failed"); }
+    if (apt::build_bvh(prims, n_prims, obj_info, n_objects, b->data) != 0 || apt::build_bvh(prims, n_prims, obj_info, n_objects, b->bin3, 3) != 0 ||
+        apt::build_wide_bvh(b->bin3, b->wide) != 0) { delete b; return fail(APT_E_INVALID, "apt_bvh_build: build failed"); }
     *out = b;
     return APT_OK;
 }
@@ -217,6 +219,18 @@ APT_EXPORT int apt_bvh_export(const apt_bvh* b, float* nodes, int32_t* prim_orde
     if (!b || !nodes || !prim_order) return fail(APT_E_INVALID, "apt_bvh_export: bad argument");
     memcpy(nodes, b->data.nodes.data(), b->data.nodes.size() * sizeof(float));
     memcpy(prim_order, b->data.prim_order.data(), b->data.prim_order.size() * sizeof(int32_t));
+    return APT_OK;
+}
+APT_EXPORT int apt_bvh_wide_counts(const apt_bvh* b, int32_t* n_nodes, int32_t* n_levels) {
+    if (!b) return fail(APT_E_INVALID, "apt_bvh_wide_counts: null handle");
+    if (n_nodes) *n_nodes = b->wide.n_nodes();
+    if (n_levels) *n_levels = b->wide.max_depth;
+    return APT_OK;
+}
+APT_EXPORT int apt_bvh_wide_export(const apt_bvh* b, uint32_t* nodes, int32_t* prim_order) {
+    if (!b || !nodes || !prim_order) return fail(APT_E_INVALID, "apt_bvh_wide_export: bad argument");
+    memcpy(nodes, b->wide.nodes.data(), b->wide.nodes.size() * sizeof(uint32_t));
+    memcpy(prim_order, b->wide.prim_order.data(), b->wide.prim_order.size() * sizeof(int32_t));
     return APT_OK;
 }
 APT_EXPORT void apt_bvh_free(apt_bvh* b) { delete b; }
@@ -265,7 +279,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     s->device = device;
     const int N = d->n_prims, O = d->n_objects, S = d->n_sources;
     s->n_prims = N; s->n_objects = O; s->n_sources = S;
-    if (apt::build_bvh(d->prims, N, d->obj_info, O, s->bvh) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH build failed"); }
+    if (apt::build_bvh(d->prims, N, d->obj_info, O, s->bvh, 3) != 0 || apt::build_wide_bvh(s->bvh, s->wide) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH build failed"); }
 
     std::vector<int> prim_obj((size_t)N, 0);
     std::vector<uint8_t> sphere((size_t)N, 0);
@@ -282,7 +296,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         else for (int a = 0; a < 3; a++) { pc[a] = v[3 + a] - v[a]; pc[3 + a] = v[6 + a] - v[a]; pc[6 + a] = v[a]; }
     }
     for (int slot = 0; slot < N; slot++) {
-        int k = s->bvh.prim_order[(size_t)slot];
+        int k = s->wide.prim_order[(size_t)slot];
         const float* v = d->prims + 9 * (size_t)k; const float* pc = prec.data() + 9 * (size_t)k; float* r = recs.data() + 12 * (size_t)slot;
         int32_t kid = k, flag = sphere[(size_t)k] ? 1 : 0;
         if (flag) { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; }
@@ -357,10 +371,10 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     if (d->v_normals) vn.assign(d->v_normals, d->v_normals + (size_t)N * 9);
     std::vector<int> oi(d->obj_info, d->obj_info + (size_t)O * 3), ei(d->emitter_id, d->emitter_id + (size_t)O);
 #define UP(buf, vec) do { hipError_t e_ = upload(s->buf, vec); if (e_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload " #buf ": ") + hipGetErrorString(e_)); } } while (0)
-    UP(nodes, s->bvh.nodes); UP(prims, recs); UP(normals, nrm); UP(vnormals, vn); UP(precom, prec); UP(prim_obj, prim_obj);
+    UP(nodes, s->wide.nodes); UP(prims, recs); UP(normals, nrm); UP(vnormals, vn); UP(precom, prec); UP(prim_obj, prim_obj);
     UP(obj_info, oi); UP(emitter_id, ei); UP(bxdf, bx); UP(src, sr); UP(sweep_recs, sw); UP(sweep_tab, sw_tab); UP(obj_aabb, aabb);
     DevScene& ds = s->dev;
-    ds.bvh.nodes = s->nodes.as<float4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.n_nodes = s->bvh.n_nodes(); ds.bvh.n_prims = N;
+    ds.bvh.nodes = s->nodes.as<uint4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.n_nodes = s->wide.n_nodes(); ds.bvh.n_prims = N;
     ds.sweep.stream = s->sweep_recs.as<float>(); ds.sweep.obj_tab = s->sweep_tab.as<int>(); ds.sweep.prim_obj = s->prim_obj.as<int>(); ds.sweep.n_objects = O;
     s->has_aabb = d->obj_aabb != nullptr;
     ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float>(); ds.precom = s->precom.as<float>();
@@ -617,32 +631,19 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         else if (!strcmp(force, "sweep") && sc->has_aabb) r->trace_mode = 1;
         else if (!strcmp(force, "tile") && tile_ok) r->trace_mode = 2;
     }
-    // LDS plan: the per-lane stack must cover the tree depth.  Staging the top of the tree (or the primitive records) in
-    // LDS was measured to lose against the occupancy the same bytes buy, so by default nothing is staged (knobs remain).
+    // LDS plan of the BVH walk: the per-lane stack of 8-byte groups.  A node visit leaves at most one group behind (the rest of its
+    // hit children), so the stack never holds more groups than the tree has levels.
     {
-        const apt::BvhData& bd = sc->bvh;
         LdsPlan pl;
-        const int full_depth = bd.max_depth + 2;
-        int lds_levels = 20;                                 // 20 KiB per workgroup: eight workgroups (8 waves per SIMD, the VGPR limit) per CU; measured: 27 -> 20 levels = -8 % walk time
-        if (const char* sd = getenv("APT_BVH_LDS_LEVELS")) lds_levels = std::max(4, atoi(sd));
+        const int full_depth = sc->wide.max_depth + 2;
+        int lds_levels = 10;                                 // 20 KiB per 256-thread workgroup
+        if (const char* sd = getenv("APT_BVH_LDS_LEVELS")) lds_levels = std::max(2, atoi(sd));
         pl.stack_depth = std::min(full_depth, lds_levels);   // deeper levels spill to per-lane global columns (traverse.hpp TravStack)
         r->ovf_levels = full_depth - pl.stack_depth;
-        pl.ovf = nullptr; pl.ovf_stride = 0;
-        size_t stack_b = (size_t)pl.stack_depth * BLOCK * 4;
-        size_t lds_target = 8 * 1024;                        // per-workgroup LDS target of the BVH walk beyond which nothing is staged: the stack alone is ~27 KiB on the 95 k / 285 k-triangle scenes
-        if (const char* kb = getenv("APT_BVH_LDS_KB")) lds_target = (size_t)std::max(8, atoi(kb)) * 1024;
-        size_t min_stage = 0;                                // staging the tree top in LDS buys nothing (C4 575 -> 605, C5 588 -> 621 Msamples/s without it): every KiB goes to occupancy
-        if (const char* kb = getenv("APT_BVH_STAGE_KB")) min_stage = (size_t)std::max(0, atoi(kb)) * 1024;
-        size_t budget = lds_target > stack_b + min_stage ? lds_target - stack_b : min_stage;
-        int n_nodes = bd.n_nodes(), n_prims = sc->n_prims;
-        pl.lds_prims = ((size_t)n_prims * 48 <= budget / 2) ? n_prims : 0;
-        size_t left = budget - (size_t)pl.lds_prims * 48;
-        pl.lds_nodes = (int)std::min<size_t>((size_t)n_nodes, left / 64);
-#if !APT_BVH_STAGING
-        pl.lds_prims = 0; pl.lds_nodes = 0;                  // staging is compiled out of the walk (traverse.hpp)
-#endif
+        pl.ovf = nullptr; pl.ovf_stride = 0; pl.lds_nodes = 0; pl.lds_prims = 0;
+        const size_t stack_b = (size_t)pl.stack_depth * BLOCK * 8;
         r->plan = pl;
-        r->lds_bytes = (size_t)pl.lds_nodes * 64 + (size_t)pl.lds_prims * 48 + stack_b;
+        r->lds_bytes = stack_b;
         if (r->lds_bytes > 160 * 1024) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: BVH too deep for the LDS traversal stack"); }
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->lds_bytes));
         r->grid_trace = cus * per_cu;
@@ -695,12 +696,12 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     for (auto& ln : r->extra) ln.plan = r->plan;
     if (r->trace_mode == 0 && r->ovf_levels > 0) {
         const int max_grid = std::max(r->grid_trace, std::max(r->grid_shadow, r->grid_vshadow));
-        const size_t stride = (size_t)max_grid * BLOCK, bytes = stride * (size_t)r->ovf_levels * 4;
+        const size_t stride = (size_t)max_grid * BLOCK, bytes = stride * (size_t)r->ovf_levels * 8;
         if ((e = r->ovf.alloc(bytes)) != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("traversal stack spill: ") + hipGetErrorString(e)); }
-        r->plan.ovf = r->ovf.as<int>(); r->plan.ovf_stride = (int)stride;
+        r->plan.ovf = r->ovf.as<uint2>(); r->plan.ovf_stride = (int)stride;
         for (auto& ln : r->extra) {
             if ((e = ln.ovf.alloc(bytes)) != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("traversal stack spill (lane): ") + hipGetErrorString(e)); }
-            ln.plan = r->plan; ln.plan.ovf = ln.ovf.as<int>();
+            ln.plan = r->plan; ln.plan.ovf = ln.ovf.as<uint2>();
         }
     }
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -985,6 +986,11 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
     }
     fprintf(stderr, "[shade prof] wave-cycles: load+hit %lld | mis/rr %lld | nee %lld | shadow append %lld | bsdf sample %lld | wave lifetime (100MHz ticks) %lld | wave lifetime (cycles) %lld | iterations %lld ; launches %lld kernel_ms %.3f\n",
             (long long)sum(8), (long long)sum(9), (long long)sum(10), (long long)sum(11), (long long)sum(12), (long long)sum(13), (long long)sum(14), (long long)sum(15), (long long)r->launches[2], r->kernel_ms[2]);
+#endif
+#ifdef APT_WALK_STATS
+    fprintf(stderr, "[walk stats] closest-hit rays %lld: %.2f node steps, %.2f primitive tests per ray | shadow rays %lld: %.2f node steps, %.2f primitive tests per ray\n",
+            (long long)out->n_extend, (double)sum(9) / (double)std::max<int64_t>(1, out->n_extend), (double)sum(10) / (double)std::max<int64_t>(1, out->n_extend),
+            (long long)out->n_shadow_traced, (double)sum(11) / (double)std::max<int64_t>(1, out->n_shadow_traced), (double)sum(12) / (double)std::max<int64_t>(1, out->n_shadow_traced));
 #endif
 #ifdef APT_TILE_PROF
     fprintf(stderr, "[tile prof] wave-cycles: stage %lld | A %lld | wait %lld | B %lld | wait %lld | sweep total %lld | append %lld | tiles*waves %lld\n",

@@ -23,7 +23,6 @@ namespace apt {
 
 namespace {
 constexpr int kBins = 16;
-constexpr int kMaxLeaf = 4;
 constexpr float kTraverseCost = 1.0f;   // relative to one primitive test
 
 struct Box {
@@ -43,6 +42,7 @@ struct Builder {
     std::vector<Ref> refs;
     std::vector<float> nodes;     // 16 floats per node
     int max_depth = 0;
+    int kMaxLeaf = 4;
 
     static float as_float(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
 
@@ -104,9 +104,10 @@ struct Builder {
 };
 }  // namespace
 
-int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, BvhData& out) {
-    if (n_prims <= 0 || !prims || !obj_info) return -1;
+int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, BvhData& out, int max_leaf) {
+    if (n_prims <= 0 || !prims || !obj_info || max_leaf < 1 || max_leaf > 15) return -1;
     Builder b;
+    b.kMaxLeaf = max_leaf;
     b.refs.resize((size_t)n_prims);
     std::vector<uint8_t> is_sphere((size_t)n_prims, 0);
     for (int o = 0; o < n_objects; o++)

@@ -11,7 +11,17 @@ struct BvhData {
     int n_nodes() const { return (int)(nodes.size() / 16); }
 };
 // prims: n_prims*9 (triangle v0 v1 v2 | sphere centre, r r r, -); obj_info: n_objects*3 (first, count, is_sphere)
-int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, BvhData& out);
+// max_leaf: primitives per leaf (1..4; the 8-wide tree below wants 3)
+int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, BvhData& out, int max_leaf = 4);
+
+// 8-wide tree with quantised child boxes, what the traversal kernels walk (bvh_wide.cpp; layout in traverse.hpp).
+struct WideBvhData {
+    std::vector<uint32_t> nodes;       // 20 dwords (80 bytes) per node, node 0 = root, breadth-first
+    std::vector<int32_t> prim_order;   // leaf-order slot -> original primitive index
+    int max_depth = 0;                 // levels of 8-wide nodes
+    int n_nodes() const { return (int)(nodes.size() / 20); }
+};
+int build_wide_bvh(const BvhData& bvh2, WideBvhData& out);
 
 // bvh_linear.cpp: the four arrays `bvh_cpp.bvh_build` returns (tracer/bvh/bvh.cpp:274-296), preorder with subtree-skip offsets
 struct LinearBvhData {

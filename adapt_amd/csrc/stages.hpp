@@ -144,21 +144,14 @@ APT_D uint32_t pack_meta(uint32_t draw, uint32_t bounce, bool spec) { return (dr
 
 #define BLOCK 256
 
-// LDS carve for the traversal stages (dynamic, sized per scene by the host):
-//   [ lds_nodes * 64 B node records | lds_prims * 48 B primitive records | stack_depth * BLOCK ints ]
-struct LdsPlan { int lds_nodes, lds_prims, stack_depth; int* ovf; int ovf_stride; };     // stack_depth: levels kept in LDS; ovf: global spill columns (one per thread of the largest grid)
+// LDS of the BVH-walk stages (dynamic, sized per scene by the host): the traversal stack, stack_depth * BLOCK 8-byte groups laid out [level][lane]
+struct LdsPlan { int lds_nodes, lds_prims, stack_depth; uint2* ovf; int ovf_stride; };     // stack_depth: levels kept in LDS; ovf: global spill columns (one per thread of the largest grid); lds_nodes / lds_prims: unused (nothing is staged)
 extern __shared__ float4 s_dyn[];
-APT_D int* carve_lds(const DevBvh& b, const LdsPlan& plan, StagedBvh& out) {
-    float4* s_nodes = s_dyn;
-    float4* s_prims = s_dyn + 4 * plan.lds_nodes;
-    stage_bvh(b, s_nodes, plan.lds_nodes, s_prims, plan.lds_prims, out);
-    __syncthreads();
-    return reinterpret_cast<int*>(s_prims + 3 * plan.lds_prims) + threadIdx.x;
-}
-APT_D TravStack make_stack(int* lds_column, const LdsPlan& plan) {
+APT_D TravStack make_stack(const LdsPlan& plan) {
     TravStack ts;
-    ts.lds = lds_column; ts.stride = BLOCK; ts.k = plan.stack_depth; ts.ovf_stride = plan.ovf_stride;
-    ts.ovf = plan.ovf ? plan.ovf + (blockIdx.x * blockDim.x + threadIdx.x) : nullptr;
+    ts.lds = (lds_u2*)(reinterpret_cast<grp_t*>(s_dyn)) + threadIdx.x;
+    ts.stride = BLOCK; ts.k = plan.stack_depth; ts.ovf_stride = plan.ovf_stride;
+    ts.ovf = plan.ovf ? (glb_u2*)(reinterpret_cast<grp_t*>(plan.ovf) + (blockIdx.x * blockDim.x + threadIdx.x)) : (glb_u2*)nullptr;
     return ts;
 }
 
@@ -305,10 +298,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
 // MODE 0: BVH traversal (LDS-staged nodes + per-lane LDS stack); MODE 1: wave-uniform sweep (small scenes)
 template <int MODE, int SORTED>
 __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 1)) k_extend(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
-    StagedBvh bvh;
-    int* my_stack = nullptr;
     __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
-    if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
     const SubLoop sl = sub_loop(p.nq, TRACE_NT(MODE));
     const uint32_t n = n_src[sl.q * CNT_PAD];
     if (cnt && sl.first == 0 && threadIdx.x == 0) {
@@ -332,7 +322,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
         const f3 o = ld3q(ro, p.cap, io);
         const f3 d = ld3q(rd, p.cap, io);
         HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
-        if (MODE == 0) traverse<false>(bvh, make_stack(my_stack, plan), o, d, rec);
+        if (MODE == 0) traverse<false>(sc.bvh, make_stack(plan), o, d, rec);
         else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
 #ifdef APT_TILE_PROF
         else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn), tile_prof);
@@ -383,8 +373,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 #endif
 template <int SORTED>
 __global__ void __launch_bounds__(BLOCK) k_extend_dyn(DevScene sc, Params p, Queues q, Counters* cnt, int cur_q, const uint32_t* n_src, LdsPlan plan) {
-    StagedBvh bvh;
-    const TravStack ts = make_stack(carve_lds(sc.bvh, plan, bvh), plan);
+    const TravStack ts = make_stack(plan);
     const int sq = (int)(blockIdx.x % (uint32_t)p.nq);
     const uint32_t n = n_src[sq * CNT_PAD];
     if (blockIdx.x / (uint32_t)p.nq == 0 && threadIdx.x == 0) {
@@ -398,9 +387,11 @@ __global__ void __launch_bounds__(BLOCK) k_extend_dyn(DevScene sc, Params p, Que
     // per-lane ray state
     int state = 0;                              // 0 no ray, 1 walking, 2 finished (result not yet handed in)
     uint32_t io = 0;
-    f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), inv_d = splat3(1.f);
+    WalkRay r = make_walk_ray(splat3(0.f), mk3(0.f, 0.f, 1.f));
     HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-    int sp = 0, cur = APT_TRAV_DONE;
+    WalkStats ws; ws.nodes = ws.prims = 0;
+    int sp = 0;
+    grp_t ng = mk_grp(0u, 0u), tg = mk_grp(0u, 0u);       // node group / triangle group of the ray being walked (traverse.hpp)
     bool exhausted = false;                     // wave-uniform: the work counter has run past the queue
     for (;;) {
         // ---- hand in finished rays (all lanes take part: the class appends are ballot-compacted)
@@ -415,8 +406,8 @@ __global__ void __launch_bounds__(BLOCK) k_extend_dyn(DevScene sc, Params p, Que
                 if (mine) {
                     const Queues::ClassQ& k = q.cls[c];
                     const uint32_t so = (qbase + cpos) << 2;
-                    st3q(k.ray_o, p.cap, so, o);
-                    st3q(k.ray_d, p.cap, so, d);
+                    st3q(k.ray_o, p.cap, so, r.o);
+                    st3q(k.ray_d, p.cap, so, r.d);
                     st3q(k.thr, p.cap, so, ld3q(q.thr[cur_q], p.cap, io));
                     stq(k.id, so, ldq(q.id[cur_q], io)); stq(k.meta, so, ldq(q.meta[cur_q], io)); stq(k.pdf, so, ldq(q.pdf[cur_q], io));
                     stq(k.t, so, rec.t); stq(k.prim, so, rec.prim); stq(k.u, so, rec.u); stq(k.v, so, rec.v);
@@ -434,10 +425,9 @@ __global__ void __launch_bounds__(BLOCK) k_extend_dyn(DevScene sc, Params p, Que
             const uint32_t pos = base + rank_in(m);
             if (need && pos < n) {
                 io = (qbase + pos) << 2;
-                o = ld3q(ro, p.cap, io); d = ld3q(rd, p.cap, io);
-                inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                r = make_walk_ray(ld3q(ro, p.cap, io), ld3q(rd, p.cap, io));
                 rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
-                sp = 0; cur = 0; state = 1;
+                sp = 0; ng = APT_ROOT_GROUP; state = 1;
             }
             if (base + (uint32_t)__popcll(m) >= n) exhausted = true;
         }
@@ -445,36 +435,16 @@ __global__ void __launch_bounds__(BLOCK) k_extend_dyn(DevScene sc, Params p, Que
         // ---- walk: the while-while loop of traverse<false>, left as soon as too few lanes still hold a ray
         const uint32_t min_active = exhausted ? 1u : (uint32_t)APT_DYN_MIN_ACTIVE;
         do {
-            while (cur >= 0) {
-                float4 q0 = bvh.node(cur, 0), q1 = bvh.node(cur, 1), q2 = bvh.node(cur, 2), q3 = bvh.node(cur, 3);
-                float tl = box_entry(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, inv_d, rec.t);
-                float tr = box_entry(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, inv_d, rec.t);
-                int l = __float_as_int(q3.x), r = __float_as_int(q3.y);
-                bool hl = tl >= 0.f, hr = tr >= 0.f;
-                if (hl && hr) {
-                    bool swap = tr < tl;
-                    tpush(ts, sp, swap ? l : r);
-                    cur = swap ? r : l;
-                } else if (hl) cur = l;
-                else if (hr) cur = r;
-                else if (sp > 0) cur = tpop(ts, sp);
-                else cur = APT_TRAV_DONE;
+            if (state == 1) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
+            tri_group<false>(sc.bvh, tg, r, rec, ws);
+            if (state == 1 && !APT_GROUP_HAS_NODES(ng)) {
+                if (sp == 0) state = 2; else ng = tpop(ts, sp);
             }
-            while (cur < 0 && cur != APT_TRAV_DONE) {
-                int code = ~cur;
-                int first = code >> 4, count = code & 15;
-                for (int k = 0; k < count; k++) {
-                    float4 p0 = bvh.prim(first + k, 0), p1 = bvh.prim(first + k, 1), p2 = bvh.prim(first + k, 2);
-                    float u, v;
-                    float t = prim_test(p0, p1, p2, o, d, u, v);
-                    if (t > 1e-4f && t < rec.t) { rec.t = t; rec.prim = __float_as_int(p2.y); rec.u = u; rec.v = v; }
-                }
-                if (sp > 0) cur = tpop(ts, sp);
-                else cur = APT_TRAV_DONE;
-            }
-            if (state == 1 && cur == APT_TRAV_DONE) state = 2;
         } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
     }
+#ifdef APT_WALK_STATS
+    flush_stat(ws.nodes, &cnt->stats[sq][9]); flush_stat(ws.prims, &cnt->stats[sq][10]);
+#endif
 }
 
 // ----------------------------------------------------------------- textures
@@ -743,10 +713,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_
 // ------------------------------------------------------------------- shadow
 template <int MODE>
 __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 1)) k_shadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
-    StagedBvh bvh;
-    int* my_stack = nullptr;
     __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
-    if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
     const SubLoop sl = sub_loop(p.nq, TRACE_NT(MODE));
     const uint32_t n = min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
     if (sl.first == 0 && threadIdx.x == 0) {
@@ -764,7 +731,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
         const f3 d = ld3q(q.sh_d, sc_, io);
         const float dist = ldq(q.sh_tmax, io);
         HitRec rec; rec.t = (dist > 0.0f) ? dist - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        const bool occluded = (MODE == 0) ? traverse<true>(bvh, make_stack(my_stack, plan), o, d, rec)
+        const bool occluded = (MODE == 0) ? traverse<true>(sc.bvh, make_stack(plan), o, d, rec)
                             : (MODE == 1) ? sweep_wg<true, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep)
                                           : sweep_tile<true, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         if (valid) {
@@ -791,8 +758,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 // Any-hit twin of k_extend_dyn: a lane leaves the walk at its first occluder or when its stack runs empty, adds its contribution if
 // unoccluded, and claims the next shadow ray as soon as the wave runs low on walking lanes.
 __global__ void __launch_bounds__(BLOCK) k_shadow_dyn(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
-    StagedBvh bvh;
-    const TravStack ts = make_stack(carve_lds(sc.bvh, plan, bvh), plan);
+    const TravStack ts = make_stack(plan);
     const int sq = (int)(blockIdx.x % (uint32_t)p.nq);
     const uint32_t n = min(cnt->n_shadow[sq * CNT_PAD], q.sh_subcap);
     if (blockIdx.x / (uint32_t)p.nq == 0 && threadIdx.x == 0) {
@@ -804,9 +770,11 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_dyn(DevScene sc, Params p, Que
     int state = 0;                              // 0 no ray, 1 walking, 2 finished
     bool occluded = false;
     uint32_t io = 0;
-    f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), inv_d = splat3(1.f);
-    float tmax = 0.f;
-    int sp = 0, cur = APT_TRAV_DONE;
+    WalkRay r = make_walk_ray(splat3(0.f), mk3(0.f, 0.f, 1.f));
+    HitRec rec; rec.t = 0.f; rec.prim = -1; rec.u = rec.v = 0.f;      // rec.t = the search limit (distance to the light - 1e-4)
+    WalkStats ws; ws.nodes = ws.prims = 0;
+    int sp = 0;
+    grp_t ng = mk_grp(0u, 0u), tg = mk_grp(0u, 0u);
     bool exhausted = false;
     uint32_t t_lit = 0;
     for (;;) {
@@ -833,48 +801,27 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_dyn(DevScene sc, Params p, Que
             const uint32_t pos = base + rank_in(m);
             if (need && pos < n) {
                 io = (qbase + pos) << 2;
-                o = ld3q(q.sh_o, sc_, io); d = ld3q(q.sh_d, sc_, io);
+                r = make_walk_ray(ld3q(q.sh_o, sc_, io), ld3q(q.sh_d, sc_, io));
                 const float dist = ldq(q.sh_tmax, io);
-                tmax = (dist > 0.0f) ? dist - 1e-4f : 1e7f;
-                inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                occluded = false; sp = 0; cur = 0; state = 1;
+                rec.t = (dist > 0.0f) ? dist - 1e-4f : 1e7f;
+                occluded = false; sp = 0; ng = APT_ROOT_GROUP; state = 1;
             }
             if (base + (uint32_t)__popcll(m) >= n) exhausted = true;
         }
         if (!__any(state == 1)) break;
         const uint32_t min_active = exhausted ? 1u : (uint32_t)APT_DYN_MIN_ACTIVE;
         do {
-            while (cur >= 0) {
-                float4 q0 = bvh.node(cur, 0), q1 = bvh.node(cur, 1), q2 = bvh.node(cur, 2), q3 = bvh.node(cur, 3);
-                float tl = box_entry(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, inv_d, tmax);
-                float tr = box_entry(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, inv_d, tmax);
-                int l = __float_as_int(q3.x), r = __float_as_int(q3.y);
-                bool hl = tl >= 0.f, hr = tr >= 0.f;
-                if (hl && hr) {
-                    bool swap = tr < tl;
-                    tpush(ts, sp, swap ? l : r);
-                    cur = swap ? r : l;
-                } else if (hl) cur = l;
-                else if (hr) cur = r;
-                else if (sp > 0) cur = tpop(ts, sp);
-                else cur = APT_TRAV_DONE;
+            if (state == 1) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
+            if (tri_group<true>(sc.bvh, tg, r, rec, ws)) { occluded = true; sp = 0; ng.y = 0u; tg.y = 0u; }      // first occluder ends the walk
+            if (state == 1 && !APT_GROUP_HAS_NODES(ng)) {
+                if (sp == 0) state = 2; else ng = tpop(ts, sp);
             }
-            while (cur < 0 && cur != APT_TRAV_DONE) {
-                int code = ~cur;
-                int first = code >> 4, count = code & 15;
-                for (int k = 0; k < count; k++) {
-                    float4 p0 = bvh.prim(first + k, 0), p1 = bvh.prim(first + k, 1), p2 = bvh.prim(first + k, 2);
-                    float u, v;
-                    float t = prim_test(p0, p1, p2, o, d, u, v);
-                    if (t > 1e-4f && t < tmax) { occluded = true; sp = 0; break; }      // first occluder ends the walk
-                }
-                if (sp > 0) cur = tpop(ts, sp);
-                else cur = APT_TRAV_DONE;
-            }
-            if (state == 1 && cur == APT_TRAV_DONE) state = 2;
         } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
     }
     flush_stat(t_lit, &cnt->stats[sq][ST_LIT]);
+#ifdef APT_WALK_STATS
+    flush_stat(ws.nodes, &cnt->stats[sq][11]); flush_stat(ws.prims, &cnt->stats[sq][12]);
+#endif
 }
 
 // ----------------------------------------------------------------- finalize
@@ -901,16 +848,13 @@ __global__ void k_divide(const float* accum, float* out, uint32_t n, float cnt) 
 // ------------------------------------------------------- unit entry kernels
 template <int MODE>
 __global__ void __launch_bounds__(TRACE_NT(MODE)) k_occluded(DevScene sc, uint32_t n, const float* o_, const float* d_, const float* tmax, int* occ, LdsPlan plan) {
-    StagedBvh bvh;
-    int* my_stack = nullptr;
-    if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
     for (uint32_t base = blockIdx.x * TRACE_NT(MODE); base < n; base += gridDim.x * TRACE_NT(MODE)) {
         const uint32_t pos = base + threadIdx.x;
         const bool valid = pos < n;
         const uint32_t idx = valid ? pos : n - 1;
         f3 o = mk3(o_[idx], o_[n + idx], o_[2 * n + idx]), d = mk3(d_[idx], d_[n + idx], d_[2 * n + idx]);
         HitRec rec; rec.t = (tmax[idx] > 0.0f) ? tmax[idx] - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        const bool hit = (MODE == 0) ? traverse<true>(bvh, make_stack(my_stack, plan), o, d, rec)
+        const bool hit = (MODE == 0) ? traverse<true>(sc.bvh, make_stack(plan), o, d, rec)
                        : (MODE == 1) ? sweep_any(sc.sweep, o, d, rec)
                                      : sweep_tile<true, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         if (valid) occ[idx] = hit ? 1 : 0;

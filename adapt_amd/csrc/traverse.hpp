@@ -1,61 +1,49 @@
-// traverse.hpp — software BVH traversal for gfx950 (no RT hardware on CDNA4).
+// traverse.hpp — software ray traversal for gfx950 (no RT hardware on CDNA4).
 //
 // Replaces the reference's intersectors: brute force `TracerBase.ray_intersect/does_intersect`
 // (tracer/tracer_base.py:168-278) and the stackless preorder walk
 // `PathTracer.ray_intersect_bvh/does_intersect_bvh` (tracer/path_tracer.py:338-422).
 // The per-primitive tests are the reference's, operation for operation (triangle: solve
 // [e1 e2 -d] (u v t)^T = o - p0 with the adjugate inverse; sphere: tracer_base.py:184-199),
-// so the closest hit is the same hit; the tree around them is ours (bvh_build.cpp):
-//   * ordered traversal (near child first) with a per-lane stack kept in LDS, laid out
-//     [depth][lane] so a wave's pushes/pops are bank-conflict free,
-//   * the top `n_staged` nodes and (for small scenes) every primitive record are staged into
-//     LDS once per workgroup; deeper nodes come from global memory through L1/L2.
+// so the closest hit is the same hit; the tree around them is ours (bvh_build.cpp -> bvh_wide.cpp):
+//   * an 8-wide tree with child boxes quantised to 8 bits per plane: one 80-byte node fetch decides up to eight subtrees.  The
+//     walk is bound by the latency of its DEPENDENT fetches (measured: with the binary tree, 15 fetches per ray, 74 % of the wave
+//     cycles waiting on memory), so the wide node cuts the round trips to a third and the node bytes to a fifth;
+//   * front-to-back order without sorting: child slots are assigned by octant at build time, a ray visits the hit slots in the
+//     order `slot XOR ray octant`; the hits of a node travel as one bit mask ("node group"), its leaf primitives as another
+//     ("triangle group"), and the per-lane stack holds 8-byte groups, in LDS laid out [level][lane] (bank-conflict free), deep
+//     levels spilling to a per-lane global column;
+//   * box tests are conservative, not exact: decoded boxes contain the builder's boxes, which are padded by 1e-4 + 1e-5 |x| —
+//     three orders of magnitude more than the rounding of the fused slab arithmetic — so no box that contains a hit is ever
+//     culled and the RESULT is that of the exact per-primitive tests alone.
 #pragma once
 #include "vec.hpp"
 
 struct DevBvh {
-    const float4* nodes;     // 4 float4 per node (bvh_build.cpp layout)
-    const float4* prims;     // 3 float4 per primitive, BVH order
+    const uint4* nodes;      // 5 uint4 (80 bytes) per node, layout in bvh_wide.cpp
+    const float4* prims;     // 3 float4 per primitive, leaf order
     int n_nodes, n_prims;
 };
 // primitive record: triangle q0=(p0, e1.x) q1=(e1.yz, e2.xy) q2=(e2.z, prim_id, 0, -)
 //                   sphere   q0=(centre, r)                  q2=(-, prim_id, 1, -)
 
-#ifndef APT_BVH_STAGING
-#define APT_BVH_STAGING 0
-#endif
-struct StagedBvh {           // LDS view; falls through to global beyond the staged prefix
-    const float4* g_nodes; const float4* g_prims;
-    const float4* s_nodes; const float4* s_prims;
-    int n_staged_nodes, n_staged_prims;
-#if APT_BVH_STAGING
-    APT_D float4 node(int i, int q) const { return (i < n_staged_nodes) ? s_nodes[4 * i + q] : g_nodes[4 * i + q]; }
-    APT_D float4 prim(int i, int q) const { return (i < n_staged_prims) ? s_prims[3 * i + q] : g_prims[3 * i + q]; }
-#else
-    // default build: nothing is staged (measured: the LDS bytes buy more as occupancy), and the walk carries no LDS-or-global
-    // select on every record fetch (C4 641 -> 658, C5 600 -> 618 Msamples/s)
-    APT_D float4 node(int i, int q) const { return g_nodes[4 * i + q]; }
-    APT_D float4 prim(int i, int q) const { return g_prims[3 * i + q]; }
-#endif
-};
-
-// cooperative copy of the staged prefix; call from every thread of the block, then __syncthreads()
-APT_D void stage_bvh(const DevBvh& b, float4* s_nodes, int cap_nodes, float4* s_prims, int cap_prims, StagedBvh& out) {
-    int nn = min(b.n_nodes, cap_nodes), np = (b.n_prims <= cap_prims) ? b.n_prims : 0;
-    for (int i = threadIdx.x; i < 4 * nn; i += blockDim.x) s_nodes[i] = b.nodes[i];
-    for (int i = threadIdx.x; i < 3 * np; i += blockDim.x) s_prims[i] = b.prims[i];
-    out.g_nodes = b.nodes; out.g_prims = b.prims; out.s_nodes = s_nodes; out.s_prims = s_prims;
-    out.n_staged_nodes = nn; out.n_staged_prims = np;
-}
-
 struct HitRec { float t; int prim; float u, v; };
 
-// entry distance of the slab test, or -1 when the box is missed / behind / beyond tmax
-APT_D float box_entry(f3 lo, f3 hi, f3 o, f3 inv_d, float tmax) {
-    f3 t0 = (lo - o) * inv_d, t1 = (hi - o) * inv_d;
-    float tn = max3(min3v(t0, t1));
-    float tf = min3(max3v(t0, t1));
-    return (tn <= tf && tf > 0.f && tn <= tmax) ? fmaxf(tn, 0.f) : -1.f;
+typedef float v2f __attribute__((ext_vector_type(2)));
+APT_D v2f sp2(float s) { v2f r; r.x = s; r.y = s; return r; }
+APT_D v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+
+// Ray as the walk wants it.  The reciprocal direction is clamped to +-1e30 so that axis-parallel rays produce huge but finite slab
+// distances of the right sign (inf would turn the fused form q * s + c into inf - inf = NaN and the axis would stop culling).
+struct WalkRay { f3 o, d, inv, noo; uint32_t octinv4; };
+APT_D float walk_rcp(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e30f, d) : 1.0f / d; }
+APT_D WalkRay make_walk_ray(f3 o, f3 d) {
+    WalkRay r; r.o = o; r.d = d;
+    r.inv = mk3(walk_rcp(d.x), walk_rcp(d.y), walk_rcp(d.z));
+    r.noo = mk3(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
+    const uint32_t oct = (r.inv.x < 0.f ? 4u : 0u) | (r.inv.y < 0.f ? 2u : 0u) | (r.inv.z < 0.f ? 1u : 0u);
+    r.octinv4 = (7u - oct) * 0x01010101u;
+    return r;
 }
 
 // One primitive against the ray.  Returns the reference's ray_t (or -1) and barycentrics.
@@ -88,61 +76,130 @@ APT_D float prim_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float& u, flo
     return (u >= 0.f && v >= 0.f && u + v <= 1.0f) ? t : -1.f;
 }
 
-// ANY = false: closest hit, rec.t starts at the search limit and ends at min_depth.
-// ANY = true : returns true on the first hit with 1e-4 < t < rec.t.
-// `stack` points at this lane's column of an LDS array [depth][stride].
-//
-// Loop shape ("while-while"): all lanes of the wave walk inner nodes together until each of them holds a
-// leaf (or is finished), then all of them test primitives together.  One mixed loop, where some lanes do a
-// box pair while others do up to four primitive tests, costs the sum of both bodies on every iteration.
-#define APT_TRAV_DONE ((int)0x80000000)      // not a valid leaf link: ~link would be first_prim = 2^27
-// Per-lane traversal stack: the first `k` levels live in LDS ([level][lane], bank-conflict free), deeper levels - rare, the LDS part
-// is sized so that eight waves per SIMD fit - spill to a per-lane column of a global buffer.  Sizing the LDS part for the full tree
-// depth (27-28 levels on the 95 k / 285 k-triangle scenes) caps occupancy at 5 waves per SIMD and costs 8 % of the walk.
-struct TravStack { int* lds; int stride; int* ovf; int ovf_stride; int k; };
-APT_D void tpush(const TravStack& s, int& sp, int v) {
+// Per-lane traversal stack of 8-byte groups: the first `k` levels live in LDS ([level][lane]), deeper levels - rare - spill to a
+// per-lane column of a global buffer.  The two halves are addressed through typed pointers (ds_read_b64 / ds_write_b64 and global
+// accesses; a generic pointer would make every push and pop a flat access plus an address select).
+typedef unsigned int grp_t __attribute__((ext_vector_type(2)));      // (x, y) group word pair: a plain vector type, so that it can live behind address-space pointers
+APT_D grp_t mk_grp(uint32_t x, uint32_t y) { grp_t g; g.x = x; g.y = y; return g; }
+typedef __attribute__((address_space(3))) grp_t lds_u2;
+typedef __attribute__((address_space(1))) grp_t glb_u2;
+struct TravStack { lds_u2* lds; int stride; glb_u2* ovf; int ovf_stride; int k; };
+APT_D void tpush(const TravStack& s, int& sp, grp_t v) {
     if (sp < s.k) s.lds[sp * s.stride] = v; else s.ovf[(sp - s.k) * s.ovf_stride] = v;
     sp++;
 }
-APT_D int tpop(const TravStack& s, int& sp) {
+APT_D grp_t tpop(const TravStack& s, int& sp) {
     sp--;
-    return (sp < s.k) ? s.lds[sp * s.stride] : s.ovf[(sp - s.k) * s.ovf_stride];
+    grp_t v;
+    if (sp < s.k) v = s.lds[sp * s.stride]; else v = s.ovf[(sp - s.k) * s.ovf_stride];
+    return v;
 }
-template <bool ANY>
-APT_D bool traverse(const StagedBvh& bvh, const TravStack& ts, f3 o, f3 d, HitRec& rec) {
-    const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    int sp = 0;
-    int cur = 0;
-    while (cur != APT_TRAV_DONE) {
-        while (cur >= 0) {
-            float4 q0 = bvh.node(cur, 0), q1 = bvh.node(cur, 1), q2 = bvh.node(cur, 2), q3 = bvh.node(cur, 3);
-            float tl = box_entry(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), o, inv_d, rec.t);
-            float tr = box_entry(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), o, inv_d, rec.t);
-            int l = __float_as_int(q3.x), r = __float_as_int(q3.y);
-            bool hl = tl >= 0.f, hr = tr >= 0.f;
-            if (hl && hr) {
-                bool swap = tr < tl;
-                tpush(ts, sp, swap ? l : r);                       // far child waits
-                cur = swap ? r : l;
-            } else if (hl) cur = l;
-            else if (hr) cur = r;
-            else if (sp > 0) cur = tpop(ts, sp);
-            else cur = APT_TRAV_DONE;
+#ifdef APT_WALK_STATS
+#define WALK_COUNT(x) ((x)++)
+#else
+#define WALK_COUNT(x) ((void)0)
+#endif
+struct WalkStats { uint32_t nodes, prims; };
+
+APT_D float ubyte_f(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); }       // v_cvt_f32_ubyte<b>
+
+// Fetch node `idx` and test its eight child boxes against the ray segment [0, tmax].
+// Out: hit mask - bits 31..24 the INNER children that are hit, at position 24 + (slot ^ (7 - ray octant)) so that "highest bit
+// first" is front to back; bits 23..0 the primitives of the hit leaf children, by offset from tri_base.
+APT_D uint32_t node8_test(const DevBvh& b, uint32_t idx, const WalkRay& r, float tmax, uint32_t& child_base, uint32_t& tri_base, uint32_t& imask) {
+    const char* base = reinterpret_cast<const char*>(b.nodes) + idx * 80u;          // wave-uniform base + 32-bit offset
+    const uint4 n0 = *reinterpret_cast<const uint4*>(base), n1 = *reinterpret_cast<const uint4*>(base + 16), n2 = *reinterpret_cast<const uint4*>(base + 32),
+                n3 = *reinterpret_cast<const uint4*>(base + 48), n4 = *reinterpret_cast<const uint4*>(base + 64);
+    child_base = n1.x; tri_base = n1.y; imask = n0.w >> 24;
+    // slab arithmetic in the node's quantised frame: t = q * (2^e / d) + (p - o) / d
+    const float sx = ldexpf(r.inv.x, (int)(n0.w << 24) >> 24), sy = ldexpf(r.inv.y, (int)(n0.w << 16) >> 24), sz = ldexpf(r.inv.z, (int)(n0.w << 8) >> 24);
+    const float cx = __builtin_fmaf(__uint_as_float(n0.x), r.inv.x, r.noo.x), cy = __builtin_fmaf(__uint_as_float(n0.y), r.inv.y, r.noo.y),
+                cz = __builtin_fmaf(__uint_as_float(n0.z), r.inv.z, r.noo.z);
+    // near / far planes by the sign of the direction, four children per dword
+    const bool nx = r.inv.x < 0.f, ny = r.inv.y < 0.f, nz = r.inv.z < 0.f;
+    const uint32_t nearx[2] = {nx ? n3.z : n2.x, nx ? n3.w : n2.y}, farx[2] = {nx ? n2.x : n3.z, nx ? n2.y : n3.w};
+    const uint32_t neary[2] = {ny ? n4.x : n2.z, ny ? n4.y : n2.w}, fary[2] = {ny ? n2.z : n4.x, ny ? n2.w : n4.y};
+    const uint32_t nearz[2] = {nz ? n4.z : n3.x, nz ? n4.w : n3.y}, farz[2] = {nz ? n3.x : n4.z, nz ? n3.y : n4.w};
+    const uint32_t meta[2] = {n1.z, n1.w};
+    uint32_t hitmask = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t m4 = meta[h];
+        const uint32_t inner4 = ((m4 & (m4 << 1)) & 0x10101010u) >> 4;                 // 1 per byte whose low five bits are >= 24
+        const uint32_t shift4 = (m4 ^ (r.octinv4 & (inner4 * 0xffu))) & 0x1f1f1f1fu;    // bit position of the child's first bit
+        const uint32_t bits4 = (m4 >> 5) & 0x07070707u;                                 // 1 (inner) or unary primitive count
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const v2f tx = __builtin_elementwise_fma(mk2(ubyte_f(nearx[h], c), ubyte_f(farx[h], c)), sp2(sx), sp2(cx));
+            const v2f ty = __builtin_elementwise_fma(mk2(ubyte_f(neary[h], c), ubyte_f(fary[h], c)), sp2(sy), sp2(cy));
+            const v2f tz = __builtin_elementwise_fma(mk2(ubyte_f(nearz[h], c), ubyte_f(farz[h], c)), sp2(sz), sp2(cz));
+            const float tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);
+            const float tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), tmax);
+            const uint32_t bits = ((bits4 >> (8 * c)) & 0xffu) << ((shift4 >> (8 * c)) & 0xffu);
+            hitmask |= (tn <= tf) ? bits : 0u;
         }
-        while (cur < 0 && cur != APT_TRAV_DONE) {
-            int code = ~cur;
-            int first = code >> 4, count = code & 15;
-            for (int k = 0; k < count; k++) {
-                float4 p0 = bvh.prim(first + k, 0), p1 = bvh.prim(first + k, 1), p2 = bvh.prim(first + k, 2);
-                float u, v;
-                float t = prim_test(p0, p1, p2, o, d, u, v);
-                if (t > 1e-4f && t < rec.t) {
-                    if (ANY) return true;
-                    rec.t = t; rec.prim = __float_as_int(p2.y); rec.u = u; rec.v = v;
-                }
-            }
-            if (sp > 0) cur = tpop(ts, sp);
-            else cur = APT_TRAV_DONE;
+    }
+    return hitmask;
+}
+
+// The primitives of a triangle group.  Closest hit: strictly nearer wins, and of two primitives at EXACTLY the same t the lower
+// original index - the reference's brute-force loop keeps the first strictly-closer hit in index order (tracer_base.py:208), so
+// the answer does not depend on the order in which the tree presents the primitives.  Any hit: true at the first primitive
+// with 1e-4 < t < rec.t.
+template <bool ANY>
+APT_D bool tri_group(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
+    while (tg.y != 0u) {
+        const uint32_t k = 31u - (uint32_t)__clz((int)tg.y);
+        tg.y &= ~(1u << k);
+        const char* base = reinterpret_cast<const char*>(b.prims) + (tg.x + k) * 48u;
+        const float4 p0 = *reinterpret_cast<const float4*>(base), p1 = *reinterpret_cast<const float4*>(base + 16), p2 = *reinterpret_cast<const float4*>(base + 32);
+        float u, v;
+        const float t = prim_test(p0, p1, p2, r.o, r.d, u, v);
+        WALK_COUNT(ws.prims);
+        if (ANY) { if (t > 1e-4f && t < rec.t) return true; }
+        else {
+            const int kid = __float_as_int(p2.y);
+            if (t > 1e-4f && (t < rec.t || (t == rec.t && kid < rec.prim))) { rec.t = t; rec.prim = kid; rec.u = u; rec.v = v; }
+        }
+    }
+    return false;
+}
+
+// One traversal step of a lane that holds node group `ng` (x = index of the parent's first inner child, y = hit bits 31..24 |
+// the parent's inner-child mask 7..0): take the nearest pending child, leave the rest of the group on the stack, test the child's
+// boxes.  A group without inner bits is a postponed triangle group.
+#define APT_GROUP_HAS_NODES(g) ((g).y > 0x00ffffffu)
+APT_D void group_step(const DevBvh& b, const TravStack& ts, int& sp, grp_t& ng, grp_t& tg, const WalkRay& r, float tmax, WalkStats& ws) {
+    if (APT_GROUP_HAS_NODES(ng)) {
+        const uint32_t bit = 31u - (uint32_t)__clz((int)ng.y);
+        const uint32_t pim = ng.y & 0xffu;
+        ng.y &= ~(1u << bit);
+        if (APT_GROUP_HAS_NODES(ng)) tpush(ts, sp, ng);
+        const uint32_t slot = (bit - 24u) ^ (r.octinv4 & 7u);
+        const uint32_t idx = ng.x + (uint32_t)__popc(pim & ((1u << slot) - 1u));
+        uint32_t cb, tb, im;
+        const uint32_t hm = node8_test(b, idx, r, tmax, cb, tb, im);
+        WALK_COUNT(ws.nodes);
+        ng.x = cb; ng.y = (hm & 0xff000000u) | im;
+        tg.x = tb; tg.y = hm & 0x00ffffffu;
+    } else { tg = ng; ng.x = 0u; ng.y = 0u; }
+}
+#define APT_ROOT_GROUP mk_grp(0u, 0x80000000u)           // "child in priority position 7 of a parent with no inner-child mask" = node 0
+
+// ANY = false: closest hit, rec.t starts at the search limit and ends at min_depth.
+// ANY = true : returns true on the first hit with 1e-4 < t < rec.t.
+template <bool ANY>
+APT_D bool traverse(const DevBvh& bvh, const TravStack& ts, f3 o, f3 d, HitRec& rec) {
+    const WalkRay r = make_walk_ray(o, d);
+    WalkStats ws; ws.nodes = ws.prims = 0;
+    int sp = 0;
+    grp_t ng = APT_ROOT_GROUP, tg = mk_grp(0u, 0u);
+    for (;;) {
+        group_step(bvh, ts, sp, ng, tg, r, rec.t, ws);
+        if (tri_group<ANY>(bvh, tg, r, rec, ws)) return true;
+        if (!APT_GROUP_HAS_NODES(ng)) {
+            if (sp == 0) break;
+            ng = tpop(ts, sp);
         }
     }
     return false;
@@ -167,10 +224,8 @@ typedef const int __attribute__((address_space(4))) * ci_ptr;
 // scalar forms, and a packed multiply or add rounds each half exactly like the scalar instruction, so testing
 // triangles k and k+1 in the two halves of a 64-bit register pair halves the VALU work without touching a bit
 // of the result.  (No packed FMA is formed: -ffp-contract=off applies to vectors too.)
-typedef float v2f __attribute__((ext_vector_type(2)));
 APT_D float4 ld4c(cf_ptr p) { return make_float4(p[0], p[1], p[2], p[3]); }
 APT_D v2f ld2c(cf_ptr p) { v2f r; r.x = p[0]; r.y = p[1]; return r; }
-APT_D v2f sp2(float s) { v2f r; r.x = s; r.y = s; return r; }
 
 // Sweep stream (built in apt_scene_create), one block per object in scene order, 8-float aligned:
 //   [ (lo.x hi.x) (lo.y hi.y) (lo.z hi.z) 0 0 ]                        object slab bounds, interleaved

@@ -412,10 +412,7 @@ __global__ void __launch_bounds__(BLOCK, (((BM == 0x402 || BM == 0x00a || BM == 
 // reads.  The reference walks at most seven segments; the host launches pass p + 1 only where null surfaces exist.
 template <int MODE>
 __global__ void __launch_bounds__(VSHADOW_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAVES : 1)) k_vshadow(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan, int pass) {
-    StagedBvh bvh;
-    int* my_stack = nullptr;
     __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
-    if (MODE == 0) my_stack = carve_lds(sc.bvh, plan, bvh);
     const SubLoop sl = sub_loop(p.nq, VSHADOW_NT(MODE));
     const uint32_t n = min(pass == 0 ? cnt->n_shadow[sl.q * CNT_PAD] : cnt->n_walk[pass][sl.q * CNT_PAD], q.sh_subcap);
     if (pass == 0 && sl.first == 0 && threadIdx.x == 0) {
@@ -439,7 +436,7 @@ __global__ void __launch_bounds__(VSHADOW_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAV
         const f3 d = ld3q(q.sh_d, sc_, io);
         float depth = ldq(q.sh_tmax, io);
         HitRec rec; rec.t = (depth > 0.0f) ? depth - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        if (MODE == 0) traverse<false>(bvh, make_stack(my_stack, plan), o, d, rec);
+        if (MODE == 0) traverse<false>(sc.bvh, make_stack(plan), o, d, rec);
         else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
         else sweep_tile<false, APT_VSHADOW_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         bool arrived = false, walk_on = false;

@@ -272,3 +272,145 @@ def test_bvh_cpp_drop_in_equals_the_oracle_builder_on_mesh_scenes(levels):
         assert a.shape == b.shape and np.array_equal(a, b)
     ni = mine[3]
     assert ni[ni[:, 2] == 1, 1].max() <= 4          # a rejected split happens only in the <= 4 branch or when SAH says so
+
+
+# ---- the 8-wide quantised tree the kernels walk (csrc/bvh_wide.cpp), exported through apt_bvh_wide_export
+def build_wide(fs):
+    lib = _lib.load()
+    prims, info = np.ascontiguousarray(fs.prims), np.ascontiguousarray(fs.obj_info)
+    h = C.c_void_p()
+    _lib.check(lib.apt_bvh_build(prims.ctypes.data_as(_lib.f32p), fs.n_prims, info.ctypes.data_as(_lib.i32p), fs.n_objects, C.byref(h)))
+    nn, lv = C.c_int32(), C.c_int32()
+    _lib.check(lib.apt_bvh_wide_counts(h, C.byref(nn), C.byref(lv)))
+    nodes, order = np.zeros((nn.value, 20), np.uint32), np.zeros(fs.n_prims, np.int32)
+    _lib.check(lib.apt_bvh_wide_export(h, nodes.ctypes.data_as(_lib.u32p), order.ctypes.data_as(_lib.i32p)))
+    lib.apt_bvh_free(h)
+    return nodes, order, lv.value
+
+
+def decode_wide(nodes):
+    """-> per node: p (3,), scale (3,) = 2^e, imask, child_base, tri_base, meta (8,), qlo (3, 8), qhi (3, 8)"""
+    p = nodes[:, 0:3].copy().view(np.float32)
+    e = nodes[:, 3]
+    ex = np.stack([(e >> (8 * a)) & 0xff for a in range(3)], 1).astype(np.uint8).view(np.int8).astype(np.int32)
+    by = np.ascontiguousarray(nodes[:, 6:20]).view(np.uint8).reshape(-1, 7, 8)
+    return p, np.ldexp(np.float32(1), ex).astype(np.float32), (e >> 24).astype(np.int32), nodes[:, 4].astype(np.int64), nodes[:, 5].astype(np.int64), by[:, 0], by[:, 1:4], by[:, 4:7]
+
+
+@pytest.mark.parametrize("scene", ["cbox", "balls_mono", "bunnies1"])
+def test_wide_bvh_invariants(scene, flat):
+    """Every primitive sits in exactly one leaf (<= 3 per leaf, <= 24 per node); inner children are consecutive and counted by the
+    inner-child mask; every decoded child box contains the boxes of all primitives below it (the quantisation rounds outwards)."""
+    if scene == "bunnies1":
+        from adapt_amd.scene_pack import pack_scene
+        from adapt_amd.synth import three_bunnies
+        fs = pack_scene(*three_bunnies(1))
+    else:
+        fs = flat(scene)
+    nodes, order, levels = build_wide(fs)
+    assert sorted(order.tolist()) == list(range(fs.n_prims))
+    p, sc, imask, cbase, tbase, meta, qlo, qhi = decode_wide(nodes)
+    sphere = np.repeat(fs.obj_info[:, 2], fs.obj_info[:, 1]).astype(bool)
+    seen_nodes, seen_slots, depth_seen = set(), [], [0]
+
+    def walk(n, d):
+        assert n not in seen_nodes and d <= levels
+        seen_nodes.add(n); depth_seen[0] = max(depth_seen[0], d)
+        lo_all, hi_all = np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
+        rank, tri_next = 0, 0
+        for s in range(8):
+            m = int(meta[n, s])
+            inner = (m & 0x1f) >= 24
+            assert bool((imask[n] >> s) & 1) == (m != 0 and inner)
+            if m == 0:
+                assert (qlo[n, :, s] == 255).all() and (qhi[n, :, s] == 0).all()          # inverted box: never hit
+                continue
+            blo = p[n] + qlo[n, :, s].astype(np.float32) * sc[n]
+            bhi = p[n] + qhi[n, :, s].astype(np.float32) * sc[n]
+            if inner:
+                assert (m & 0x1f) == 24 + s and (m >> 5) == 1
+                clo, chi = walk(int(cbase[n]) + rank, d + 1)
+                rank += 1
+            else:
+                cnt = {1: 1, 3: 2, 7: 3}[m >> 5]
+                assert (m & 0x1f) == tri_next and tri_next + cnt <= 24
+                clo, chi = np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
+                for slot in range(int(tbase[n]) + tri_next, int(tbase[n]) + tri_next + cnt):
+                    a, b = prim_bounds(fs, order[slot], sphere[order[slot]])
+                    clo, chi = np.minimum(clo, a), np.maximum(chi, b)
+                    seen_slots.append(slot)
+                tri_next += cnt
+            assert np.all(blo <= clo) and np.all(bhi >= chi), (n, s)
+            lo_all, hi_all = np.minimum(lo_all, clo), np.maximum(hi_all, chi)
+        return lo_all, hi_all
+
+    walk(0, 1)
+    assert sorted(seen_slots) == list(range(fs.n_prims)) and len(seen_nodes) == nodes.shape[0] and depth_seen[0] == levels
+    if fs.n_prims > 1000:
+        assert nodes.shape[0] < fs.n_prims / 4 and levels <= 12           # 80-byte nodes, ~6 children each
+
+
+def test_wide_bvh_walk_finds_every_brute_force_hit():
+    """The device walk restated in numpy float32 (same fused slab arithmetic, same octant order, same stack discipline) on the
+    5 950-triangle scene: the primitives it reaches always include the brute-force closest hit, for rays in every octant and for
+    axis-parallel rays."""
+    from adapt_amd.scene_pack import pack_scene
+    from adapt_amd.synth import three_bunnies
+    fs = pack_scene(*three_bunnies(1))
+    nodes, order, levels = build_wide(fs)
+    p, sc, imask, cbase, tbase, meta, qlo, qhi = decode_wide(nodes)
+    rs = np.random.RandomState(9)
+    n = 300
+    O = rs.uniform([0.3, 0.2, 0.3], [5.2, 5.2, 5.2], size=(n, 3)).astype(np.float32)
+    D = rs.normal(size=(n, 3)).astype(np.float32); D /= np.linalg.norm(D, axis=1, keepdims=True)
+    D[:12] = np.float32([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]] * 2)
+    tri = fs.prims.astype(np.float64)
+    e1, e2, p0 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0], tri[:, 0]
+
+    def brute(o, d):                      # Moeller-Trumbore in double: which primitive is nearest
+        pv = np.cross(d, e2); det = (e1 * pv).sum(1)
+        with np.errstate(all="ignore"):
+            inv = 1.0 / det; tv = o - p0; u = (tv * pv).sum(1) * inv; qv = np.cross(tv, e1); v = (qv * d).sum(1) * inv; t = (e2 * qv).sum(1) * inv
+        ok = (np.abs(det) > 1e-12) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 1e-4)
+        if not ok.any():
+            return -1, np.inf
+        k = np.argmin(np.where(ok, t, np.inf))
+        return int(k), float(t[k])
+
+    f32 = np.float32
+    for o, d in zip(O, D):
+        k_true, t_true = brute(o.astype(np.float64), d.astype(np.float64))
+        with np.errstate(all="ignore"):
+            inv = np.where(np.abs(d) < 1e-30, np.copysign(f32(1e30), d), f32(1) / d).astype(np.float32)
+        noo = (-(o * inv)).astype(np.float32)
+        octinv = 7 - ((4 if inv[0] < 0 else 0) | (2 if inv[1] < 0 else 0) | (1 if inv[2] < 0 else 0))
+        reached, stack, tmax = set(), [(0, 0x80000000)], f32(1e7)
+        order_ok = True
+        while stack:
+            base, bits = stack.pop()
+            if bits <= 0x00ffffff:
+                continue
+            bit = bits.bit_length() - 1
+            pim = bits & 0xff
+            bits &= ~(1 << bit)
+            if bits > 0x00ffffff:
+                stack.append((base, bits))
+            slot = (bit - 24) ^ octinv
+            nidx = base + bin(pim & ((1 << slot) - 1)).count("1")
+            s_ = (inv * sc[nidx]).astype(np.float32); c_ = (p[nidx] * inv + noo).astype(np.float32)       # (numpy: separate roundings; the margin is the builder's padding)
+            hm = 0
+            for sl in range(8):
+                m = int(meta[nidx, sl])
+                if m == 0:
+                    continue
+                qn = np.where(inv < 0, qhi[nidx, :, sl], qlo[nidx, :, sl]).astype(np.float32); qf = np.where(inv < 0, qlo[nidx, :, sl], qhi[nidx, :, sl]).astype(np.float32)
+                tn = max(float((qn * s_ + c_).max()), 0.0); tf = min(float((qf * s_ + c_).min()), float(tmax))
+                if tn <= tf:
+                    inner = (m & 0x1f) >= 24
+                    hm |= (m >> 5) << (((m & 0x1f) ^ octinv) if inner else (m & 0x1f))
+            for k in range(24):
+                if (hm >> k) & 1:
+                    reached.add(int(order[int(tbase[nidx]) + k]))
+            if hm & 0xff000000:
+                stack.append((int(cbase[nidx]), (hm & 0xff000000) | int(imask[nidx])))
+        assert k_true < 0 or k_true in reached, (o, d, k_true, t_true)
