@@ -89,6 +89,7 @@ SYMBOLS = {
     "apt_emitter_probe": (C.c_int, [C.c_void_p, C.c_int32, f32p, C.c_uint32, f32p]),
     "apt_texture_probe": (C.c_int, [C.c_void_p, C.c_int32, i32p, f32p, f32p]),
     "apt_renderer_info": (C.c_int, [C.c_void_p, i32p, i32p, C.POINTER(C.c_int64), i32p, C.POINTER(C.c_char_p), i32p]),
+    "apt_measure_sclk_mhz": (C.c_int, [C.c_int32, f32p]),
     "apt_last_error": (C.c_char_p, []),
     "apt_version": (C.c_char_p, []),
 }

@@ -636,7 +636,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     {
         LdsPlan pl;
         const int full_depth = sc->wide.max_depth + 2;
-        int lds_levels = 10;                                 // 20 KiB per 256-thread workgroup
+        int lds_levels = 8;                                  // 16 KiB per 256-thread workgroup (measured: 6, 10 and 14 levels run alike - the 8-wide tree is at most 8-9 levels deep)
         if (const char* sd = getenv("APT_BVH_LDS_LEVELS")) lds_levels = std::max(2, atoi(sd));
         pl.stack_depth = std::min(full_depth, lds_levels);   // deeper levels spill to per-lane global columns (traverse.hpp TravStack)
         r->ovf_levels = full_depth - pl.stack_depth;
@@ -1146,6 +1146,33 @@ APT_EXPORT int apt_texture_probe(const apt_scene* sc, int32_t n, const int32_t* 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out3, dout.p, (size_t)n * 12, hipMemcpyDeviceToHost));
+    return APT_OK;
+}
+// Shader clock while the whole chip is busy (bench.py prices its VALU roofline with it): median over the waves of a full grid of
+// cycle-counter ticks per 100 MHz wall-clock tick.
+APT_EXPORT int apt_measure_sclk_mhz(int32_t device, float* mhz) {
+    if (!mhz) return fail(APT_E_INVALID, "apt_measure_sclk_mhz: bad argument");
+    int ndev = 0;
+    if (int rc = count_device(&ndev)) return rc;
+    if (device < 0 || device >= ndev) return fail(APT_E_INVALID, "apt_measure_sclk_mhz: device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const int grid = std::max(1, prop.multiProcessorCount) * 8, n_waves = grid * (BLOCK / 64);
+    DevBuf out, sink;
+    HIP_TRY(out.alloc((size_t)n_waves * 16)); HIP_TRY(sink.alloc(16));
+    for (int pass = 0; pass < 2; pass++) {            // the first pass warms the clocks up
+        hipLaunchKernelGGL(k_clock_probe, dim3(grid), dim3(BLOCK), 0, 0, 400000, 1.0f, out.as<unsigned long long>(), sink.as<float>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    std::vector<unsigned long long> h((size_t)n_waves * 2);
+    HIP_TRY(hipMemcpy(h.data(), out.p, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> r;
+    for (int w = 0; w < n_waves; w++) if (h[2 * (size_t)w + 1] > 0) r.push_back(100.0 * (double)h[2 * (size_t)w] / (double)h[2 * (size_t)w + 1]);
+    if (r.empty()) return fail(APT_E_STATE, "apt_measure_sclk_mhz: the wall clock did not advance");
+    std::nth_element(r.begin(), r.begin() + r.size() / 2, r.end());
+    *mhz = (float)r[r.size() / 2];
     return APT_OK;
 }
 APT_EXPORT int apt_renderer_info(const apt_renderer* r, int32_t* spp_batch, int32_t* n_subqueues, int64_t* queue_bytes, int32_t* lds_bytes, const char** shade_variant, int32_t* trace_mode) {

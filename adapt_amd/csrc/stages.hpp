@@ -371,8 +371,13 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 #ifndef APT_DYN_MIN_ACTIVE
 #define APT_DYN_MIN_ACTIVE 40
 #endif
+#ifdef APT_WALK_WAVES
+#define APT_WALK_ATTR __attribute__((amdgpu_waves_per_eu(APT_WALK_WAVES, APT_WALK_WAVES)))
+#else
+#define APT_WALK_ATTR
+#endif
 template <int SORTED>
-__global__ void __launch_bounds__(BLOCK) k_extend_dyn(DevScene sc, Params p, Queues q, Counters* cnt, int cur_q, const uint32_t* n_src, LdsPlan plan) {
+__global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc, Params p, Queues q, Counters* cnt, int cur_q, const uint32_t* n_src, LdsPlan plan) {
     const TravStack ts = make_stack(plan);
     const int sq = (int)(blockIdx.x % (uint32_t)p.nq);
     const uint32_t n = n_src[sq * CNT_PAD];
@@ -757,7 +762,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 // ------------------------------------------------------- shadow, BVH walk with dynamic ray fetch
 // Any-hit twin of k_extend_dyn: a lane leaves the walk at its first occluder or when its stack runs empty, adds its contribution if
 // unoccluded, and claims the next shadow ray as soon as the wave runs low on walking lanes.
-__global__ void __launch_bounds__(BLOCK) k_shadow_dyn(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
+__global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
     const TravStack ts = make_stack(plan);
     const int sq = (int)(blockIdx.x % (uint32_t)p.nq);
     const uint32_t n = min(cnt->n_shadow[sq * CNT_PAD], q.sh_subcap);
@@ -843,6 +848,20 @@ __global__ void __launch_bounds__(BLOCK) k_finalize(Params p, Queues q, float* a
 __global__ void k_divide(const float* accum, float* out, uint32_t n, float cnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = accum[i] / cnt;        // pixels = color / cnt (vanilla_renderer.py:120)
+}
+
+// Shader clock under load: every wave of a full grid runs a dependent FMA chain for a fixed number of iterations and reports the
+// cycle counter (s_memtime-class counter, shader clock) against the constant 100 MHz wall clock.  out[2*w] = cycles, out[2*w+1] = ticks.
+__global__ void __launch_bounds__(BLOCK) k_clock_probe(int iters, float seed, unsigned long long* out, float* sink) {
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    float a = seed + (float)threadIdx.x, b = 1.000001f;
+    for (int i = 0; i < iters; i++) { a = __builtin_fmaf(a, b, 0.5f); b = __builtin_fmaf(b, 0.999999f, 1e-7f); }
+    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    if (a == 12345.678f) sink[0] = a + b;                  // keeps the chain alive
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t w = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
+        out[2 * w] = c1 - c0; out[2 * w + 1] = w1 - w0;
+    }
 }
 
 // ------------------------------------------------------- unit entry kernels

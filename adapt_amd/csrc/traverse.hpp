@@ -142,26 +142,27 @@ APT_D uint32_t node8_test(const DevBvh& b, uint32_t idx, const WalkRay& r, float
     return hitmask;
 }
 
-// The primitives of a triangle group.  Closest hit: strictly nearer wins, and of two primitives at EXACTLY the same t the lower
-// original index - the reference's brute-force loop keeps the first strictly-closer hit in index order (tracer_base.py:208), so
-// the answer does not depend on the order in which the tree presents the primitives.  Any hit: true at the first primitive
-// with 1e-4 < t < rec.t.
+// One primitive of a triangle group (the highest pending bit).  Closest hit: strictly nearer wins, and of two primitives at
+// EXACTLY the same t the lower original index - the reference's brute-force loop keeps the first strictly-closer hit in index
+// order (tracer_base.py:208), so the answer does not depend on the order in which the tree presents the primitives.
+// Any hit: true at a primitive with 1e-4 < t < rec.t.
+template <bool ANY>
+APT_D bool tri_one(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
+    const uint32_t k = 31u - (uint32_t)__clz((int)tg.y);
+    tg.y &= ~(1u << k);
+    const char* base = reinterpret_cast<const char*>(b.prims) + (tg.x + k) * 48u;
+    const float4 p0 = *reinterpret_cast<const float4*>(base), p1 = *reinterpret_cast<const float4*>(base + 16), p2 = *reinterpret_cast<const float4*>(base + 32);
+    float u, v;
+    const float t = prim_test(p0, p1, p2, r.o, r.d, u, v);
+    WALK_COUNT(ws.prims);
+    if (ANY) return t > 1e-4f && t < rec.t;
+    const int kid = __float_as_int(p2.y);
+    if (t > 1e-4f && (t < rec.t || (t == rec.t && kid < rec.prim))) { rec.t = t; rec.prim = kid; rec.u = u; rec.v = v; }
+    return false;
+}
 template <bool ANY>
 APT_D bool tri_group(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
-    while (tg.y != 0u) {
-        const uint32_t k = 31u - (uint32_t)__clz((int)tg.y);
-        tg.y &= ~(1u << k);
-        const char* base = reinterpret_cast<const char*>(b.prims) + (tg.x + k) * 48u;
-        const float4 p0 = *reinterpret_cast<const float4*>(base), p1 = *reinterpret_cast<const float4*>(base + 16), p2 = *reinterpret_cast<const float4*>(base + 32);
-        float u, v;
-        const float t = prim_test(p0, p1, p2, r.o, r.d, u, v);
-        WALK_COUNT(ws.prims);
-        if (ANY) { if (t > 1e-4f && t < rec.t) return true; }
-        else {
-            const int kid = __float_as_int(p2.y);
-            if (t > 1e-4f && (t < rec.t || (t == rec.t && kid < rec.prim))) { rec.t = t; rec.prim = kid; rec.u = u; rec.v = v; }
-        }
-    }
+    while (tg.y != 0u) if (tri_one<ANY>(b, tg, r, rec, ws)) return true;
     return false;
 }
 

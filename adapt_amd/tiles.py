@@ -18,7 +18,7 @@ from typing import Optional
 
 import numpy as np
 
-__all__ = ["TilePlan", "gather_tiles", "gather_image", "assemble", "device_tile"]
+__all__ = ["TilePlan", "gather_tiles", "gather_tiles_device", "gather_image", "assemble", "device_tile"]
 
 
 class TilePlan:
@@ -64,6 +64,25 @@ class _DevView:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
 
 
+def gather_tiles_device(tile, plan: TilePlan, world_size: int, group=None):
+    """The collective alone: all_gather of this rank's (n_cols, H, 3) torch tensor (padded to the widest rank) into a
+    (world_size, max_cols, H, 3) tensor on the same device.  No host copy, no synchronisation beyond the collective itself:
+    this is what a render loop calls per step; `assemble` turns the result into the (W, H, 3) image once, at the end."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        raise RuntimeError("gather_tiles_device: torch.distributed is not initialised")
+    mc = plan.max_cols()
+    if tile.shape[0] == mc:
+        padded = tile.contiguous()
+    else:
+        padded = torch.zeros((mc, plan.height, 3), dtype=torch.float32, device=tile.device)
+        padded[:tile.shape[0]] = tile
+    out = torch.empty((world_size * mc, plan.height, 3), dtype=torch.float32, device=tile.device)    # rank-major concatenation
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return out.view(world_size, mc, plan.height, 3)
+
+
 def gather_tiles(tile, plan: TilePlan, rank: int, world_size: int, group=None, force_collective: bool = False) -> np.ndarray:
     """All-gather the per-rank tiles and assemble the full image (returned on every rank).
 
@@ -74,27 +93,29 @@ def gather_tiles(tile, plan: TilePlan, rank: int, world_size: int, group=None, f
         t = tile.detach().cpu().numpy() if hasattr(tile, "detach") else np.asarray(tile)
         return assemble(plan, [t])
     import torch
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        raise RuntimeError("gather_tiles: torch.distributed is not initialised")
     t = tile if isinstance(tile, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(tile, np.float32))
-    mc = plan.max_cols()
-    padded = torch.zeros((mc, plan.height, 3), dtype=torch.float32, device=t.device)
-    padded[:t.shape[0]] = t
-    out = torch.empty((world_size * mc, plan.height, 3), dtype=torch.float32, device=t.device)    # rank-major concatenation
-    dist.all_gather_into_tensor(out, padded, group=group)
-    return assemble(plan, out.view(world_size, mc, plan.height, 3).cpu().numpy())
+    return assemble(plan, gather_tiles_device(t, plan, world_size, group).cpu().numpy())
+
+
+_warned_staged = [False]
 
 
 def device_tile(rdr):
-    """This rank's accumulation tile as a torch tensor on its GPU: a zero-copy view of the renderer's
-    framebuffer (apt_device_ptr) when torch accepts the raw pointer, else a staged host copy."""
+    """This rank's accumulation tile as a torch tensor on its GPU: a zero-copy view of the renderer's framebuffer
+    (apt_device_ptr) through __cuda_array_interface__, cloned on the device.  If this torch build does not take a raw pointer
+    that way (TypeError / ValueError / RuntimeError from `as_tensor`), the tile is staged through the host instead - slower by
+    one D2H + H2D of the tile, and said so once, loudly, rather than silently."""
     import torch
     dev = torch.device(f"cuda:{rdr.device}")
     try:
         view = _DevView(rdr.device_accum_ptr(), (rdr.n_cols, rdr.h, 3))
         return torch.as_tensor(view, device=dev).clone()
-    except Exception:
+    except (TypeError, ValueError, RuntimeError) as e:
+        if not _warned_staged[0]:
+            import warnings
+            warnings.warn(f"adapt_amd.tiles.device_tile: zero-copy view of the device framebuffer failed ({type(e).__name__}: {e}); "
+                          "staging the tile through host memory", RuntimeWarning)
+            _warned_staged[0] = True
         return torch.from_numpy(rdr.tile_accum()).to(dev)
 
 

@@ -185,6 +185,10 @@ int apt_emitter_probe(const apt_scene*, int32_t n, const float* in11, uint32_t s
 int apt_renderer_info(const apt_renderer*, int32_t* spp_batch, int32_t* n_subqueues, int64_t* queue_bytes,
                       int32_t* lds_bytes, const char** shade_variant, int32_t* trace_mode);
 
+/* Shader clock (MHz) with every CU busy: cycle counter against the 100 MHz wall clock over a full-grid FMA chain (~1 ms).
+ * bench.py prices the VALU roofline of the trace kernels with it.  (No reference counterpart.) */
+int apt_measure_sclk_mhz(int32_t device, float* mhz);
+
 const char* apt_last_error(void);
 const char* apt_version(void);
 

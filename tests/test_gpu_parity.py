@@ -1005,3 +1005,47 @@ def test_ragged_film_partitions(w, h, world, bw, renderer):
         tiles.append(r.tile_accum())
         assert tiles[-1].shape == (len(plan.columns(rank)), h, 3)
     assert np.array_equal(assemble(plan, tiles), ref)
+
+
+# ---------------------------------------------------------------- what the driver launches on the 8-GPU node: bench.py under torch.distributed.run
+def _run_bench(n, extra, tmp_path, tag):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    img = str(tmp_path / f"{tag}.npy")
+    common = ["bench.py", "--gpus", str(n), "--config", "c1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-exclusive-pass", "--dump-image", img] + extra
+    if n > 1:
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port)] + common + ["--single-device", "--backend", "gloo"]
+    else:
+        cmd = [sys.executable] + common
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line), np.load(img)
+
+
+def test_two_and_three_rank_bench_on_one_gpu_equal_the_single_rank_image(tmp_path):
+    """bench.py exactly as the driver starts it for N > 1 (torch.distributed.run, one process per rank), except that every rank renders
+    on cuda:0 and the tiles travel over gloo: real `Renderer(rank, world_size)` instances in separate processes, the all_gather, the
+    tile assembly.  Weak scaling (N x the samples) and strong scaling (same film and samples) both reproduce the single-process
+    image BIT FOR BIT, because the Philox key is the global pixel; the JSON line carries the contract's fields and per-rank timings."""
+    one, img1 = _run_bench(1, ["--spp", "6"], tmp_path, "n1")
+    assert one["n_gpus"] == 1 and one["scaling"] == "weak" and one["config"]["spp_per_step"] == 6 and img1.shape == (256, 256, 3)
+    weak, img2 = _run_bench(2, ["--spp", "3"], tmp_path, "n2w")                        # 2 ranks x 3 spp = 6 spp per step
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["config"]["spp_per_step"] == 6
+    assert np.array_equal(img2, img1)
+    strong, img3 = _run_bench(3, ["--spp", "6", "--scaling", "strong"], tmp_path, "n3s")
+    assert strong["n_gpus"] == 3 and strong["scaling"] == "strong" and strong["config"]["spp_per_step"] == 6
+    assert np.array_equal(img3, img1)
+    for d in (weak, strong):
+        pr = d["per_rank"]
+        assert len(pr["render_ms_per_step"]) == d["n_gpus"] and len(pr["gather_ms_per_step"]) == d["n_gpus"] and min(pr["render_ms_per_step"]) > 0
+        assert sum(pr["samples"]) == 256 * 256 * 6                                          # the ranks' pixels partition the film
+        for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in d
+        assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and set(d["roofline"]["stages"]) == {"extend", "shade", "shadow"}
