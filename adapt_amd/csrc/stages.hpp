@@ -143,6 +143,9 @@ struct Counters {
 APT_D uint32_t pack_meta(uint32_t draw, uint32_t bounce, bool spec) { return (draw & 0xffffu) | ((bounce & 0xffu) << 16) | (spec ? (1u << 24) : 0u); }
 
 #define BLOCK 256
+#ifndef APT_EXCLUSIVE_L
+#define APT_EXCLUSIVE_L(p) ((p).S == 1)
+#endif
 
 // LDS of the BVH-walk stages (dynamic, sized per scene by the host): the traversal stack, stack_depth * BLOCK 8-byte groups laid out [level][lane]
 struct LdsPlan { int lds_nodes, lds_prims, stack_depth; uint2* ovf; int ovf_stride; };     // stack_depth: levels kept in LDS; ovf: global spill columns (one per thread of the largest grid); lds_nodes / lds_prims: unused (nothing is staged)
@@ -156,6 +159,16 @@ APT_D TravStack make_stack(const LdsPlan& plan) {
 }
 
 APT_D uint32_t lane_id() { return threadIdx.x & 63u; }
+// A light sample's contribution into its path's radiance slot (byte offset lo_ in the SoA array L).  With ONE light sample per
+// path vertex (p.S == 1) no two entries of a shadow launch share a slot and nothing else writes L while the launch runs, so the add is
+// a plain read-modify-write: deterministic, and not an L2 atomic per component.  With several samples per vertex the entries of one
+// path sit in different waves: float atomics (their order is the one thing in the image that may differ from run to run).
+APT_D void add_radiance(float* L, uint32_t cap, uint32_t lo_, f3 c, bool exclusive) {
+    char* Lb = reinterpret_cast<char*>(L);
+    float* px = reinterpret_cast<float*>(Lb + lo_); float* py = reinterpret_cast<float*>(Lb + (size_t)cap * 4 + lo_); float* pz = reinterpret_cast<float*>(Lb + (size_t)cap * 8 + lo_);
+    if (exclusive) { *px = *px + c.x; *py = *py + c.y; *pz = *pz + c.z; }
+    else { atomicAdd(px, c.x); atomicAdd(py, c.y); atomicAdd(pz, c.z); }
+}
 // number of set bits of a ballot mask below this lane (v_mbcnt: no lane-mask registers to keep alive)
 APT_D uint32_t rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 // append `flag` lanes of the wave to the queue counted by *counter; returns this lane's position
@@ -747,11 +760,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
             const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
             if (occluded && weird) c = c * 0.f;
             if (!occluded || weird) {
-                const uint32_t lo_ = ldq(q.sh_id, io);                  // byte offset of the path's radiance slot
-                char* Lb = reinterpret_cast<char*>(q.L);
-                atomicAdd(reinterpret_cast<float*>(Lb + lo_), c.x);
-                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 4 + lo_), c.y);
-                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 8 + lo_), c.z);
+                add_radiance(q.L, p.cap, ldq(q.sh_id, io), c, APT_EXCLUSIVE_L(p));      // sh_id: byte offset of the path's radiance slot
             }
             if (!occluded) t_lit++;
         }
@@ -788,11 +797,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
             const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));       // see k_shadow
             if (occluded && weird) c = c * 0.f;
             if (!occluded || weird) {
-                const uint32_t lo_ = ldq(q.sh_id, io);
-                char* Lb = reinterpret_cast<char*>(q.L);
-                atomicAdd(reinterpret_cast<float*>(Lb + lo_), c.x);
-                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 4 + lo_), c.y);
-                atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 8 + lo_), c.z);
+                add_radiance(q.L, p.cap, ldq(q.sh_id, io), c, APT_EXCLUSIVE_L(p));
             }
             if (!occluded) t_lit++;
             state = 0;
