@@ -5,6 +5,9 @@ Mirrors the reference driver's flags and control flow for `--type pt|vpt --no_gu
 `iter_num + 1` samples (the reference's `--no_gui` loop runs `range(iter_num + 1)`,
 render.py:80-81,118), periodic checkpoint saves, summary, optional quantile normalisation
 (`utils/watermark.py:28-29`), image file `<output_path><img_name>-<scene file stem>-pt.<ext>`.
+A cropped render writes the crop window `[start_x:end_x, start_y:end_y]` of the (w, h, 3) image; the reference slices
+`[start_y:end_y, start_x:end_x]` on that same (w, h, 3) array (`utils/watermark.py:25`), which is the intended window only for
+square crops - a deliberate deviation.
 Differences: there is no GUI and no Taichi (`--arch` is accepted and ignored unless it is not
 one of the known names), only `--type pt` and `--type vpt` exist (homogeneous media), the "RENDERED WITH AdaPT" watermark is not
 stamped (`--no_watermark` is accepted), PNG/BMP are written by a small built-in encoder.
@@ -64,6 +67,8 @@ def get_options(argv=None):
                 continue
             key, _, val = line.partition("=")
             key, val = key.strip().lstrip("-"), val.strip()
+            if val.lower() in ("false", "0", "no", "off") and any(a.dest == key and a.nargs == 0 for a in p._actions):
+                continue                    # a switch set to false: leave it off (configargparse accepts `no_gui = false`)
             extra += [f"--{key}"] + ([val] if val and val.lower() not in ("true",) else [])
         argv = extra + argv           # command line wins over the file
     return p.parse_args(argv)

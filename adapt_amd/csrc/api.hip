@@ -117,7 +117,7 @@ template <class T> static hipError_t upload(DevBuf& b, const std::vector<T>& v) 
     return v.empty() ? hipSuccess : hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
 }
 
-struct apt_bvh { apt::BvhData data; apt::BvhData bin3; apt::WideBvhData wide; };     // data: the exported binary tree (leaves <= 4); bin3 -> wide: what the kernels walk
+struct apt_bvh { apt::BvhData data; apt::BvhData bin3; apt::WideBvhData wide; };     // data: the exported binary tree (leaves <= 4); bin3 (single-primitive leaves) -> wide: what the kernels walk
 
 struct apt_scene {
     int device = 0;
@@ -203,7 +203,7 @@ APT_EXPORT const char* apt_version(void) { return "adapt_mi 0.1 (gfx950 wavefron
 APT_EXPORT int apt_bvh_build(const float* prims, int32_t n_prims, const int32_t* obj_info, int32_t n_objects, apt_bvh** out) {
     if (!prims || !obj_info || !out || n_prims <= 0 || n_objects <= 0) return fail(APT_E_INVALID, "apt_bvh_build: bad argument");
     apt_bvh* b = new apt_bvh();
-    if (apt::build_bvh(prims, n_prims, obj_info, n_objects, b->data) != 0 || apt::build_bvh(prims, n_prims, obj_info, n_objects, b->bin3, 3) != 0 ||
+    if (apt::build_bvh(prims, n_prims, obj_info, n_objects, b->data) != 0 || apt::build_bvh(prims, n_prims, obj_info, n_objects, b->bin3, 1) != 0 ||
         apt::build_wide_bvh(b->bin3, b->wide) != 0) { delete b; return fail(APT_E_INVALID, "apt_bvh_build: build failed"); }
     *out = b;
     return APT_OK;
@@ -279,7 +279,9 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     s->device = device;
     const int N = d->n_prims, O = d->n_objects, S = d->n_sources;
     s->n_prims = N; s->n_objects = O; s->n_sources = S;
-    if (apt::build_bvh(d->prims, N, d->obj_info, O, s->bvh, 3) != 0 || apt::build_wide_bvh(s->bvh, s->wide) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH build failed"); }
+    int max_leaf = 1;                     // primitives per leaf of the binary tree (the 8-wide node encodes at most 3 per leaf child); measured 1 / 2 / 3: C4 1274 / 1236 / 1228, C5 1117 / 1073 / 1043 Msamples/s - a primitive test costs ~75 instructions whatever the fraction of the wave that needs it, a child box 19
+    if (const char* ml = getenv("APT_BVH_LEAF")) max_leaf = std::min(3, std::max(1, atoi(ml)));
+    if (apt::build_bvh(d->prims, N, d->obj_info, O, s->bvh, max_leaf) != 0 || apt::build_wide_bvh(s->bvh, s->wide) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH build failed"); }
 
     std::vector<int> prim_obj((size_t)N, 0);
     std::vector<uint8_t> sphere((size_t)N, 0);
@@ -469,6 +471,7 @@ static int owned_columns(const apt_render_cfg& c) {
     return n;
 }
 
+APT_EXPORT void apt_renderer_destroy(apt_renderer* r);
 APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cfg, apt_renderer** out) {
     if (!sc || !cfg || !out) return fail(APT_E_INVALID, "apt_renderer_create: null argument");
     apt_render_cfg c = *cfg;
@@ -482,11 +485,12 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (c.device != sc->device) return fail(APT_E_INVALID, "apt_renderer_create: renderer and scene must live on the same device");
     HIP_TRY(hipSetDevice(c.device));
     apt_renderer* r = new apt_renderer();
+    struct Owner { apt_renderer* r; ~Owner() { if (r) apt_renderer_destroy(r); } } owner{r};     // every early return below releases streams, events and queue pools
     r->scene = sc; r->cfg = c;
     r->n_cols = owned_columns(c);
     // every owned band must be complete except possibly the last: local->global mapping assumes it
     r->npix = r->n_cols * c.height;
-    if (r->npix <= 0) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: this rank owns no pixels"); }
+    if (r->npix <= 0) { return fail(APT_E_INVALID, "apt_renderer_create: this rank owns no pixels"); }
     int B = c.spp_per_batch;
     r->n_lanes = (c.volumetric && sc->has_null_surface) ? 4 : 3;   // volumetric scenes with null surfaces: a fourth lane hides the host read-backs of their tails (V1 752 -> 782, V2 488 -> 517 Msamples/s); measured on C2: 1 lane 1 827, 2 lanes 2 196, 3 lanes 2 268, 4 lanes 2 178 Msamples/s (64 spp per lane-batch)
     if (const char* nl = getenv("APT_LANES")) r->n_lanes = std::min(4, std::max(1, atoi(nl)));
@@ -499,10 +503,10 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     const size_t cap = subcap * (size_t)nq;
     const size_t sh_subcap = subcap * (size_t)(S > 0 ? S : 1);
     const size_t sh_cap = sh_subcap * (size_t)nq;
-    if (cap >= (1ull << 31)) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: batch too large (spp_per_batch * pixels must stay below 2^31)"); }
+    if (cap >= (1ull << 31)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (spp_per_batch * pixels must stay below 2^31)"); }
     for (const ShadeVariant& v : kShadeVariants)
         if ((sc->bx_mask & ~v.bm) == 0 && (sc->src_mask & ~v.sm) == 0) { r->shade = &v; break; }
-    if (!r->shade) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: scene uses a material or emitter type the kernels do not know"); }
+    if (!r->shade) { return fail(APT_E_INVALID, "apt_renderer_create: scene uses a material or emitter type the kernels do not know"); }
     const bool textured = sc->dev.tex_i != nullptr;
     if (textured) r->shade = &kTexturedShade;                   // the one kernel compiled with texture lookups; unsorted
     Params& p = r->par;
@@ -516,7 +520,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     p.rr_bounce_th = c.rr_bounce_th; p.rr_threshold = c.rr_threshold; p.seed = c.seed; p.cap = (uint32_t)cap; p.subcap = (uint32_t)subcap; p.nq = nq;
     p.inv_ns = 1.f / (float)sc->n_sources; p.inv_ns1 = (sc->n_sources > 1) ? 1.f / (float)(sc->n_sources - 1) : 1.f;
     p.pix_bits = 0; while ((1u << p.pix_bits) < (uint32_t)r->npix) p.pix_bits++;
-    if (((uint64_t)B << p.pix_bits) > (1ull << 32)) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: spp_per_batch x pixels does not fit the 32-bit path id"); }
+    if (((uint64_t)B << p.pix_bits) > (1ull << 32)) { return fail(APT_E_INVALID, "apt_renderer_create: spp_per_batch x pixels does not fit the 32-bit path id"); }
     {   // local pixel -> RNG key (global pixel index), same mapping as local_to_global in stages.hpp
         std::vector<uint32_t> key((size_t)r->npix);
         for (int lp = 0; lp < r->npix; lp++) {
@@ -525,7 +529,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
             key[(size_t)lp] = (uint32_t)(i * c.height + j);
         }
         hipError_t e_ = upload(r->pix_key, key);
-        if (e_ != hipSuccess) { delete r; return fail(APT_E_HIP, std::string("upload pix_key: ") + hipGetErrorString(e_)); }
+        if (e_ != hipSuccess) { return fail(APT_E_HIP, std::string("upload pix_key: ") + hipGetErrorString(e_)); }
         p.pix_key = r->pix_key.as<uint32_t>();
     }
     r->sorted = (sc->n_classes >= 2) ? 1 : 0;
@@ -533,8 +537,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (textured) r->sorted = 0;
     r->volumetric = c.volumetric ? 1 : 0;
     if (r->volumetric) {
-        if (c.max_bounce > 255) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer keeps the bounce count in 8 bits (max_bounce <= 255)"); }
-        if (!sc->has_aabb) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer needs the object boxes (world bound)"); }
+        if (c.max_bounce > 255) { return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer keeps the bounce count in 8 bits (max_bounce <= 255)"); }
+        if (!sc->has_aabb) { return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer needs the object boxes (world bound)"); }
         r->sorted = 0;
         if (sc->has_volume) {
             for (const VShadeVariant& v : kVShadeVolVariants)
@@ -542,7 +546,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         } else
         for (const VShadeVariant& v : kVShadeVariants)
             if ((sc->bx_mask & ~v.bm) == 0 && (sc->src_mask & ~v.sm) == 0 && !(textured && v.bm != APT_BX_ALL)) { r->vshade = &v; break; }
-        if (!r->vshade) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: scene uses a material or emitter type the volumetric kernels do not know"); }
+        if (!r->vshade) { return fail(APT_E_INVALID, "apt_renderer_create: scene uses a material or emitter type the volumetric kernels do not know"); }
         // event-class sorting pays when the all-models kernel would be needed for a scene of several material classes
         const bool keep_miss = sc->world_scattering || sc->has_volume;
         int vs = (!textured && r->vshade->bm == APT_BX_ALL && sc->n_classes >= 2 && sc->n_classes + (keep_miss ? 1 : 0) <= APT_MAX_CLASSES) ? 1 : 0;
@@ -573,7 +577,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         }
     }
     // the kernels address queue slots with 32-bit byte offsets (stages.hpp "Queue addressing")
-    if (cap >= ((size_t)1 << 30) || sh_cap >= ((size_t)1 << 30)) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: batch too large (queue capacity must stay below 2^30 slots)"); }
+    if (cap >= ((size_t)1 << 30) || sh_cap >= ((size_t)1 << 30)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (queue capacity must stay below 2^30 slots)"); }
     // one pool per lane, carved into the SoA arrays (all 4-byte lanes)
     const bool walk_lists = r->volumetric && sc->has_null_surface;      // light samples that cross null surfaces are re-queued by slot
     const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 3) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
@@ -599,13 +603,13 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         return hipSuccess;
     };
     hipError_t e = carve(r->pool, r->q);
-    if (e != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("queue pool: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { return fail(APT_E_NOMEM, std::string("queue pool: ") + hipGetErrorString(e)); }
     r->extra.resize((size_t)r->n_lanes - 1);
     for (auto& ln : r->extra) {
-        if ((e = carve(ln.pool, ln.q)) != hipSuccess || (e = ln.counters.alloc(sizeof(Counters))) != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("queue pool (lane): ") + hipGetErrorString(e)); }
+        if ((e = carve(ln.pool, ln.q)) != hipSuccess || (e = ln.counters.alloc(sizeof(Counters))) != hipSuccess) { return fail(APT_E_NOMEM, std::string("queue pool (lane): ") + hipGetErrorString(e)); }
     }
     if ((e = r->counters.alloc(sizeof(Counters))) != hipSuccess || (e = r->accum.alloc((size_t)r->npix * 12)) != hipSuccess ||
-        (e = r->scratch.alloc((size_t)r->npix * 12)) != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("framebuffer: ") + hipGetErrorString(e)); }
+        (e = r->scratch.alloc((size_t)r->npix * 12)) != hipSuccess) { return fail(APT_E_NOMEM, std::string("framebuffer: ") + hipGetErrorString(e)); }
     HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
     HIP_TRY(hipMemsetAsync(r->counters.p, 0, sizeof(Counters), r->stream));
     HIP_TRY(hipEventCreateWithFlags(&r->fin0, hipEventDisableTiming));
@@ -644,7 +648,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         const size_t stack_b = (size_t)pl.stack_depth * BLOCK * 8;
         r->plan = pl;
         r->lds_bytes = stack_b;
-        if (r->lds_bytes > 160 * 1024) { delete r; return fail(APT_E_INVALID, "apt_renderer_create: BVH too deep for the LDS traversal stack"); }
+        if (r->lds_bytes > 160 * 1024) { return fail(APT_E_INVALID, "apt_renderer_create: BVH too deep for the LDS traversal stack"); }
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->lds_bytes));
         r->grid_trace = cus * per_cu;
         if (r->trace_mode == 1) { r->lds_bytes = 0; r->grid_trace = cus * 8; }
@@ -697,14 +701,15 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (r->trace_mode == 0 && r->ovf_levels > 0) {
         const int max_grid = std::max(r->grid_trace, std::max(r->grid_shadow, r->grid_vshadow));
         const size_t stride = (size_t)max_grid * BLOCK, bytes = stride * (size_t)r->ovf_levels * 8;
-        if ((e = r->ovf.alloc(bytes)) != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("traversal stack spill: ") + hipGetErrorString(e)); }
+        if ((e = r->ovf.alloc(bytes)) != hipSuccess) { return fail(APT_E_NOMEM, std::string("traversal stack spill: ") + hipGetErrorString(e)); }
         r->plan.ovf = r->ovf.as<uint2>(); r->plan.ovf_stride = (int)stride;
         for (auto& ln : r->extra) {
-            if ((e = ln.ovf.alloc(bytes)) != hipSuccess) { delete r; return fail(APT_E_NOMEM, std::string("traversal stack spill (lane): ") + hipGetErrorString(e)); }
+            if ((e = ln.ovf.alloc(bytes)) != hipSuccess) { return fail(APT_E_NOMEM, std::string("traversal stack spill (lane): ") + hipGetErrorString(e)); }
             ln.plan = r->plan; ln.plan.ovf = ln.ovf.as<uint2>();
         }
     }
     HIP_TRY(hipStreamSynchronize(r->stream));
+    owner.r = nullptr;
     *out = r;
     return APT_OK;
 }
@@ -783,13 +788,13 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
             round.push_back(is);
             r->cnt += B; done += B;
         }
-        auto iterate = [&](Issued& is, int n_iter) {
+        auto iterate = [&](Issued& is, int n_iter) -> int {
             hipStream_t st = is.li ? r->extra[(size_t)is.li - 1].stream : r->stream;
             const Queues& q = is.li ? r->extra[(size_t)is.li - 1].q : r->q;
             Counters* cnt = is.li ? r->extra[(size_t)is.li - 1].counters.as<Counters>() : r->counters.as<Counters>();
             const LdsPlan& lane_plan = is.li ? r->extra[(size_t)is.li - 1].plan : r->plan;
             for (int b = 0; b < n_iter; b++) {
-                if (r->dyn_fetch) HIP_TRY_VOID(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st));
+                if (r->dyn_fetch) HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st));
                 { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
                 if (!r->sorted) {
                     ShadeIn in = {q.ray_o[is.cur], q.ray_d[is.cur], q.thr[is.cur], q.id[is.cur], q.meta[is.cur], q.pdf[is.cur],
@@ -801,7 +806,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
                         ShadeIn in = {k.ray_o, k.ray_d, k.thr, k.id, k.meta, k.pdf, k.t, k.prim, k.u, k.v, (const uint32_t*)cnt->n_cls[c]};
                         LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vclass_fn[c], dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, in, is.cur);
                     }
-                    if (is.p.S <= 0) HIP_TRY_VOID(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st));     // normally k_vshadow's first pass recycles these
+                    if (is.p.S <= 0) HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st));     // normally k_vshadow's first pass recycles these
                 }
                 if (is.p.S > 0) {
                     const int n_pass = r->scene->has_null_surface ? 7 : 1;       // track_ray walks at most seven segments (vpt.py:113)
@@ -812,24 +817,27 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
                 }
                 is.cur ^= 1;
             }
+            return APT_OK;
         };
         // an iteration ends a path or counts a bounce, except a null-surface pass-through: max_bounce iterations finish every
         // path that met no null surface
-        for (Issued& is : round) iterate(is, std::max(1, is.p.max_bounce));      // the loop body runs once even with max_bounce = 0 (vpt.py:161-245)
+        for (Issued& is : round) if (int rc = iterate(is, std::max(1, is.p.max_bounce))) return rc;      // the loop body runs once even with max_bounce = 0 (vpt.py:161-245)
         for (Issued& is : round) {
             hipStream_t st = is.li ? r->extra[(size_t)is.li - 1].stream : r->stream;
             const Queues& q = is.li ? r->extra[(size_t)is.li - 1].q : r->q;
             Counters* cnt = is.li ? r->extra[(size_t)is.li - 1].counters.as<Counters>() : r->counters.as<Counters>();
             hipEvent_t fin = is.li ? r->extra[(size_t)is.li - 1].fin : r->fin0;
             if (r->scene->has_null_surface) {
+                unsigned long long live = 0;
                 for (int k = 0; k < 4096; k++) {
                     HIP_TRY(hipMemcpyAsync(r->host_counters.n_active[is.cur], cnt->n_active[is.cur], sizeof(cnt->n_active[is.cur]), hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipStreamSynchronize(st));
-                    unsigned long long live = 0;
+                    live = 0;
                     for (int sq = 0; sq < nq; sq++) live += r->host_counters.n_active[is.cur][sq * CNT_PAD];
                     if (!live) break;
-                    iterate(is, 2);
+                    if (int rc = iterate(is, 2)) return rc;
                 }
+                if (live) return fail(APT_E_STATE, "apt_render: paths still crossing null surfaces after 8192 extra iterations (a closed loop of null surfaces?)");
             }
             if (prev_fin && r->n_lanes > 1) HIP_TRY(hipStreamWaitEvent(st, prev_fin, 0));
             { LaunchTimer t(r, 4, st); hipLaunchKernelGGL(k_finalize, dim3(grid_for((size_t)r->npix, r->grid_small, 1)), dim3(BLOCK), 0, st, is.p, q, r->accum.as<float>()); }
@@ -841,10 +849,24 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
     return APT_OK;
 }
 
+static int render_impl(apt_renderer* r, int32_t n_spp);
 APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
     if (!r || n_spp < 0) return fail(APT_E_INVALID, "apt_render: bad argument");
     HIP_TRY(hipSetDevice(r->cfg.device));
     if (r->render_pending) { if (int rc = resolve_events(r)) return rc; }
+    const int cnt0 = r->cnt;
+    const int rc = render_impl(r, n_spp);
+    if (rc != APT_OK) {
+        // a launch failed half-way: let every lane drain, forget the samples that were not completed, keep the error message
+        const std::string msg = g_err;
+        for (auto& ln : r->extra) if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+        if (r->stream) (void)hipStreamSynchronize(r->stream);
+        r->cnt = cnt0; r->render_pending = false;
+        g_err = msg;
+    }
+    return rc;
+}
+static int render_impl(apt_renderer* r, int32_t n_spp) {
     const DevScene& sc = r->scene->dev;
     HIP_TRY(hipEventRecord(r->ev_r0, r->stream));
     for (auto& ln : r->extra) HIP_TRY(hipStreamWaitEvent(ln.stream, r->ev_r0, 0));     // lanes start after whatever the main stream did before
@@ -968,6 +990,7 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
     out->n_samples = sum(ST_SAMPLES); out->n_extend = sum(ST_EXTEND); out->n_shade = sum(ST_SHADE);
     out->n_shadow = sum(ST_SHADOW); out->n_shadow_traced = sum(ST_SHADOW_TRACED); out->n_lit = sum(ST_LIT);
     out->n_draws = sum(ST_DRAWS); out->n_poisoned = sum(ST_POISON); out->n_track = sum(ST_TRACK);
+    const int64_t n_overflow = sum(ST_OVERFLOW);
 #ifdef APT_SHADE_PROF
     {
         std::vector<unsigned long long> dbg(2 * 16384);
@@ -989,8 +1012,8 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
 #endif
 #ifdef APT_WALK_STATS
     fprintf(stderr, "[walk stats] closest-hit rays %lld: %.2f node steps, %.2f primitive tests per ray | shadow rays %lld: %.2f node steps, %.2f primitive tests per ray\n",
-            (long long)out->n_extend, (double)sum(9) / (double)std::max<int64_t>(1, out->n_extend), (double)sum(10) / (double)std::max<int64_t>(1, out->n_extend),
-            (long long)out->n_shadow_traced, (double)sum(11) / (double)std::max<int64_t>(1, out->n_shadow_traced), (double)sum(12) / (double)std::max<int64_t>(1, out->n_shadow_traced));
+            (long long)out->n_extend, (double)sum(10) / (double)std::max<int64_t>(1, out->n_extend), (double)sum(11) / (double)std::max<int64_t>(1, out->n_extend),
+            (long long)out->n_shadow_traced, (double)sum(12) / (double)std::max<int64_t>(1, out->n_shadow_traced), (double)sum(13) / (double)std::max<int64_t>(1, out->n_shadow_traced));
 #endif
 #ifdef APT_TILE_PROF
     fprintf(stderr, "[tile prof] wave-cycles: stage %lld | A %lld | wait %lld | B %lld | wait %lld | sweep total %lld | append %lld | tiles*waves %lld\n",
@@ -998,6 +1021,7 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
 #endif
     for (int k = 0; k < APT_N_KERNELS; k++) { out->launches[k] = r->launches[k]; out->kernel_ms[k] = r->kernel_ms[k]; }
     out->render_ms = r->render_ms;
+    if (n_overflow > 0) return fail(APT_E_STATE, "apt_get_stats: " + std::to_string((long long)n_overflow) + " volumetric path(s) drew more than 2^23 random numbers: the draw index wrapped and those paths re-used part of their stream");
     return APT_OK;
 }
 APT_EXPORT int apt_device_ptr(apt_renderer* r, void** accum_dev, int32_t* cnt) {
@@ -1162,7 +1186,7 @@ APT_EXPORT int apt_measure_sclk_mhz(int32_t device, float* mhz) {
     DevBuf out, sink;
     HIP_TRY(out.alloc((size_t)n_waves * 16)); HIP_TRY(sink.alloc(16));
     for (int pass = 0; pass < 2; pass++) {            // the first pass warms the clocks up
-        hipLaunchKernelGGL(k_clock_probe, dim3(grid), dim3(BLOCK), 0, 0, 400000, 1.0f, out.as<unsigned long long>(), sink.as<float>());
+        hipLaunchKernelGGL(k_clock_probe, dim3(grid), dim3(BLOCK), 0, 0, 20000, 1.0f, out.as<unsigned long long>(), sink.as<float>());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
     }

@@ -126,7 +126,7 @@ struct ShadeIn {
 #define APT_MAX_NQ 32
 #endif
 #define CNT_PAD 32                               // one counter per 128-byte line
-enum { ST_SAMPLES = 0, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_SHADOW_TRACED, ST_LIT, ST_DRAWS, ST_POISON, ST_TRACK, ST_COUNT };
+enum { ST_SAMPLES = 0, ST_EXTEND, ST_SHADE, ST_SHADOW, ST_SHADOW_TRACED, ST_LIT, ST_DRAWS, ST_POISON, ST_TRACK, ST_OVERFLOW, ST_COUNT };      // ST_OVERFLOW: volumetric paths whose draw index left its 23 bits
 struct Counters {
     uint32_t n_active[2][APT_MAX_NQ * CNT_PAD];
     uint32_t n_shadow[APT_MAX_NQ * CNT_PAD];
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
         } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
     }
 #ifdef APT_WALK_STATS
-    flush_stat(ws.nodes, &cnt->stats[sq][9]); flush_stat(ws.prims, &cnt->stats[sq][10]);
+    flush_stat(ws.nodes, &cnt->stats[sq][10]); flush_stat(ws.prims, &cnt->stats[sq][11]);
 #endif
 }
 
@@ -830,7 +830,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
     }
     flush_stat(t_lit, &cnt->stats[sq][ST_LIT]);
 #ifdef APT_WALK_STATS
-    flush_stat(ws.nodes, &cnt->stats[sq][11]); flush_stat(ws.prims, &cnt->stats[sq][12]);
+    flush_stat(ws.nodes, &cnt->stats[sq][12]); flush_stat(ws.prims, &cnt->stats[sq][13]);
 #endif
 }
 

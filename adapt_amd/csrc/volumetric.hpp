@@ -395,6 +395,7 @@ __global__ void __launch_bounds__(BLOCK, (((BM == 0x402 || BM == 0x00a || BM == 
             st3q(q.thr[nxt], p.cap, so, thr);
             stq(q.id[nxt], so, id);
             stq(q.meta[nxt], so, (rng.draw & 0x7fffffu) | (bounce << 23));      // tracking loops draw thousands of numbers per path: 16 bits would wrap
+            if (rng.draw > 0x7fffffu) atomicAdd(&cnt->stats[sl.q][ST_OVERFLOW], 1ull);     // a path that outgrows even 23 bits would silently re-use random numbers: reported by apt_synchronize / apt_get_stats
             stq(q.pdf[nxt], so, emission_weight);
         }
     }

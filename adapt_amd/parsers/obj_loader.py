@@ -10,7 +10,10 @@ itself and produces the same four arrays:
     vns     (N,3,3) float32   per-face-vertex normals, or None if the file has no `vn`
     uvs     (N,3,2) float32   per-face-vertex uvs,     or None if the file has no `vt`
 
-Polygons are fan-triangulated (0, i, i+1).  `apply_transform` /
+Polygons are fan-triangulated (0, i, i+1), the order pywavefront emits.  Like the reference, which reads the vertex stream of the
+FIRST material of the file only (`for wrapper in obj.materials.values(): ...; break`, obj_loader.py:35-37), faces that belong to a
+second `usemtl` group are dropped - with a warning here, silently upstream; faces before any `usemtl` form the first group.
+None of the bundled meshes has more than one group.  `apply_transform` /
 `calculate_surface_area` follow reference obj_loader.py:82-122 including the
 float32/float64 mixing of numpy (rotation matrices are float64, so a rotated
 mesh is float64 until the final pack casts it back).
@@ -37,12 +40,22 @@ def read_obj(path: str):
     as per-face-vertex float32 arrays of shape (N,3,k)."""
     pos, tex, nrm = [], [], []
     tri_p, tri_t, tri_n = [], [], []
+    group, first_group, dropped = None, None, 0          # `usemtl` groups: only the first one that owns a face is kept (see above)
     with open(path, "r") as fh:
         for raw in fh:
             line = raw.strip()
             if not line or line[0] == "#":
                 continue
             head, _, rest = line.partition(" ")
+            if head == "usemtl":
+                group = rest.strip()
+                continue
+            if head == "f":
+                if first_group is None:
+                    first_group = (group,)
+                elif first_group != (group,):
+                    dropped += 1
+                    continue
             if head == "v":
                 pos.append([float(x) for x in rest.split()[:3]])
             elif head == "vt":
@@ -64,6 +77,10 @@ def read_obj(path: str):
                     tri_n.append([nrm[c[2]] if c[2] >= 0 else [0., 0., 0.] for c in tri])
     if not tri_p:
         raise ValueError(f"OBJ file '{path}' contains no faces")
+    if dropped:
+        import warnings
+        warnings.warn(f"{path}: {dropped} faces of further `usemtl` groups ignored - the reference loads the first material's faces only "
+                      "(parsers/obj_loader.py:35-37)", RuntimeWarning)
     meshes = np.float32(tri_p).reshape(-1, 3, 3)
     uvs = np.float32(tri_t).reshape(-1, 3, 2) if tex else None
     vns = np.float32(tri_n).reshape(-1, 3, 3) if nrm else None

@@ -119,7 +119,7 @@ int apt_bvh_build(const float* prims /* n_prims*9 */, int32_t n_prims,
 int apt_bvh_counts(const apt_bvh*, int32_t* n_nodes, int32_t* n_leaf_prims, int32_t* max_depth);
 /* nodes: n_nodes*16 floats (two child boxes + two child links); prim_order: n_prims ints (BVH order -> original prim) */
 int apt_bvh_export(const apt_bvh*, float* nodes, int32_t* prim_order);
-/* The tree the traversal kernels walk: the binary tree (rebuilt with leaves of <= 3 primitives) collapsed to 8-wide nodes with
+/* The tree the traversal kernels walk: the binary tree (rebuilt with single-primitive leaves) collapsed to 8-wide nodes with
  * 8-bit quantised child boxes, 80 bytes = 20 dwords per node, breadth-first, node 0 = root (layout: csrc/bvh_wide.cpp);
  * prim_order: leaf-order slot -> original primitive.  n_levels = depth in 8-wide nodes. */
 int apt_bvh_wide_counts(const apt_bvh*, int32_t* n_nodes, int32_t* n_levels);

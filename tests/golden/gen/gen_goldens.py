@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz from the reference's own source (authoring container only).
 
-    python tests/golden/gen/gen_goldens.py [--only parse|func|image] 
+    python tests/golden/gen/gen_goldens.py [--only parse|func|media|image|features|textured|refscenes|vpt|volgrid|bvh]
 
 Every fixture is produced by calling UNMODIFIED reference code (/root/reference) under the
 float32 stand-in `taichi` package in shim/ (third-party taichi==1.6.0 is not installable
@@ -21,6 +21,14 @@ from taichi.math import vec3  # noqa: E402
 
 OUT = os.path.abspath(os.path.join(refenv.HERE, ".."))
 RS = np.random.RandomState(20260928)
+
+
+def reseed(fixture):
+    """Every fixture draws its random inputs from its own stream, seeded by its file name: `--only <section>` then rewrites exactly
+    the committed vectors, whatever else ran before it in the same process."""
+    import zlib
+    global RS
+    RS = np.random.RandomState(zlib.crc32(fixture.encode()) & 0x7fffffff)
 
 
 def unit(v):
@@ -73,6 +81,7 @@ def gen_functions():
     from renderer.constants import INVALID
     from sampler import general_sampling as gs
 
+    reseed("functions.npz")
     out = {}
     # --- rotation_between (incl. parallel / anti-parallel)
     A, B, R = [], [], []
@@ -202,6 +211,7 @@ def gen_media_functions():
     (bxdf/phase.py, sampler/phase_sampling.py) on the shared Philox stream: key = test index, seeds 779 (free path) / 780 (scatter)."""
     from bxdf.medium import Medium
     from bxdf.phase import PhaseFunction
+    reseed("media_functions.npz")
     media = [   # type, ior, u_s, u_a, par, pdf
         (0, 1.0, [1.2, 1.0, 0.8], [0.15] * 3, [0.6] * 3, [1, 0, 0]),                    # forward H-G, coloured
         (0, 1.0, [1.5] * 3, [0.2] * 3, [0.0] * 3, [1, 0, 0]),                           # isotropic branch of sample_hg (|g| < 1e-4)
@@ -247,6 +257,7 @@ def gen_media_functions():
 def gen_scene(scene_dir, xml, tag, w, h, spp, overrides, seed=0, n_rays=192):
     ov = dict(overrides); ov.update(width=w, height=h)
     t0 = time.time()
+    reseed(f"scene_{tag}.npz")
     rdr, (emitters, arr, objs, cfg) = refenv.make_renderer(scene_dir, xml, ov)
     out = {"width": np.int32(w), "height": np.int32(h), "spp": np.int32(spp), "seed": np.int32(seed),
            "max_bounce": np.int32(rdr.max_bounce), "num_shadow_ray": np.int32(rdr.num_shadow_ray)}

@@ -21,7 +21,46 @@ Semantics emulated (what the pt path relies on):
 import ctypes as _C
 import numpy as _np
 
-f32 = _np.float32
+class f32(_np.float32):
+    """The scalar the reference code computes with.  A numpy float32 whose arithmetic stays in this class, so that the two places
+    where numpy's own scalar semantics differ from Taichi's can be put right:
+      * `x ** n` with a small constant integer n is a multiplication chain (Taichi's simplifier; numpy calls powf, <= 1 ulp off),
+      * float `a % b` is a - b * floor(a / b) (taichi/lang/ops.py mod; numpy's remainder differs when a / b rounds up to an integer)."""
+    __slots__ = ()
+
+    def _wrap(r):
+        return f32(r) if isinstance(r, _np.floating) else r
+
+    def __add__(s, o): return f32._wrap(_np.float32.__add__(s, o))
+    def __radd__(s, o): return f32._wrap(_np.float32.__radd__(s, o))
+    def __sub__(s, o): return f32._wrap(_np.float32.__sub__(s, o))
+    def __rsub__(s, o): return f32._wrap(_np.float32.__rsub__(s, o))
+    def __mul__(s, o): return f32._wrap(_np.float32.__mul__(s, o))
+    def __rmul__(s, o): return f32._wrap(_np.float32.__rmul__(s, o))
+    def __truediv__(s, o): return f32._wrap(_np.float32.__truediv__(s, o))
+    def __rtruediv__(s, o): return f32._wrap(_np.float32.__rtruediv__(s, o))
+    def __neg__(s): return f32(_np.float32.__neg__(s))
+    def __pos__(s): return s
+    def __abs__(s): return f32(_np.float32.__abs__(s))
+
+    def __pow__(s, o):
+        if isinstance(o, Tensor):
+            return NotImplemented
+        return pow(s, o)
+
+    def __rpow__(s, o):
+        return pow(f32(o), s)
+
+    def __mod__(s, o):
+        if isinstance(o, Tensor):
+            return NotImplemented
+        o = f32(o)
+        return f32(s - o * f32(_np.floor(_np.float32(s) / _np.float32(o))))
+
+    def __rmod__(s, o):
+        return f32(o).__mod__(s)
+
+
 i32 = int32 = int
 float32 = f32
 i8 = u8 = i16 = u32 = u64 = i64 = int
@@ -256,7 +295,7 @@ _powf, atan2 = _m2("powf"), _m2("atan2f")
 
 def pow(x, y):
     """pow with a constant integer exponent is exponentiation by squaring (what Taichi's simplifier emits), else powf.
-    NB: numpy's own `np.float32 ** 2` on SCALARS (used by a few reference lines) goes through powf and can be 1 ulp off x*x."""
+    (Scalars reach this through f32.__pow__ as well, so `x ** 2` in the reference is x * x here as it is under Taichi.)"""
     if _is_int(y) and not isinstance(y, bool) and 0 < y <= 16:
         result, base, n = None, x, int(y)
         while n:

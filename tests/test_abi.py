@@ -347,7 +347,7 @@ def test_wide_bvh_invariants(scene, flat):
     walk(0, 1)
     assert sorted(seen_slots) == list(range(fs.n_prims)) and len(seen_nodes) == nodes.shape[0] and depth_seen[0] == levels
     if fs.n_prims > 1000:
-        assert nodes.shape[0] < fs.n_prims / 4 and levels <= 12           # 80-byte nodes, ~6 children each
+        assert nodes.shape[0] < fs.n_prims / 2.5 and levels <= 12         # 80-byte nodes over single-primitive leaves
 
 
 def test_wide_bvh_walk_finds_every_brute_force_hit():
