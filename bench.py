@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
     ap.add_argument("--single-device", action="store_true", help="dry run: every rank renders on cuda:0 (use with --backend gloo on a one-GPU box)")
     args = ap.parse_args()
+    if args.dump_image:
+        args.dump_image = os.path.abspath(args.dump_image)
+    os.chdir(ROOT)                  # texture / .vol paths inside scene files are relative to the repository root (rocprofv3 runs from /tmp)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))

@@ -24,3 +24,5 @@ cd $ROOT
 TXT=$ROOT/gpurun_out/profiles/$(printf "r%02d" $RND)_${CFG}_rocprofv3.txt
 { echo "# rocprofv3 passes of: bench.py --config $CFG --steps 1 --warmup 1 --spp $SPP --lanes 1 --no-cpu-baseline --no-exclusive-pass"; echo "# (1 + $SPP + $SPP spp rendered per pass: kernel-load render, warm-up step, timed step; tools/pmc_round.sh)"; python $ROOT/tools/summarize_prof.py $OUT; } > $TXT 2>&1
 python $ROOT/tools/make_counters_json.py $CFG $SPP $OUT $RND
+cp $OUT/stats.log $ROOT/gpurun_out/profiles/$(printf "r%02d" $RND)_${CFG}_bench_stdout.log 2>/dev/null
+rm -rf $OUT            # the rocprofv3 databases are tens of MiB per config; gpurun only merges 64 MiB back
