@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadapt_mi.so")
-SOURCES = ["api.hip", "bvh_build.cpp", "bvh_linear.cpp", "bvh_wide.cpp"]
+SOURCES = ["api.hip", "bvh_gpu.hip", "bvh_build.cpp", "bvh_linear.cpp", "bvh_wide.cpp"]
 HEADERS = ["vec.hpp", "rng.hpp", "shading.hpp", "traverse.hpp", "stages.hpp", "bvh_build.hpp", os.path.join("..", "..", "include", "adapt_mi.h"), "volumetric.hpp"]
 # -ffp-contract=off: the arithmetic written in csrc/ is the arithmetic executed (no FMA fusion), which is what
 # lets the HIP path and the CPU oracle agree bit-for-bit on almost every path (DESIGN.md "float parity").

@@ -130,6 +130,7 @@ struct apt_scene {
     DevBuf med;                          // participating media, n_objects + 1 rows (volumetric path tracer)
     DevBuf vol_grid;                     // grid volume densities
     bool has_volume = false;
+    bool gpu_built = false;              // the binary tree came from the device builder (bvh_gpu.hip)
     bool world_scattering = false;       // the world medium scatters (rays that hit nothing still take part, vpt.py:176-181)
     bool has_null_surface = false;       // some object carries a null BSDF (rays pass, vpt.py:189-191)
     bool phong_no_lobe = true;           // every Blinn-Phong material has k_s = 0 and finite k_g >= 0
@@ -281,7 +282,16 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     s->n_prims = N; s->n_objects = O; s->n_sources = S;
     int max_leaf = 1;                     // primitives per leaf of the binary tree (the 8-wide node encodes at most 3 per leaf child); measured 1 / 2 / 3: C4 1274 / 1236 / 1228, C5 1117 / 1073 / 1043 Msamples/s - a primitive test costs ~75 instructions whatever the fraction of the wave that needs it, a child box 19
     if (const char* ml = getenv("APT_BVH_LEAF")) max_leaf = std::min(3, std::max(1, atoi(ml)));
-    if (apt::build_bvh(d->prims, N, d->obj_info, O, s->bvh, max_leaf) != 0 || apt::build_wide_bvh(s->bvh, s->wide) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH build failed"); }
+    // builder: binned SAH on the host (better tree) below a million primitives, LBVH on the device above (scene-load time); APT_BVH_BUILDER overrides
+    bool gpu_build = N >= 1000000;
+    if (const char* bb = getenv("APT_BVH_BUILDER")) gpu_build = !strcmp(bb, "lbvh") && N >= 2;
+    s->gpu_built = false;
+    if (gpu_build) {
+        const int rc_ = apt::build_bvh_gpu(d->prims, N, d->obj_info, O, device, s->bvh);
+        if (rc_ != 0) { delete s; return fail(APT_E_HIP, "apt_scene_create: device BVH build failed (" + std::to_string(rc_) + ")"); }
+        s->gpu_built = true;
+    } else if (apt::build_bvh(d->prims, N, d->obj_info, O, s->bvh, max_leaf) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH build failed"); }
+    if (apt::build_wide_bvh(s->bvh, s->wide) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH collapse failed"); }
 
     std::vector<int> prim_obj((size_t)N, 0);
     std::vector<uint8_t> sphere((size_t)N, 0);

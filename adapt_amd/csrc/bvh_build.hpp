@@ -14,6 +14,9 @@ struct BvhData {
 // max_leaf: primitives per leaf (1..4; the 8-wide tree below wants 3)
 int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, BvhData& out, int max_leaf = 4);
 
+// bvh_gpu.hip: the same binary tree (single-primitive leaves) built on the device: LBVH (Morton sort + Karras' radix tree + bottom-up fit)
+int build_bvh_gpu(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, int device, BvhData& out);
+
 // 8-wide tree with quantised child boxes, what the traversal kernels walk (bvh_wide.cpp; layout in traverse.hpp).
 struct WideBvhData {
     std::vector<uint32_t> nodes;       // 20 dwords (80 bytes) per node, node 0 = root, breadth-first
