@@ -160,9 +160,58 @@ APT_D bool tri_one(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, Wa
     if (t > 1e-4f && (t < rec.t || (t == rec.t && kid < rec.prim))) { rec.t = t; rec.prim = kid; rec.u = u; rec.v = v; }
     return false;
 }
+// Two primitives of a triangle group per call, in the two halves of packed f32 instructions (v_pk_mul_f32 / v_pk_add_f32 round
+// each half exactly like the scalar instruction, and -ffp-contract=off forbids a packed FMA): the same arithmetic as prim_test(),
+// ~95 instructions for two triangles instead of 2 x 75.  A lane with a single pending primitive tests it in both halves; spheres
+// (rare in scenes large enough for the tree) take the scalar path.
+template <bool ANY>
+APT_D bool tri_two(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
+    const uint32_t k0 = 31u - (uint32_t)__clz((int)tg.y);
+    const uint32_t rest = tg.y & ~(1u << k0);
+    const bool two = rest != 0u;
+    const uint32_t k1 = two ? 31u - (uint32_t)__clz((int)rest) : k0;
+    tg.y = two ? (rest & ~(1u << k1)) : 0u;
+    const char* ba = reinterpret_cast<const char*>(b.prims) + (tg.x + k0) * 48u;
+    const char* bb = reinterpret_cast<const char*>(b.prims) + (tg.x + k1) * 48u;
+    const float4 a0 = *reinterpret_cast<const float4*>(ba), a1 = *reinterpret_cast<const float4*>(ba + 16), a2 = *reinterpret_cast<const float4*>(ba + 32);
+    const float4 b0 = *reinterpret_cast<const float4*>(bb), b1 = *reinterpret_cast<const float4*>(bb + 16), b2 = *reinterpret_cast<const float4*>(bb + 32);
+    WALK_COUNT(ws.prims); if (two) WALK_COUNT(ws.prims);
+    v2f t, u, v;
+    if (__float_as_int(a2.z) != 0 || __float_as_int(b2.z) != 0) {              // a sphere among the two: scalar tests
+        float uu, vv;
+        t.x = prim_test(a0, a1, a2, r.o, r.d, uu, vv); u.x = uu; v.x = vv;
+        t.y = prim_test(b0, b1, b2, r.o, r.d, uu, vv); u.y = uu; v.y = vv;
+    } else {
+        // columns (e1, e2, -d); inverse = adjugate * (1/det), Taichi's 3x3 formula - prim_test() on two triangles at once
+        const v2f a00 = mk2(a0.w, b0.w), a10 = mk2(a1.x, b1.x), a20 = mk2(a1.y, b1.y);      // e1
+        const v2f a01 = mk2(a1.z, b1.z), a11 = mk2(a1.w, b1.w), a21 = mk2(a2.x, b2.x);      // e2
+        const v2f a02 = sp2(-r.d.x), a12 = sp2(-r.d.y), a22 = sp2(-r.d.z);
+        const v2f c00 = a11 * a22 - a21 * a12, c01 = a21 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
+        const v2f det = (a00 * c00 + a10 * c01) + a20 * c02;
+        v2f inv_det; inv_det.x = 1.0f / det.x; inv_det.y = 1.0f / det.y;
+        const v2f sx = sp2(r.o.x) - mk2(a0.x, b0.x), sy = sp2(r.o.y) - mk2(a0.y, b0.y), sz = sp2(r.o.z) - mk2(a0.z, b0.z);
+        const v2f c10 = a12 * a20 - a22 * a10, c11 = a22 * a00 - a02 * a20, c12 = a02 * a10 - a12 * a00;
+        const v2f c20 = a10 * a21 - a20 * a11, c21 = a20 * a01 - a00 * a21, c22 = a00 * a11 - a10 * a01;
+        u = ((inv_det * c00) * sx + (inv_det * c01) * sy) + (inv_det * c02) * sz;
+        v = ((inv_det * c10) * sx + (inv_det * c11) * sy) + (inv_det * c12) * sz;
+        t = ((inv_det * c20) * sx + (inv_det * c21) * sy) + (inv_det * c22) * sz;
+        const v2f uv = u + v;
+        t.x = (u.x >= 0.f && v.x >= 0.f && uv.x <= 1.0f) ? t.x : -1.f;
+        t.y = (u.y >= 0.f && v.y >= 0.f && uv.y <= 1.0f) ? t.y : -1.f;
+    }
+    if (ANY) return (t.x > 1e-4f && t.x < rec.t) || (t.y > 1e-4f && t.y < rec.t);
+    const int ka = __float_as_int(a2.y), kb = __float_as_int(b2.y);
+    if (t.x > 1e-4f && (t.x < rec.t || (t.x == rec.t && ka < rec.prim))) { rec.t = t.x; rec.prim = ka; rec.u = u.x; rec.v = v.x; }
+    if (t.y > 1e-4f && (t.y < rec.t || (t.y == rec.t && kb < rec.prim))) { rec.t = t.y; rec.prim = kb; rec.u = u.y; rec.v = v.y; }
+    return false;
+}
 template <bool ANY>
 APT_D bool tri_group(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
+#ifdef APT_TRI_SINGLE
     while (tg.y != 0u) if (tri_one<ANY>(b, tg, r, rec, ws)) return true;
+#else
+    while (tg.y != 0u) if (tri_two<ANY>(b, tg, r, rec, ws)) return true;
+#endif
     return false;
 }
 
