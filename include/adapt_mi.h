@@ -4,8 +4,9 @@
  * for its `vpt` renderer (VolumeRenderer, renderer/vpt.py: homogeneous media, null surfaces, one grid volume).
  *
  * What each entry point replaces in the reference (paths under /root/reference):
- *   apt_bvh_build / apt_bvh_*      tracer/bvh/bvh.cpp:274-296  bvh_cpp.bvh_build(...) (pybind11 module),
- *                                   called from tracer/path_tracer.py:143-179 (bvh_process)
+ *   apt_bvh_build_linear / apt_linear_bvh_*   tracer/bvh/bvh.cpp:274-296  bvh_cpp.bvh_build(...) (pybind11 module), called from
+ *                                   tracer/path_tracer.py:143-179 (bvh_process): the same four arrays in the same layout
+ *   apt_bvh_build / apt_bvh_*      the same builder's role for this library's own kernels (binary SAH tree -> 8-wide quantised tree)
  *   apt_scene_create               tracer/tracer_base.py:117-134 (load_primitives) +
  *                                   tracer/path_tracer.py:245-274 (initialze): numpy -> device fields
  *   apt_renderer_create            renderer/vanilla_renderer.py:26-30 / tracer_base.py:36-102 (film, crop, camera,
