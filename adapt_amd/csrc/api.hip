@@ -47,7 +47,7 @@ static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT
 // Material classes for sorted shading: (class mask) x (emitter mask: point+area | all)
 // A kernel's register allocation is the maximum over the models it contains, so the classes are as fine as the models'
 // footprints differ: Lambertian alone runs at 4 waves per SIMD, together with Blinn-Phong (three double pows) at 2-3.
-#define APT_N_CLASS_DEFS 8
+#define APT_N_CLASS_DEFS 9
 static const int kClassMask[APT_N_CLASS_DEFS] = {
     0x00a,      // Lambertian (and the microfacet id, compiled out upstream: shades as Lambertian)
     0x001,      // Blinn-Phong
@@ -57,19 +57,22 @@ static const int kClassMask[APT_N_CLASS_DEFS] = {
     0x020,      // Fresnel blend
     0x080,      // thin coat
     0x200,      // Lambertian transmission
+    0x801,      // Blinn-Phong objects without a specular lobe (k_s = 0, finite k_g >= 0: shading.hpp mask bit 11): no double-precision pow
 };
-static const char* kClassName[APT_N_CLASS_DEFS] = {"lambertian", "blinn-phong", "oren-nayar", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans"};
+static const char* kClassName[APT_N_CLASS_DEFS] = {"lambertian", "blinn-phong", "oren-nayar", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans", "blinn-phong(no lobe)"};
 static const shade_fn kClassShade[APT_N_CLASS_DEFS][2] = {
     {k_shade<0x00a, 0x03>, k_shade<0x00a, APT_SRC_ALL>}, {k_shade<0x001, 0x03>, k_shade<0x001, APT_SRC_ALL>},
     {k_shade<0x040, 0x03>, k_shade<0x040, APT_SRC_ALL>}, {k_shade<0x504, 0x03>, k_shade<0x504, APT_SRC_ALL>},
     {k_shade<0x010, 0x03>, k_shade<0x010, APT_SRC_ALL>}, {k_shade<0x020, 0x03>, k_shade<0x020, APT_SRC_ALL>},
     {k_shade<0x080, 0x03>, k_shade<0x080, APT_SRC_ALL>}, {k_shade<0x200, 0x03>, k_shade<0x200, APT_SRC_ALL>},
+    {k_shade<0x801, 0x03>, k_shade<0x801, APT_SRC_ALL>},
 };
-// Blinn-Phong class in scenes where none of its materials has a specular lobe (shading.hpp, mask bit 11)
-static const shade_fn kPhongDiffuseShade[2] = {k_shade<0x801, 0x03>, k_shade<0x801, APT_SRC_ALL>};
-static int class_of(int is_bsdf, int type) {
+#define APT_CLASS_PHONG 1
+#define APT_CLASS_PHONG_NO_LOBE 8
+static int class_of(int is_bsdf, int type, bool no_lobe) {
     const int bit = is_bsdf ? (type == 0 ? 8 : (type == 1 ? 9 : 10)) : (type & 7);
-    for (int c = 0; c < APT_N_CLASS_DEFS; c++) if ((kClassMask[c] >> bit) & 1) return c;
+    if (!is_bsdf && (type & 7) == 0 && no_lobe) return APT_CLASS_PHONG_NO_LOBE;
+    for (int c = 0; c < APT_N_CLASS_DEFS - 1; c++) if ((kClassMask[c] >> bit) & 1) return c;
     return 0;        // microfacet (compiled out upstream) shades as nothing; keep it with the diffuse class
 }
 typedef void (*extend_fn)(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan);
@@ -94,6 +97,7 @@ static const vshade_fn kVClassShade[APT_N_CLASS_DEFS + 1][2] = {
     {k_vshade<0x040, APT_SRC_ALL>, k_vshade<0x040, APT_SRC_ALL, 1>}, {k_vshade<0x504, APT_SRC_ALL>, k_vshade<0x504, APT_SRC_ALL, 1>},
     {k_vshade<0x010, APT_SRC_ALL>, k_vshade<0x010, APT_SRC_ALL, 1>}, {k_vshade<0x020, APT_SRC_ALL>, k_vshade<0x020, APT_SRC_ALL, 1>},
     {k_vshade<0x080, APT_SRC_ALL>, k_vshade<0x080, APT_SRC_ALL, 1>}, {k_vshade<0x200, APT_SRC_ALL>, k_vshade<0x200, APT_SRC_ALL, 1>},
+    {k_vshade<0x001, APT_SRC_ALL>, k_vshade<0x001, APT_SRC_ALL, 1>},        // (the volumetric tracer does not split Blinn-Phong by lobe)
     {k_vshade<0x000, APT_SRC_ALL>, k_vshade<0x000, APT_SRC_ALL, 1>},
 };
 static const VShadeVariant kVShadeVolVariants[] = {       // scenes with a grid volume
@@ -136,7 +140,7 @@ struct apt_scene {
     bool phong_no_lobe = true;           // every Blinn-Phong material has k_s = 0 and finite k_g >= 0
     float box_min[3] = {1e3f, 1e3f, 1e3f}, box_max[3] = {-1e3f, -1e3f, -1e3f};    // union of the object boxes (path_tracer.py:130-134)
     int n_classes = 0;                   // material classes present (compact ids 0..n_classes-1)
-    int class_def[APT_N_CLASS_DEFS] = {0, 0, 0, 0, 0, 0, 0, 0};   // compact id -> class definition
+    int class_def[APT_N_CLASS_DEFS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // compact id -> class definition
     int n_prims = 0, n_objects = 0, n_sources = 0, max_obj_prims = 0;
     int bx_mask = 0, src_mask = 0;
     bool has_aabb = false;
@@ -165,7 +169,7 @@ struct apt_renderer {
     const VShadeVariant* vshade = nullptr;
     vshade_fn vclass_fn[APT_N_CLASS_DEFS + 1] = {};     // sorted volumetric shading: kernel per class queue (the miss class last)
     int v_ncls = 0;               // class queues in use (surface classes + the miss class when misses matter)
-    shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     std::string shade_name;
     LdsPlan plan{};
     size_t lds_bytes = 0, lds_bytes_any = 0;     // dynamic LDS of the closest-hit / any-hit trace kernels
@@ -345,23 +349,36 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     std::vector<float> aabb((size_t)O * 6, 0.f);
     if (d->obj_aabb) aabb.assign(d->obj_aabb, d->obj_aabb + (size_t)O * 6);
     std::vector<DevBxdf> bx((size_t)O);
+    std::vector<uint8_t> no_lobe((size_t)O, 0);
     for (int o = 0; o < O; o++) {
         const int32_t* bi = d->bxdf_i + 4 * o; const float* bf = d->bxdf_f + 13 * o;
         DevBxdf& b = bx[(size_t)o]; memset(&b, 0, sizeof(b));
         b.type = bi[0]; b.is_delta = bi[1]; b.is_bsdf = bi[2];
         s->bx_mask |= b.is_bsdf ? (b.type == 0 ? 0x100 : (b.type == 1 ? 0x200 : 0x400)) : (1 << (b.type & 7));
         b.k_d = mk3(bf[0], bf[1], bf[2]); b.k_s = mk3(bf[3], bf[4], bf[5]); b.k_g = mk3(bf[6], bf[7], bf[8]); b.mean = mk3(bf[9], bf[10], bf[11]); b.ior = bf[12];
-        if (!b.is_bsdf && b.type == 0)
-            for (int a = 0; a < 3; a++) if (!(bf[3 + a] == 0.f && !std::signbit(bf[3 + a]) && bf[6 + a] >= 0.f && std::isfinite(bf[6 + a]))) s->phong_no_lobe = false;
+        no_lobe[(size_t)o] = 0;
+        if (!b.is_bsdf && b.type == 0) {
+            bool lean = true;
+            for (int a = 0; a < 3; a++) if (!(bf[3 + a] == 0.f && !std::signbit(bf[3 + a]) && bf[6 + a] >= 0.f && std::isfinite(bf[6 + a]))) lean = false;
+            no_lobe[(size_t)o] = lean ? 1 : 0;
+            if (!lean) s->phong_no_lobe = false;
+        }
     }
-    // material classes present in this scene -> compact ids; per-primitive class table for the sorting extend
+    // material classes present in this scene -> compact ids; per-primitive class table for the sorting extend.  Blinn-Phong objects
+    // without a specular lobe (the diffuse walls of most scenes) get a class of their own, whose kernel carries no double-precision
+    // pow - unless that would need more class queues than there are (APT_MAX_CLASSES), then they stay with the other Blinn-Phong objects
     {
-        int compact[APT_N_CLASS_DEFS]; for (int c = 0; c < APT_N_CLASS_DEFS; c++) compact[c] = -1;
+        int compact[APT_N_CLASS_DEFS];
         std::vector<int> obj_cls((size_t)O);
-        for (int o = 0; o < O; o++) {
-            int c = class_of(bx[(size_t)o].is_bsdf, bx[(size_t)o].type);
-            if (compact[c] < 0) { compact[c] = s->n_classes; s->class_def[s->n_classes++] = c; }
-            obj_cls[(size_t)o] = compact[c];
+        for (int split = 1; split >= 0; split--) {
+            for (int c = 0; c < APT_N_CLASS_DEFS; c++) compact[c] = -1;
+            s->n_classes = 0;
+            for (int o = 0; o < O; o++) {
+                int c = class_of(bx[(size_t)o].is_bsdf, bx[(size_t)o].type, split && no_lobe[(size_t)o]);
+                if (compact[c] < 0) { compact[c] = s->n_classes; s->class_def[s->n_classes++] = c; }
+                obj_cls[(size_t)o] = compact[c];
+            }
+            if (s->n_classes <= APT_MAX_CLASSES) break;
         }
         std::vector<int> pcls((size_t)N);
         for (int k = 0; k < N; k++) pcls[(size_t)k] = obj_cls[(size_t)prim_obj[(size_t)k]];
@@ -565,7 +582,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
             r->sorted = 1;
             r->v_ncls = sc->n_classes + (keep_miss ? 1 : 0);
             for (int c = 0; c < sc->n_classes; c++) r->vclass_fn[c] = kVClassShade[sc->class_def[c]][sc->has_volume ? 1 : 0];
-            if (keep_miss) r->vclass_fn[sc->n_classes] = kVClassShade[APT_N_CLASS_DEFS][sc->has_volume ? 1 : 0];
+            if (keep_miss) r->vclass_fn[sc->n_classes] = kVClassShade[APT_N_CLASS_DEFS][sc->has_volume ? 1 : 0];      // the last row: rays that hit nothing
         }
         for (int a = 0; a < 3; a++) {                         // path_tracer.py:136-138
             p.w_min[a] = std::min(c.cam_t[a], sc->box_min[a]) - 0.1f; p.w_max[a] = std::max(c.cam_t[a], sc->box_max[a]) + 0.1f;
@@ -581,9 +598,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : 1;
         r->shade_name = "sorted:";
         for (int c = 0; c < ncls; c++) {
-            const bool lean_phong = sc->class_def[c] == 1 && sc->phong_no_lobe;
-            r->class_fn[c] = lean_phong ? kPhongDiffuseShade[smi] : kClassShade[sc->class_def[c]][smi];
-            r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]] + (lean_phong ? "(no lobe)" : "");
+            r->class_fn[c] = kClassShade[sc->class_def[c]][smi];
+            r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
         }
     }
     // the kernels address queue slots with 32-bit byte offsets (stages.hpp "Queue addressing")

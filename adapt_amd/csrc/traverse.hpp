@@ -36,7 +36,13 @@ APT_D v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 // Ray as the walk wants it.  The reciprocal direction is clamped to +-1e30 so that axis-parallel rays produce huge but finite slab
 // distances of the right sign (inf would turn the fused form q * s + c into inf - inf = NaN and the axis would stop culling).
 struct WalkRay { f3 o, d, inv, noo; uint32_t octinv4; };
+#ifdef APT_WALK_IEEE_RCP
 APT_D float walk_rcp(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e30f, d) : 1.0f / d; }
+#else
+// v_rcp_f32 (1 ulp) is enough: the reciprocal only feeds the conservative box tests, whose margin (the builder's 1e-4 padding) is
+// three orders of magnitude above it; the exact per-primitive tests divide for themselves
+APT_D float walk_rcp(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e30f, d) : __builtin_amdgcn_rcpf(d); }
+#endif
 APT_D WalkRay make_walk_ray(f3 o, f3 d) {
     WalkRay r; r.o = o; r.d = d;
     r.inv = mk3(walk_rcp(d.x), walk_rcp(d.y), walk_rcp(d.z));
