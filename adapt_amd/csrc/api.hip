@@ -47,9 +47,9 @@ static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT
 // Material classes for sorted shading: (class mask) x (emitter mask: point+area | all)
 // A kernel's register allocation is the maximum over the models it contains, so the classes are as fine as the models'
 // footprints differ: Lambertian alone runs at 4 waves per SIMD, together with Blinn-Phong (three double pows) at 2-3.
-#define APT_N_CLASS_DEFS 9
+#define APT_N_CLASS_DEFS 10
 static const int kClassMask[APT_N_CLASS_DEFS] = {
-    0x00a,      // Lambertian (and the microfacet id, compiled out upstream: shades as Lambertian)
+    0x002,      // Lambertian
     0x001,      // Blinn-Phong
     0x040,      // Oren-Nayar
     0x504,      // delta: mirror BRDF, det-refraction BSDF, null BSDF
@@ -57,23 +57,24 @@ static const int kClassMask[APT_N_CLASS_DEFS] = {
     0x020,      // Fresnel blend
     0x080,      // thin coat
     0x200,      // Lambertian transmission
+    0x008,      // Trowbridge-Reitz microfacet (upstream's opt-in model: type 3 reaches the device only with the switch on)
     0x801,      // Blinn-Phong objects without a specular lobe (k_s = 0, finite k_g >= 0: shading.hpp mask bit 11): no double-precision pow
 };
-static const char* kClassName[APT_N_CLASS_DEFS] = {"lambertian", "blinn-phong", "oren-nayar", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans", "blinn-phong(no lobe)"};
+static const char* kClassName[APT_N_CLASS_DEFS] = {"lambertian", "blinn-phong", "oren-nayar", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans", "microfacet", "blinn-phong(no lobe)"};
 static const shade_fn kClassShade[APT_N_CLASS_DEFS][2] = {
-    {k_shade<0x00a, 0x03>, k_shade<0x00a, APT_SRC_ALL>}, {k_shade<0x001, 0x03>, k_shade<0x001, APT_SRC_ALL>},
+    {k_shade<0x002, 0x03>, k_shade<0x002, APT_SRC_ALL>}, {k_shade<0x001, 0x03>, k_shade<0x001, APT_SRC_ALL>},
     {k_shade<0x040, 0x03>, k_shade<0x040, APT_SRC_ALL>}, {k_shade<0x504, 0x03>, k_shade<0x504, APT_SRC_ALL>},
     {k_shade<0x010, 0x03>, k_shade<0x010, APT_SRC_ALL>}, {k_shade<0x020, 0x03>, k_shade<0x020, APT_SRC_ALL>},
     {k_shade<0x080, 0x03>, k_shade<0x080, APT_SRC_ALL>}, {k_shade<0x200, 0x03>, k_shade<0x200, APT_SRC_ALL>},
-    {k_shade<0x801, 0x03>, k_shade<0x801, APT_SRC_ALL>},
+    {k_shade<0x008, 0x03>, k_shade<0x008, APT_SRC_ALL>}, {k_shade<0x801, 0x03>, k_shade<0x801, APT_SRC_ALL>},
 };
 #define APT_CLASS_PHONG 1
-#define APT_CLASS_PHONG_NO_LOBE 8
+#define APT_CLASS_PHONG_NO_LOBE 9
 static int class_of(int is_bsdf, int type, bool no_lobe) {
     const int bit = is_bsdf ? (type == 0 ? 8 : (type == 1 ? 9 : 10)) : (type & 7);
     if (!is_bsdf && (type & 7) == 0 && no_lobe) return APT_CLASS_PHONG_NO_LOBE;
     for (int c = 0; c < APT_N_CLASS_DEFS - 1; c++) if ((kClassMask[c] >> bit) & 1) return c;
-    return 0;        // microfacet (compiled out upstream) shades as nothing; keep it with the diffuse class
+    return 0;
 }
 typedef void (*extend_fn)(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan);
 typedef void (*shadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan);
@@ -93,10 +94,11 @@ static const VShadeVariant kVShadeVariants[] = {          // first match wins; 0
 // APT_N_CLASS_DEFS: media only), without / with a grid volume.  Every class kernel carries the medium code; what it sheds is the
 // other surface models, i.e. most of the all-models kernel's 256 VGPRs + AGPR spills.
 static const vshade_fn kVClassShade[APT_N_CLASS_DEFS + 1][2] = {
-    {k_vshade<0x00a, APT_SRC_ALL>, k_vshade<0x00a, APT_SRC_ALL, 1>}, {k_vshade<0x001, APT_SRC_ALL>, k_vshade<0x001, APT_SRC_ALL, 1>},
+    {k_vshade<0x002, APT_SRC_ALL>, k_vshade<0x002, APT_SRC_ALL, 1>}, {k_vshade<0x001, APT_SRC_ALL>, k_vshade<0x001, APT_SRC_ALL, 1>},
     {k_vshade<0x040, APT_SRC_ALL>, k_vshade<0x040, APT_SRC_ALL, 1>}, {k_vshade<0x504, APT_SRC_ALL>, k_vshade<0x504, APT_SRC_ALL, 1>},
     {k_vshade<0x010, APT_SRC_ALL>, k_vshade<0x010, APT_SRC_ALL, 1>}, {k_vshade<0x020, APT_SRC_ALL>, k_vshade<0x020, APT_SRC_ALL, 1>},
     {k_vshade<0x080, APT_SRC_ALL>, k_vshade<0x080, APT_SRC_ALL, 1>}, {k_vshade<0x200, APT_SRC_ALL>, k_vshade<0x200, APT_SRC_ALL, 1>},
+    {k_vshade<0x008, APT_SRC_ALL>, k_vshade<0x008, APT_SRC_ALL, 1>},
     {k_vshade<0x001, APT_SRC_ALL>, k_vshade<0x001, APT_SRC_ALL, 1>},        // (the volumetric tracer does not split Blinn-Phong by lobe)
     {k_vshade<0x000, APT_SRC_ALL>, k_vshade<0x000, APT_SRC_ALL, 1>},
 };
@@ -140,7 +142,7 @@ struct apt_scene {
     bool phong_no_lobe = true;           // every Blinn-Phong material has k_s = 0 and finite k_g >= 0
     float box_min[3] = {1e3f, 1e3f, 1e3f}, box_max[3] = {-1e3f, -1e3f, -1e3f};    // union of the object boxes (path_tracer.py:130-134)
     int n_classes = 0;                   // material classes present (compact ids 0..n_classes-1)
-    int class_def[APT_N_CLASS_DEFS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // compact id -> class definition
+    int class_def[APT_N_CLASS_DEFS] = {};   // compact id -> class definition
     int n_prims = 0, n_objects = 0, n_sources = 0, max_obj_prims = 0;
     int bx_mask = 0, src_mask = 0;
     bool has_aabb = false;
@@ -169,7 +171,7 @@ struct apt_renderer {
     const VShadeVariant* vshade = nullptr;
     vshade_fn vclass_fn[APT_N_CLASS_DEFS + 1] = {};     // sorted volumetric shading: kernel per class queue (the miss class last)
     int v_ncls = 0;               // class queues in use (surface classes + the miss class when misses matter)
-    shade_fn class_fn[APT_N_CLASS_DEFS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    shade_fn class_fn[APT_N_CLASS_DEFS] = {};
     std::string shade_name;
     LdsPlan plan{};
     size_t lds_bytes = 0, lds_bytes_any = 0;     // dynamic LDS of the closest-hit / any-hit trace kernels
@@ -559,8 +561,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         if (e_ != hipSuccess) { return fail(APT_E_HIP, std::string("upload pix_key: ") + hipGetErrorString(e_)); }
         p.pix_key = r->pix_key.as<uint32_t>();
     }
-    r->sorted = (sc->n_classes >= 2) ? 1 : 0;
-    if (const char* force = getenv("APT_SORTED")) r->sorted = (atoi(force) != 0 && sc->n_classes >= 1) ? 1 : 0;
+    r->sorted = (sc->n_classes >= 2 && sc->n_classes <= APT_MAX_CLASSES) ? 1 : 0;        // all nine surface models in one scene: the all-models kernel
+    if (const char* force = getenv("APT_SORTED")) r->sorted = (atoi(force) != 0 && sc->n_classes >= 1 && sc->n_classes <= APT_MAX_CLASSES) ? 1 : 0;
     if (textured) r->sorted = 0;
     r->volumetric = c.volumetric ? 1 : 0;
     if (r->volumetric) {
@@ -621,6 +623,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         q.sh_walk[0] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr; q.sh_walk[1] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr;
         q.n_classes = ncls;
         q.miss_class = (r->volumetric && r->v_ncls > sc->n_classes) ? sc->n_classes : -1;
+        q.miss_rr_draw = (r->volumetric && ncls > 0 && q.miss_class < 0) ? 1 : 0;
         for (int c = 0; c < ncls; c++) {
             Queues::ClassQ& k = q.cls[c];
             k.ray_o = take(3 * cap); k.ray_d = take(3 * cap); k.thr = take(3 * cap); k.id = (uint32_t*)take(cap); k.meta = (uint32_t*)take(cap);

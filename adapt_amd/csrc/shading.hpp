@@ -1,7 +1,7 @@
 // shading.hpp — device-side surface models, emitters, frames and optics for the gfx950 path tracer.
 //
 // Behavioural contract = AdaPT's `pt` renderer (citations under /root/reference):
-//   bxdf/brdf.py:147-601        BRDF: Blinn-Phong(0) Lambertian(1) Specular(2) [Microfacet(3) compiled out]
+//   bxdf/brdf.py:147-601        BRDF: Blinn-Phong(0) Lambertian(1) Specular(2) Microfacet(3: upstream's opt-in switch)
 //                               Mod-Phong(4) Fresnel-Blend(5) Oren-Nayar(6) Thin-coat(7)
 //   bxdf/bsdf.py:61-262         BSDF: det-refraction(0) Lambertian-transmission(1) null(-1)
 //   emitters/abtract_source.py:81-232   sample_hit / eval_le / solid_angle_pdf
@@ -59,8 +59,7 @@ APT_D f3 delocalize(f3 anchor, f3 local_dir, m33& R) { rotation_between(mk3(0.f,
 APT_D f3 localize(f3 anchor, f3 global_dir) { m33 R; rotation_between(anchor, mk3(0.f, 1.f, 0.f), R); return mul(R, global_dir); }
 
 struct RawAngles { float cos_t, sin_t, cos_p, sin_p; };
-APT_D RawAngles to_raw(f3 d_in, f3 normal) {
-    f3 l = localize(normal, d_in);
+APT_D RawAngles raw_of_local(f3 l) {               // convert_to_raw(..., localize = False)
     RawAngles a;
     a.cos_t = l.y;
     a.sin_t = sqrtf(fmaxf(0.f, 1.f - a.cos_t * a.cos_t));
@@ -68,6 +67,7 @@ APT_D RawAngles to_raw(f3 d_in, f3 normal) {
     if (a.sin_t > 1e-5f) { a.cos_p = l.x / a.sin_t; a.sin_p = l.z / a.sin_t; }
     return a;
 }
+APT_D RawAngles to_raw(f3 d_in, f3 normal) { return raw_of_local(localize(normal, d_in)); }
 
 // ------------------------------------------------------------------- optics
 APT_D f3 reflect_in(f3 ray, f3 normal) {           // inci_reflect_dir
@@ -309,6 +309,127 @@ APT_D float thin_coat_fresnel(const DevBxdf& b, const Hit& it, f3 in) {
     return fresnel_dielectric(1.f, b.k_g.z, fabsf(d_in), sqrtf(cos_r2));
 }
 
+// ---------------------------------------------------- Trowbridge-Reitz microfacet BRDF (type 3)
+// sampler/microfacet.py:27-176 + bxdf/brdf.py:428-484.  Upstream ships it switched off (`__ENABLE_MICROFACET__`, brdf.py:8) and its
+// parser then turns a microfacet BRDF into a Lambertian one, so type 3 reaches the device only with the switch on
+// (adapt_amd/materials.py ENABLE_MICROFACET): that is what type 3 means here.  k_g = (alpha_x, alpha_y, .), k_s = (ior outside, ior inside, .).
+APT_D float fresnel_eval(float cos_v, float n_in, float n_tr) {            // geo_optics.py:29-44
+    const bool neg = cos_v < 0.f;
+    const float cv = neg ? -cos_v : cos_v;
+    const float ior_in = neg ? n_tr : n_in, ior_tr = neg ? n_in : n_tr;
+    const float sin_v = sqrtf(fmaxf(0.f, 1.f - cv * cv));
+    const float sin_t = ior_in / ior_tr * sin_v;
+    const float cos_tr = sqrtf(fmaxf(0.f, 1.f - sin_t * sin_t));
+    return fresnel_dielectric(ior_in, ior_tr, cv, cos_tr);
+}
+APT_D float trow_reitz_D(const RawAngles& w, f3 alphas) {
+    float pdf = 0.f;
+    if (w.cos_t > 0.f) {
+        const float d2 = w.cos_t * w.cos_t, d4 = d2 * d2;
+        const float tan2 = w.sin_t * w.sin_t / d2;
+        const float e = (w.cos_p * w.cos_p / (alphas.x * alphas.x) + w.sin_p * w.sin_p / (alphas.y * alphas.y)) * tan2;
+        pdf = 1.f / (APT_PI * alphas.x * alphas.y * d4 * (1.f + e) * (1.f + e));
+    }
+    return pdf;
+}
+APT_D float trow_reitz_lambda(f3 dir_vec, f3 alphas, f3 normal) {
+    float value = 0.f;
+    const RawAngles w = to_raw(dir_vec, normal);
+    const float abs_cos = fabsf(w.cos_t);
+    if (abs_cos > 1e-5f) {
+        const float abs_tan = w.sin_t / abs_cos;
+        const float alpha = sqrtf(w.cos_p * w.cos_p * alphas.x * alphas.x + w.sin_p * w.sin_p * alphas.y * alphas.y);
+        float at2 = alpha * abs_tan;
+        at2 *= at2;
+        value = (-1.f + sqrtf(1.f + at2)) * 0.5f;
+    }
+    return value;
+}
+APT_D float trow_reitz_G1(f3 d, f3 alphas, f3 normal) { return 1.f / (1.f + trow_reitz_lambda(d, alphas, normal)); }
+APT_D float trow_reitz_G(f3 in, f3 out, f3 alphas, f3 normal) { return 1.f / (1.f + trow_reitz_lambda(in, alphas, normal) + trow_reitz_lambda(out, alphas, normal)); }
+APT_D void trow_reitz_slopes(float cos_theta, Philox& r, float& sx, float& sy) {          // microfacet.py:65-99 (two draws, always)
+    const float u1 = rng_float(r);
+    float u2 = rng_float(r);
+    if (cos_theta > (float)(1.0 - 1e-5)) {
+        const float rad = sqrtf(u1 / (1.f - u1)), phi = 6.28318530718f * u2;
+        float sn, cs; apt_sincos(phi, &sn, &cs);
+        sx = rad * cs; sy = rad * sn;
+        return;
+    }
+    const float sin_theta = sqrtf(fmaxf(0.f, 1.f - cos_theta * cos_theta));
+    const float tan_theta = sin_theta / cos_theta;
+    const float G1 = 2.f / (1.f + sqrtf(1.f + tan_theta * tan_theta));
+    const float A = 2.f * u1 / G1 - 1.f;
+    const float tmp = fminf(1e10f, 1.f / (A * A - 1.f));
+    const float D = sqrtf(fmaxf(tan_theta * tan_theta * tmp * tmp - (A * A - tan_theta * tan_theta) * tmp, 0.f));
+    const float s1 = tan_theta * tmp - D, s2 = s1 + D * 2.f;
+    const float slope_x = ((A < 0.f) || (s2 > 1.f / tan_theta)) ? s1 : s2;
+    float S;
+    if (u2 > 0.5f) { S = 1.f; u2 = 2.0f * (u2 - 0.5f); }
+    else { S = -1.f; u2 = 2.f * (0.5f - u2); }
+    const float z = (u2 * (u2 * (u2 * 0.27385f - 0.73369f) + 0.46341f)) / (u2 * (u2 * (u2 * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
+    sx = slope_x; sy = S * z * sqrtf(1.f + slope_x * slope_x);
+}
+// half vector in the LOCAL frame (+y = normal) and its angles; note upstream stretches the WORLD-frame direction by (alpha_x, 1, alpha_y)
+APT_D f3 trow_reitz_sample_wh(f3 incid, f3 normal, float ax, float ay, Philox& r, RawAngles& raw) {
+    const bool flip = dot(incid, normal) > 0.f;
+    const f3 wi = flip ? incid : -incid;
+    const RawAngles w = to_raw(normalize(wi * mk3(ax, 1.f, ay)), normal);
+    float sx, sy;
+    trow_reitz_slopes(w.cos_t, r, sx, sy);
+    const float tmp = w.cos_p * sx - w.sin_p * sy;
+    sy = w.sin_p * sx + w.cos_p * sy;
+    sx = tmp;
+    sx = ax * sx; sy = ay * sy;
+    f3 wh = normalize(mk3(-sx, 1.f, -sy));
+    if (flip) wh = -wh;
+    raw = raw_of_local(wh);
+    return wh;
+}
+APT_D float trow_reitz_pdf(f3 incid, f3 wh, f3 alphas, f3 normal) {
+    return trow_reitz_D(to_raw(wh, normal), alphas) * trow_reitz_G1(incid, alphas, normal) * fabsf(dot(wh, incid)) / fabsf(dot(normal, incid));
+}
+APT_D f3 microfacet_eval_raw(const DevBxdf& b, const Hit& it, f3 wh, const RawAngles& raw, f3 in, f3 out) {        // not yet / (4 cos_i cos_o)
+    f3 ret = splat3(0.f);
+    if (fabsf(wh.x) > BRDF_EPS || fabsf(wh.y) > BRDF_EPS || fabsf(wh.z) > BRDF_EPS) {
+        wh = normalize(wh);
+        const float fresnel = fresnel_eval(dot(wh, out), b.k_s.x, b.k_s.y);
+        const float cosine_term = fabsf(dot(it.n_s, out));
+        ret = (((b.k_d * trow_reitz_D(raw, b.k_g)) * trow_reitz_G(-in, out, b.k_g, it.n_s)) * fresnel) * cosine_term;
+    }
+    return ret;
+}
+APT_D f3 microfacet_eval(const DevBxdf& b, const Hit& it, f3 in, f3 out) {
+    f3 ret = splat3(0.f);
+    const float cos_mult = dot(it.n_s, out) * dot(it.n_s, in);
+    if (cos_mult < 0.f) {
+        const f3 wh = normalize(out - in);
+        ret = microfacet_eval_raw(b, it, wh, to_raw(wh, it.n_s), in, out) / (-4.f * cos_mult);
+    }
+    return ret;
+}
+APT_D f3 microfacet_sample(const DevBxdf& b, const Hit& it, f3 incid, Philox& r, f3& spec, float& pdf) {
+    RawAngles raw;
+    const f3 local_wh = trow_reitz_sample_wh(incid, it.n_s, b.k_g.x, b.k_g.y, r, raw);
+    const f3 half_vector = delocalize(it.n_s, local_wh);
+    const float dot_val = -dot(incid, half_vector);
+    f3 out_d = mk3(0.f, 1.f, 0.f);
+    spec = splat3(0.f); pdf = 1.0f;
+    if (dot_val > 0.f) {
+        out_d = reflect_in(incid, half_vector);
+        float cos_o = dot(it.n_s, out_d), cos_i = dot(it.n_s, incid);
+        if (cos_o * cos_i < 0.f) {
+            cos_i = fabsf(cos_i); cos_o = fabsf(cos_o);
+            if (cos_o > BRDF_EPS && cos_i > BRDF_EPS) {
+                spec = microfacet_eval_raw(b, it, half_vector, raw, incid, out_d) / (4.f * cos_o * cos_i);
+                pdf = trow_reitz_pdf(-incid, half_vector, b.k_g, it.n_s);
+                pdf /= 4.f * dot_val;
+            }
+        }
+    }
+    return out_d;
+}
+
 // Material-set masks: bit t (0..7) = BRDF type t present, bit 8 = det-refraction BSDF, bit 9 = Lambertian
 // transmission BSDF, bit 10 = null BSDF.  Emitter mask: bit = emitter type (0 point, 1 area, 2 spot, 4 collimated).
 // The dispatchers take the scene's mask as a template argument so that a shade kernel specialised for,
@@ -329,6 +450,7 @@ APT_D f3 brdf_eval(const DevBxdf& b, const Hit& it, f3 incid, f3 out) {
             case 5: if (BXHAS(BM, 5)) { m33 R; rotation_between(mk3(0.f, 1.f, 0.f), it.n_s, R); ret = fresnel_blend_eval(b, it, incid, out, R); } break;
             case 6: if (BXHAS(BM, 6)) ret = oren_nayar_eval(b, it, incid, out); break;
             case 7: if (BXHAS(BM, 7)) ret = thin_coat_eval(b, it, incid, out); break;
+            case 3: if (BXHAS(BM, 3)) ret = microfacet_eval(b, it, incid, out); break;
             default: break;
         }
     }
@@ -349,7 +471,7 @@ APT_D f3 brdf_sample(const DevBxdf& b, const Hit& it, f3 incid, Philox& r, f3& s
         case 7: if (BXHAS(BM, 7)) dir = thin_coat_sample(b, it, incid, r, spec, pdf, is_specular); break;
         case 4: if (BXHAS(BM, 4)) dir = mod_phong_sample(b, it, incid, r, spec, pdf); break;
         case 5: if (BXHAS(BM, 5)) dir = fresnel_blend_sample(b, it, incid, r, spec, pdf); break;
-        case 3: spec = splat3(0.f); break;
+        case 3: if (BXHAS(BM, 3)) dir = microfacet_sample(b, it, incid, r, spec, pdf); break;
         default: break;
     }
     if (!(dot(dir, it.n_g) > 0.f)) spec = splat3(0.f);
@@ -383,6 +505,10 @@ APT_D float brdf_pdf(const DevBxdf& b, const Hit& it, f3 outdir, f3 incid) {
                 float c2, s2; fb_cos2_sin2(h, it.n_s, R, d_half, c2, s2);
                 pdf = b.k_g.z * apt_pow(d_half, b.k_g.x * c2 + b.k_g.y * s2) / fabsf(dot(incid, h));
                 pdf = 0.5f * (pdf + d_out * APT_INV_PI);
+            } break;
+            case 3: if (BXHAS(BM, 3)) {
+                const f3 wh = normalize(outdir - incid);
+                pdf = trow_reitz_pdf(-incid, wh, b.k_g, it.n_s) / (-4.f * dot(wh, incid));
             } break;
             default: break;
         }

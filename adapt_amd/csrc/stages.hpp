@@ -113,6 +113,7 @@ struct Queues {
     ClassQ cls[8];
     int n_classes;
     int miss_class;                              // volumetric, sorted: class queue that receives the rays that hit nothing (-1: misses are dropped)
+    int miss_rr_draw;                            // volumetric, sorted, misses dropped: a dropped miss still counts the roulette draw k_vshade would have made for it (vpt.py:164-172 precedes the hit test), so n_draws stays the reference's
 };
 #define APT_MAX_CLASSES 8
 // what one shade launch reads: either ray queue `cur` + the hit arrays (unsorted) or one class queue (sorted)
@@ -309,6 +310,15 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
 // next-ray queue of this bounce (it was the current queue of the previous bounce) and the
 // shadow queue.  `n_src` = per-sub-queue counts (normally cnt->n_active[cur]).
 // MODE 0: BVH traversal (LDS-staged nodes + per-lane LDS stack); MODE 1: wave-uniform sweep (small scenes)
+// Volumetric tracer, sorted shading, scenes where a ray that hits nothing has nothing left to do: such rays are dropped by the extend
+// stage instead of travelling to a shade kernel.  Upstream's loop plays Russian roulette BEFORE it looks at the hit (vpt.py:164-172),
+// so a dropped ray may owe one random number; count it, so that the draw statistic equals the reference's loop draw for draw.
+APT_D void count_dropped_miss(const Params& p, const Queues& q, Counters* cnt, int cur, uint32_t io, int sq) {
+    if (!p.use_rr) return;
+    const f3 thr = ld3q(q.thr[cur], p.cap, io);
+    const uint32_t bounce = (ldq(q.meta[cur], io) >> 23) & 0xffu;
+    if (max3(thr) < p.rr_threshold && (int)bounce >= p.rr_bounce_th) atomicAdd(&cnt->stats[sq][ST_DRAWS], 1ull);
+}
 template <int MODE, int SORTED>
 __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 1)) k_extend(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
     __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
@@ -362,6 +372,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
                     stq(k.t, so, rec.t); stq(k.prim, so, rec.prim); stq(k.u, so, rec.u); stq(k.v, so, rec.v);
                 }
             }
+            if (q.miss_rr_draw && valid && rec.prim < 0) count_dropped_miss(p, q, cnt, cur, io, sl.q);
         }
 #ifdef APT_TILE_PROF
         if (MODE == 2) { unsigned long long t2_ = __builtin_readcyclecounter(); tile_prof[5] += tile_t1 - tile_t0; tile_prof[6] += t2_ - tile_t1; tile_prof[7] += 1; }
@@ -431,6 +442,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
                     stq(k.t, so, rec.t); stq(k.prim, so, rec.prim); stq(k.u, so, rec.u); stq(k.v, so, rec.v);
                 }
             }
+            if (q.miss_rr_draw && fin && rec.prim < 0) count_dropped_miss(p, q, cnt, cur_q, io, sq);
         }
         if (fin) state = 0;
         // ---- claim fresh rays for the idle lanes

@@ -9,6 +9,7 @@ returns the flat float/int record the C-ABI scene description wants.
 """
 from __future__ import annotations
 
+import os
 import xml.etree.ElementTree as xet
 
 import numpy as np
@@ -18,6 +19,12 @@ from .parsers.general_parser import get, rgb_parse
 __all__ = ["BRDFTag", "BRDF_np", "BSDF_np", "Medium_np"]
 
 DEG2RAD = np.pi / 180.
+
+# The reference's module switch `__ENABLE_MICROFACET__` (bxdf/brdf.py:8), off upstream "since microfacet functions can slow down JIT
+# compilation".  Off: a microfacet BRDF parses to a Lambertian one, as upstream (brdf.py:60-65).  On (set it here, or
+# ADAPT_ENABLE_MICROFACET=1 in the environment): BRDF type 3 reaches the device and shades as upstream's Trowbridge-Reitz model
+# (sampler/microfacet.py, brdf.py:428-484) - there is nothing to compile at run time here, so the switch costs nothing.
+ENABLE_MICROFACET = os.environ.get("ADAPT_ENABLE_MICROFACET", "0") == "1"
 
 
 class BRDFTag:
@@ -60,8 +67,8 @@ class BRDF_np:
         self.k_s = np.zeros(3, np.float32)
         self.k_g = np.ones(3, np.float32)
         self.is_delta = False
-        if self.type_id == BRDFTag.MICROFACET:
-            # microfacet is compiled out upstream (brdf.py:8,60-65): Lambertian fallback
+        if self.type_id == BRDFTag.MICROFACET and not ENABLE_MICROFACET:
+            # microfacet is switched off upstream (brdf.py:8,60-65): Lambertian fallback
             self.type, self.type_id = "lambertian", BRDFTag.LAMBERTIAN
         for node in elem.findall("rgb"):
             name = node.get("name")

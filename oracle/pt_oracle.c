@@ -305,8 +305,9 @@ static v3 localize_rotate(v3 anchor, v3 global_dir) {
     return m3mulv(&R, global_dir);
 }
 /* convert_to_raw (cam_transform.py:71-88): (cos_theta, sin_theta, cos_phi, sin_phi) */
-static void convert_to_raw(v3 d_in, v3 normal, float raw[4]) {
-    v3 l = localize_rotate(normal, d_in);
+static void raw_of_local(v3 l, float raw[4]);
+static void convert_to_raw(v3 d_in, v3 normal, float raw[4]) { raw_of_local(localize_rotate(normal, d_in), raw); }
+static void raw_of_local(v3 l, float raw[4]) {              /* convert_to_raw(..., localize = False) */
     float cos_theta = l.y;
     float sin_theta = sqrtf(fmaxf(0.f, 1.f - cos_theta * cos_theta));
     float cos_phi = 1.f, sin_phi = 0.f;
@@ -330,6 +331,15 @@ static float fresnel_equation(float n_in, float n_out, float cos_inc, float cos_
     float rs = (n1cos_i - n2cos_r) / (n1cos_i + n2cos_r);
     float rp = (n1cos_r - n2cos_i) / (n1cos_r + n2cos_i);
     return 0.5f * (rs * rs + rp * rp);
+}
+static float fresnel_eval(float cos_v, float n_in, float n_tr) {          /* geo_optics.py:29-44 */
+    int neg = cos_v < 0.f;
+    float cos_value = neg ? -cos_v : cos_v;
+    float ior_in = neg ? n_tr : n_in, ior_tr = neg ? n_in : n_tr;
+    float sin_v = sqrtf(fmaxf(0.f, 1.f - cos_value * cos_value));
+    float sin_t = ior_in / ior_tr * sin_v;
+    float cos_tr = sqrtf(fmaxf(0.f, 1.f - sin_t * sin_t));
+    return fresnel_equation(ior_in, ior_tr, cos_value, cos_tr);
 }
 static int is_total_reflection(float dot_normal, float ni, float nr) {
     return (1.f - sq(ni / nr) * (1.f - sq(dot_normal))) < 0.f;
@@ -573,6 +583,130 @@ static float thin_coat_fresnel(const bxdf_t* b, const isect_t* it, v3 ray_in) {
 }
 
 /* BRDF.eval, brdf.py:503-526 */
+/* ------------------------------------------------ sampler/microfacet.py:27-176 + bxdf/brdf.py:428-484
+ * Trowbridge-Reitz microfacet BRDF.  Upstream ships it switched off (`__ENABLE_MICROFACET__ = False`, brdf.py:8) and its parser
+ * then turns a microfacet BRDF into a Lambertian one (brdf.py:60-65), so BRDF type 3 only ever reaches the device with the switch
+ * on: that is what type 3 means here.  Pinned by tests/golden/microfacet_*.npz, generated with the switch flipped. */
+static float trow_reitz_D(const float raw[4], v3 alphas) {
+    float pdf = 0.f;
+    if (raw[0] > 0.f) {
+        float wh_dot2 = raw[0] * raw[0];
+        float wh_dot4 = wh_dot2 * wh_dot2;
+        float tan_theta2 = raw[1] * raw[1] / wh_dot2;
+        float ax = alphas.x, ay = alphas.y;
+        float e = (raw[2] * raw[2] / (ax * ax) + raw[3] * raw[3] / (ay * ay)) * tan_theta2;
+        pdf = 1.f / (F_PI * ax * ay * wh_dot4 * (1.f + e) * (1.f + e));
+    }
+    return pdf;
+}
+static float trow_reitz_lambda(v3 dir_vec, v3 alphas, v3 normal) {
+    float value = 0.f, raw[4];
+    convert_to_raw(dir_vec, normal, raw);
+    float abs_cos = fabsf(raw[0]);
+    if (abs_cos > 1e-5f) {
+        float abs_tan = raw[1] / abs_cos;
+        float alpha = sqrtf(raw[2] * raw[2] * alphas.x * alphas.x + raw[3] * raw[3] * alphas.y * alphas.y);
+        float at2 = alpha * abs_tan;
+        at2 *= at2;
+        value = (-1.f + sqrtf(1.f + at2)) * 0.5f;
+    }
+    return value;
+}
+static float trow_reitz_G1(v3 d, v3 alphas, v3 normal) { return 1.f / (1.f + trow_reitz_lambda(d, alphas, normal)); }
+static float trow_reitz_G(v3 incid, v3 outdir, v3 alphas, v3 normal) {
+    return 1.f / (1.f + trow_reitz_lambda(incid, alphas, normal) + trow_reitz_lambda(outdir, alphas, normal));
+}
+static void trow_reitz_slopes(float cos_theta, rng_t* r, float* sx, float* sy) {       /* microfacet.py:65-99 */
+    float u1 = rng_float(r), u2 = rng_float(r);
+    if (cos_theta > (float)(1.0 - 1e-5)) {
+        float rad = sqrtf(u1 / (1.f - u1));
+        float phi = 6.28318530718f * u2;
+        *sx = rad * cosf(phi); *sy = rad * sinf(phi);
+        return;
+    }
+    float sin_theta = sqrtf(fmaxf(0.f, 1.f - cos_theta * cos_theta));
+    float tan_theta = sin_theta / cos_theta;
+    float G1 = 2.f / (1.f + sqrtf(1.f + tan_theta * tan_theta));
+    float A = 2.f * u1 / G1 - 1.f;
+    float tmp = fminf(1e10f, 1.f / (A * A - 1.f));
+    float D = sqrtf(fmaxf(tan_theta * tan_theta * tmp * tmp - (A * A - tan_theta * tan_theta) * tmp, 0.f));
+    float s1 = tan_theta * tmp - D;
+    float s2 = s1 + D * 2.f;
+    float slope_x = ((A < 0.f) || (s2 > 1.f / tan_theta)) ? s1 : s2;
+    float S;
+    if (u2 > 0.5f) { S = 1.f; u2 = 2.0f * (u2 - 0.5f); }
+    else { S = -1.f; u2 = 2.f * (0.5f - u2); }
+    float z = (u2 * (u2 * (u2 * 0.27385f - 0.73369f) + 0.46341f)) / (u2 * (u2 * (u2 * 0.093073f + 0.309420f) - 1.0f) + 0.597999f);
+    *sx = slope_x; *sy = S * z * sqrtf(1.f + slope_x * slope_x);
+}
+static v3 trow_reitz_sample(v3 incid, v3 normal, float ax, float ay, rng_t* r) {       /* microfacet.py:101-124: a LOCAL direction */
+    v3 stretch = vnormalized(vmul(incid, V(ax, 1.f, ay)));
+    float raw[4], sx, sy;
+    convert_to_raw(stretch, normal, raw);
+    trow_reitz_slopes(raw[0], r, &sx, &sy);
+    float tmp = raw[2] * sx - raw[3] * sy;
+    sy = raw[3] * sx + raw[2] * sy;
+    sx = tmp;
+    sx = ax * sx; sy = ay * sy;
+    return vnormalized(V(-sx, 1.f, -sy));
+}
+static v3 trow_reitz_sample_wh(v3 incid, v3 normal, float ax, float ay, rng_t* r, float raw[4]) {     /* microfacet.py:161-169 */
+    int flip = vdot(incid, normal) > 0.f;
+    v3 wh = trow_reitz_sample(flip ? incid : vneg(incid), normal, ax, ay, r);
+    if (flip) wh = vneg(wh);
+    raw_of_local(wh, raw);
+    return wh;
+}
+static float trow_reitz_pdf(v3 incid, v3 wh, v3 alphas, v3 normal) {                  /* microfacet.py:171-176 */
+    float raw[4];
+    convert_to_raw(wh, normal, raw);
+    return trow_reitz_D(raw, alphas) * trow_reitz_G1(incid, alphas, normal) * fabsf(vdot(wh, incid)) / fabsf(vdot(normal, incid));
+}
+static v3 eval_microfacet_with_raw(const bxdf_t* b, const isect_t* it, v3 wh, const float raw[4], v3 ray_in, v3 ray_out) {   /* brdf.py:457-471 */
+    v3 ret = ZERO3;
+    if (fabsf(wh.x) > 1e-7f || fabsf(wh.y) > 1e-7f || fabsf(wh.z) > 1e-7f) {
+        wh = vnormalized(wh);
+        float dot_hk = vdot(wh, ray_out);
+        float fresnel = fresnel_eval(dot_hk, b->k_s.x, b->k_s.y);
+        float cosine_term = fabsf(vdot(it->n_s, ray_out));
+        ret = vscale(vscale(vscale(vscale(diffuse_color(b, it), trow_reitz_D(raw, b->k_g)), trow_reitz_G(vneg(ray_in), ray_out, b->k_g, it->n_s)), fresnel), cosine_term);
+    }
+    return ret;
+}
+static v3 eval_microfacet(const bxdf_t* b, const isect_t* it, v3 ray_in, v3 ray_out) {                /* brdf.py:473-484 */
+    v3 ret = ZERO3;
+    float cos_mult = vdot(it->n_s, ray_out) * vdot(it->n_s, ray_in);
+    if (cos_mult < 0.f) {
+        v3 wh = vnormalized(vsub(ray_out, ray_in));
+        float raw[4];
+        convert_to_raw(wh, it->n_s, raw);
+        ret = vdivs(eval_microfacet_with_raw(b, it, wh, raw, ray_in, ray_out), -4.f * cos_mult);
+    }
+    return ret;
+}
+static v3 sample_microfacet(const bxdf_t* b, const isect_t* it, v3 incid, rng_t* r, v3* spec_out, float* pdf_out) {   /* brdf.py:429-455 */
+    float raw[4];
+    v3 local_wh = trow_reitz_sample_wh(incid, it->n_s, b->k_g.x, b->k_g.y, r, raw);
+    v3 half_vector = delocalize_rotate(it->n_s, local_wh, NULL);
+    float dot_val = -vdot(incid, half_vector);
+    v3 spec = ZERO3, out_d = V(0.f, 1.f, 0.f);
+    float pdf = 1.0f;
+    if (dot_val > 0.f) {
+        out_d = inci_reflect_dir(incid, half_vector, NULL);
+        float cos_o = vdot(it->n_s, out_d), cos_i = vdot(it->n_s, incid);
+        if (cos_o * cos_i < 0.f) {
+            cos_i = fabsf(cos_i); cos_o = fabsf(cos_o);
+            if (cos_o > 1e-7f && cos_i > 1e-7f) {
+                spec = vdivs(eval_microfacet_with_raw(b, it, half_vector, raw, incid, out_d), 4.f * cos_o * cos_i);
+                pdf = trow_reitz_pdf(vneg(incid), half_vector, b->k_g, it->n_s);
+                pdf /= 4.f * dot_val;
+            }
+        }
+    }
+    *spec_out = spec; *pdf_out = pdf;
+    return out_d;
+}
+
 static v3 brdf_eval(const bxdf_t* b, const isect_t* it, v3 incid, v3 out) {
     v3 ret = ZERO3;
     if (vdot(incid, it->n_g) * vdot(out, it->n_g) < 0.f) {
@@ -583,7 +717,8 @@ static v3 brdf_eval(const bxdf_t* b, const isect_t* it, v3 incid, v3 out) {
         case 5: { m3 R; rotation_between(V(0.f, 1.f, 0.f), it->n_s, &R); ret = eval_fresnel_blend(b, it, incid, out, &R); break; }
         case 6: ret = eval_oren_nayar(b, it, incid, out); break;
         case 7: ret = eval_thin_coating(b, it, incid, out); break;
-        default: break;            /* specular(2), microfacet(3, compiled out) -> 0 */
+        case 3: ret = eval_microfacet(b, it, incid, out); break;
+        default: break;            /* specular(2) -> 0 */
         }
     }
     return ret;
@@ -603,7 +738,7 @@ static v3 brdf_sample(const bxdf_t* b, const isect_t* it, v3 incid, rng_t* r, v3
     case 7: dir = sample_thin_coat(b, it, incid, r, &spec, &pdf, is_specular); break;
     case 4: dir = sample_mod_phong(b, it, incid, r, &spec, &pdf); break;
     case 5: dir = sample_fresnel_blend(b, it, incid, r, &spec, &pdf); break;
-    case 3: dir = V(0.f, 1.f, 0.f); spec = ZERO3; pdf = 1.0f; break;
+    case 3: dir = sample_microfacet(b, it, incid, r, &spec, &pdf); break;
     default: break;
     }
     if (!(vdot(dir, it->n_g) > 0.f)) spec = ZERO3;     /* brdf.py:558-559 */
@@ -638,6 +773,10 @@ static float brdf_pdf(const bxdf_t* b, const isect_t* it, v3 outdir, v3 incid) {
             float c2, s2; fresnel_cos2_sin2(half_vec, it->n_s, &R, dot_half, &c2, &s2);
             pdf = b->k_g.z * powf(dot_half, b->k_g.x * c2 + b->k_g.y * s2) / fabsf(vdot(incid, half_vec));
             pdf = 0.5f * (pdf + dot_outdir * F_INV_PI);
+            break; }
+        case 3: {                                                    /* brdf.py:597-600 */
+            v3 wh = vnormalized(vsub(outdir, incid));
+            pdf = trow_reitz_pdf(vneg(incid), wh, b->k_g, it->n_s) / (-4.f * vdot(wh, incid));
             break; }
         default: break;
         }

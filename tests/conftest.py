@@ -21,8 +21,11 @@ SCENES = {
     "features_c": (os.path.join(ROOT, "scenes", "test"), "features_c.xml", "features_c"),
     # image textures (albedo / normal / bump maps on meshes); texture paths in the file are relative to the repository root
     "textured": (os.path.join(ROOT, "scenes", "test"), "textured.xml", "textured"),
+    # Trowbridge-Reitz microfacet BRDFs: parsed with the reference's `__ENABLE_MICROFACET__` switch on (MICROFACET_TAGS below)
+    "microfacet": (os.path.join(ROOT, "scenes", "test"), "microfacet.xml", "microfacet"),
 }
 ALL_TAGS = list(SCENES)
+MICROFACET_TAGS = {"microfacet"}
 
 
 def pytest_configure(config):
@@ -58,12 +61,15 @@ def parsed():
     def get(tag):
         if tag not in cache:
             d, f, _ = SCENES[tag]
-            cwd = os.getcwd()
+            from adapt_amd import materials
+            cwd, switch = os.getcwd(), materials.ENABLE_MICROFACET
             os.chdir(ROOT)                      # texture paths are relative to the repository root
+            materials.ENABLE_MICROFACET = tag in MICROFACET_TAGS
             try:
                 cache[tag] = scene_parsing(d, f)
             finally:
                 os.chdir(cwd)
+                materials.ENABLE_MICROFACET = switch
         return cache[tag]
     return get
 

@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz from the reference's own source (authoring container only).
 
-    python tests/golden/gen/gen_goldens.py [--only parse|func|media|image|features|textured|refscenes|vpt|volgrid|bvh]
+    python tests/golden/gen/gen_goldens.py [--only parse|func|media|image|features|textured|refscenes|vpt|volgrid|bvh|microfacet]
 
 Every fixture is produced by calling UNMODIFIED reference code (/root/reference) under the
 float32 stand-in `taichi` package in shim/ (third-party taichi==1.6.0 is not installable
 here).  Fixtures are plain input/output arrays; no reference source text is stored.
+
+`--only microfacet` is the one section that runs the reference with a setting other than its default: the module switch
+`__ENABLE_MICROFACET__` of bxdf/brdf.py:8, which upstream tells its users to flip by hand (brdf.py:63), is True for that
+section (refenv.py flips it at import, in memory).  It is never part of `all`: the switch is process-wide, so the section
+runs in a process of its own (`ADAPT_REF_MICROFACET=1`, set by this script when it re-executes itself).
 """
 import argparse
 import os
@@ -202,6 +207,61 @@ def gen_functions():
         out[f"smp_{name}_script"], out[f"smp_{name}_out"] = np.float64(scr), np.float32(res)
     np.savez_compressed(os.path.join(OUT, "functions.npz"), **out)
     print("functions:", {k: v.shape for k, v in out.items()})
+
+
+def gen_microfacet_functions():
+    """BRDF.eval / get_pdf / sample_new_rays of the reference for microfacet BRDFs (type 3), switch on.  Same layout as functions.npz."""
+    from bxdf import brdf as brdf_mod
+    from bxdf.brdf import BRDF, BRDF_np
+    from tracer.interaction import Interaction
+    from la.geo_optics import inci_reflect_dir
+    from renderer.constants import INVALID
+    import xml.etree.ElementTree as xet
+    assert brdf_mod.__ENABLE_MICROFACET__ is True
+    reseed("microfacet_functions.npz")
+    out = {}
+    specs = [('#E0C8A0', '0.08', 'r="1.0" g="1.5" b="0.0"'), ('#A0C8E0', '0.45', 'r="1.0" g="1.33" b="0.0"'),
+             ('#D8D8D8', None, 'r="1.0" g="2.4" b="0.0"'), ('#FFFFFF', '1.0', 'r="1.5" g="1.0" b="0.0"'), ('#808080', '0.0', 'r="1.0" g="1.5" b="0.0"')]
+    mats = []
+    for kd, rough, ior in specs:
+        rnode = f'<rgb name="roughness" value="{rough}"/>' if rough is not None else '<rgb name="roughness" r="0.05" g="0.5" b="0.0"/>'
+        m = BRDF_np(xet.fromstring(f'<brdf type="microfacet" id="m"><rgb name="k_d" value="{kd}"/>{rnode}<rgb name="ref_ior" {ior}/></brdf>'))
+        assert m.type_id == 3
+        mats.append(m)
+    mat_i, mat_f, ev_in, ev_out, sm_in, sm_out = [], [], [], [], [], []
+    for mi, m in enumerate(mats):
+        obj = m.export()
+        mean = np.float32([m.k_d.mean(), m.k_s.mean(), m.k_g.mean()])
+        mat_i.append([3, 0, 0, 0]); mat_f.append(np.concatenate([m.k_d, m.k_s, m.k_g, mean, [1.0]]))
+        for k in range(40):
+            n_s = rand_dir() if k % 5 else np.float32([0, 1, 0])
+            n_g = unit(n_s + np.float32(RS.normal(size=3) * 0.05))
+            incid = rand_dir()
+            if np.dot(incid, n_s) > 0 and RS.rand() < 0.85:
+                incid = -incid
+            outd = rand_dir()
+            if np.dot(outd, n_s) < 0 and RS.rand() < 0.85:
+                outd = -outd
+            if RS.rand() < 0.3:                                  # near the mirror direction, where a smooth lobe lives
+                outd = unit(inci_reflect_dir(vec3(incid), vec3(n_s))[0].to_numpy() + np.float32(RS.normal(size=3) * 0.05))
+            if k % 11 == 0:
+                incid = unit(-n_s + np.float32(RS.normal(size=3) * 1e-4))       # (almost) normal incidence: the `cos_theta > 1 - eps` sampling branch
+            it = Interaction(n_s=vec3(n_s), n_g=vec3(n_g), tex=INVALID)
+            e = obj.eval(it, vec3(incid), vec3(outd))
+            p = obj.get_pdf(it, vec3(outd), vec3(incid))
+            ev_in.append(np.concatenate([[mi], n_s, n_g, incid, outd])); ev_out.append(np.concatenate([e.to_numpy(), [p]]))
+            ti.RNG.set_philox(len(sm_in), 777, 1)
+            it = Interaction(n_s=vec3(n_s), n_g=vec3(n_g), tex=INVALID)
+            d, sp, pdf, spec = obj.sample_new_rays(it, vec3(incid))
+            sm_in.append(np.concatenate([[mi], n_s, n_g, incid]))
+            sm_out.append(np.concatenate([np.float32(d.to_numpy()), np.float32(sp.to_numpy()), [pdf, float(bool(spec)), ti.RNG.draw]]))
+    out["mat_i"], out["mat_f"] = np.int32(mat_i), np.float32(mat_f)
+    out["eval_in"], out["eval_out"] = np.float32(ev_in), np.float32(ev_out)
+    out["sample_in"], out["sample_out"] = np.float32(sm_in), np.float32(sm_out)
+    np.savez_compressed(os.path.join(OUT, "microfacet_functions.npz"), **out)
+    ev, so = out["eval_out"], out["sample_out"]
+    print("microfacet_functions:", {k: v.shape for k, v in out.items()}, "nonzero evals", int(np.any(ev[:, :3] != 0, axis=1).sum()),
+          "nonzero pdfs", int((ev[:, 3] != 0).sum()), "nonzero sampled", int(np.any(so[:, 3:6] != 0, axis=1).sum()), "NaNs", int(np.isnan(ev).sum() + np.isnan(so).sum()))
 
 
 # ---------------------------------------------- scene-bound functions + images
@@ -606,6 +666,13 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="all")
     a = ap.parse_args()
+    if a.only == "microfacet":
+        if os.environ.get("ADAPT_REF_MICROFACET") != "1":                  # the switch is read when bxdf.brdf is imported: own process
+            os.execve(sys.executable, [sys.executable] + sys.argv, dict(os.environ, ADAPT_REF_MICROFACET="1"))
+        gen_microfacet_functions()
+        gen_scene(os.path.join(refenv.REPO, "scenes", "test"), "microfacet.xml", "microfacet", 40, 30, 4, {}, n_rays=48)
+        gen_vptrun(os.path.join(refenv.REPO, "scenes", "test"), "microfacet.xml", "microfacet", 40, 30, 2)       # the same BRDFs in the volumetric loop
+        sys.exit(0)
     if a.only in ("all", "parse"):
         dump_parse("cbox", "cbox.xml", "cbox")
         dump_parse("csphere", "balls-mono.xml", "balls_mono")

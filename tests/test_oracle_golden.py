@@ -30,27 +30,35 @@ def test_fresnel_known_answer_and_vectors():
         assert np.float32(ob.fresnel_equation(*map(float, x))) == y
 
 
-def test_bxdf_eval_pdf_bit_exact():
-    mi, mf = F["mat_i"], F["mat_f"]
+# microfacet_functions.npz: the reference's Trowbridge-Reitz BRDF (type 3), recorded with its `__ENABLE_MICROFACET__` switch on
+@pytest.mark.parametrize("fixture", ["functions.npz", "microfacet_functions.npz"])
+def test_bxdf_eval_pdf_bit_exact(fixture):
+    g = golden(fixture)
+    mi, mf = g["mat_i"], g["mat_f"]
     nonzero = 0
-    for x, y in zip(F["eval_in"], F["eval_out"]):
+    for x, y in zip(g["eval_in"], g["eval_out"]):
         m = int(x[0])
         ev, pdf = ob.bxdf_eval_pdf(mi[m], mf[m], 1.0, x[1:4], x[4:7], x[7:10], x[10:13])
-        assert same(ev, y[:3]) and same(pdf, y[3]), (m, x)
+        assert same(ev, y[:3]) and same(pdf, y[3]), (m, x, ev, pdf, y)
         nonzero += bool(np.any(y != 0))
     assert nonzero > 80          # the vectors exercise the non-trivial branches
 
 
-def test_bxdf_sample_bit_exact():
-    mi, mf = F["mat_i"], F["mat_f"]
-    for k, (x, y) in enumerate(zip(F["sample_in"], F["sample_out"])):
+@pytest.mark.parametrize("fixture", ["functions.npz", "microfacet_functions.npz"])
+def test_bxdf_sample_bit_exact(fixture):
+    g = golden(fixture)
+    mi, mf = g["mat_i"], g["mat_f"]
+    lit = 0
+    for k, (x, y) in enumerate(zip(g["sample_in"], g["sample_out"])):
         m = int(x[0])
         d, s, pdf, spec, nd = ob.bxdf_sample(mi[m], mf[m], 1.0, x[1:4], x[4:7], x[7:10], None, key=k, seed=777)
-        assert same(d, y[:3]) and same(s, y[3:6]) and same(pdf, y[6]), (m, k)
+        assert same(d, y[:3]) and same(s, y[3:6]) and same(pdf, y[6]), (m, k, d, s, pdf, y)
         assert spec == bool(y[7]) and nd == int(y[8])
+        lit += bool(np.any(y[3:6] != 0))
+    assert lit > 80
 
 
-@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_b", "features_c", "textured"])
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_b", "features_c", "textured", "microfacet"])
 def test_scene_functions_bit_exact(tag, parsed, oracle_scene):
     g = golden(f"scene_{SCENES[tag][2]}.npz")
     rc = make_config(parsed(tag)[3], width=int(g["width"]), height=int(g["height"]), max_bounce=int(g["max_bounce"]))
@@ -61,7 +69,7 @@ def test_scene_functions_bit_exact(tag, parsed, oracle_scene):
     h = g["ray_hit"]
     assert np.array_equal(obj, h[:, 0]) and np.array_equal(prim, h[:, 1]) and np.array_equal(t, h[:, 2])
     assert np.array_equal(uv, h[:, 3:5]) and np.array_equal(ns, h[:, 5:8])
-    assert (obj >= 0).sum() > 60
+    assert (obj >= 0).sum() > min(60, len(obj) // 2)
     assert np.array_equal(sc.occluded(g["ray_o"], g["ray_d"], g["ray_tmax"]), g["ray_occ"])
     for k, (x, y) in enumerate(zip(g["emit_in"], g["emit_out"])):
         pos, inten, pdf, nd = sc.src_sample_hit(int(x[0]), x[1:4], None, key=k, seed=778)
@@ -70,7 +78,7 @@ def test_scene_functions_bit_exact(tag, parsed, oracle_scene):
         assert same(le, y[8:11]) and same(sap, y[11])
 
 
-@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_b", "features_c", "textured"])
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_b", "features_c", "textured", "microfacet"])
 def test_whole_kernel_matches_reference_run(tag, parsed, oracle_scene):
     """Renderer.render of the reference, spp by spp on the Philox stream, vs orc_render."""
     g = golden(f"scene_{SCENES[tag][2]}.npz")
@@ -186,7 +194,7 @@ def test_medium_functions_bit_exact():
         assert np.array_equal(out.view(np.uint32), y.view(np.uint32)), (m, k, out, y)
 
 
-@pytest.mark.parametrize("tag", ["features_a", "features_b", "textured"])
+@pytest.mark.parametrize("tag", ["features_a", "features_b", "textured", "microfacet"])
 def test_volumetric_loop_on_surface_scenes_matches_reference_run(tag, parsed, oracle_scene):
     """VolumeRenderer.render of the reference on surface-only scenes of this repo (every BRDF / BSDF / emitter type; two-sided BRDFs
     without RR and MIS; image textures): the volumetric loop differs from the surface tracer's even when nothing scatters."""

@@ -274,3 +274,26 @@ def test_vol_reader_and_refusals(tmp_path):
         GridVolume_np(mk("", kind="smoke"))
     with pytest.raises(RuntimeError):
         GridVolume_np(xet.fromstring('<volume name="v" type="mono" phase_type="hg"><string name="density_grid" path="/nonexistent.vol"/></volume>'))
+
+
+def test_microfacet_switch_mirrors_the_reference(monkeypatch):
+    """`__ENABLE_MICROFACET__` (bxdf/brdf.py:8): off, a microfacet BRDF parses to a Lambertian one (brdf.py:60-65); on, type 3 stays
+    and `roughness` becomes the Trowbridge-Reitz alphas (brdf.py:96-103,115-120).  The expected records are the ones the reference's
+    own BRDF_np produced with the switch on (tests/golden/microfacet_functions.npz: k_d, k_s, k_g, mean, ior per material)."""
+    from conftest import golden
+    from adapt_amd import materials
+    specs = [('#E0C8A0', 'value="0.08"', 'r="1.0" g="1.5" b="0.0"'), ('#A0C8E0', 'value="0.45"', 'r="1.0" g="1.33" b="0.0"'),
+             ('#D8D8D8', 'r="0.05" g="0.5" b="0.0"', 'r="1.0" g="2.4" b="0.0"'), ('#FFFFFF', 'value="1.0"', 'r="1.5" g="1.0" b="0.0"'),
+             ('#808080', 'value="0.0"', 'r="1.0" g="1.5" b="0.0"')]
+    xml = [f'<brdf type="microfacet" id="m"><rgb name="k_d" value="{kd}"/><rgb name="roughness" {r}/><rgb name="ref_ior" {ior}/></brdf>' for kd, r, ior in specs]
+    g = golden("microfacet_functions.npz")
+    monkeypatch.setattr(materials, "ENABLE_MICROFACET", True)
+    for k, x in enumerate(xml):
+        ints, flts = materials.BRDF_np(xet.fromstring(x)).pack()
+        assert ints.tolist() == g["mat_i"][k].tolist() == [3, 0, 0, 0]
+        assert np.array_equal(flts, g["mat_f"][k])
+    monkeypatch.setattr(materials, "ENABLE_MICROFACET", False)
+    for k, x in enumerate(xml):
+        b = materials.BRDF_np(xet.fromstring(x))
+        assert (b.type, b.type_id) == ("lambertian", 1)
+        assert np.array_equal(b.k_g, g["mat_f"][k][6:9])              # the roughness -> alpha conversion goes by the attribute's name, switch or not
