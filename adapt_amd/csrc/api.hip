@@ -288,12 +288,15 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     s->n_prims = N; s->n_objects = O; s->n_sources = S;
     int max_leaf = 1;                     // primitives per leaf of the binary tree (the 8-wide node encodes at most 3 per leaf child); measured 1 / 2 / 3: C4 1274 / 1236 / 1228, C5 1117 / 1073 / 1043 Msamples/s - a primitive test costs ~75 instructions whatever the fraction of the wave that needs it, a child box 19
     if (const char* ml = getenv("APT_BVH_LEAF")) max_leaf = std::min(3, std::max(1, atoi(ml)));
-    // builder: binned SAH on the host (better tree) below a million primitives, LBVH on the device above (scene-load time); APT_BVH_BUILDER overrides
+    // builder: binned SAH on the host (best tree) below a million primitives, PLOC on the device above (scene-load time); APT_BVH_BUILDER=sah|ploc|lbvh overrides.
+    // Measured on one MI355X (Msamples/s, C4 95 k / C5 285 k triangles): SAH 1303 / 1216, PLOC 1287 / 1157, LBVH 1186 / 1048; apt_scene_create at 1.14 M
+    // primitives: SAH ~800 ms, PLOC or LBVH ~500 ms (what is left is the 8-wide collapse and the table uploads, shared by all three)
     bool gpu_build = N >= 1000000;
-    if (const char* bb = getenv("APT_BVH_BUILDER")) gpu_build = !strcmp(bb, "lbvh") && N >= 2;
+    int gpu_algo = 1;                     // 0 LBVH (radix tree), 1 PLOC (nearest-neighbour merging by box area)
+    if (const char* bb = getenv("APT_BVH_BUILDER")) { gpu_build = (!strcmp(bb, "lbvh") || !strcmp(bb, "ploc")) && N >= 2; gpu_algo = !strcmp(bb, "ploc") ? 1 : 0; }
     s->gpu_built = false;
     if (gpu_build) {
-        const int rc_ = apt::build_bvh_gpu(d->prims, N, d->obj_info, O, device, s->bvh);
+        const int rc_ = apt::build_bvh_gpu(d->prims, N, d->obj_info, O, device, s->bvh, gpu_algo);
         if (rc_ != 0) { delete s; return fail(APT_E_HIP, "apt_scene_create: device BVH build failed (" + std::to_string(rc_) + ")"); }
         s->gpu_built = true;
     } else if (apt::build_bvh(d->prims, N, d->obj_info, O, s->bvh, max_leaf) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH build failed"); }

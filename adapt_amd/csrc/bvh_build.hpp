@@ -14,8 +14,9 @@ struct BvhData {
 // max_leaf: primitives per leaf (1..4; the 8-wide tree below wants 3)
 int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, BvhData& out, int max_leaf = 4);
 
-// bvh_gpu.hip: the same binary tree (single-primitive leaves) built on the device: LBVH (Morton sort + Karras' radix tree + bottom-up fit)
-int build_bvh_gpu(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, int device, BvhData& out);
+// bvh_gpu.hip: the same binary tree (single-primitive leaves) built on the device.  algo 0: LBVH (Morton sort + Karras' radix tree +
+// bottom-up fit); algo 1: PLOC (Morton sort + rounds of nearest-neighbour merging by union area: SAH-class quality)
+int build_bvh_gpu(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, int device, BvhData& out, int algo = 0);
 
 // 8-wide tree with quantised child boxes, what the traversal kernels walk (bvh_wide.cpp; layout in traverse.hpp).
 struct WideBvhData {

@@ -1,19 +1,23 @@
-// bvh_gpu.hip — binary BVH built on the GPU (LBVH), the alternative to the host SAH builder of bvh_build.cpp.
+// bvh_gpu.hip — binary BVH built on the GPU (PLOC or LBVH), the alternative to the host SAH builder of bvh_build.cpp.
 //
 // Replaces the same reference component, the recursive single-threaded SAH build of `bvh_cpp.bvh_build`
-// (tracer/bvh/bvh.cpp:83-212), where scene-load time matters more than tree quality ("removes the CPU build from
-// scene-load time for 290k+ prims").  All O(n log n) work runs on the device:
+// (tracer/bvh/bvh.cpp:83-212), where scene-load time matters more than the last per cent of tree quality ("removes
+// the CPU build from scene-load time for 290k+ prims").  All O(n log n) work runs on the device:
 //   1. k_prim_boxes    padded primitive boxes (the host builder's padding) + centroids, centroid bounds by ordered-int atomics
 //   2. k_morton        30-bit Morton code of the centroid, made unique by the primitive index in the low word (64-bit key)
 //   3. hipcub radix sort of the keys (only the 30 + ceil(log2 n) significant bits)
+// then either (algo 1, the default) PLOC:
+//   4. k_ploc_*        rounds of: nearest neighbour by union area within +-16 places, merge of mutual pairs, compaction (see below)
+//   5. k_ploc_emit     the two-boxes-per-node record of bvh_build.cpp, single-primitive leaves, root at node 0
+// or (algo 0) LBVH:
 //   4. k_radix_tree    Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees": every inner
 //                      node finds its key range and split independently from the common-prefix lengths of neighbouring keys
 //   5. k_fit           leaves walk up, the second child to arrive at a node merges the two child boxes (one atomic counter per node)
-//   6. k_emit          the two-boxes-per-node record of bvh_build.cpp, single-primitive leaves
+//   6. k_emit          the exported record
 // The result is downloaded in the layout of apt::BvhData, so that everything downstream (collapse to the 8-wide quantised tree,
 // primitive records in leaf order) is shared with the SAH path.  Closest-hit results do not depend on the tree (exact
-// per-primitive tests, exact tie-break); only the amount of work per ray does: a Morton-ordered tree costs ~15-25 % more node
-// visits than the binned-SAH tree, which is why SAH stays the default below a million primitives (APT_BVH_BUILDER=lbvh|sah).
+// per-primitive tests, exact tie-break); only the amount of work per ray does.  Measured (api.hip, builder choice): rendering on the
+// PLOC tree is 1-5 % slower than on the binned-SAH tree, on the radix tree 9-14 %; SAH stays the default below a million primitives.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -142,6 +146,87 @@ __global__ void k_emit(int n, const unsigned long long* __restrict__ keys, const
     nd[14] = 0.f; nd[15] = 0.f;
 }
 
+// ---------------------------------------------------------------- PLOC (parallel locally-ordered clustering)
+// Meister, Bittner, "Parallel locally-ordered clustering for bounding volume hierarchy construction" (TVCG 2018): bottom-up
+// agglomeration over the Morton-ordered cluster array.  Every round each cluster looks `radius` places to either side for the
+// neighbour whose union with it has the smallest surface area; clusters that chose each other merge into a new node; the array is
+// compacted (prefix sum) and the next round starts, until one cluster is left.  Unlike the radix tree above, where a split is
+// decided by key bits alone, every merge here is decided by box areas - the quantity the SAH prices - so the tree walks like
+// a SAH tree while the whole build still runs on the device.
+// Ties are broken by the lower position, which guarantees a mutual pair in every round (the pair of smallest (area, lower
+// position, higher position) chooses each other), so the loop always terminates.
+#define PLOC_RADIUS 16
+__device__ __forceinline__ float union_half_area(const float* __restrict__ a, const float* __restrict__ b) {
+    const float d0 = fmaxf(a[3], b[3]) - fminf(a[0], b[0]), d1 = fmaxf(a[4], b[4]) - fminf(a[1], b[1]), d2 = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
+    return d0 * d1 + d1 * d2 + d0 * d2;
+}
+__global__ void k_ploc_init(int n, const unsigned long long* __restrict__ keys, const float* __restrict__ prim_box, float* __restrict__ cbox, int* __restrict__ clink) {
+    const int i = blockIdx.x * GB + threadIdx.x;
+    if (i >= n) return;
+    const float* b = prim_box + 6 * (size_t)(uint32_t)(keys[i] & 0xffffffffull);
+    for (int a = 0; a < 6; a++) cbox[6 * (size_t)i + a] = b[a];
+    clink[i] = ~i;                                                  // leaf = ~(position in Morton order)
+}
+__global__ void k_ploc_nn(int m, const float* __restrict__ cbox, int* __restrict__ nn) {
+    const int i = blockIdx.x * GB + threadIdx.x;
+    if (i >= m) return;
+    float mine[6];
+    for (int a = 0; a < 6; a++) mine[a] = cbox[6 * (size_t)i + a];
+    float best = 3.0e38f; int best_j = -1;
+    const int lo = max(0, i - PLOC_RADIUS), hi = min(m - 1, i + PLOC_RADIUS);
+    for (int j = lo; j <= hi; j++) {                                // ascending: of equal areas the lower position stays
+        if (j == i) continue;
+        const float d = union_half_area(mine, cbox + 6 * (size_t)j);
+        if (d < best) { best = d; best_j = j; }
+    }
+    nn[i] = best_j;
+}
+// flags[i]: low word 1 = cluster i survives the round (alone, or as the merged cluster), high word 1 = it is the lower half of a merging pair
+__global__ void k_ploc_mark(int m, const int* __restrict__ nn, unsigned long long* __restrict__ flags) {
+    const int i = blockIdx.x * GB + threadIdx.x;
+    if (i >= m) return;
+    const int j = nn[i];
+    const bool mutual = j >= 0 && nn[j] == i;
+    flags[i] = (mutual && i > j) ? 0ull : (1ull | ((mutual ? 1ull : 0ull) << 32));
+}
+__global__ void k_ploc_apply(int m, int node_base, const int* __restrict__ nn, const unsigned long long* __restrict__ flags, const unsigned long long* __restrict__ pos,
+                             const float* __restrict__ cbox, const int* __restrict__ clink, float* __restrict__ cbox2, int* __restrict__ clink2,
+                             int* __restrict__ left, int* __restrict__ right, float* __restrict__ node_box) {
+    const int i = blockIdx.x * GB + threadIdx.x;
+    if (i >= m) return;
+    const unsigned long long f = flags[i];
+    if (!(f & 1ull)) return;
+    const int p = (int)(uint32_t)(pos[i] & 0xffffffffull);
+    float box[6];
+    for (int a = 0; a < 6; a++) box[a] = cbox[6 * (size_t)i + a];
+    int link = clink[i];
+    if (f >> 32) {
+        const int j = nn[i], node = node_base + (int)(uint32_t)(pos[i] >> 32);
+        const float* o = cbox + 6 * (size_t)j;
+        for (int a = 0; a < 3; a++) { box[a] = fminf(box[a], o[a]); box[3 + a] = fmaxf(box[3 + a], o[3 + a]); }
+        left[node] = link; right[node] = clink[j];
+        for (int a = 0; a < 6; a++) node_box[6 * (size_t)node + a] = box[a];
+        link = node;
+    }
+    for (int a = 0; a < 6; a++) cbox2[6 * (size_t)p + a] = box[a];
+    clink2[p] = link;
+}
+// nodes were numbered in creation order, the root last: the exported tree wants the root at 0 -> index n - 2 - k
+__global__ void k_ploc_emit(int n, const unsigned long long* __restrict__ keys, const float* __restrict__ prim_box, const float* __restrict__ node_box,
+                            const int* __restrict__ left, const int* __restrict__ right, float* __restrict__ out, int* __restrict__ prim_order) {
+    const int i = blockIdx.x * GB + threadIdx.x;
+    if (i < n) prim_order[i] = (int)(uint32_t)(keys[i] & 0xffffffffull);
+    if (i >= n - 1) return;
+    float* nd = out + 16 * (size_t)(n - 2 - i);
+    for (int c = 0; c < 2; c++) {
+        const int link = c ? right[i] : left[i];
+        const float* b = (link < 0) ? prim_box + 6 * (size_t)(uint32_t)(keys[~link] & 0xffffffffull) : node_box + 6 * (size_t)link;
+        for (int a = 0; a < 6; a++) nd[6 * c + a] = b[a];
+        nd[12 + c] = __int_as_float((link < 0) ? ~(((~link) << 4) | 1) : (n - 2 - link));
+    }
+    nd[14] = 0.f; nd[15] = 0.f;
+}
+
 struct Buf {
     void* p = nullptr;
     ~Buf() { if (p) (void)hipFree(p); }
@@ -152,7 +237,7 @@ struct Buf {
 
 }  // namespace
 
-int build_bvh_gpu(const float* prims, int n, const int32_t* obj_info, int n_objects, int device, BvhData& out) {
+int build_bvh_gpu(const float* prims, int n, const int32_t* obj_info, int n_objects, int device, BvhData& out, int algo) {
     if (!prims || !obj_info || n < 2) return -1;
     if ((long long)n >= (1ll << 27)) return -1;                      // leaf links keep the slot in 27 bits
     GTRY(hipSetDevice(device));
@@ -180,11 +265,42 @@ int build_bvh_gpu(const float* prims, int n, const int32_t* obj_info, int n_obje
     GTRY(d_tmp.alloc(tmp_bytes));
     GTRY(hipcub::DeviceRadixSort::SortKeys(d_tmp.p, tmp_bytes, d_keys.as<unsigned long long>(), d_keys2.as<unsigned long long>(), n, 32, 62));
     std::swap(d_keys.p, d_keys2.p);
-    hipLaunchKernelGGL(k_radix_tree, dim3(grid), dim3(GB), 0, 0, d_keys.as<unsigned long long>(), n, d_left.as<int>(), d_right.as<int>(), d_pi.as<int>(), d_pl.as<int>());
-    hipLaunchKernelGGL(k_fit, dim3(grid), dim3(GB), 0, 0, n, d_keys.as<unsigned long long>(), d_box.as<float>(), d_left.as<int>(), d_right.as<int>(), d_pi.as<int>(), d_pl.as<int>(),
-                       d_nbox.as<float>(), d_arr.as<int>());
-    hipLaunchKernelGGL(k_emit, dim3(grid), dim3(GB), 0, 0, n, d_keys.as<unsigned long long>(), d_box.as<float>(), d_nbox.as<float>(), d_left.as<int>(), d_right.as<int>(),
-                       d_out.as<float>(), d_order.as<int>());
+    if (algo == 1) {
+        // PLOC: d_left / d_right / d_nbox are indexed by node creation order here; d_pi, d_pl, d_arr are free to serve as round buffers
+        Buf d_cb[2], d_cl[2], d_flags, d_pos, d_scan;
+        for (int k = 0; k < 2; k++) { GTRY(d_cb[k].alloc((size_t)n * 24)); GTRY(d_cl[k].alloc((size_t)n * 4)); }
+        GTRY(d_flags.alloc((size_t)n * 8)); GTRY(d_pos.alloc((size_t)n * 8));
+        size_t scan_bytes = 0;
+        GTRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_flags.as<unsigned long long>(), d_pos.as<unsigned long long>(), n));
+        GTRY(d_scan.alloc(scan_bytes));
+        hipLaunchKernelGGL(k_ploc_init, dim3(grid), dim3(GB), 0, 0, n, d_keys.as<unsigned long long>(), d_box.as<float>(), d_cb[0].as<float>(), d_cl[0].as<int>());
+        int m = n, node_base = 0, cur = 0;
+        for (int round = 0; m > 1; round++) {
+            if (round > 4096) return -3;                                 // cannot happen: every round merges at least one pair
+            const int g = (m + GB - 1) / GB;
+            hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(GB), 0, 0, m, d_cb[cur].as<float>(), d_pi.as<int>());
+            hipLaunchKernelGGL(k_ploc_mark, dim3(g), dim3(GB), 0, 0, m, d_pi.as<int>(), d_flags.as<unsigned long long>());
+            GTRY(hipcub::DeviceScan::ExclusiveSum(d_scan.p, scan_bytes, d_flags.as<unsigned long long>(), d_pos.as<unsigned long long>(), m));
+            hipLaunchKernelGGL(k_ploc_apply, dim3(g), dim3(GB), 0, 0, m, node_base, d_pi.as<int>(), d_flags.as<unsigned long long>(), d_pos.as<unsigned long long>(),
+                               d_cb[cur].as<float>(), d_cl[cur].as<int>(), d_cb[cur ^ 1].as<float>(), d_cl[cur ^ 1].as<int>(), d_left.as<int>(), d_right.as<int>(), d_nbox.as<float>());
+            unsigned long long last_pos = 0, last_flag = 0;
+            GTRY(hipMemcpy(&last_pos, d_pos.as<unsigned long long>() + (m - 1), 8, hipMemcpyDeviceToHost));
+            GTRY(hipMemcpy(&last_flag, d_flags.as<unsigned long long>() + (m - 1), 8, hipMemcpyDeviceToHost));
+            const unsigned long long tot = last_pos + last_flag;
+            const int survivors = (int)(uint32_t)(tot & 0xffffffffull), merges = (int)(uint32_t)(tot >> 32);
+            if (merges < 1 || survivors != m - merges) return -4;
+            node_base += merges; m = survivors; cur ^= 1;
+        }
+        if (node_base != n - 1) return -5;
+        hipLaunchKernelGGL(k_ploc_emit, dim3(grid), dim3(GB), 0, 0, n, d_keys.as<unsigned long long>(), d_box.as<float>(), d_nbox.as<float>(), d_left.as<int>(), d_right.as<int>(),
+                           d_out.as<float>(), d_order.as<int>());
+    } else {
+        hipLaunchKernelGGL(k_radix_tree, dim3(grid), dim3(GB), 0, 0, d_keys.as<unsigned long long>(), n, d_left.as<int>(), d_right.as<int>(), d_pi.as<int>(), d_pl.as<int>());
+        hipLaunchKernelGGL(k_fit, dim3(grid), dim3(GB), 0, 0, n, d_keys.as<unsigned long long>(), d_box.as<float>(), d_left.as<int>(), d_right.as<int>(), d_pi.as<int>(), d_pl.as<int>(),
+                           d_nbox.as<float>(), d_arr.as<int>());
+        hipLaunchKernelGGL(k_emit, dim3(grid), dim3(GB), 0, 0, n, d_keys.as<unsigned long long>(), d_box.as<float>(), d_nbox.as<float>(), d_left.as<int>(), d_right.as<int>(),
+                           d_out.as<float>(), d_order.as<int>());
+    }
     GTRY(hipGetLastError());
     GTRY(hipDeviceSynchronize());
     out.nodes.resize((size_t)(n - 1) * 16);

@@ -1021,8 +1021,8 @@ def test_ragged_film_partitions(w, h, world, bw, renderer):
 
 
 def test_device_bvh_builder_gives_the_same_answers(bunnies_small, monkeypatch):
-    """APT_BVH_BUILDER=lbvh: the binary tree is built on the GPU (Morton sort + radix tree + bottom-up fit, csrc/bvh_gpu.hip) instead of
-    by the host's binned SAH.  A different tree, the same answers: closest hits (primitive, t, barycentrics) and occlusion flags equal
+    """APT_BVH_BUILDER=lbvh | ploc: the binary tree is built on the GPU (csrc/bvh_gpu.hip: Morton sort, then either Karras' radix tree +
+    bottom-up fit, or rounds of nearest-neighbour merging by box area) instead of by the host's binned SAH.  Different trees, the same answers: closest hits (primitive, t, barycentrics) and occlusion flags equal
     the oracle's brute force exactly, and on a scene with one light sample per vertex the image is BIT-identical to the SAH build's."""
     from adapt_amd.renderer import Renderer
     from adapt_amd.scene_pack import pack_scene
@@ -1039,7 +1039,7 @@ def test_device_bvh_builder_gives_the_same_answers(bunnies_small, monkeypatch):
     field = bunny_field(levels=1)
     cfg = dict(field[3]); cfg["film"] = {"width": 1280, "height": 720, "crop_x": 640, "crop_y": 330, "crop_rx": 60, "crop_ry": 40}
     images = {}
-    for builder in ("sah", "lbvh"):
+    for builder in ("sah", "lbvh", "ploc"):
         monkeypatch.setenv("APT_BVH_BUILDER", builder)
         r = Renderer(*bunnies_small, width=64, height=64)
         prim, t, uv = r.intersect(o, d)
@@ -1051,7 +1051,7 @@ def test_device_bvh_builder_gives_the_same_answers(bunnies_small, monkeypatch):
         images[builder] = f.color.to_numpy()
         assert f.stats()["n_samples"] == 3 * 120 * 80
         f.close()
-    assert np.array_equal(images["sah"], images["lbvh"]) and images["sah"].max() > 0
+    assert np.array_equal(images["sah"], images["lbvh"]) and np.array_equal(images["sah"], images["ploc"]) and images["sah"].max() > 0
 
 
 # ---------------------------------------------------------------- what the driver launches on the 8-GPU node: bench.py under torch.distributed.run

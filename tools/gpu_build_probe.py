@@ -1,4 +1,4 @@
-"""Scene-load time of the two BVH builders (host binned SAH vs device LBVH) on the bunny-field stand-in at three sizes.
+"""Scene-load time of the three BVH builders (host binned SAH vs device LBVH / PLOC) on the bunny-field stand-in at three sizes.
     python tools/gpu_build_probe.py        (GPU box)"""
 import os
 import sys
@@ -11,7 +11,7 @@ from adapt_amd.synth import bunny_field
 
 for levels in (2, 3, 4):
     fs = pack_scene(*bunny_field(levels=levels))
-    for builder in ("sah", "lbvh", "sah", "lbvh"):
+    for builder in ("sah", "lbvh", "ploc", "sah", "lbvh", "ploc"):
         os.environ["APT_BVH_BUILDER"] = builder
         t = time.perf_counter(); sc = DeviceScene(fs, 0); dt = time.perf_counter() - t
         sc.close()
