@@ -6,6 +6,7 @@
 // scene upload, BVH build, queue allocation in HBM, the per-batch stage schedule on a private
 // HIP stream, statistics and HIP-event timing.  Stage kernels live in stages.hpp.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -146,6 +147,7 @@ struct apt_scene {
     int n_prims = 0, n_objects = 0, n_sources = 0, max_obj_prims = 0;
     int bx_mask = 0, src_mask = 0;
     bool has_aabb = false;
+    bool has_sweep = false;              // the sweep stream exists (scenes small enough that a sweep could ever be asked for)
 };
 
 struct EventPair { hipEvent_t a, b; int kernel; };
@@ -286,6 +288,14 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     s->device = device;
     const int N = d->n_prims, O = d->n_objects, S = d->n_sources;
     s->n_prims = N; s->n_objects = O; s->n_sources = S;
+    const bool timing = getenv("APT_SCENE_TIMING") != nullptr;      // stderr: where apt_scene_create spends its time
+    auto t_prev = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[scene timing] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     int max_leaf = 1;                     // primitives per leaf of the binary tree (the 8-wide node encodes at most 3 per leaf child); measured 1 / 2 / 3: C4 1274 / 1236 / 1228, C5 1117 / 1073 / 1043 Msamples/s - a primitive test costs ~75 instructions whatever the fraction of the wave that needs it, a child box 19
     if (const char* ml = getenv("APT_BVH_LEAF")) max_leaf = std::min(3, std::max(1, atoi(ml)));
     // builder: binned SAH on the host (best tree) below a million primitives, PLOC on the device above (scene-load time); APT_BVH_BUILDER=sah|ploc|lbvh overrides.
@@ -300,7 +310,9 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         if (rc_ != 0) { delete s; return fail(APT_E_HIP, "apt_scene_create: device BVH build failed (" + std::to_string(rc_) + ")"); }
         s->gpu_built = true;
     } else if (apt::build_bvh(d->prims, N, d->obj_info, O, s->bvh, max_leaf) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH build failed"); }
+    tick(gpu_build ? (gpu_algo ? "binary tree (PLOC, device)" : "binary tree (LBVH, device)") : "binary tree (SAH, host)");
     if (apt::build_wide_bvh(s->bvh, s->wide) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH collapse failed"); }
+    tick("8-wide collapse");
 
     std::vector<int> prim_obj((size_t)N, 0);
     std::vector<uint8_t> sphere((size_t)N, 0);
@@ -324,13 +336,16 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         else { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = pc[0]; r[4] = pc[1]; r[5] = pc[2]; r[6] = pc[3]; r[7] = pc[4]; r[8] = pc[5]; }
         memcpy(&r[9], &kid, 4); memcpy(&r[10], &flag, 4);
     }
+    tick("primitive records");
     // sweep stream in scene order (layout: traverse.hpp SweepScene); the t-row cofactors of [e1 e2 .] are
     // ray-independent, so they are computed once here with the same float operations the device would use
     std::vector<float> sw;
     std::vector<int> sw_tab((size_t)O * 4, 0);
+    s->has_sweep = N < 65536;            // larger scenes always walk the BVH (and would pay 48 B per primitive and their share of the load time for a stream nobody reads)
     for (int o = 0; o < O; o++) {
         const int first = d->obj_info[3 * o], count = d->obj_info[3 * o + 1], is_sphere = d->obj_info[3 * o + 2] != 0;
         if (!is_sphere) s->max_obj_prims = std::max(s->max_obj_prims, count);
+        if (!s->has_sweep) continue;
         sw_tab[4 * (size_t)o] = (int)sw.size(); sw_tab[4 * (size_t)o + 1] = count; sw_tab[4 * (size_t)o + 2] = is_sphere; sw_tab[4 * (size_t)o + 3] = first;
         size_t base = sw.size();
         sw.resize(base + 8, 0.f);
@@ -351,6 +366,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
             r[18] = a10 * a21 - a20 * a11; r[20] = a20 * a01 - a00 * a21; r[22] = a00 * a11 - a10 * a01;
         }
     }
+    tick("sweep stream");
     std::vector<float> aabb((size_t)O * 6, 0.f);
     if (d->obj_aabb) aabb.assign(d->obj_aabb, d->obj_aabb + (size_t)O * 6);
     std::vector<DevBxdf> bx((size_t)O);
@@ -491,6 +507,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         s->has_volume = true;
     }
 #undef UP
+    tick("tables + uploads");
     *out = s;
     return APT_OK;
 }
@@ -659,12 +676,12 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     // traversal mode: small scenes sweep all primitives wave-uniformly in the reference's brute-force order
     // the tiled sweep pays off once some object has enough primitives that skipping it per ray matters;
     // scenes of spheres and quads only are as fast in the plain wave sweep
-    const bool tile_ok = sc->has_aabb && sc->n_objects <= APT_TILE_MAX_OBJECTS && sc->n_prims < 65536 &&
+    const bool tile_ok = sc->has_aabb && sc->has_sweep && sc->n_objects <= APT_TILE_MAX_OBJECTS && sc->n_prims < 65536 &&
                          APT_TILE_LDS_BYTES(APT_TILE_NT, sc->n_objects) <= 160 * 1024;      // the per-object lists of a tile must fit the CU's LDS (34 objects at 512 threads)
-    r->trace_mode = (sc->n_prims <= APT_SWEEP_MAX_PRIMS && sc->has_aabb) ? ((tile_ok && sc->max_obj_prims >= APT_SWEEP_LIST_MIN) ? 2 : 1) : 0;
+    r->trace_mode = (sc->n_prims <= APT_SWEEP_MAX_PRIMS && sc->has_aabb && sc->has_sweep) ? ((tile_ok && sc->max_obj_prims >= APT_SWEEP_LIST_MIN) ? 2 : 1) : 0;
     if (const char* force = getenv("APT_TRAVERSAL")) {
         if (!strcmp(force, "bvh")) r->trace_mode = 0;
-        else if (!strcmp(force, "sweep") && sc->has_aabb) r->trace_mode = 1;
+        else if (!strcmp(force, "sweep") && sc->has_aabb && sc->has_sweep) r->trace_mode = 1;
         else if (!strcmp(force, "tile") && tile_ok) r->trace_mode = 2;
     }
     // LDS plan of the BVH walk: the per-lane stack of 8-byte groups.  A node visit leaves at most one group behind (the rest of its

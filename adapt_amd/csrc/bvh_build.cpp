@@ -11,10 +11,13 @@
 // Node = 16 dwords: [0..5] left min/max, [6..11] right min/max, [12] left link, [13] right link.
 // link >= 0: inner node index; link < 0: leaf, ~link = (first_prim << 4) | prim_count.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
+#include <thread>
 #include <vector>
 
 #include "bvh_build.hpp"
@@ -38,20 +41,26 @@ struct Box {
 };
 struct Ref { Box box; float c[3]; int prim; };
 
+// a subtree left for a worker thread: its primitive range, and the link slot of the node that waits for its root
+struct Task { int first, count; Box box; int depth, parent, slot; };
+
 struct Builder {
-    std::vector<Ref> refs;
+    Ref* refs = nullptr;          // shared array; a builder only touches the range it was given
     std::vector<float> nodes;     // 16 floats per node
     int max_depth = 0;
     int kMaxLeaf = 4;
+    int grain = 0;                // > 0: subtrees of at most this many primitives are not built but recorded in `tasks`
+    std::vector<Task>* tasks = nullptr;
 
     static float as_float(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
 
     int32_t leaf_link(int first, int count) { return ~((first << 4) | count); }
 
     // returns link for the subtree over refs[first, first+count); `box` = its bounds
-    int32_t build(int first, int count, const Box& box, int depth) {
+    int32_t build(int first, int count, const Box& box, int depth, int parent = -1, int slot = 0) {
         max_depth = std::max(max_depth, depth);
         if (count <= 1) return leaf_link(first, count);
+        if (tasks && parent >= 0 && count <= grain) { tasks->push_back({first, count, box, depth, parent, slot}); return 0; }      // link patched in later
         Box cb; cb.reset();
         for (int i = first; i < first + count; i++) cb.grow(refs[i].c);
         int axis = 0;
@@ -78,24 +87,22 @@ struct Builder {
                 if (cost < best) { best = cost; best_b = b; }
             }
             if (best_b >= 0 && (count > kMaxLeaf || best < (float)count)) {
-                auto it = std::stable_partition(refs.begin() + first, refs.begin() + first + count,
-                                                [&](const Ref& r) { return bin_of(r) <= best_b; });
-                mid = (int)(it - refs.begin());
+                Ref* it = std::stable_partition(refs + first, refs + first + count, [&](const Ref& r) { return bin_of(r) <= best_b; });
+                mid = (int)(it - refs);
             }
         }
         if (mid < 0) {
             if (count <= kMaxLeaf) return leaf_link(first, count);
             mid = first + count / 2;         // degenerate centroids: split by index
-            std::stable_sort(refs.begin() + first, refs.begin() + first + count,
-                             [&](const Ref& a, const Ref& b) { return a.c[axis] < b.c[axis]; });
+            std::stable_sort(refs + first, refs + first + count, [&](const Ref& a, const Ref& b) { return a.c[axis] < b.c[axis]; });
         }
         lbox.reset(); rbox.reset();
         for (int i = first; i < mid; i++) lbox.grow(refs[i].box);
         for (int i = mid; i < first + count; i++) rbox.grow(refs[i].box);
         int me = (int)(nodes.size() / 16);
         nodes.resize(nodes.size() + 16, 0.f);
-        int32_t l = build(first, mid - first, lbox, depth + 1);
-        int32_t r = build(mid, first + count - mid, rbox, depth + 1);
+        int32_t l = build(first, mid - first, lbox, depth + 1, me, 0);
+        int32_t r = build(mid, first + count - mid, rbox, depth + 1, me, 1);
         float* nd = nodes.data() + 16 * (size_t)me;
         for (int a = 0; a < 3; a++) { nd[a] = lbox.lo[a]; nd[3 + a] = lbox.hi[a]; nd[6 + a] = rbox.lo[a]; nd[9 + a] = rbox.hi[a]; }
         nd[12] = as_float(l); nd[13] = as_float(r);
@@ -106,16 +113,17 @@ struct Builder {
 
 int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, BvhData& out, int max_leaf) {
     if (n_prims <= 0 || !prims || !obj_info || max_leaf < 1 || max_leaf > 15) return -1;
+    std::vector<Ref> refs((size_t)n_prims);
     Builder b;
     b.kMaxLeaf = max_leaf;
-    b.refs.resize((size_t)n_prims);
+    b.refs = refs.data();
     std::vector<uint8_t> is_sphere((size_t)n_prims, 0);
     for (int o = 0; o < n_objects; o++)
         for (int p = obj_info[3 * o]; p < obj_info[3 * o] + obj_info[3 * o + 1]; p++)
             if (p >= 0 && p < n_prims) is_sphere[(size_t)p] = obj_info[3 * o + 2] != 0;
     for (int p = 0; p < n_prims; p++) {
         const float* v = prims + 9 * (size_t)p;
-        Ref& r = b.refs[(size_t)p];
+        Ref& r = refs[(size_t)p];
         r.prim = p;
         r.box.reset();
         if (is_sphere[(size_t)p]) {
@@ -131,8 +139,45 @@ int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_ob
         }
     }
     Box root; root.reset();
-    for (auto& r : b.refs) root.grow(r.box);
+    for (auto& r : refs) root.grow(r.box);
+    // Large scenes: the top of the tree is built here, subtrees of at most n / 64 primitives by worker threads (same splits, same tree:
+    // a subtree's build only reads and permutes its own primitive range), then the pieces are appended and their links rebased.
+    int threads = (int)std::thread::hardware_concurrency();
+    threads = std::max(1, std::min(threads, 32));
+    if (const char* e = std::getenv("APT_HOST_THREADS")) threads = std::max(1, std::atoi(e));
+    std::vector<Task> tasks;
+    if (threads > 1 && n_prims >= 65536) { b.tasks = &tasks; b.grain = std::max(4096, n_prims / 64); }
     int32_t link = b.build(0, n_prims, root, 0);
+    if (!tasks.empty()) {
+        std::vector<Builder> sub(tasks.size());
+        std::vector<int32_t> sub_link(tasks.size(), 0);
+        std::atomic<size_t> next_task{0};
+        auto worker = [&]() {
+            for (size_t t = next_task.fetch_add(1); t < tasks.size(); t = next_task.fetch_add(1)) {
+                Builder& w = sub[t];
+                w.refs = refs.data(); w.kMaxLeaf = max_leaf;
+                sub_link[t] = w.build(tasks[t].first, tasks[t].count, tasks[t].box, tasks[t].depth);
+            }
+        };
+        std::vector<std::thread> pool;
+        const int n_workers = (int)std::min<size_t>((size_t)threads, tasks.size());
+        for (int k = 0; k < n_workers; k++) pool.emplace_back(worker);
+        for (auto& th : pool) th.join();
+        for (size_t t = 0; t < tasks.size(); t++) {
+            const int32_t offset = (int32_t)(b.nodes.size() / 16);
+            Builder& w = sub[t];
+            for (size_t k = 0; k < w.nodes.size() / 16; k++)
+                for (int c = 0; c < 2; c++) {
+                    int32_t l; std::memcpy(&l, &w.nodes[16 * k + 12 + (size_t)c], 4);
+                    if (l >= 0) { l += offset; std::memcpy(&w.nodes[16 * k + 12 + (size_t)c], &l, 4); }
+                }
+            b.nodes.insert(b.nodes.end(), w.nodes.begin(), w.nodes.end());
+            const int32_t l = (sub_link[t] >= 0) ? sub_link[t] + offset : sub_link[t];
+            b.nodes[16 * (size_t)tasks[t].parent + 12 + (size_t)tasks[t].slot] = Builder::as_float(l);
+            b.max_depth = std::max(b.max_depth, w.max_depth);
+            std::vector<float>().swap(w.nodes);
+        }
+    }
     if (link < 0) {
         // the whole scene is one leaf: wrap it so that node 0 always exists
         b.nodes.assign(16, 0.f);
@@ -144,7 +189,7 @@ int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_ob
     }
     out.nodes = std::move(b.nodes);
     out.prim_order.resize((size_t)n_prims);
-    for (int i = 0; i < n_prims; i++) out.prim_order[(size_t)i] = b.refs[(size_t)i].prim;
+    for (int i = 0; i < n_prims; i++) out.prim_order[(size_t)i] = refs[(size_t)i].prim;
     out.max_depth = b.max_depth;
     return 0;
 }
