@@ -53,7 +53,9 @@ typedef struct apt_scene_desc {
     const int32_t* obj_info;    /* n_objects*3 first prim, prim count, 0 = mesh | 1 = sphere */
     const float*   obj_aabb;    /* n_objects*6 min xyz, max xyz */
     const int32_t* emitter_id;  /* n_objects   attached emitter index or -1 */
-    const int32_t* bxdf_i;      /* n_objects*4 type, is_delta, is_bsdf, 0     (bxdf/brdf.py:152-158, bsdf.py:68-73) */
+    const int32_t* bxdf_i;      /* n_objects*4 type, is_delta, is_bsdf, 0     (bxdf/brdf.py:152-158, bsdf.py:68-73).  BRDF type 3 (microfacet) shades as the
+                                 * reference's Trowbridge-Reitz model, i.e. as the reference does with `__ENABLE_MICROFACET__ = True` (brdf.py:8,428-484); with its
+                                 * default False the reference's parser never emits type 3 (it rewrites such a BRDF to Lambertian, brdf.py:60-65): so does the host side here */
     const float*   bxdf_f;      /* n_objects*13 k_d k_s k_g mean, medium ior */
     const int32_t* src_i;       /* n_sources*4 type, bool_bits, obj_ref_id, 0 (emitters/abtract_source.py:44-54) */
     const float*   src_f;       /* n_sources*11 intensity dir pos inv_area r */
