@@ -700,7 +700,15 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         if (r->lds_bytes > 160 * 1024) { return fail(APT_E_INVALID, "apt_renderer_create: BVH too deep for the LDS traversal stack"); }
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->lds_bytes));
         r->grid_trace = cus * per_cu;
-        if (r->trace_mode == 1) { r->lds_bytes = 0; r->grid_trace = cus * 8; }
+        if (r->trace_mode == 1) {
+            // persistent grid = a whole number of rounds of what the CU can hold: the sweep kernels allocate 85-89 VGPRs, five 256-thread
+            // workgroups per CU, and a grid of 8 per CU ran as one full round plus a 3/5 one (C3, ms per 64 spp, extend / shadow at
+            // 4 / 5 / 6 / 8 / 10 / 16 workgroups per CU: 6.4 / 5.7 / 7.2 / 6.2 / 5.6 / 5.8 and 14.0 / 13.6 / 15.0 / 13.8 / 13.3 / 13.3)
+            r->lds_bytes = 0;
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kShadow[1], BLOCK, 0) != hipSuccess || occ < 1) occ = 4;
+            r->grid_trace = cus * std::min(occ, 8) * 2;
+        }
         if (r->trace_mode == 2) {
             r->trace_nt = APT_TILE_NT;
             r->lds_bytes = APT_TILE_LDS_BYTES(APT_TILE_NT, sc->n_objects);

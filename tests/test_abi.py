@@ -414,3 +414,20 @@ def test_wide_bvh_walk_finds_every_brute_force_hit():
             if hm & 0xff000000:
                 stack.append((int(cbase[nidx]), (hm & 0xff000000) | int(imask[nidx])))
         assert k_true < 0 or k_true in reached, (o, d, k_true, t_true)
+
+
+def test_host_threads_build_the_same_tree(monkeypatch):
+    """Big scenes build on host threads (csrc/bvh_build.cpp: subtrees of n/64 primitives to workers; csrc/bvh_wide.cpp: one level of the
+    8-wide tree at a time, numbered by a prefix sum).  The result must not depend on the thread count: byte-identical nodes, the same
+    primitive order, the same depth as with APT_HOST_THREADS=1 - on a scene large enough (71 k primitives) to take both threaded paths."""
+    from adapt_amd.scene_pack import pack_scene
+    from adapt_amd.synth import bunny_field
+    fs = pack_scene(*bunny_field(levels=2))
+    assert fs.n_prims >= 65536
+    out = {}
+    for threads in ("1", "2", "7", "32"):
+        monkeypatch.setenv("APT_HOST_THREADS", threads)
+        out[threads] = build_wide(fs)
+    for threads in ("2", "7", "32"):
+        assert np.array_equal(out["1"][0], out[threads][0]) and np.array_equal(out["1"][1], out[threads][1]) and out["1"][2] == out[threads][2], threads
+    assert sorted(out["1"][1].tolist()) == list(range(fs.n_prims))
