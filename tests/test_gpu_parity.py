@@ -1054,6 +1054,48 @@ def test_device_bvh_builder_gives_the_same_answers(bunnies_small, monkeypatch):
     assert np.array_equal(images["sah"], images["lbvh"]) and np.array_equal(images["sah"], images["ploc"]) and images["sah"].max() > 0
 
 
+@pytest.mark.parametrize("builder", ["sah", "lbvh", "ploc"])
+def test_tree_builders_on_degenerate_inputs(builder, monkeypatch):
+    """What trips agglomerative and radix builders: forty COINCIDENT triangles (identical boxes and centroids: every Morton key ties, every
+    union area ties - PLOC must still find a mutual pair each round), a sliver fan sharing one edge, and a scene of just two primitives.
+    Closest hits equal the oracle's brute force bit for bit; coincident triangles resolve to the lowest primitive index, as upstream."""
+    from adapt_amd.renderer import Renderer
+    from adapt_amd.scene_pack import pack_scene
+    from adapt_amd.synth import _Builder, _brdf, _room, _sensor, _spot
+    from oracle import binding as ob
+    monkeypatch.setenv("APT_BVH_BUILDER", builder)
+    monkeypatch.setenv("APT_TRAVERSAL", "bvh")
+    white = _brdf("lambertian", "#BDBDBD")
+    light = [_spot("6.0, 6.0, 6.0", "100.0", (2.7, 5.2, 2.7), (0.0, -1.0, 0.1), 40.0, "s")]
+    tri = np.float32([[[2.0, 1.0, 2.5], [3.4, 1.0, 2.5], [2.0, 2.6, 2.5]]])
+    fan = np.float32([[[1.0, 0.5, 3.0], [1.0, 3.5, 3.0], [1.0 + 1e-3 * (k + 1), 2.0, 3.0 - 0.2 * k]] for k in range(9)])
+    scenes = []
+    b = _Builder(); _room(b, white, white, white); b.mesh(np.repeat(tri, 40, axis=0), white); b.mesh(fan, white)
+    scenes.append(b.finish(light, _sensor(64, 64, 4, 1)))
+    b = _Builder(); b.mesh(np.concatenate([tri, tri + np.float32([0.3, 0.2, 0.8])]), white)
+    scenes.append(b.finish(light, _sensor(64, 64, 4, 1)))
+    rs = np.random.RandomState(31)
+    for tup in scenes:
+        n = 6000
+        o = rs.uniform([0.3, 0.2, -2.0], [5.2, 5.2, 1.5], size=(n, 3)).astype(np.float32)
+        tgt = rs.uniform([1.0, 0.5, 2.0], [3.6, 3.6, 3.4], size=(n, 3)).astype(np.float32)
+        d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+        tmax = rs.uniform(0.5, 8.0, n).astype(np.float32)
+        sc = ob.OracleScene(pack_scene(*tup), make_config(tup[3]).cam_t)
+        _, prim_o, t_o, uv_o, _ = sc.intersect(o, d)
+        r = Renderer(*tup, width=32, height=32)
+        try:
+            assert r.info()["traversal"] == "bvh"
+            prim, t, uv = r.intersect(o, d)
+            assert (prim_o >= 0).sum() > n // 10
+            assert np.array_equal(prim, prim_o) and np.array_equal(t, t_o) and np.array_equal(uv[prim >= 0], uv_o[prim >= 0])
+            assert np.array_equal(r.occluded(o, d, tmax), sc.occluded(o, d, tmax))
+            r.render(n_spp=2)
+            assert np.isfinite(r.color.to_numpy()).all()
+        finally:
+            r.close()
+
+
 # ---------------------------------------------------------------- what the driver launches on the 8-GPU node: bench.py under torch.distributed.run
 def _run_bench(n, extra, tmp_path, tag):
     import json
