@@ -7,6 +7,8 @@ Tolerances (float32 path tracing):
   * images, HIP vs oracle with the SAME Philox stream: >= 99.5 % of pixels within 1e-3*(1+|x|) per channel and
     relMSE <= 1e-4 (an ulp-level difference can flip a branch and re-draw a path; nothing else may differ).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -352,6 +354,36 @@ def test_full_size_properties_c2(renderer):
     # red wall (x ~ 5.5) shows at small i, green (x = 0) at large i: x decreases with i (tracer_base.py:156)
     red, green = img[12:72, 200:300].mean(axis=(0, 1)), img[440:500, 200:300].mean(axis=(0, 1))
     assert red[0] > 2 * red[1] and green[1] > 2 * green[0]
+
+
+FULL_SIZE = os.environ.get("APT_FULL_SIZE_PARITY") == "1"
+
+
+@pytest.mark.skipif(not FULL_SIZE, reason="minutes of host time for the oracle: APT_FULL_SIZE_PARITY=1 (the run of record is profiles/r0N_full_size_parity.log)")
+@pytest.mark.parametrize("tag,spp", [("cbox", 1024), ("balls_mono", 1024)])
+def test_full_size_parity_c2_c3(tag, spp, renderer, parsed, oracle_scene, capsys):
+    """BASELINE configs[1] and [2] at their FULL size - 512x512, 1024 samples per pixel, 8 / 16 bounces - HIP against the oracle on the
+    same Philox stream, every pixel: the per-pixel tolerance of the small cases holds at 268 M samples, and the path statistics agree."""
+    r = renderer(tag)
+    assert (r.w, r.h) == (512, 512) and r.max_bounce == (8 if tag == "cbox" else 16)
+    r.render(n_spp=spp)
+    acc = r.color.to_numpy()
+    st = r.stats()
+    rc = make_config(parsed(tag)[3])
+    ref, cnt, ost = oracle_scene(tag).render(rc, spp, threads=0)
+    fin = np.isfinite(acc).all(axis=2) & np.isfinite(ref).all(axis=2)
+    assert np.array_equal(np.isfinite(acc), np.isfinite(ref))                     # the one inf pixel of C2 (vanilla_renderer.py:119 zeroes NaN only) coincides
+    a, b = np.where(fin[..., None], acc, 0) / spp, np.where(fin[..., None], ref, 0) / spp
+    m = image_metrics(a, b)
+    l2 = np.sqrt(((a - b) ** 2).sum(axis=2))
+    with capsys.disabled():
+        print(f"\n[full size] {tag}: 512x512x{spp} spp  relMSE {m['relMSE']:.3e}  max|diff| {m['max_abs']:.3e}  pixels within 1e-3(1+x) {100 * m['frac_within']:.4f} %  "
+              f"per-pixel L2 mean {l2.mean():.3e} max {l2.max():.3e}  non-finite pixels {int((~fin).sum())}  "
+              f"n_shade {st['n_shade']} / {ost['n_shade']}  n_shadow {st['n_shadow']} / {ost['n_shadow']}  n_draws {st['n_draws']} / {ost['n_draws']}")
+    assert m["frac_within"] >= 0.9999 and m["relMSE"] <= 1e-7, m
+    assert st["n_samples"] == ost["n_samples"] == 512 * 512 * spp
+    for k in ("n_shade", "n_shadow", "n_draws"):
+        assert abs(st[k] - ost[k]) <= 1e-5 * ost[k], (k, st[k], ost[k])
 
 
 # ---------------------------------------------------------------- large scenes: BVH traversal path
