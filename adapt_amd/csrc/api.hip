@@ -323,19 +323,20 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         }
     // primitive records in BVH order + precom rows (tracer_base.py:117-134)
     std::vector<float> prec((size_t)N * 9), recs((size_t)N * 12, 0.f);
-    for (int k = 0; k < N; k++) {
+    const int host_thr = apt::host_threads();           // per-primitive loops below: independent rows, chunked over host threads (bvh_build.hpp)
+    apt::parallel_for(N, host_thr, [&](int k) {
         const float* v = d->prims + 9 * (size_t)k; float* pc = prec.data() + 9 * (size_t)k;
         if (sphere[(size_t)k]) { for (int a = 0; a < 6; a++) pc[a] = v[a]; for (int a = 0; a < 3; a++) pc[6 + a] = v[a]; }
         else for (int a = 0; a < 3; a++) { pc[a] = v[3 + a] - v[a]; pc[3 + a] = v[6 + a] - v[a]; pc[6 + a] = v[a]; }
-    }
-    for (int slot = 0; slot < N; slot++) {
+    });
+    apt::parallel_for(N, host_thr, [&](int slot) {
         int k = s->wide.prim_order[(size_t)slot];
         const float* v = d->prims + 9 * (size_t)k; const float* pc = prec.data() + 9 * (size_t)k; float* r = recs.data() + 12 * (size_t)slot;
         int32_t kid = k, flag = sphere[(size_t)k] ? 1 : 0;
         if (flag) { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; }
         else { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = pc[0]; r[4] = pc[1]; r[5] = pc[2]; r[6] = pc[3]; r[7] = pc[4]; r[8] = pc[5]; }
         memcpy(&r[9], &kid, 4); memcpy(&r[10], &flag, 4);
-    }
+    });
     tick("primitive records");
     // sweep stream in scene order (layout: traverse.hpp SweepScene); the t-row cofactors of [e1 e2 .] are
     // ray-independent, so they are computed once here with the same float operations the device would use
@@ -454,7 +455,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     }
     {   // per-primitive shading records
         std::vector<float> ps((size_t)N * 8, 0.f);
-        for (int k = 0; k < N; k++) {
+        apt::parallel_for(N, host_thr, [&](int k) {
             float* r = ps.data() + 8 * (size_t)k;
             const int o = prim_obj[(size_t)k];
             int32_t code = sphere[(size_t)k] ? ~o : o, light = d->emitter_id[o];
@@ -462,7 +463,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
             r[0] = src3[0]; r[1] = src3[1]; r[2] = src3[2];
             memcpy(&r[3], &code, 4); memcpy(&r[4], &light, 4);
             r[5] = d->bxdf_f[13 * o]; r[6] = d->bxdf_f[13 * o + 1]; r[7] = d->bxdf_f[13 * o + 2];
-        }
+        });
         UP(prim_shade, ps);
         ds.prim_shade = s->prim_shade.as<float4>();
     }

@@ -142,9 +142,7 @@ int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_ob
     for (auto& r : refs) root.grow(r.box);
     // Large scenes: the top of the tree is built here, subtrees of at most n / 64 primitives by worker threads (same splits, same tree:
     // a subtree's build only reads and permutes its own primitive range), then the pieces are appended and their links rebased.
-    int threads = (int)std::thread::hardware_concurrency();
-    threads = std::max(1, std::min(threads, 32));
-    if (const char* e = std::getenv("APT_HOST_THREADS")) threads = std::max(1, std::atoi(e));
+    const int threads = host_threads();
     std::vector<Task> tasks;
     if (threads > 1 && n_prims >= 65536) { b.tasks = &tasks; b.grain = std::max(4096, n_prims / 64); }
     int32_t link = b.build(0, n_prims, root, 0);

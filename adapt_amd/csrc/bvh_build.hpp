@@ -1,9 +1,34 @@
 // bvh_build.hpp — host BVH builder interface (see bvh_build.cpp).
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 namespace apt {
+// Host threads for the per-primitive and per-node loops of scene creation (tree build, collapse, record packing): the machine's, at most
+// 32, or APT_HOST_THREADS.  Results never depend on the count.
+inline int host_threads() {
+    int t = (int)std::thread::hardware_concurrency();
+    t = std::max(1, std::min(t, 32));
+    if (const char* e = std::getenv("APT_HOST_THREADS")) t = std::max(1, std::atoi(e));
+    return t;
+}
+// f(i) for i in [0, n) on up to `threads` host threads (contiguous chunks); small ranges stay on the caller
+template <class F>
+void parallel_for(int n, int threads, F f) {
+    if (threads <= 1 || n < 2048) { for (int i = 0; i < n; i++) f(i); return; }
+    const int t = std::min(threads, (n + 511) / 512);
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)t);
+    for (int k = 0; k < t; k++) {
+        const int a = (int)((long long)n * k / t), b = (int)((long long)n * (k + 1) / t);
+        pool.emplace_back([a, b, &f]() { for (int i = a; i < b; i++) f(i); });
+    }
+    for (auto& th : pool) th.join();
+}
+
 struct BvhData {
     std::vector<float> nodes;          // 16 floats per node, node 0 = root
     std::vector<int32_t> prim_order;   // BVH-order slot -> original primitive index

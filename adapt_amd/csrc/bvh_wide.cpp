@@ -160,20 +160,6 @@ int emit_node(const BvhData& bvh2, const Work& wk, uint32_t* nodes, int32_t* pri
     return 0;
 }
 
-// f(i) for i in [0, n) on up to `threads` host threads (contiguous chunks); small ranges stay on the caller
-template <class F>
-void parallel_for(int n, int threads, F f) {
-    if (threads <= 1 || n < 2048) { for (int i = 0; i < n; i++) f(i); return; }
-    const int t = std::min(threads, (n + 511) / 512);
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)t);
-    for (int k = 0; k < t; k++) {
-        const int a = (int)((long long)n * k / t), b = (int)((long long)n * (k + 1) / t);
-        pool.emplace_back([a, b, &f]() { for (int i = a; i < b; i++) f(i); });
-    }
-    for (auto& th : pool) th.join();
-}
-
 }  // namespace
 
 // Breadth first, one level at a time: the nodes of a level are planned in parallel, numbered by a prefix sum over the level (inner
@@ -184,9 +170,7 @@ int build_wide_bvh(const BvhData& bvh2, WideBvhData& out) {
     if (bvh2.n_nodes() <= 0) return -1;
     out.nodes.clear(); out.prim_order.clear(); out.max_depth = 0;
     out.prim_order.assign(bvh2.prim_order.size(), 0);
-    int threads = (int)std::thread::hardware_concurrency();
-    threads = std::max(1, std::min(threads, 32));
-    if (const char* e = std::getenv("APT_HOST_THREADS")) threads = std::max(1, std::atoi(e));
+    const int threads = host_threads();
     std::vector<Item> level(1), next;
     level[0].node2 = 0; level[0].node8 = 0; level[0].depth = 1;
     std::unique_ptr<Work[]> work;
