@@ -1086,6 +1086,43 @@ def test_device_bvh_builder_gives_the_same_answers(bunnies_small, monkeypatch):
     assert np.array_equal(images["sah"], images["lbvh"]) and np.array_equal(images["sah"], images["ploc"]) and images["sah"].max() > 0
 
 
+def test_million_primitive_scene_takes_the_device_builder(monkeypatch):
+    """Above a million primitives the tree is built on the device (PLOC) by default, the collapse and the record tables on host threads.
+    The 1.14 M-triangle bunny field: same closest hits (primitive, t, barycentrics) and occlusion flags as with the host SAH builder,
+    on rays through the field; a cropped window renders to the same image bit for bit."""
+    from adapt_amd.renderer import Renderer
+    from adapt_amd.synth import bunny_field
+    field = bunny_field(levels=4)
+    assert field[1]["primitives"].shape[0] >= 1000000
+    cfg = dict(field[3]); cfg["film"] = {"width": 1280, "height": 720, "crop_x": 640, "crop_y": 330, "crop_rx": 48, "crop_ry": 32}
+    rs = np.random.RandomState(77)
+    n = 20000
+    o = rs.uniform([0.3, 0.2, -1.0], [5.2, 5.2, 1.0], size=(n, 3)).astype(np.float32)
+    tgt = rs.uniform([0.5, 0.0, 1.0], [5.0, 2.0, 5.0], size=(n, 3)).astype(np.float32)
+    d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tmax = rs.uniform(0.5, 8.0, n).astype(np.float32)
+    out = {}
+    for builder in (None, "sah"):
+        if builder is None:
+            monkeypatch.delenv("APT_BVH_BUILDER", raising=False)
+        else:
+            monkeypatch.setenv("APT_BVH_BUILDER", builder)
+        r = Renderer(field[0], field[1], field[2], cfg)
+        try:
+            assert r.info()["traversal"] == "bvh"
+            prim, t, uv = r.intersect(o, d)
+            occ = r.occluded(o, d, tmax)
+            r.render(n_spp=2)
+            out[builder] = (prim, t, uv, occ, r.color.to_numpy())
+        finally:
+            r.close()
+    a, b = out[None], out["sah"]
+    assert (a[0] >= 0).mean() > 0.9 and len(np.unique(a[0])) > 3000
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert a[4].max() > 0
+
+
 @pytest.mark.parametrize("builder", ["sah", "lbvh", "ploc"])
 def test_tree_builders_on_degenerate_inputs(builder, monkeypatch):
     """What trips agglomerative and radix builders: forty COINCIDENT triangles (identical boxes and centroids: every Morton key ties, every
