@@ -14,7 +14,8 @@ struct Philox {
     uint32_t key0, key1, ctr0;
     uint32_t draw;
     uint32_t blk;        // block index held in c[] (0xffffffff = none)
-    uint32_t c[4];
+    uint32_t nblk;       // block index held in n[] (0xffffffff = none): only ever set by rng_open
+    uint32_t c[4], n[4];
 };
 
 APT_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -39,15 +40,28 @@ APT_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 }
 
 APT_HD void rng_init(Philox& r, uint32_t pixel, uint32_t seed, uint32_t sample, uint32_t draw) {
-    r.key0 = pixel; r.key1 = seed; r.ctr0 = sample; r.draw = draw; r.blk = 0xffffffffu;
+    r.key0 = pixel; r.key1 = seed; r.ctr0 = sample; r.draw = draw; r.blk = 0xffffffffu; r.nblk = 0xffffffffu;
     r.c[0] = r.c[1] = r.c[2] = r.c[3] = 0u;
+    r.n[0] = r.n[1] = r.n[2] = r.n[3] = 0u;
 }
 APT_HD uint32_t rng_u32(Philox& r) {
-    uint32_t d = r.draw++;
-    uint32_t b = d >> 2;
-    if (b != r.blk) { philox4x32_10(r.ctr0, b, 0u, 0u, r.key0, r.key1, r.c); r.blk = b; }
-    uint32_t w = d & 3u;     // select without dynamic register indexing
+    const uint32_t d = r.draw++;
+    const uint32_t b = d >> 2;
+    const bool step = b != r.blk;
+    if (step && b != r.nblk) { philox4x32_10(r.ctr0, b, 0u, 0u, r.key0, r.key1, r.n); r.nblk = b; }      // not opened ahead: generate here
+    if (step) { r.c[0] = r.n[0]; r.c[1] = r.n[1]; r.c[2] = r.n[2]; r.c[3] = r.n[3]; r.blk = b; r.nblk = 0xffffffffu; }
+    const uint32_t w = d & 3u;     // select without dynamic register indexing
     return (w == 0u) ? r.c[0] : ((w == 1u) ? r.c[1] : ((w == 2u) ? r.c[2] : r.c[3]));
+}
+// For a stage that draws at most five numbers per path: both blocks those draws can touch, generated now, unconditionally.  A generation
+// computes every lane's own block in one pass, but left to the draw sites it runs at every site where ANY lane steps into a new block,
+// and the lanes of an unsorted queue sit at unrelated offsets of their streams: 3.4 passes per shade on the Cornell box where two
+// serve every lane (k_shade, point lights, one light sample: 3.03 -> 2.83 ms per 64 spp).  Stages that draw more keep the lazy
+// per-site generation: there the second buffer only costs registers (measured: C3 13.2 -> 14.7 ms with it).
+APT_HD void rng_open(Philox& r) {
+    const uint32_t b = r.draw >> 2;
+    philox4x32_10(r.ctr0, b, 0u, 0u, r.key0, r.key1, r.c); r.blk = b;
+    philox4x32_10(r.ctr0, b + 1u, 0u, 0u, r.key0, r.key1, r.n); r.nblk = b + 1u;
 }
 APT_HD float rng_float(Philox& r) { return (float)(rng_u32(r) >> 8) * (1.0f / 16777216.0f); }
 APT_HD int32_t rng_int(Philox& r) { return (int32_t)rng_u32(r); }

@@ -609,6 +609,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_
                     if (hit_light >= 0 && bx.is_delta == 0 && !was_spec) e_pdf = emitter_solid_angle_pdf(sc.src[hit_light], it, d);
                     emission_weight = balance(ray_pdf, e_pdf);
                 }
+                if (!(SM & 2)) rng_open(rng);                   // no area lights: a shade with one light sample draws at most five numbers (rng.hpp)
                 // Russian roulette / cut-off (vanilla_renderer.py:50-57)
                 if (p.use_rr) {
                     float mx = max3(thr);
