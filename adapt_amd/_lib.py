@@ -6,8 +6,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ADAPT_MI_LIB: load another build of the same library (kernel tuning experiments); still no fallback.
-LIB_PATH = os.environ.get("ADAPT_MI_LIB") or os.path.join(_HERE, "libadapt_mi.so")
+# Two builds of the same sources (adapt_amd/build.py): "fast" = the product (libadapt_mi.so: what render.py, bench.py and smoke() run),
+# "exact" = the reference's float32 arithmetic operation for operation (libadapt_mi_exact.so: the build the bit-exact parity tests pin;
+# APT_EXACT=1 makes it the default, `use("exact")` switches at run time).  Both export the same C-ABI; neither has a CPU fallback.
+# ADAPT_MI_LIB: load another build in place of the fast one (kernel tuning experiments).
+LIB_PATHS = {"fast": os.environ.get("ADAPT_MI_LIB") or os.path.join(_HERE, "libadapt_mi.so"),
+             "exact": os.environ.get("ADAPT_MI_LIB_EXACT") or os.path.join(_HERE, "libadapt_mi_exact.so")}
+_variant = "exact" if os.environ.get("APT_EXACT", "0") not in ("", "0") else "fast"
+LIB_PATH = LIB_PATHS[_variant]
 
 f32p = C.POINTER(C.c_float)
 i32p = C.POINTER(C.c_int32)
@@ -94,26 +100,51 @@ SYMBOLS = {
     "apt_version": (C.c_char_p, []),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """dlopen the in-tree library and bind every declared symbol (raises if any is missing)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise AptError(f"{LIB_PATH} is missing: build it with `python -m adapt_amd.build` (needs hipcc); "
+def use(variant: str) -> str:
+    """Make `variant` ("fast" | "exact") the library `load()` hands out from now on; returns the previous choice.  Objects created
+    earlier keep the library they were created with."""
+    global _variant, LIB_PATH
+    if variant not in LIB_PATHS:
+        raise ValueError(f"unknown build variant {variant!r}")
+    prev, _variant = _variant, variant
+    LIB_PATH = LIB_PATHS[variant]
+    return prev
+
+
+def variant() -> str:
+    return _variant
+
+
+def load(variant: str | None = None):
+    """dlopen the in-tree library (of the current, or the given, variant) and bind every declared symbol (raises if any is missing)."""
+    v = variant or _variant
+    if v in _libs:
+        return _libs[v]
+    path = LIB_PATHS[v]
+    if not os.path.exists(path):
+        raise AptError(f"{path} is missing: build it with `python -m adapt_amd.build` (needs hipcc); "
                        "adapt_amd has no CPU fallback")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args
-    _lib = lib
+    tag = lib.apt_version()
+    if f"arithmetic: {v}".encode() not in tag and not os.environ.get("ADAPT_MI_LIB"):
+        raise AptError(f"{path} reports {tag!r}: not the {v} build")
+    _libs[v] = lib
     return lib
 
 
-def check(rc: int, what: str = ""):
+def arithmetic(lib=None) -> str:
+    """"fast" or "exact": what the loaded library says about itself (apt_version)."""
+    tag = (lib or load()).apt_version().decode()
+    return "exact" if "arithmetic: exact" in tag else "fast"
+
+
+def check(rc: int, what: str = "", lib=None):
     if rc != 0:
-        msg = load().apt_last_error()
+        msg = (lib or load()).apt_last_error()
         raise AptError(f"{what or 'adapt_mi'} failed ({rc}): {msg.decode() if msg else '?'}")

@@ -80,10 +80,16 @@ static int class_of(int is_bsdf, int type, bool no_lobe) {
 typedef void (*extend_fn)(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan);
 typedef void (*shadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan);
 typedef void (*occluded_fn)(DevScene, uint32_t, const float*, const float*, const float*, int*, LdsPlan);
-static const extend_fn kExtend[3][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_extend<1, 0>, k_extend<1, 1>}, {k_extend<2, 0>, k_extend<2, 1>}};   // [mode][sorted]
+#if APT_FAST
+#define APT_FLAT_FN(...) __VA_ARGS__
+#else
+#define APT_FLAT_FN(...) nullptr          // the flat sweep exists in the fast build only (traverse.hpp)
+#endif
+static const extend_fn kExtend[4][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_extend<1, 0>, k_extend<1, 1>}, {k_extend<2, 0>, k_extend<2, 1>},
+                                        {APT_FLAT_FN(k_extend_flat<0>), APT_FLAT_FN(k_extend_flat<1>)}};   // [mode][sorted]
 static const extend_fn kExtendDyn[2] = {k_extend_dyn<0>, k_extend_dyn<1>};      // BVH walk with dynamic ray fetch [sorted]
-static const shadow_fn kShadow[3] = {k_shadow<0>, k_shadow<1>, k_shadow<2>};
-static const occluded_fn kOccluded[3] = {k_occluded<0>, k_occluded<1>, k_occluded<2>};
+static const shadow_fn kShadow[4] = {k_shadow<0>, k_shadow<1>, k_shadow<2>, APT_FLAT_FN(k_shadow_flat)};
+static const occluded_fn kOccluded[4] = {k_occluded<0>, k_occluded<1>, k_occluded<2>, APT_FLAT_FN(k_occluded_flat)};
 typedef void (*vshade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int);
 struct VShadeVariant { int bm, sm; vshade_fn fn; const char* name; };
 static const VShadeVariant kVShadeVariants[] = {          // first match wins; 0x400 = "other BSDF" = the null surface
@@ -108,7 +114,7 @@ static const VShadeVariant kVShadeVolVariants[] = {       // scenes with a grid 
     {APT_BX_ALL, APT_SRC_ALL, k_vshade<APT_BX_ALL, APT_SRC_ALL, 1>, "volumetric + grid volume: all models"},
 };
 typedef void (*vshadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan, int);
-static const vshadow_fn kVShadow[3] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>};     // volumetric: transmittance walk (one closest-hit query per pass)
+static const vshadow_fn kVShadow[4] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>, APT_FLAT_FN(k_vshadow<3>)};     // volumetric: transmittance walk (one closest-hit query per pass)
 #define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
 
 // ============================================================== host side
@@ -132,6 +138,8 @@ struct apt_scene {
     apt::BvhData bvh;                    // binary SAH tree (leaves of <= 3 primitives): the intermediate of the build
     apt::WideBvhData wide;               // 8-wide quantised tree: what the kernels walk
     DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
+    DevBuf flat_recs, flat_tab;          // flat sweep (fast build, small scenes): records and the per-record table (traverse.hpp FlatScene)
+    bool has_flat = false;
     DevBuf uvs, tex_i, tex_f, atlas[3];      // image textures (empty when the scene has none)
     DevBuf prim_shade;                   // per-primitive shading records (stages.hpp DevScene::prim_shade)
     DevBuf med;                          // participating media, n_objects + 1 rows (volumetric path tracer)
@@ -166,6 +174,7 @@ struct apt_renderer {
     const ShadeVariant* shade = nullptr;
     int trace_mode = 0;           // 0 = BVH traversal, 1 = wave-uniform sweep, 2 = tiled sweep (small scenes)
     int trace_nt = BLOCK;         // workgroup size of the trace kernels
+    int trace_items = BLOCK;      // queue entries per workgroup pass (flat sweep: two per thread)
     int sorted = 0;               // 1 = material-sorted shading (>= 2 material classes in the scene)
     int volumetric = 0;           // 1 = VolumeRenderer.render semantics (volumetric.hpp)
     int dyn_fetch = 0;            // BVH mode: closest-hit walk with dynamic ray fetch (k_extend_dyn)
@@ -206,7 +215,11 @@ static int count_device(int* n) {
 }
 
 APT_EXPORT const char* apt_last_error(void) { return g_err.c_str(); }
-APT_EXPORT const char* apt_version(void) { return "adapt_mi 0.1 (gfx950 wavefront path tracer)"; }
+#if APT_FAST
+APT_EXPORT const char* apt_version(void) { return "adapt_mi 0.3 (gfx950 wavefront path tracer; arithmetic: fast)"; }
+#else
+APT_EXPORT const char* apt_version(void) { return "adapt_mi 0.3 (gfx950 wavefront path tracer; arithmetic: exact)"; }
+#endif
 
 // ---- BVH build (host only, no device needed)
 APT_EXPORT int apt_bvh_build(const float* prims, int32_t n_prims, const int32_t* obj_info, int32_t n_objects, apt_bvh** out) {
@@ -406,6 +419,24 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         for (int k = 0; k < N; k++) pcls[(size_t)k] = obj_cls[(size_t)prim_obj[(size_t)k]];
         hipError_t e_ = upload(s->prim_class, pcls);
         if (e_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload prim_class: ") + hipGetErrorString(e_)); }
+        memset(&s->dev.flat, 0, sizeof(s->dev.flat));
+#if APT_FAST
+        if (N <= APT_FLAT_MAX_PRIMS && s->has_sweep && d->obj_aabb) {          // flat sweep records (traverse.hpp "Flat sweep"); the sweep stream serves its zero-component fallback
+            std::vector<float> fr, ft;
+            FlatScene& fl = s->dev.flat;
+            std::vector<uint8_t> trans((size_t)O);
+            for (int o = 0; o < O; o++) trans[(size_t)o] = bx[(size_t)o].is_bsdf ? 1 : 0;
+            int fc[5];
+            if (apt::build_flat(d->prims, N, d->obj_info, O, pcls.data(), trans.data(), fr, ft, fc) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: flat records: obj_info range outside the primitive array"); }
+            fl.n_quads = fc[0]; fl.n_quads_tie = fc[1]; fl.n_tris = fc[2]; fl.n_tris_tie = fc[3]; fl.n_spheres = fc[4];
+            hipError_t e1_ = upload(s->flat_recs, fr), e2_ = (e1_ == hipSuccess) ? upload(s->flat_tab, ft) : e1_;
+            if (e2_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload flat records: ") + hipGetErrorString(e2_)); }
+            fl.stream = s->flat_recs.as<float>(); fl.tab = s->flat_tab.as<float4>();
+            s->has_flat = true;
+            if (timing) fprintf(stderr, "[scene timing] flat records: %d + %d parallelograms, %d + %d triangles (plain + coplanar groups), %d spheres of %d primitives\n", fc[0], fc[1], fc[2], fc[3], fc[4], N);
+            tick("flat records");
+        }
+#endif
     }
     std::vector<DevSrc> sr((size_t)S);
     for (int k = 0; k < S; k++) {
@@ -429,6 +460,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     ds.sweep.stream = s->sweep_recs.as<float>(); ds.sweep.obj_tab = s->sweep_tab.as<int>(); ds.sweep.prim_obj = s->prim_obj.as<int>(); ds.sweep.n_objects = O;
     s->has_aabb = d->obj_aabb != nullptr;
     ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float>(); ds.precom = s->precom.as<float>();
+    ds.flat.precom = ds.precom;
     ds.prim_obj = s->prim_obj.as<int>(); ds.prim_class = s->prim_class.as<int>(); ds.obj_info = s->obj_info.as<int>(); ds.emitter_id = s->emitter_id.as<int>();
     ds.bxdf = s->bxdf.as<DevBxdf>(); ds.src = s->src.as<DevSrc>();
     ds.n_prims = N; ds.n_objects = O; ds.n_sources = S; ds.has_vn = d->has_vertex_normal; ds.world_ior = d->world_ior;
@@ -569,6 +601,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     p.use_rr = c.use_rr; p.use_mis = c.use_mis; p.anti_alias = c.anti_alias; p.stratified = c.stratified; p.two_sides = c.brdf_two_sides;
     p.rr_bounce_th = c.rr_bounce_th; p.rr_threshold = c.rr_threshold; p.seed = c.seed; p.cap = (uint32_t)cap; p.subcap = (uint32_t)subcap; p.nq = nq;
     p.inv_ns = 1.f / (float)sc->n_sources; p.inv_ns1 = (sc->n_sources > 1) ? 1.f / (float)(sc->n_sources - 1) : 1.f;
+    p.l_planes = (!c.volumetric && S >= 2 && S <= 4) ? S : 1;        // stages.hpp APT_EXCLUSIVE_L: one radiance plane per light sample of a vertex
     p.pix_bits = 0; while ((1u << p.pix_bits) < (uint32_t)r->npix) p.pix_bits++;
     if (((uint64_t)B << p.pix_bits) > (1ull << 32)) { return fail(APT_E_INVALID, "apt_renderer_create: spp_per_batch x pixels does not fit the 32-bit path id"); }
     {   // local pixel -> RNG key (global pixel index), same mapping as local_to_global in stages.hpp
@@ -629,7 +662,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (cap >= ((size_t)1 << 30) || sh_cap >= ((size_t)1 << 30)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (queue capacity must stay below 2^30 slots)"); }
     // one pool per lane, carved into the SoA arrays (all 4-byte lanes)
     const bool walk_lists = r->volumetric && sc->has_null_surface;      // light samples that cross null surfaces are re-queued by slot
-    const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 3) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
+    const size_t l_planes = (size_t)p.l_planes;
+    const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 3 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
         hipError_t e_ = pool.alloc(words * 4);
         if (e_ != hipSuccess) return e_;
@@ -638,7 +672,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         for (int k = 0; k < 2; k++) { q.ray_o[k] = take(3 * cap); q.ray_d[k] = take(3 * cap); }
         q.hit_t = take(cap); q.hit_prim = (int*)take(cap); q.hit_u = take(cap); q.hit_v = take(cap);
         for (int k = 0; k < 2; k++) { q.thr[k] = take(3 * cap); q.id[k] = (uint32_t*)take(cap); q.meta[k] = (uint32_t*)take(cap); q.pdf[k] = take(cap); }
-        q.L = take(3 * cap);
+        q.L = take(3 * cap * l_planes);
         q.sh_o = take(3 * sh_cap); q.sh_d = take(3 * sh_cap); q.sh_tmax = take(sh_cap); q.sh_c = take(3 * sh_cap); q.sh_id = (uint32_t*)take(sh_cap);
         q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
         q.sh_walk[0] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr; q.sh_walk[1] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr;
@@ -680,8 +714,10 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     const bool tile_ok = sc->has_aabb && sc->has_sweep && sc->n_objects <= APT_TILE_MAX_OBJECTS && sc->n_prims < 65536 &&
                          APT_TILE_LDS_BYTES(APT_TILE_NT, sc->n_objects) <= 160 * 1024;      // the per-object lists of a tile must fit the CU's LDS (34 objects at 512 threads)
     r->trace_mode = (sc->n_prims <= APT_SWEEP_MAX_PRIMS && sc->has_aabb && sc->has_sweep) ? ((tile_ok && sc->max_obj_prims >= APT_SWEEP_LIST_MIN) ? 2 : 1) : 0;
+    if (sc->has_flat) r->trace_mode = 3;                 // fast build: the flat sweep serves every scene small enough to have its records
     if (const char* force = getenv("APT_TRAVERSAL")) {
         if (!strcmp(force, "bvh")) r->trace_mode = 0;
+        else if (!strcmp(force, "flat") && sc->has_flat) r->trace_mode = 3;
         else if (!strcmp(force, "sweep") && sc->has_aabb && sc->has_sweep) r->trace_mode = 1;
         else if (!strcmp(force, "tile") && tile_ok) r->trace_mode = 2;
     }
@@ -701,6 +737,13 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         if (r->lds_bytes > 160 * 1024) { return fail(APT_E_INVALID, "apt_renderer_create: BVH too deep for the LDS traversal stack"); }
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->lds_bytes));
         r->grid_trace = cus * per_cu;
+        if (r->trace_mode == 3) {
+            // no LDS; the grid is a whole number of rounds of what the register allocation lets a CU hold
+            r->lds_bytes = 0; r->trace_items = 2 * BLOCK;
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kShadow[3], BLOCK, 0) != hipSuccess || occ < 1) occ = 4;
+            r->grid_trace = cus * std::min(occ, 8) * 2;
+        }
         if (r->trace_mode == 1) {
             // persistent grid = a whole number of rounds of what the CU can hold: the sweep kernels allocate 85-89 VGPRs, five 256-thread
             // workgroups per CU, and a grid of 8 per CU ran as one full round plus a 3/5 one (C3, ms per 64 spp, extend / shadow at
@@ -711,7 +754,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
             r->grid_trace = cus * std::min(occ, 8) * 2;
         }
         if (r->trace_mode == 2) {
-            r->trace_nt = APT_TILE_NT;
+            r->trace_nt = APT_TILE_NT; r->trace_items = APT_TILE_NT;
             r->lds_bytes = APT_TILE_LDS_BYTES(APT_TILE_NT, sc->n_objects);
             r->lds_bytes_any = APT_TILE_LDS_BYTES_ANY(APT_TILE_NT, sc->n_objects);
             r->grid_trace = cus * (int)std::max<size_t>(1, std::min<size_t>(2048 / APT_TILE_NT, (160 * 1024) / r->lds_bytes));
@@ -853,7 +896,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
             const LdsPlan& lane_plan = is.li ? r->extra[(size_t)is.li - 1].plan : r->plan;
             for (int b = 0; b < n_iter; b++) {
                 if (r->dyn_fetch) HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st));
-                { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
+                { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
                 if (!r->sorted) {
                     ShadeIn in = {q.ray_o[is.cur], q.ray_d[is.cur], q.thr[is.cur], q.id[is.cur], q.meta[is.cur], q.pdf[is.cur],
                                   q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[is.cur]};
@@ -955,7 +998,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
         int cur = 0;
         for (int b = 0; b < p.max_bounce; b++) {
             if (r->dyn_fetch) HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st));
-            { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
+            { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
             if (!r->sorted) {
                 ShadeIn in = {q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.id[cur], q.meta[cur], q.pdf[cur],
                               q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur]};
@@ -970,8 +1013,8 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             }
             if (p.S > 0 && r->dyn_fetch) {
                 HIP_TRY(hipMemsetAsync(cnt->n_work[1], 0, sizeof(cnt->n_work[1]), st));
-                LaunchTimer t(r, 3, st); hipLaunchKernelGGL(k_shadow_dyn, dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan);
-            } else if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan); }
+                LaunchTimer t(r, 3, st); hipLaunchKernelGGL(k_shadow_dyn, dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan);
+            } else if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan); }
             cur ^= 1;
         }
         // the framebuffer is shared: batch k's samples are added after batch k-1's, whichever lanes they ran on
@@ -1110,7 +1153,7 @@ APT_EXPORT int apt_intersect(apt_renderer* r, int32_t n, const float* o, const f
     uint32_t un = (uint32_t)n;
     HIP_TRY(hipMemcpy(r->scratch.p, &un, 4, hipMemcpyHostToDevice));
     Params flat = r->par; flat.nq = 1; flat.subcap = flat.cap;          // one flat queue for explicit rays
-    hipLaunchKernelGGL(kExtend[r->trace_mode][0], dim3(grid_for((size_t)n, r->grid_trace, 1, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes, r->stream, r->scene->dev, flat, r->q, (Counters*)nullptr, 0,
+    hipLaunchKernelGGL(kExtend[r->trace_mode][0], dim3(grid_for((size_t)n, r->grid_trace, 1, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, r->stream, r->scene->dev, flat, r->q, (Counters*)nullptr, 0,
                        (const uint32_t*)r->scratch.p, r->plan);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(r->stream));
@@ -1134,7 +1177,7 @@ APT_EXPORT int apt_occluded(apt_renderer* r, int32_t n, const float* o, const fl
     HIP_TRY(upload(bo, so)); HIP_TRY(upload(bd, sd));
     std::vector<float> tm(tmax, tmax + n);
     HIP_TRY(upload(bt, tm)); HIP_TRY(bocc.alloc((size_t)n * 4));
-    hipLaunchKernelGGL(kOccluded[r->trace_mode], dim3(grid_for((size_t)n, r->grid_shadow, 1, r->trace_nt)), dim3(r->trace_nt), r->lds_bytes_any, r->stream, r->scene->dev, (uint32_t)n,
+    hipLaunchKernelGGL(kOccluded[r->trace_mode], dim3(grid_for((size_t)n, r->grid_shadow, 1, r->trace_items)), dim3(r->trace_nt), r->lds_bytes_any, r->stream, r->scene->dev, (uint32_t)n,
                        bo.as<float>(), bd.as<float>(), bt.as<float>(), bocc.as<int>(), r->plan);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(r->stream));

@@ -49,6 +49,7 @@ struct DevVolume {            // bxdf/volume.py:221-246 (grid volume of the volu
 struct DevScene {
     DevBvh bvh;
     SweepScene sweep;         // small scenes: uniform brute-force sweep instead of the BVH
+    FlatScene flat;           // small scenes, fast build: precomputed-transform records, two per packed instruction (traverse.hpp "Flat sweep")
     const float* normals;     // n_prims*3
     const float* vnormals;    // n_prims*9
     const float* precom;      // n_prims*9  (v1-v0, v2-v0, v0) | sphere (centre, rrr, centre)
@@ -94,6 +95,7 @@ struct Params {
     uint32_t pix_bits;
     const uint32_t* pix_key;  // local pixel -> global pixel index x * H + y = the RNG key (host-built; band mapping folded in)
     float inv_ns, inv_ns1;    // 1 / n_sources, 1 / (n_sources - 1): sample_light's pdfs (path_tracer.py:537-554)
+    int l_planes;             // radiance planes of L: light sample s of a vertex adds into plane s (2 <= S <= 4), so that no two entries of a shadow launch share a slot; 1 otherwise
     float w_min[3], w_max[3]; // world box = (objects U camera) +- 0.1 (path_tracer.py:130-138); volumetric tracer only
 };
 
@@ -144,8 +146,11 @@ struct Counters {
 APT_D uint32_t pack_meta(uint32_t draw, uint32_t bounce, bool spec) { return (draw & 0xffffu) | ((bounce & 0xffu) << 16) | (spec ? (1u << 24) : 0u); }
 
 #define BLOCK 256
+// One light sample per vertex, or one radiance plane per light sample (Params::l_planes): no two entries of a shadow launch add into the
+// same slot and the adds are plain read-modify-writes.  Measured on C3 (S = 4) with float atomics instead: k_shadow 17 % VALU-busy, 3.9x
+// its algorithmic HBM writes (every atomic is an L2 read-modify-write of a sector), and run-to-run differences in the last bit.
 #ifndef APT_EXCLUSIVE_L
-#define APT_EXCLUSIVE_L(p) ((p).S == 1)
+#define APT_EXCLUSIVE_L(p) ((p).S == 1 || (p).l_planes == (p).S)
 #endif
 
 // LDS of the BVH-walk stages (dynamic, sized per scene by the host): the traversal stack, stack_depth * BLOCK 8-byte groups laid out [level][lane]
@@ -164,8 +169,9 @@ APT_D uint32_t lane_id() { return threadIdx.x & 63u; }
 // path vertex (p.S == 1) no two entries of a shadow launch share a slot and nothing else writes L while the launch runs, so the add is
 // a plain read-modify-write: deterministic, and not an L2 atomic per component.  With several samples per vertex the entries of one
 // path sit in different waves: float atomics (their order is the one thing in the image that may differ from run to run).
-APT_D void add_radiance(float* L, uint32_t cap, uint32_t lo_, f3 c, bool exclusive) {
-    char* Lb = reinterpret_cast<char*>(L);
+APT_D void add_radiance(float* L, uint32_t cap, uint32_t code, f3 c, bool exclusive) {
+    const uint32_t lo_ = code & ~3u;                                   // the entry's slot: byte offset (a multiple of 4) | radiance plane in the low two bits
+    char* Lb = reinterpret_cast<char*>(L) + (size_t)(code & 3u) * ((size_t)cap * 12);
     float* px = reinterpret_cast<float*>(Lb + lo_); float* py = reinterpret_cast<float*>(Lb + (size_t)cap * 4 + lo_); float* pz = reinterpret_cast<float*>(Lb + (size_t)cap * 8 + lo_);
     if (exclusive) { *px = *px + c.x; *py = *py + c.y; *pz = *pz + c.z; }
     else { atomicAdd(px, c.x); atomicAdd(py, c.y); atomicAdd(pz, c.z); }
@@ -226,7 +232,7 @@ APT_D SubLoop sub_loop(int nq, int nt = BLOCK) {
     s.stride = (gridDim.x / (uint32_t)nq) * (uint32_t)nt;
     return s;
 }
-// trace kernels: MODE 0 BVH walk, 1 wave/workgroup sweep, 2 tiled sweep (its own, larger workgroup)
+// trace kernels: MODE 0 BVH walk, 1 wave/workgroup sweep, 2 tiled sweep (its own, larger workgroup), 3 flat sweep (fast build only)
 #ifndef APT_TILE_NT
 #define APT_TILE_NT 512
 #endif
@@ -257,7 +263,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
         if (valid) {
             uint32_t lp = idx % (uint32_t)p.npix, s = idx / (uint32_t)p.npix;
             int i, j; local_to_global(p, lp, i, j);
-            st3q(q.L, p.cap, idx << 2, splat3(0.f));
+            for (int pl = 0; pl < p.l_planes; pl++) st3q(q.L + (size_t)pl * 3 * p.cap, p.cap, idx << 2, splat3(0.f));
             alive = !p.do_crop || (i >= p.sx && i < p.ex && j >= p.sy && j < p.ey);
             if (alive) {
                 int sample_cnt = p.cnt_base + (int)s + 1;        // cnt is incremented before the pixel loop
@@ -357,18 +363,29 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
         if (!SORTED) {
             if (valid) { stq(q.hit_t, io, rec.t); stq(q.hit_prim, io, rec.prim); stq(q.hit_u, io, rec.u); stq(q.hit_v, io, rec.v); }
         } else {
-            // sort by material class: one ballot-compacted append per class present in the scene; misses vanish here
+            // sort by material class: misses vanish here, every hit path's record goes to the dense queue of its class.  The queue tails
+            // of ALL classes move with one atomic instruction (lane c carries class c's count), so a tile pays one memory round trip for
+            // its appends instead of one per class present; the record stores then run class by class with scalar queue pointers.
+            // the rest of the path's record travels with the hit: requested before the class lookup and the tail atomic, so that all three round trips overlap
+            const f3 st_thr = ld3q(q.thr[cur], p.cap, io); const uint32_t st_id = ldq(q.id[cur], io), st_meta = ldq(q.meta[cur], io); const float st_pdf = ldq(q.pdf[cur], io);
             const int cls = !valid ? -1 : ((rec.prim >= 0) ? sc.prim_class[rec.prim] : q.miss_class);
+            uint32_t my_rank = 0, cnt_vec = 0;
             for (int c = 0; c < q.n_classes; c++) {
-                const bool mine = cls == c;
-                const uint32_t cpos = wave_append(mine, &cnt->n_cls[c][sl.q * CNT_PAD]);
-                if (mine) {
+                const unsigned long long m = __ballot(cls == c);
+                if (cls == c) my_rank = rank_in(m);
+                if ((int)lane_id() == c) cnt_vec = (uint32_t)__popcll(m);
+            }
+            uint32_t tail = 0;
+            if ((int)lane_id() < q.n_classes && cnt_vec) tail = atomicAdd(&cnt->n_cls[lane_id()][sl.q * CNT_PAD], cnt_vec);
+            const uint32_t cpos = (uint32_t)__shfl((int)tail, cls < 0 ? 0 : cls) + my_rank;
+            const uint32_t so = (qbase + cpos) << 2;
+            for (int c = 0; c < q.n_classes; c++) {
+                if (cls == c) {
                     const Queues::ClassQ& k = q.cls[c];
-                    const uint32_t so = (qbase + cpos) << 2;
                     st3q(k.ray_o, p.cap, so, o);
                     st3q(k.ray_d, p.cap, so, d);
-                    st3q(k.thr, p.cap, so, ld3q(q.thr[cur], p.cap, io));
-                    stq(k.id, so, ldq(q.id[cur], io)); stq(k.meta, so, ldq(q.meta[cur], io)); stq(k.pdf, so, ldq(q.pdf[cur], io));
+                    st3q(k.thr, p.cap, so, st_thr);
+                    stq(k.id, so, st_id); stq(k.meta, so, st_meta); stq(k.pdf, so, st_pdf);
                     stq(k.t, so, rec.t); stq(k.prim, so, rec.prim); stq(k.u, so, rec.u); stq(k.v, so, rec.v);
                 }
             }
@@ -689,7 +706,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_
                 st3q(q.sh_d, sc_, so, light_dir);
                 stq(q.sh_tmax, so, emitter_d);
                 st3q(q.sh_c, sc_, so, contrib);
-                stq(q.sh_id, so, l_off);
+                stq(q.sh_id, so, l_off | ((p.l_planes > 1) ? (uint32_t)s : 0u));
             }
         }
 
@@ -847,6 +864,147 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
 #endif
 }
 
+// ------------------------------------------------------- flat sweep stages (fast build, small scenes)
+// Two queue entries per lane (traverse.hpp "Flat sweep"): lane k of a 256-thread workgroup owns entries 2k and 2k + 1 of a 512-entry
+// tile, every record component arrives as one 8-byte load, and what the lane writes back is 8 bytes per component too.
+#if APT_FAST
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+template <typename T2> APT_D T2 ld2q(const void* base, uint32_t off) { return *reinterpret_cast<const T2*>(reinterpret_cast<const char*>(base) + off); }
+template <typename T2> APT_D void st2q(void* base, uint32_t off, T2 v) { *reinterpret_cast<T2*>(reinterpret_cast<char*>(base) + off) = v; }
+#define FLAT_NT (2 * BLOCK)
+
+template <int SORTED>
+__global__ void __launch_bounds__(BLOCK) k_extend_flat(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
+    const SubLoop sl = sub_loop(p.nq, FLAT_NT);
+    const uint32_t n = n_src[sl.q * CNT_PAD];
+    if (cnt && sl.first == 0 && threadIdx.x == 0) {
+        cnt->n_shadow[sl.q * CNT_PAD] = 0; cnt->n_active[cur ^ 1][sl.q * CNT_PAD] = 0;
+        for (int w = 0; w < 8; w++) cnt->n_walk[w][sl.q * CNT_PAD] = 0;
+        cnt->stats[sl.q][ST_EXTEND] += n;
+    }
+    const float* ro = q.ray_o[cur]; const float* rd = q.ray_d[cur];
+    const uint32_t qbase = (uint32_t)sl.q * p.subcap, cs = p.cap * 4u;             // component stride in bytes
+    for (uint32_t base = sl.first; base < n; base += sl.stride) {
+        const uint32_t pos = base + 2u * threadIdx.x;
+        const bool v0 = pos < n, v1 = pos + 1u < n;
+        const uint32_t io = (qbase + (v0 ? pos : ((n - 1u) & ~1u))) << 2;           // idle lanes re-read the last pair (never written back)
+        const v2f ox = ld2q<v2f>(ro, io), oy = ld2q<v2f>(ro, io + cs), oz = ld2q<v2f>(ro, io + 2u * cs);
+        const v2f dx = ld2q<v2f>(rd, io), dy = ld2q<v2f>(rd, io + cs), dz = ld2q<v2f>(rd, io + 2u * cs);
+        const f3 o0 = mk3(ox.x, oy.x, oz.x), d0 = mk3(dx.x, dy.x, dz.x), o1 = mk3(ox.y, oy.y, oz.y), d1 = mk3(dx.y, dy.y, dz.y);
+        HitRec r0, r1; r0.t = r1.t = 1e7f; r0.prim = r1.prim = -1; r0.u = r0.v = r1.u = r1.v = 0.f;
+        int c0, c1;
+        flat_closest2(sc.flat, sc.sweep, sc.prim_class, o0, d0, o1, d1, r0, r1, c0, c1);
+        if (!SORTED) {
+            if (v1) {
+                st2q<v2f>(q.hit_t, io, mk2(r0.t, r1.t)); v2i pr; pr.x = r0.prim; pr.y = r1.prim; st2q<v2i>(q.hit_prim, io, pr);
+                st2q<v2f>(q.hit_u, io, mk2(r0.u, r1.u)); st2q<v2f>(q.hit_v, io, mk2(r0.v, r1.v));
+            } else if (v0) { stq(q.hit_t, io, r0.t); stq(q.hit_prim, io, r0.prim); stq(q.hit_u, io, r0.u); stq(q.hit_v, io, r0.v); }
+        } else {
+            // sort by material class (see k_extend): the tails of all class queues move with ONE atomic instruction per tile row
+            const v2f tx = ld2q<v2f>(q.thr[cur], io), ty = ld2q<v2f>(q.thr[cur], io + cs), tz = ld2q<v2f>(q.thr[cur], io + 2u * cs);
+            const v2u pid = ld2q<v2u>(q.id[cur], io), pmeta = ld2q<v2u>(q.meta[cur], io); const v2f ppdf = ld2q<v2f>(q.pdf[cur], io);
+            const int cls0 = !v0 ? -1 : ((r0.prim >= 0) ? c0 : q.miss_class), cls1 = !v1 ? -1 : ((r1.prim >= 0) ? c1 : q.miss_class);
+            uint32_t rank0 = 0, rank1 = 0, cnt_vec = 0;
+            for (int c = 0; c < q.n_classes; c++) {
+                const unsigned long long m0 = __ballot(cls0 == c), m1 = __ballot(cls1 == c);
+                const uint32_t n0 = (uint32_t)__popcll(m0);
+                if (cls0 == c) rank0 = rank_in(m0);
+                if (cls1 == c) rank1 = n0 + rank_in(m1);
+                if ((int)lane_id() == c) cnt_vec = n0 + (uint32_t)__popcll(m1);
+            }
+            uint32_t tail = 0;
+            if ((int)lane_id() < q.n_classes && cnt_vec) tail = atomicAdd(&cnt->n_cls[lane_id()][sl.q * CNT_PAD], cnt_vec);
+            const uint32_t so0 = (qbase + (uint32_t)__shfl((int)tail, cls0 < 0 ? 0 : cls0) + rank0) << 2;
+            const uint32_t so1 = (qbase + (uint32_t)__shfl((int)tail, cls1 < 0 ? 0 : cls1) + rank1) << 2;
+            for (int c = 0; c < q.n_classes; c++) {
+                const Queues::ClassQ& k = q.cls[c];
+                if (cls0 == c) {
+                    st3q(k.ray_o, p.cap, so0, o0); st3q(k.ray_d, p.cap, so0, d0); st3q(k.thr, p.cap, so0, mk3(tx.x, ty.x, tz.x));
+                    stq(k.id, so0, pid.x); stq(k.meta, so0, pmeta.x); stq(k.pdf, so0, ppdf.x);
+                    stq(k.t, so0, r0.t); stq(k.prim, so0, r0.prim); stq(k.u, so0, r0.u); stq(k.v, so0, r0.v);
+                }
+                if (cls1 == c) {
+                    st3q(k.ray_o, p.cap, so1, o1); st3q(k.ray_d, p.cap, so1, d1); st3q(k.thr, p.cap, so1, mk3(tx.y, ty.y, tz.y));
+                    stq(k.id, so1, pid.y); stq(k.meta, so1, pmeta.y); stq(k.pdf, so1, ppdf.y);
+                    stq(k.t, so1, r1.t); stq(k.prim, so1, r1.prim); stq(k.u, so1, r1.u); stq(k.v, so1, r1.v);
+                }
+            }
+            if (q.miss_rr_draw) {
+                if (v0 && r0.prim < 0) count_dropped_miss(p, q, cnt, cur, io, sl.q);
+                if (v1 && r1.prim < 0) count_dropped_miss(p, q, cnt, cur, io + 4u, sl.q);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_shadow_flat(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
+    const SubLoop sl = sub_loop(p.nq, FLAT_NT);
+    const uint32_t n = min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
+    if (sl.first == 0 && threadIdx.x == 0) {
+        cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
+        for (int c = 0; c < q.n_classes; c++) cnt->n_cls[c][sl.q * CNT_PAD] = 0;      // every shade of this bounce is done
+    }
+    const uint32_t qbase = (uint32_t)sl.q * q.sh_subcap, cs = q.sh_cap * 4u;
+    uint32_t t_lit = 0;
+    for (uint32_t base = sl.first; base < n; base += sl.stride) {
+        const uint32_t pos = base + 2u * threadIdx.x;
+        const bool v0 = pos < n, v1 = pos + 1u < n;
+        const uint32_t io = (qbase + (v0 ? pos : ((n - 1u) & ~1u))) << 2;
+        const v2f ox = ld2q<v2f>(q.sh_o, io), oy = ld2q<v2f>(q.sh_o, io + cs), oz = ld2q<v2f>(q.sh_o, io + 2u * cs);
+        const v2f dx = ld2q<v2f>(q.sh_d, io), dy = ld2q<v2f>(q.sh_d, io + cs), dz = ld2q<v2f>(q.sh_d, io + 2u * cs);
+        const v2f dist = ld2q<v2f>(q.sh_tmax, io);
+        // the radiance slots are requested with the rays, so that after the sweep ONE round trip fetches contribution and radiance of both entries
+        const v2u slot = ld2q<v2u>(q.sh_id, io);
+        bool occ0, occ1;
+        flat_any2(sc.flat, sc.sweep, mk3(ox.x, oy.x, oz.x), mk3(dx.x, dy.x, dz.x), mk3(ox.y, oy.y, oz.y), mk3(dx.y, dy.y, dz.y),
+                  (dist.x > 0.0f) ? dist.x - 1e-4f : 1e7f, (dist.y > 0.0f) ? dist.y - 1e-4f : 1e7f, occ0, occ1);
+        const v2f cx = ld2q<v2f>(q.sh_c, io), cy = ld2q<v2f>(q.sh_c, io + cs), cz = ld2q<v2f>(q.sh_c, io + 2u * cs);
+        const bool excl = APT_EXCLUSIVE_L(p);
+        // no two entries of the launch share a slot (excl): plain read-modify-writes; the radiance of both entries is requested together with
+        // the contributions (whether it will be written is only known once they arrive)
+        const uint32_t lo0 = slot.x & ~3u, lo1 = slot.y & ~3u;
+        float* L0 = q.L + (size_t)(slot.x & 3u) * 3 * p.cap; float* L1 = q.L + (size_t)(slot.y & 3u) * 3 * p.cap;
+        f3 a0 = splat3(0.f), a1 = splat3(0.f);
+#ifdef APT_PROBE_NO_L      // measurement only (tools/build_variant.sh nol -DAPT_PROBE_NO_L=1): how much of the stage is the radiance read-modify-write
+        if (cx.x == 123.456f) { a0 = ld3q(L0, p.cap, lo0); st3q(L0, p.cap, lo0, a0); }
+        t_lit += (v0 && !occ0 ? 1u : 0u) + (v1 && !occ1 ? 1u : 0u);
+        continue;
+#endif
+        if (excl && v0 && !occ0) a0 = ld3q(L0, p.cap, lo0);
+        if (excl && v1 && !occ1) a1 = ld3q(L1, p.cap, lo1);
+        // see k_shadow: an occluded sample still enters the sum as 0 * contribution, which is NaN for a non-finite contribution
+        f3 c0 = mk3(cx.x, cy.x, cz.x), c1 = mk3(cx.y, cy.y, cz.y);
+        const bool weird0 = !(isfinite(c0.x) && isfinite(c0.y) && isfinite(c0.z)), weird1 = !(isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z));
+        if (excl) {
+            if (v0 && !occ0) st3q(L0, p.cap, lo0, mk3(a0.x + c0.x, a0.y + c0.y, a0.z + c0.z));
+            else if (v0 && weird0) add_radiance(q.L, p.cap, slot.x, c0 * 0.f, true);          // rare: poisons the slot
+            if (v1 && !occ1) st3q(L1, p.cap, lo1, mk3(a1.x + c1.x, a1.y + c1.y, a1.z + c1.z));
+            else if (v1 && weird1) add_radiance(q.L, p.cap, slot.y, c1 * 0.f, true);
+        } else {
+            if (v0 && (!occ0 || weird0)) add_radiance(q.L, p.cap, slot.x, (occ0 && weird0) ? c0 * 0.f : c0, false);
+            if (v1 && (!occ1 || weird1)) add_radiance(q.L, p.cap, slot.y, (occ1 && weird1) ? c1 * 0.f : c1, false);
+        }
+        t_lit += (v0 && !occ0 ? 1u : 0u) + (v1 && !occ1 ? 1u : 0u);
+    }
+    flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_occluded_flat(DevScene sc, uint32_t n, const float* o_, const float* d_, const float* tmax, int* occ, LdsPlan plan) {
+    for (uint32_t base = blockIdx.x * FLAT_NT; base < n; base += gridDim.x * FLAT_NT) {
+        const uint32_t pos = base + 2u * threadIdx.x;
+        const bool v0 = pos < n, v1 = pos + 1u < n;
+        const uint32_t i0 = v0 ? pos : n - 1, i1 = v1 ? pos + 1u : n - 1;
+        const f3 o0 = mk3(o_[i0], o_[n + i0], o_[2 * n + i0]), d0 = mk3(d_[i0], d_[n + i0], d_[2 * n + i0]);
+        const f3 o1 = mk3(o_[i1], o_[n + i1], o_[2 * n + i1]), d1 = mk3(d_[i1], d_[n + i1], d_[2 * n + i1]);
+        bool a, b;
+        flat_any2(sc.flat, sc.sweep, o0, d0, o1, d1, (tmax[i0] > 0.0f) ? tmax[i0] - 1e-4f : 1e7f, (tmax[i1] > 0.0f) ? tmax[i1] - 1e-4f : 1e7f, a, b);
+        if (v0) occ[i0] = a ? 1 : 0;
+        if (v1) occ[i1] = b ? 1 : 0;
+    }
+}
+#endif
+
 // ----------------------------------------------------------------- finalize
 // one thread per owned pixel: samples summed in sample order -> bit-reproducible, no atomics
 __global__ void __launch_bounds__(BLOCK) k_finalize(Params p, Queues q, float* accum) {
@@ -855,7 +1013,8 @@ __global__ void __launch_bounds__(BLOCK) k_finalize(Params p, Queues q, float* a
         float r = accum[3 * lp], g = accum[3 * lp + 1], b = accum[3 * lp + 2];
         for (int s = 0; s < p.spp_batch; s++) {
             const uint32_t lo_ = ((uint32_t)s * (uint32_t)p.npix + lp) << 2;
-            const f3 c_ = ld3q(q.L, p.cap, lo_);
+            f3 c_ = ld3q(q.L, p.cap, lo_);
+            for (int pl = 1; pl < p.l_planes; pl++) c_ = c_ + ld3q(q.L + (size_t)pl * 3 * p.cap, p.cap, lo_);      // planes in light-sample order
             float cr = c_.x, cg = c_.y, cb = c_.z;
             r += isnan(cr) ? 0.f : cr; g += isnan(cg) ? 0.f : cg; b += isnan(cb) ? 0.f : cb;
         }

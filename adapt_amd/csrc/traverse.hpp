@@ -599,3 +599,213 @@ APT_D bool sweep_tile(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active
     return false;
 }
 APT_D bool sweep_any(const SweepScene& sc, f3 o, f3 d, HitRec& rec) { return sweep<true>(sc, o, d, rec); }
+
+// ---------------------------------------------------------------------------------------------
+// Flat sweep (fast build, scenes of up to APT_FLAT_MAX_PRIMS primitives: the Cornell configs).
+//
+// The exact build's small-scene modes above execute the reference's loop (tracer_base.py:168-278) operation for operation: slab cull
+// per object, then the adjugate solve of [e1 e2 -d] per triangle - ~35 VALU instructions per triangle plus the culls, list building
+// and barriers that keep lanes from testing objects they do not need.  Inside SURVEY 8(d)'s tolerance (t within 1e-5 relative, same
+// object unless tied) the same hit costs a third of that:
+//   * every planar primitive carries a precomputed affine map world -> (u, v, h) (rows U, V, T of [e1 e2 n]^-1 with the translation
+//     folded in; Baldwin & Weber, JCGT 2016): t = -T(o) / T(d), u = U(o) + t U(d), v = V(o) + t V(d) - nine FMAs for the origin,
+//     nine for the direction, ONE reciprocal;
+//   * two triangles that form a parallelogram (every wall and box face of the Cornell scenes) are ONE record: inside <=> u, v in [0, 1];
+//     which of the two triangles was hit, and its own barycentrics, are decided once per ray from the winner's (u, v);
+//   * TWO RAYS PER LANE: a lane owns queue entries 2k and 2k + 1, which arrive as one 8-byte load per component straight into the
+//     register pair a packed instruction wants (v_pk_fma_f32: ray A in the low half, ray B in the high half), while the record is a
+//     wave-uniform scalar-load operand broadcast to both halves.  A wave therefore tests 128 rays per record fetch, has twice the
+//     loads in flight per round trip (the stage is latency-bound: a few hundred instructions between dependent memory accesses), and
+//     pays its loop control, address arithmetic and scalar traffic once per 128 rays;
+//   * no culls, no lists, no LDS, no barriers: a ray's work is the scene's record count, the same for every lane.
+// The one place where the reference's per-object slab cull decides a result - 0 / 0 = NaN slabs of rays with a zero direction
+// component whose origin lies on a box plane (tracer_base.py:159-166; DESIGN.md "the per-object slab cull is part of the result") - is
+// kept: such rays re-run the reference-order sweep() above after the flat loop.
+#ifndef APT_FLAT_MAX_PRIMS
+#define APT_FLAT_MAX_PRIMS 96
+#endif
+struct FlatScene {
+    const float* stream;      // [quads][quads in a coplanar group][triangles][triangles in a coplanar group] x 12 floats (corner p0, rows U, V, T) | [spheres] x 4 (centre, r^2)
+    const float4* tab;        // per record, 7 float4: (U, p0.x) (V, p0.y) | prim_a prim_b class_a class_b | map_a (u0 uu uv v0 vu vv) map_b (same) | (p0.z, -, -, -)
+    const float* precom;      // n_prims * 9: (e1, e2, p0) per triangle - the reference's own test decides between near-tied coplanar candidates
+    int n_quads, n_quads_tie, n_tris, n_tris_tie, n_spheres;
+};
+#if APT_FAST
+APT_D v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+struct FlatRays { v2f ox, oy, oz, dx, dy, dz; };           // two rays: .x = entry 2k, .y = entry 2k + 1
+// (t, u, v) of both rays against one planar record: 12 wave-uniform floats at r = corner p0, rows U, V, T of [e1 e2 n]^-1.
+// The origin enters as s = o - p0, exactly the reference's first operation (tracer_base.py:206): for a ray that STARTS on the primitive
+// (every continuation and shadow ray does, on one) the height T . s is then a sum of small products, and its rounding noise - which decides
+// whether a grazing ray re-hits its own surface beyond the 1e-4 threshold - stays at the reference's level.  (With the translation folded
+// into a fourth column the terms were of the size of the coordinates: twice the noise, +0.3 % path vertices on scenes/test/textured.xml.)
+APT_D void planar_solve(cf_ptr r, const FlatRays& q, v2f& t, v2f& u, v2f& v) {
+    const v2f sx = q.ox - sp2(r[0]), sy = q.oy - sp2(r[1]), sz = q.oz - sp2(r[2]);
+    const v2f ux = sp2(r[3]), uy = sp2(r[4]), uz = sp2(r[5]);
+    const v2f vx = sp2(r[6]), vy = sp2(r[7]), vz = sp2(r[8]);
+    const v2f tx = sp2(r[9]), ty = sp2(r[10]), tz = sp2(r[11]);
+    const v2f t_o = fma2(tx, sx, fma2(ty, sy, tz * sz));
+    const v2f t_d = fma2(tx, q.dx, fma2(ty, q.dy, tz * q.dz));
+    v2f inv; inv.x = __builtin_amdgcn_rcpf(t_d.x); inv.y = __builtin_amdgcn_rcpf(t_d.y);
+    t = -t_o * inv;
+    const v2f u_o = fma2(ux, sx, fma2(uy, sy, uz * sz));
+    const v2f u_d = fma2(ux, q.dx, fma2(uy, q.dy, uz * q.dz));
+    const v2f v_o = fma2(vx, sx, fma2(vy, sy, vz * sz));
+    const v2f v_d = fma2(vx, q.dx, fma2(vy, q.dy, vz * q.dz));
+    u = fma2(t, u_d, u_o);
+    v = fma2(t, v_d, v_o);
+}
+struct FlatHit2 { v2f t; int idx0, idx1, run0, run1; };   // closest record per ray (-1: none), its distance (or the search limit), and a near-tied runner-up (-1: none)
+// Coplanar primitives (a glass box resting on the floor): which of two faces at the SAME distance a ray "hits" is decided upstream by
+// the last bit of two separately rounded distances and the strict `t < min_depth` of its loop (tracer_base.py:208) - the earlier primitive
+// wins unless the later one's t rounds lower.  The records of such groups (found at scene creation: identical plane, overlapping extent)
+// sit in sections of their own whose loop also remembers a
+// candidate within FLAT_TIE_EPS of the running minimum; flat_tie_break() then lets the reference's own arithmetic decide between the two.
+#define FLAT_TIE_REL 1e-5f
+#define FLAT_TIE_ABS 1e-6f
+template <bool ANY, bool TIE>
+APT_D void flat_candidate(bool inside, float t, int idx, float& best, int& bidx, int& runner, bool& occ) {
+    const bool valid = inside && t > 1e-4f;
+    if (ANY) { occ = occ || (valid && t < best); return; }
+    if (TIE) {
+        const float gap = FLAT_TIE_REL * best + FLAT_TIE_ABS;
+        if (valid && t < best) { runner = (best - t <= gap) ? bidx : -1; best = t; bidx = idx; }
+        else if (valid && t - best <= gap) runner = idx;
+    } else if (valid && t < best) { best = t; bidx = idx; }
+}
+// Both rays against every record.  ANY = false: closest hit below `lim` per ray.  ANY = true: occ0 / occ1 = something lies in (1e-4, lim).
+template <bool ANY>
+APT_D void flat_loop(const FlatScene& fl, const FlatRays& q, v2f lim, FlatHit2& h, bool& occ0, bool& occ1) {
+    cf_ptr at = (cf_ptr)fl.stream;
+    float best0 = lim.x, best1 = lim.y;
+    int b0 = -1, b1 = -1, r0 = -1, r1 = -1;
+    occ0 = false; occ1 = false;
+    int idx = 0;                                           // wave-uniform record index
+    // parallelograms: inside <=> |u - 1/2| <= 1/2 and |v - 1/2| <= 1/2
+    const int nq_plain = ANY ? fl.n_quads + fl.n_quads_tie : fl.n_quads;
+    for (int j = 0; j < nq_plain; j++, idx++, at += 12) {
+        v2f t, u, v; planar_solve(at, q, t, u, v);
+        const v2f a = u - sp2(0.5f), b = v - sp2(0.5f);
+        flat_candidate<ANY, false>(fmaxf(fabsf(a.x), fabsf(b.x)) <= 0.5f, t.x, idx, best0, b0, r0, occ0);
+        flat_candidate<ANY, false>(fmaxf(fabsf(a.y), fabsf(b.y)) <= 0.5f, t.y, idx, best1, b1, r1, occ1);
+    }
+    if (!ANY) for (int j = 0; j < fl.n_quads_tie; j++, idx++, at += 12) {
+        v2f t, u, v; planar_solve(at, q, t, u, v);
+        const v2f a = u - sp2(0.5f), b = v - sp2(0.5f);
+        flat_candidate<ANY, true>(fmaxf(fabsf(a.x), fabsf(b.x)) <= 0.5f, t.x, idx, best0, b0, r0, occ0);
+        flat_candidate<ANY, true>(fmaxf(fabsf(a.y), fabsf(b.y)) <= 0.5f, t.y, idx, best1, b1, r1, occ1);
+    }
+    // triangles: inside <=> min(u, v, 1 - u - v) >= 0
+    const int nt_plain = ANY ? fl.n_tris + fl.n_tris_tie : fl.n_tris;
+    for (int j = 0; j < nt_plain; j++, idx++, at += 12) {
+        v2f t, u, v; planar_solve(at, q, t, u, v);
+        const v2f w = (sp2(1.0f) - u) - v;
+        flat_candidate<ANY, false>(fminf(fminf(u.x, v.x), w.x) >= 0.f, t.x, idx, best0, b0, r0, occ0);
+        flat_candidate<ANY, false>(fminf(fminf(u.y, v.y), w.y) >= 0.f, t.y, idx, best1, b1, r1, occ1);
+    }
+    if (!ANY) for (int j = 0; j < fl.n_tris_tie; j++, idx++, at += 12) {
+        v2f t, u, v; planar_solve(at, q, t, u, v);
+        const v2f w = (sp2(1.0f) - u) - v;
+        flat_candidate<ANY, true>(fminf(fminf(u.x, v.x), w.x) >= 0.f, t.x, idx, best0, b0, r0, occ0);
+        flat_candidate<ANY, true>(fminf(fminf(u.y, v.y), w.y) >= 0.f, t.y, idx, best1, b1, r1, occ1);
+    }
+    // spheres: the reference's test operation for operation (tracer_base.py:184-199; un-fused products, IEEE square root) - a grazing hit is a
+    // difference of two nearly equal squares, and on the mirror and glass balls of the Cornell scenes every digit of it is amplified by
+    // the bounces that follow; with the same ray the distance is the exact build's, bit for bit.  Record = centre.xyz, r^2.
+    for (int j = 0; j < fl.n_spheres; j++, idx++, at += 4) {
+        const v2f r2 = sp2(at[3]);
+        const v2f sx = sp2(at[0]) - q.ox, sy = sp2(at[1]) - q.oy, sz = sp2(at[2]) - q.oz;
+        const v2f cn2 = (sx * sx + sy * sy) + sz * sz;
+        const v2f proj = (q.dx * sx + q.dy * sy) + q.dz * sz;
+        const v2f c2ray = cn2 - proj * proj;
+        const v2f disc = r2 - c2ray;
+        const float cut0 = sqrtf(disc.x), cut1 = sqrtf(disc.y);
+        const float ta = proj.x + ((cn2.x > r2.x + 1e-4f) ? -cut0 : cut0), tb = proj.y + ((cn2.y > r2.y + 1e-4f) ? -cut1 : cut1);
+        flat_candidate<ANY, false>(c2ray.x < r2.x, ta, idx, best0, b0, r0, occ0);
+        flat_candidate<ANY, false>(c2ray.y < r2.y, tb, idx, best1, b1, r1, occ1);
+    }
+    h.t = mk2(best0, best1); h.idx0 = b0; h.idx1 = b1; h.run0 = r0; h.run1 = r1;
+}
+// the winning record's own triangle, barycentrics and material class: hit point -> (u, v) of the record, then the triangle's affine map
+APT_D void flat_resolve(const FlatScene& fl, int idx, float t, f3 o, f3 d, HitRec& rec, int& cls) {
+    const float4* e = fl.tab + 7 * idx;
+    const float4 U = e[0], V = e[1], ids = e[2], ma0 = e[3], mab = e[4], mb1 = e[5], pz = e[6];      // U.w, V.w, pz.x = the record's corner p0
+    const f3 P = mk3(__builtin_fmaf(t, d.x, o.x) - U.w, __builtin_fmaf(t, d.y, o.y) - V.w, __builtin_fmaf(t, d.z, o.z) - pz.x);
+    const float u = __builtin_fmaf(U.x, P.x, __builtin_fmaf(U.y, P.y, U.z * P.z));
+    const float v = __builtin_fmaf(V.x, P.x, __builtin_fmaf(V.y, P.y, V.z * P.z));
+    const int prim_b = __float_as_int(ids.y);
+    const bool second = prim_b >= 0 && u + v > 1.0f;
+    const float m0 = second ? mab.z : ma0.x, m1 = second ? mab.w : ma0.y, m2 = second ? mb1.x : ma0.z;
+    const float m3 = second ? mb1.y : ma0.w, m4 = second ? mb1.z : mab.x, m5 = second ? mb1.w : mab.y;
+    rec.t = t; rec.prim = second ? prim_b : __float_as_int(ids.x);
+    cls = second ? __float_as_int(ids.w) : __float_as_int(ids.z);
+    rec.u = __builtin_fmaf(m1, u, __builtin_fmaf(m2, v, m0));
+    rec.v = __builtin_fmaf(m4, u, __builtin_fmaf(m5, v, m3));
+}
+// Near-tied coplanar candidates: the reference's own triangle test (prim_test: the adjugate solve, un-fused) on the two triangles, taken in
+// the reference's order (primitive index) with its strict `t < min_depth` - i.e. what upstream's loop would have kept.
+APT_D void flat_tie_break(const FlatScene& fl, int idx_win, int idx_run, float t_flat, float lim, f3 o, f3 d, HitRec& rec, int& cls) {
+    HitRec ra, rb; int ca, cb;
+    flat_resolve(fl, idx_win, t_flat, o, d, ra, ca);
+    flat_resolve(fl, idx_run, t_flat, o, d, rb, cb);          // (the runner-up's plane is the winner's: the same hit point picks its triangle)
+    if (rb.prim < ra.prim) { const HitRec tr = ra; ra = rb; rb = tr; const int tc = ca; ca = cb; cb = tc; }     // ra: the earlier primitive
+    float cur = lim; bool got = false;
+    const HitRec cand[2] = {ra, rb}; const int ccls[2] = {ca, cb};
+    for (int k = 0; k < 2; k++) {
+        const float* pc = fl.precom + 9 * cand[k].prim;
+        float u, v;
+        const float t = prim_test(make_float4(pc[6], pc[7], pc[8], pc[0]), make_float4(pc[1], pc[2], pc[3], pc[4]), make_float4(pc[5], 0.f, 0.f, 0.f), o, d, u, v);
+        if (t > 1e-4f && t < cur) { cur = t; rec.t = t; rec.prim = cand[k].prim; rec.u = u; rec.v = v; cls = ccls[k]; got = true; }
+    }
+    if (!got) flat_resolve(fl, idx_win, t_flat, o, d, rec, cls);     // both rejected by the exact test (an edge in the last bit): keep the flat answer
+}
+// Rays for which upstream's per-object slab cull (tracer_base.py:159-166,178-180) is part of the RESULT, not just a speed-up:
+//  * a zero direction component: the cull may see 0 / 0 = NaN and skip an object the primitive test would accept;
+//  * a direction that is not of unit length, in a scene with spheres: upstream's sphere test (tracer_base.py:184-199) assumes |d| = 1 and
+//    reports hits a longer direction does not have - except where the sphere's box has already rejected the ray.  Such directions exist:
+//    a normal map makes the shading normal, and with it the sampled direction, any length (scenes/test/textured.xml: |d| up to 1.2;
+//    18 % more energy in that picture when the cull was left out).
+// These rays re-run the reference-order sweep() after the flat loop.
+APT_D bool flat_needs_cull(const FlatScene& fl, f3 d) {
+    return d.x == 0.f || d.y == 0.f || d.z == 0.f || (fl.n_spheres > 0 && fabsf(((d.x * d.x + d.y * d.y) + d.z * d.z) - 1.0f) > 1e-4f);
+}
+
+// Closest hits of the lane's two rays (search limits in rec0.t / rec1.t); cls0 / cls1 = material class of the hit primitive (-1: miss)
+APT_D void flat_closest2(const FlatScene& fl, const SweepScene& sw, const int* prim_class, f3 o0, f3 d0, f3 o1, f3 d1, HitRec& rec0, HitRec& rec1, int& cls0, int& cls1) {
+    FlatRays q; q.ox = mk2(o0.x, o1.x); q.oy = mk2(o0.y, o1.y); q.oz = mk2(o0.z, o1.z); q.dx = mk2(d0.x, d1.x); q.dy = mk2(d0.y, d1.y); q.dz = mk2(d0.z, d1.z);
+    FlatHit2 h; bool x0, x1;
+    const float lim0 = rec0.t, lim1 = rec1.t;
+    flat_loop<false>(fl, q, mk2(lim0, lim1), h, x0, x1);
+    cls0 = -1; cls1 = -1;
+    if (h.idx0 >= 0) flat_resolve(fl, h.idx0, h.t.x, o0, d0, rec0, cls0);
+    if (h.idx1 >= 0) flat_resolve(fl, h.idx1, h.t.y, o1, d1, rec1, cls1);
+    if (__any(h.run0 >= 0 || h.run1 >= 0)) {                 // only scenes with reachable coplanar faces ever get here
+        if (h.run0 >= 0) flat_tie_break(fl, h.idx0, h.run0, h.t.x, lim0, o0, d0, rec0, cls0);
+        if (h.run1 >= 0) flat_tie_break(fl, h.idx1, h.run1, h.t.y, lim1, o1, d1, rec1, cls1);
+    }
+    const bool z0 = flat_needs_cull(fl, d0), z1 = flat_needs_cull(fl, d1);
+    if (__any(z0 || z1)) {                                   // rare: directions like (0, 1, 0) come from degenerate samples only
+        if (z0) { rec0.t = lim0; rec0.prim = -1; rec0.u = rec0.v = 0.f; sweep<false>(sw, o0, d0, rec0); cls0 = rec0.prim >= 0 ? prim_class[rec0.prim] : -1; }
+        if (z1) { rec1.t = lim1; rec1.prim = -1; rec1.u = rec1.v = 0.f; sweep<false>(sw, o1, d1, rec1); cls1 = rec1.prim >= 0 ? prim_class[rec1.prim] : -1; }
+    }
+}
+// Occlusion of the lane's two rays below lim0 / lim1
+APT_D void flat_any2(const FlatScene& fl, const SweepScene& sw, f3 o0, f3 d0, f3 o1, f3 d1, float lim0, float lim1, bool& occ0, bool& occ1) {
+    FlatRays q; q.ox = mk2(o0.x, o1.x); q.oy = mk2(o0.y, o1.y); q.oz = mk2(o0.z, o1.z); q.dx = mk2(d0.x, d1.x); q.dy = mk2(d0.y, d1.y); q.dz = mk2(d0.z, d1.z);
+    FlatHit2 h;
+    flat_loop<true>(fl, q, mk2(lim0, lim1), h, occ0, occ1);
+    const bool z0 = flat_needs_cull(fl, d0), z1 = flat_needs_cull(fl, d1);
+    if (__any(z0 || z1)) {
+        HitRec r; r.prim = -1; r.u = r.v = 0.f;
+        if (z0) { r.t = lim0; occ0 = sweep<true>(sw, o0, d0, r); }
+        if (z1) { r.t = lim1; occ1 = sweep<true>(sw, o1, d1, r); }
+    }
+}
+// one-ray adapters (volumetric transmittance walk, which keeps its one-entry-per-lane loop): the ray rides in both halves
+template <bool ANY>
+APT_D bool flat_sweep(const FlatScene& fl, const SweepScene& sw, f3 o, f3 d, HitRec& rec) {
+    if (ANY) { bool a, b; flat_any2(fl, sw, o, d, o, d, rec.t, rec.t, a, b); return a; }
+    HitRec other = rec; int c0, c1;
+    flat_closest2(fl, sw, sw.prim_obj, o, d, o, d, rec, other, c0, c1);     // (class output unused here: any int table serves the fallback lookup)
+    return false;
+}
+#endif

@@ -7,6 +7,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// APT_FAST (set by adapt_amd/build.py): 1 = the product build - small-scene intersectors re-derived for speed inside SURVEY 8(d)'s
+// tolerances (traverse.hpp "Flat sweep"); 0 = the exact build, whose intersectors are the reference's loop operation for operation (the
+// build the bit-exact parity tests pin).  The shading arithmetic is the same in both.  See DESIGN.md "float parity policy".
+#ifndef APT_FAST
+#define APT_FAST 0
+#endif
+
 #define APT_HD __host__ __device__ __forceinline__
 #define APT_D __device__ __forceinline__
 

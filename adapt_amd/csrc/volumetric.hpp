@@ -439,6 +439,9 @@ __global__ void __launch_bounds__(VSHADOW_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAV
         HitRec rec; rec.t = (depth > 0.0f) ? depth - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
         if (MODE == 0) traverse<false>(sc.bvh, make_stack(plan), o, d, rec);
         else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
+#if APT_FAST
+        else if (MODE == 3) flat_sweep<false>(sc.flat, sc.sweep, o, d, rec);
+#endif
         else sweep_tile<false, APT_VSHADOW_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         bool arrived = false, walk_on = false;
         f3 c = splat3(0.f);

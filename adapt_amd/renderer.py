@@ -72,8 +72,9 @@ def rng_stream(pixel: int, seed: int, sample: int, n: int, device: int = 0) -> n
 class DeviceScene:
     """Scene arrays resident in HBM (apt_scene handle); shareable by several renderers on one device."""
 
-    def __init__(self, fs: FlatScene, device: int = 0):
-        lib = _lib.load()
+    def __init__(self, fs: FlatScene, device: int = 0, lib=None):
+        lib = lib or _lib.load()
+        self.lib = lib                          # the build this scene lives in (adapt_amd/_lib.py: "fast" or "exact"); handles never cross builds
         self.fs, self.device = fs, device
         keep = [np.ascontiguousarray(a) for a in (fs.prims, fs.normals, fs.v_normals, fs.obj_info, fs.obj_aabb, fs.emitter_id,
                                                   fs.bxdf_i, fs.bxdf_f, fs.src_i, fs.src_f)]
@@ -97,7 +98,7 @@ class DeviceScene:
             keep += vol
             desc.vol_i, desc.vol_f, desc.vol_grid = _ip(vol[0]), _fp(vol[1]), _fp(vol[2])
         h = C.c_void_p()
-        _lib.check(lib.apt_scene_create(C.byref(desc), int(device), C.byref(h)), "apt_scene_create")
+        _lib.check(lib.apt_scene_create(C.byref(desc), int(device), C.byref(h)), "apt_scene_create", lib)
         self.handle = h
 
     def texture_query(self, maps, objs, uv):
@@ -105,12 +106,12 @@ class DeviceScene:
         mo = np.ascontiguousarray(np.stack([np.int32(maps), np.int32(objs)], 1), np.int32)
         uv = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
         out = np.zeros((uv.shape[0], 3), np.float32)
-        _lib.check(_lib.load().apt_texture_probe(self.handle, uv.shape[0], _ip(mo), _fp(uv), _fp(out)), "apt_texture_probe")
+        _lib.check(self.lib.apt_texture_probe(self.handle, uv.shape[0], _ip(mo), _fp(uv), _fp(out)), "apt_texture_probe", self.lib)
         return out
 
     def close(self):
         if getattr(self, "handle", None):
-            _lib.load().apt_scene_destroy(self.handle)
+            self.lib.apt_scene_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -145,8 +146,12 @@ class Renderer:
                  device: int = 0, rank: int = 0, world_size: int = 1, band_width: int = 4,
                  seed: int = 0, spp_per_batch: int = 0, profile: bool = False,
                  width: Optional[int] = None, height: Optional[int] = None,
-                 max_bounce: Optional[int] = None, num_shadow_ray: Optional[int] = None, volumetric: Optional[bool] = None):
-        self.lib = _lib.load()
+                 max_bounce: Optional[int] = None, num_shadow_ray: Optional[int] = None, volumetric: Optional[bool] = None,
+                 exact: Optional[bool] = None):
+        # exact = True: the bit-parity build (the reference's float32 arithmetic operation for operation; debugging and the exact
+        # parity tests), False: the fast build, None: whatever adapt_amd._lib currently hands out (fast unless APT_EXACT=1)
+        self.lib = _lib.load(None if exact is None else ("exact" if exact else "fast"))
+        self.arithmetic = _lib.arithmetic(self.lib)
         if volumetric is None:
             volumetric = self.VOLUMETRIC
         self.flat: FlatScene = pack_scene(emitters, array_info, objects, prop)
@@ -169,7 +174,7 @@ class Renderer:
         self._cnt = 0
         self._t0 = time.time()
 
-        self.scene = DeviceScene(self.flat, self.device)
+        self.scene = DeviceScene(self.flat, self.device, self.lib)
         cfg = _lib.RenderCfg()
         for name in ("width", "height", "start_x", "end_x", "start_y", "end_y", "max_bounce", "num_shadow_ray", "rr_bounce_th"):
             setattr(cfg, name, int(getattr(rc, name)))
@@ -184,10 +189,10 @@ class Renderer:
         cfg.spp_per_batch, cfg.device, cfg.profile = int(spp_per_batch), self.device, int(bool(profile))
         cfg.volumetric = int(self.volumetric)
         h = C.c_void_p()
-        _lib.check(self.lib.apt_renderer_create(self.scene.handle, C.byref(cfg), C.byref(h)), "apt_renderer_create")
+        _lib.check(self.lib.apt_renderer_create(self.scene.handle, C.byref(cfg), C.byref(h)), "apt_renderer_create", self.lib)
         self.handle = h
         nc, hh = C.c_int32(0), C.c_int32(0)
-        _lib.check(self.lib.apt_tile_shape(self.handle, C.byref(nc), C.byref(hh)), "apt_tile_shape")
+        _lib.check(self.lib.apt_tile_shape(self.handle, C.byref(nc), C.byref(hh)), "apt_tile_shape", self.lib)
         self.n_cols = int(nc.value)
         assert self.n_cols == len(self.plan.columns(self.rank))
         self.cnt = _Counter(self)
@@ -198,18 +203,18 @@ class Renderer:
     def render(self, _t_start: int = 0, _t_end: int = 0, _s_start: int = 0, _s_end: int = 0, _a: int = 0, _b: int = 0,
                *, n_spp: int = 1):
         """Accumulate `n_spp` more samples for every owned pixel (asynchronous; reads synchronise)."""
-        _lib.check(self.lib.apt_render(self.handle, int(n_spp)), "apt_render")
+        _lib.check(self.lib.apt_render(self.handle, int(n_spp)), "apt_render", self.lib)
         self._cnt += int(n_spp)
 
     def synchronize(self):
-        _lib.check(self.lib.apt_synchronize(self.handle), "apt_synchronize")
+        _lib.check(self.lib.apt_synchronize(self.handle), "apt_synchronize", self.lib)
 
     def reset(self):
         """No-op, exactly like the reference (`TracerBase.reset` is an empty kernel, tracer_base.py:284-286)."""
 
     def clear(self):
         """Zero the accumulation, the sample counter and the statistics."""
-        _lib.check(self.lib.apt_reset(self.handle), "apt_reset")
+        _lib.check(self.lib.apt_reset(self.handle), "apt_reset", self.lib)
         self._cnt = 0
 
     # ------------------------------------------------------------- readback
@@ -217,12 +222,12 @@ class Renderer:
         """This rank's accumulation tile, (n_cols, h, 3) float32."""
         out = np.empty((self.n_cols, self.h, 3), np.float32)
         c = C.c_int32(0)
-        _lib.check(self.lib.apt_get_accum(self.handle, _fp(out), C.byref(c)), "apt_get_accum")
+        _lib.check(self.lib.apt_get_accum(self.handle, _fp(out), C.byref(c)), "apt_get_accum", self.lib)
         return out
 
     def tile_pixels(self) -> np.ndarray:
         out = np.empty((self.n_cols, self.h, 3), np.float32)
-        _lib.check(self.lib.apt_read_pixels(self.handle, _fp(out)), "apt_read_pixels")
+        _lib.check(self.lib.apt_read_pixels(self.handle, _fp(out)), "apt_read_pixels", self.lib)
         return out
 
     def _image(self, normalised: bool) -> np.ndarray:
@@ -242,22 +247,22 @@ class Renderer:
                 arr = np.ascontiguousarray(arr[self.plan.columns(self.rank)])
             else:
                 raise ValueError(f"accumulation must be ({self.w},{self.h},3) or the tile ({self.n_cols},{self.h},3)")
-        _lib.check(self.lib.apt_set_accum(self.handle, _fp(arr), int(cnt)), "apt_set_accum")
+        _lib.check(self.lib.apt_set_accum(self.handle, _fp(arr), int(cnt)), "apt_set_accum", self.lib)
         self._cnt = int(cnt)
 
     def device_accum_ptr(self) -> int:
         p, c = C.c_void_p(), C.c_int32(0)
-        _lib.check(self.lib.apt_device_ptr(self.handle, C.byref(p), C.byref(c)), "apt_device_ptr")
+        _lib.check(self.lib.apt_device_ptr(self.handle, C.byref(p), C.byref(c)), "apt_device_ptr", self.lib)
         return int(p.value)
 
     def stream_ptr(self) -> int:
         p = C.c_void_p()
-        _lib.check(self.lib.apt_stream(self.handle, C.byref(p)), "apt_stream")
+        _lib.check(self.lib.apt_stream(self.handle, C.byref(p)), "apt_stream", self.lib)
         return int(p.value or 0)
 
     def stats(self) -> dict:
         st = _lib.Stats()
-        _lib.check(self.lib.apt_get_stats(self.handle, C.byref(st)), "apt_get_stats")
+        _lib.check(self.lib.apt_get_stats(self.handle, C.byref(st)), "apt_get_stats", self.lib)
         return st.as_dict()
 
     # ----------------------------------------------------------- unit entry points
@@ -265,31 +270,31 @@ class Renderer:
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
         n = o.shape[0]
         prim, t, uv = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros((n, 2), np.float32)
-        _lib.check(self.lib.apt_intersect(self.handle, n, _fp(o), _fp(d), _ip(prim), _fp(t), _fp(uv)), "apt_intersect")
+        _lib.check(self.lib.apt_intersect(self.handle, n, _fp(o), _fp(d), _ip(prim), _fp(t), _fp(uv)), "apt_intersect", self.lib)
         return prim, t, uv
 
     def occluded(self, o, d, tmax):
         o = np.ascontiguousarray(o, np.float32).reshape(-1, 3); d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
         tmax = np.ascontiguousarray(tmax, np.float32).reshape(-1)
         occ = np.zeros(o.shape[0], np.int32)
-        _lib.check(self.lib.apt_occluded(self.handle, o.shape[0], _fp(o), _fp(d), _fp(tmax), _ip(occ)), "apt_occluded")
+        _lib.check(self.lib.apt_occluded(self.handle, o.shape[0], _fp(o), _fp(d), _fp(tmax), _ip(occ)), "apt_occluded", self.lib)
         return occ
 
     def emitter_probe(self, in11, seed: int = 0) -> np.ndarray:
         """apt_emitter_probe: rows (src index, hit_pos, normal, ray_d, min_depth) -> (n,12)."""
         x = np.ascontiguousarray(in11, np.float32).reshape(-1, 11)
         out = np.zeros((x.shape[0], 12), np.float32)
-        _lib.check(self.lib.apt_emitter_probe(self.scene.handle, x.shape[0], _fp(x), int(seed) & 0xffffffff, _fp(out)), "apt_emitter_probe")
+        _lib.check(self.lib.apt_emitter_probe(self.scene.handle, x.shape[0], _fp(x), int(seed) & 0xffffffff, _fp(out)), "apt_emitter_probe", self.lib)
         return out
 
     def info(self) -> dict:
         b, nq, lds, tm = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int32(0)
         qb = C.c_int64(0)
         name = C.c_char_p()
-        _lib.check(self.lib.apt_renderer_info(self.handle, C.byref(b), C.byref(nq), C.byref(qb), C.byref(lds), C.byref(name), C.byref(tm)), "apt_renderer_info")
+        _lib.check(self.lib.apt_renderer_info(self.handle, C.byref(b), C.byref(nq), C.byref(qb), C.byref(lds), C.byref(name), C.byref(tm)), "apt_renderer_info", self.lib)
         return {"spp_per_batch": b.value, "n_subqueues": nq.value, "queue_bytes": qb.value, "lds_bytes": lds.value,
                 "shade_variant": name.value.decode() if name.value else "",
-                "traversal": {0: "bvh", 1: "sweep", 2: "tile"}.get(tm.value, str(tm.value))}
+                "traversal": {0: "bvh", 1: "sweep", 2: "tile", 3: "flat"}.get(tm.value, str(tm.value)), "arithmetic": self.arithmetic}
 
     # ------------------------------------------------------------ checkpoint
     def get_check_point(self) -> dict:

@@ -18,14 +18,17 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(apt_[a-z_0-9]+)\s*\(", text)))
 
 
-def test_library_exports_every_declared_symbol():
-    lib = _lib.load()
+@pytest.mark.parametrize("variant", ["fast", "exact"])
+def test_library_exports_every_declared_symbol(variant):
+    """both builds of the library (adapt_amd/build.py: the product and the bit-parity build) carry the whole C-ABI and say which one they are"""
+    lib = _lib.load(variant)
     names = declared_symbols()
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/adapt_mi.h but not exported"
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
-    assert b"gfx950" in lib.apt_version()
+    assert b"gfx950" in lib.apt_version() and f"arithmetic: {variant}".encode() in lib.apt_version()
+    assert _lib.arithmetic(lib) == variant
 
 
 def test_no_product_code_touches_the_oracle():
