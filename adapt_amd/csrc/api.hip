@@ -300,6 +300,8 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     apt_scene* s = new apt_scene();
     s->device = device;
     const int N = d->n_prims, O = d->n_objects, S = d->n_sources;
+    // the walk addresses primitive (48 B) and node (80 B, at most one per primitive) records with 32-bit byte offsets (traverse.hpp)
+    if ((uint64_t)N * 80ull >= (1ull << 32)) { delete s; return fail(APT_E_INVALID, "apt_scene_create: more than 53 687 091 primitives (32-bit record offsets)"); }
     s->n_prims = N; s->n_objects = O; s->n_sources = S;
     const bool timing = getenv("APT_SCENE_TIMING") != nullptr;      // stderr: where apt_scene_create spends its time
     auto t_prev = std::chrono::steady_clock::now();
@@ -320,8 +322,11 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     s->gpu_built = false;
     if (gpu_build) {
         const int rc_ = apt::build_bvh_gpu(d->prims, N, d->obj_info, O, device, s->bvh, gpu_algo);
-        if (rc_ != 0) { delete s; return fail(APT_E_HIP, "apt_scene_create: device BVH build failed (" + std::to_string(rc_) + ")"); }
-        s->gpu_built = true;
+        if (rc_ != 0) {                                      // a valid scene must load: the host builder takes over (slower, never fails on valid input)
+            fprintf(stderr, "adapt_mi: device BVH build failed (%d), falling back to the host SAH builder\n", rc_);
+            if (apt::build_bvh(d->prims, N, d->obj_info, O, s->bvh, max_leaf) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH build failed"); }
+            gpu_build = false;
+        } else s->gpu_built = true;
     } else if (apt::build_bvh(d->prims, N, d->obj_info, O, s->bvh, max_leaf) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH build failed"); }
     tick(gpu_build ? (gpu_algo ? "binary tree (PLOC, device)" : "binary tree (LBVH, device)") : "binary tree (SAH, host)");
     if (apt::build_wide_bvh(s->bvh, s->wide) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: BVH collapse failed"); }
@@ -663,7 +668,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     // one pool per lane, carved into the SoA arrays (all 4-byte lanes)
     const bool walk_lists = r->volumetric && sc->has_null_surface;      // light samples that cross null surfaces are re-queued by slot
     const size_t l_planes = (size_t)p.l_planes;
-    const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 3 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
+    const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
         hipError_t e_ = pool.alloc(words * 4);
         if (e_ != hipSuccess) return e_;
@@ -672,7 +677,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         for (int k = 0; k < 2; k++) { q.ray_o[k] = take(3 * cap); q.ray_d[k] = take(3 * cap); }
         q.hit_t = take(cap); q.hit_prim = (int*)take(cap); q.hit_u = take(cap); q.hit_v = take(cap);
         for (int k = 0; k < 2; k++) { q.thr[k] = take(3 * cap); q.id[k] = (uint32_t*)take(cap); q.meta[k] = (uint32_t*)take(cap); q.pdf[k] = take(cap); }
-        q.L = take(3 * cap * l_planes);
+        q.L = take(4 * cap * l_planes);
         q.sh_o = take(3 * sh_cap); q.sh_d = take(3 * sh_cap); q.sh_tmax = take(sh_cap); q.sh_c = take(3 * sh_cap); q.sh_id = (uint32_t*)take(sh_cap);
         q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
         q.sh_walk[0] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr; q.sh_walk[1] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr;
@@ -1091,7 +1096,11 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
     out->n_samples = sum(ST_SAMPLES); out->n_extend = sum(ST_EXTEND); out->n_shade = sum(ST_SHADE);
     out->n_shadow = sum(ST_SHADOW); out->n_shadow_traced = sum(ST_SHADOW_TRACED); out->n_lit = sum(ST_LIT);
     out->n_draws = sum(ST_DRAWS); out->n_poisoned = sum(ST_POISON); out->n_track = sum(ST_TRACK);
+#if defined(APT_SHADE_PROF) || defined(APT_TILE_PROF) || defined(APT_WALK_STATS)
+    const int64_t n_overflow = 0;                // profiling builds keep their counters in stats[8..15], which overlaps ST_OVERFLOW
+#else
     const int64_t n_overflow = sum(ST_OVERFLOW);
+#endif
 #ifdef APT_SHADE_PROF
     {
         std::vector<unsigned long long> dbg(2 * 16384);

@@ -153,8 +153,8 @@ __global__ void k_emit(int n, const unsigned long long* __restrict__ keys, const
 // compacted (prefix sum) and the next round starts, until one cluster is left.  Unlike the radix tree above, where a split is
 // decided by key bits alone, every merge here is decided by box areas - the quantity the SAH prices - so the tree walks like
 // a SAH tree while the whole build still runs on the device.
-// Ties are broken by the lower position, which guarantees a mutual pair in every round (the pair of smallest (area, lower
-// position, higher position) chooses each other), so the loop always terminates.
+// Ties go to the aligned partner i ^ 1, then to the lower position, which guarantees a mutual pair in every round (k_ploc_nn), so the
+// loop always terminates; should a build fail all the same, the caller falls back to the radix tree and then to the host builder.
 #define PLOC_RADIUS 16
 __device__ __forceinline__ float union_half_area(const float* __restrict__ a, const float* __restrict__ b) {
     const float d0 = fmaxf(a[3], b[3]) - fminf(a[0], b[0]), d1 = fmaxf(a[4], b[4]) - fminf(a[1], b[1]), d2 = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
@@ -174,11 +174,17 @@ __global__ void k_ploc_nn(int m, const float* __restrict__ cbox, int* __restrict
     for (int a = 0; a < 6; a++) mine[a] = cbox[6 * (size_t)i + a];
     float best = 3.0e38f; int best_j = -1;
     const int lo = max(0, i - PLOC_RADIUS), hi = min(m - 1, i + PLOC_RADIUS);
-    for (int j = lo; j <= hi; j++) {                                // ascending: of equal areas the lower position stays
+    for (int j = lo; j <= hi; j++) {                                // ascending: of equal areas the lower position stays ...
         if (j == i) continue;
         const float d = union_half_area(mine, cbox + 6 * (size_t)j);
         if (d < best) { best = d; best_j = j; }
     }
+    // ... unless the aligned partner i ^ 1 ties with the best: duplicated primitives or a ribbon of equal triangles make EVERY area equal,
+    // and "the lower neighbour" then forms a chain i -> i - 1 -> i - 2 ... with one mutual pair per round (rounds linear in n: 4 095 for
+    // 4 096 identical triangles).  Preferring i ^ 1 pairs such runs off two by two; a mutual pair still exists in every round (an aligned
+    // tie is mutual by itself, and without one the argument for the lowest pair holds as before).
+    const int pj = i ^ 1;
+    if (pj >= lo && pj <= hi && pj < m && union_half_area(mine, cbox + 6 * (size_t)pj) == best) best_j = pj;
     nn[i] = best_j;
 }
 // flags[i]: low word 1 = cluster i survives the round (alone, or as the merged cluster), high word 1 = it is the lower half of a merging pair
@@ -237,7 +243,7 @@ struct Buf {
 
 }  // namespace
 
-int build_bvh_gpu(const float* prims, int n, const int32_t* obj_info, int n_objects, int device, BvhData& out, int algo) {
+static int build_bvh_gpu_impl(const float* prims, int n, const int32_t* obj_info, int n_objects, int device, BvhData& out, int algo) {
     if (!prims || !obj_info || n < 2) return -1;
     if ((long long)n >= (1ll << 27)) return -1;                      // leaf links keep the slot in 27 bits
     GTRY(hipSetDevice(device));
@@ -276,7 +282,7 @@ int build_bvh_gpu(const float* prims, int n, const int32_t* obj_info, int n_obje
         hipLaunchKernelGGL(k_ploc_init, dim3(grid), dim3(GB), 0, 0, n, d_keys.as<unsigned long long>(), d_box.as<float>(), d_cb[0].as<float>(), d_cl[0].as<int>());
         int m = n, node_base = 0, cur = 0;
         for (int round = 0; m > 1; round++) {
-            if (round > 4096) return -3;                                 // cannot happen: every round merges at least one pair
+            if (round > 4096) return -3;                                 // (every round merges at least one pair; the caller falls back to the radix tree)
             const int g = (m + GB - 1) / GB;
             hipLaunchKernelGGL(k_ploc_nn, dim3(g), dim3(GB), 0, 0, m, d_cb[cur].as<float>(), d_pi.as<int>());
             hipLaunchKernelGGL(k_ploc_mark, dim3(g), dim3(GB), 0, 0, m, d_pi.as<int>(), d_flags.as<unsigned long long>());
@@ -309,6 +315,11 @@ int build_bvh_gpu(const float* prims, int n, const int32_t* obj_info, int n_obje
     GTRY(hipMemcpy(out.prim_order.data(), d_order.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     out.max_depth = 64;                 // a radix tree over 62-bit keys is at most that deep; nobody sizes anything by it (the 8-wide collapse recounts)
     return 0;
+}
+int build_bvh_gpu(const float* prims, int n, const int32_t* obj_info, int n_objects, int device, BvhData& out, int algo) {
+    int rc = build_bvh_gpu_impl(prims, n, obj_info, n_objects, device, out, algo);
+    if (rc != 0 && rc > -10 && algo == 1) rc = build_bvh_gpu_impl(prims, n, obj_info, n_objects, device, out, 0);      // PLOC gave up (-3 .. -5): the radix tree always builds
+    return rc;
 }
 
 }  // namespace apt

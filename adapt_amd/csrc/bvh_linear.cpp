@@ -151,7 +151,8 @@ int build_linear_bvh(const float* prims, int n_prims, const int32_t* obj_prim_cn
                 for (int a = 0; a < 3; a++) {
                     r.box.lo[a] = std::min(std::min(v[a], v[3 + a]), v[6 + a]);
                     r.box.hi[a] = std::max(std::max(v[a], v[3 + a]), v[6 + a]);
-                    if (r.box.hi[a] - r.box.lo[a] < 1e-4f) { r.box.lo[a] -= 1e-4f; r.box.hi[a] += 1e-4f; }
+                    // bvh_helper.h:38-42: the float difference is compared with the DOUBLE literal 1e-4 and the bounds move in double before they are stored as float
+                    if ((double)(r.box.hi[a] - r.box.lo[a]) < 1e-4) { r.box.lo[a] = (float)((double)r.box.lo[a] - 1e-4); r.box.hi[a] = (float)((double)r.box.hi[a] + 1e-4); }
                     // vertex mean as Eigen 3.4's fixed-size reduction evaluates it for three terms: x0 + (x1 + x2), then / 3
                     r.c[a] = (v[a] + (v[3 + a] + v[6 + a])) / 3.0f;
                 }

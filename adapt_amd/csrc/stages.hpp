@@ -165,16 +165,21 @@ APT_D TravStack make_stack(const LdsPlan& plan) {
 }
 
 APT_D uint32_t lane_id() { return threadIdx.x & 63u; }
-// A light sample's contribution into its path's radiance slot (byte offset lo_ in the SoA array L).  With ONE light sample per
+// Radiance slots L: one float4 (r, g, b, -) per path and radiance plane, addressed by the slot word `l_off` = slot index << 2 (its low two
+// bits carry the plane in a shadow-queue entry).  AoS on purpose: these are the only accesses keyed by PATH ID instead of queue position -
+// scattered once queues are compacted and sorted - and as three 4-byte accesses to three component planes every read-modify-write touched
+// three sectors; as one 16-byte access it touches one.
+// (Planes are whole arrays, plane p at L + p * 4 * cap: keeping a path's planes next to each other in one 64-byte line measured the same or slightly worse, C3 shadow 17.5 -> 19.0 ms per 128 spp.)
+APT_D float* L_slot(float* L, uint32_t cap, uint32_t code) { return L + (size_t)(code & 3u) * 4 * cap + (size_t)(code & ~3u); }      // (slot << 2 floats = 16 bytes per slot)
+APT_D f3 ldL(float* L, uint32_t cap, uint32_t code) { const float4 v = *reinterpret_cast<const float4*>(L_slot(L, cap, code)); return mk3(v.x, v.y, v.z); }
+APT_D void stL(float* L, uint32_t cap, uint32_t code, f3 v) { *reinterpret_cast<float4*>(L_slot(L, cap, code)) = make_float4(v.x, v.y, v.z, 0.f); }
+// A light sample's contribution into its path's radiance slot.  With ONE light sample per
 // path vertex (p.S == 1) no two entries of a shadow launch share a slot and nothing else writes L while the launch runs, so the add is
 // a plain read-modify-write: deterministic, and not an L2 atomic per component.  With several samples per vertex the entries of one
-// path sit in different waves: float atomics (their order is the one thing in the image that may differ from run to run).
+// path sit in different waves: each sample adds into its own radiance plane (Params::l_planes; 2 <= S <= 4), or, beyond four samples, float atomics.
 APT_D void add_radiance(float* L, uint32_t cap, uint32_t code, f3 c, bool exclusive) {
-    const uint32_t lo_ = code & ~3u;                                   // the entry's slot: byte offset (a multiple of 4) | radiance plane in the low two bits
-    char* Lb = reinterpret_cast<char*>(L) + (size_t)(code & 3u) * ((size_t)cap * 12);
-    float* px = reinterpret_cast<float*>(Lb + lo_); float* py = reinterpret_cast<float*>(Lb + (size_t)cap * 4 + lo_); float* pz = reinterpret_cast<float*>(Lb + (size_t)cap * 8 + lo_);
-    if (exclusive) { *px = *px + c.x; *py = *py + c.y; *pz = *pz + c.z; }
-    else { atomicAdd(px, c.x); atomicAdd(py, c.y); atomicAdd(pz, c.z); }
+    if (exclusive) { const f3 a = ldL(L, cap, code); stL(L, cap, code, mk3(a.x + c.x, a.y + c.y, a.z + c.z)); }
+    else { float* p_ = L_slot(L, cap, code); atomicAdd(p_, c.x); atomicAdd(p_ + 1, c.y); atomicAdd(p_ + 2, c.z); }
 }
 // number of set bits of a ballot mask below this lane (v_mbcnt: no lane-mask registers to keep alive)
 APT_D uint32_t rank_in(unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
@@ -263,7 +268,7 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
         if (valid) {
             uint32_t lp = idx % (uint32_t)p.npix, s = idx / (uint32_t)p.npix;
             int i, j; local_to_global(p, lp, i, j);
-            for (int pl = 0; pl < p.l_planes; pl++) st3q(q.L + (size_t)pl * 3 * p.cap, p.cap, idx << 2, splat3(0.f));
+            for (int pl = 0; pl < p.l_planes; pl++) stL(q.L, p.cap, (idx << 2) | (uint32_t)pl, splat3(0.f));
             alive = !p.do_crop || (i >= p.sx && i < p.ex && j >= p.sy && j < p.ey);
             if (alive) {
                 int sample_cnt = p.cnt_base + (int)s + 1;        // cnt is incremented before the pixel loop
@@ -687,7 +692,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_
                         // Upstream the MIS weight multiplies the light sample even when the shadow ray is
                         // occluded (0 * NaN), so a NaN weight poisons the whole pixel-sample, which is then
                         // zeroed at the end (vanilla_renderer.py:87-95,119).  Reproduce that without tracing.
-                        st3q(q.L, p.cap, l_off, splat3(mis_w));
+                        stL(q.L, p.cap, l_off, splat3(mis_w));
                         poisoned = true;
                     } else {
                         f3 c = (direct_spec * shadow_int) * mis_w;
@@ -723,8 +728,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_
                 f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_s);
                 if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
                     f3 add = (emit_int * emission_weight) * thr;
-                    f3 cur_L = ld3q(q.L, p.cap, l_off);
-                    st3q(q.L, p.cap, l_off, mk3(cur_L.x + add.x, cur_L.y + add.y, cur_L.z + add.z));
+                    add_radiance(q.L, p.cap, l_off, add, true);      // (nothing else touches the path's slot while its shade kernel runs)
                 }
             }
             f3 spec;
@@ -961,25 +965,23 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_flat(DevScene sc, Params p, Qu
                   (dist.x > 0.0f) ? dist.x - 1e-4f : 1e7f, (dist.y > 0.0f) ? dist.y - 1e-4f : 1e7f, occ0, occ1);
         const v2f cx = ld2q<v2f>(q.sh_c, io), cy = ld2q<v2f>(q.sh_c, io + cs), cz = ld2q<v2f>(q.sh_c, io + 2u * cs);
         const bool excl = APT_EXCLUSIVE_L(p);
-        // no two entries of the launch share a slot (excl): plain read-modify-writes; the radiance of both entries is requested together with
-        // the contributions (whether it will be written is only known once they arrive)
-        const uint32_t lo0 = slot.x & ~3u, lo1 = slot.y & ~3u;
-        float* L0 = q.L + (size_t)(slot.x & 3u) * 3 * p.cap; float* L1 = q.L + (size_t)(slot.y & 3u) * 3 * p.cap;
-        f3 a0 = splat3(0.f), a1 = splat3(0.f);
 #ifdef APT_PROBE_NO_L      // measurement only (tools/build_variant.sh nol -DAPT_PROBE_NO_L=1): how much of the stage is the radiance read-modify-write
-        if (cx.x == 123.456f) { a0 = ld3q(L0, p.cap, lo0); st3q(L0, p.cap, lo0, a0); }
+        if (cx.x == 123.456f) stL(q.L, p.cap, slot.x, ldL(q.L, p.cap, slot.x));
         t_lit += (v0 && !occ0 ? 1u : 0u) + (v1 && !occ1 ? 1u : 0u);
         continue;
 #endif
-        if (excl && v0 && !occ0) a0 = ld3q(L0, p.cap, lo0);
-        if (excl && v1 && !occ1) a1 = ld3q(L1, p.cap, lo1);
+        // no two entries of the launch share a slot (excl): plain read-modify-writes of one 16-byte slot each; the radiance of both entries is
+        // requested together with the contributions (whether it will be written is only known once they arrive)
+        f3 a0 = splat3(0.f), a1 = splat3(0.f);
+        if (excl && v0 && !occ0) a0 = ldL(q.L, p.cap, slot.x);
+        if (excl && v1 && !occ1) a1 = ldL(q.L, p.cap, slot.y);
         // see k_shadow: an occluded sample still enters the sum as 0 * contribution, which is NaN for a non-finite contribution
         f3 c0 = mk3(cx.x, cy.x, cz.x), c1 = mk3(cx.y, cy.y, cz.y);
         const bool weird0 = !(isfinite(c0.x) && isfinite(c0.y) && isfinite(c0.z)), weird1 = !(isfinite(c1.x) && isfinite(c1.y) && isfinite(c1.z));
         if (excl) {
-            if (v0 && !occ0) st3q(L0, p.cap, lo0, mk3(a0.x + c0.x, a0.y + c0.y, a0.z + c0.z));
+            if (v0 && !occ0) stL(q.L, p.cap, slot.x, mk3(a0.x + c0.x, a0.y + c0.y, a0.z + c0.z));
             else if (v0 && weird0) add_radiance(q.L, p.cap, slot.x, c0 * 0.f, true);          // rare: poisons the slot
-            if (v1 && !occ1) st3q(L1, p.cap, lo1, mk3(a1.x + c1.x, a1.y + c1.y, a1.z + c1.z));
+            if (v1 && !occ1) stL(q.L, p.cap, slot.y, mk3(a1.x + c1.x, a1.y + c1.y, a1.z + c1.z));
             else if (v1 && weird1) add_radiance(q.L, p.cap, slot.y, c1 * 0.f, true);
         } else {
             if (v0 && (!occ0 || weird0)) add_radiance(q.L, p.cap, slot.x, (occ0 && weird0) ? c0 * 0.f : c0, false);
@@ -1013,8 +1015,8 @@ __global__ void __launch_bounds__(BLOCK) k_finalize(Params p, Queues q, float* a
         float r = accum[3 * lp], g = accum[3 * lp + 1], b = accum[3 * lp + 2];
         for (int s = 0; s < p.spp_batch; s++) {
             const uint32_t lo_ = ((uint32_t)s * (uint32_t)p.npix + lp) << 2;
-            f3 c_ = ld3q(q.L, p.cap, lo_);
-            for (int pl = 1; pl < p.l_planes; pl++) c_ = c_ + ld3q(q.L + (size_t)pl * 3 * p.cap, p.cap, lo_);      // planes in light-sample order
+            f3 c_ = ldL(q.L, p.cap, lo_);
+            for (int pl = 1; pl < p.l_planes; pl++) c_ = c_ + ldL(q.L, p.cap, lo_ | (uint32_t)pl);      // planes in light-sample order
             float cr = c_.x, cg = c_.y, cb = c_.z;
             r += isnan(cr) ? 0.f : cr; g += isnan(cg) ? 0.f : cg; b += isnan(cb) ? 0.f : cb;
         }

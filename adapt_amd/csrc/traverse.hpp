@@ -749,12 +749,15 @@ APT_D void flat_tie_break(const FlatScene& fl, int idx_win, int idx_run, float t
     flat_resolve(fl, idx_run, t_flat, o, d, rb, cb);          // (the runner-up's plane is the winner's: the same hit point picks its triangle)
     if (rb.prim < ra.prim) { const HitRec tr = ra; ra = rb; rb = tr; const int tc = ca; ca = cb; cb = tc; }     // ra: the earlier primitive
     float cur = lim; bool got = false;
-    const HitRec cand[2] = {ra, rb}; const int ccls[2] = {ca, cb};
-    for (int k = 0; k < 2; k++) {
-        const float* pc = fl.precom + 9 * cand[k].prim;
-        float u, v;
+    {
+        const float* pc = fl.precom + 9 * ra.prim; float u, v;
         const float t = prim_test(make_float4(pc[6], pc[7], pc[8], pc[0]), make_float4(pc[1], pc[2], pc[3], pc[4]), make_float4(pc[5], 0.f, 0.f, 0.f), o, d, u, v);
-        if (t > 1e-4f && t < cur) { cur = t; rec.t = t; rec.prim = cand[k].prim; rec.u = u; rec.v = v; cls = ccls[k]; got = true; }
+        if (t > 1e-4f && t < cur) { cur = t; rec.t = t; rec.prim = ra.prim; rec.u = u; rec.v = v; cls = ca; got = true; }
+    }
+    {
+        const float* pc = fl.precom + 9 * rb.prim; float u, v;
+        const float t = prim_test(make_float4(pc[6], pc[7], pc[8], pc[0]), make_float4(pc[1], pc[2], pc[3], pc[4]), make_float4(pc[5], 0.f, 0.f, 0.f), o, d, u, v);
+        if (t > 1e-4f && t < cur) { cur = t; rec.t = t; rec.prim = rb.prim; rec.u = u; rec.v = v; cls = cb; got = true; }
     }
     if (!got) flat_resolve(fl, idx_win, t_flat, o, d, rec, cls);     // both rejected by the exact test (an edge in the last bit): keep the flat answer
 }

@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(BLOCK, (((BM == 0x402 || BM == 0x00a || BM == 
                         const float bsdf_pdf_v = is_mi ? direct_spec.x : surface_pdf<BM>(bx, it, light_dir, d, sc.world_ior, p.two_sides);
                         mis_w = balance(light_pdf, bsdf_pdf_v);
                     }
-                    if (isnan(mis_w)) { st3q(q.L, p.cap, l_off, splat3(mis_w)); poisoned = true; }     // as in k_shade: the sample is zeroed at the end
+                    if (isnan(mis_w)) { stL(q.L, p.cap, l_off, splat3(mis_w)); poisoned = true; }     // as in k_shade: the sample is zeroed at the end
                     else {
                         f3 c = (direct_spec * shadow_int) * mis_w;
                         if (ns != 1) c = c / emitter_pdf;
@@ -355,8 +355,7 @@ __global__ void __launch_bounds__(BLOCK, (((BM == 0x402 || BM == 0x00a || BM == 
                 const f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_g);      // geometric normal here (vpt.py:233)
                 if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
                     const f3 add = (emit_int * emission_weight) * thr;
-                    const f3 cur_L = ld3q(q.L, p.cap, l_off);
-                    st3q(q.L, p.cap, l_off, mk3(cur_L.x + add.x, cur_L.y + add.y, cur_L.z + add.z));
+                    add_radiance(q.L, p.cap, l_off, add, true);
                 }
             }
             float ray_pdf = 1.f;
@@ -471,11 +470,7 @@ __global__ void __launch_bounds__(VSHADOW_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAV
             }
             if (arrived || blocked) {
                 if (!(c.x == 0.f && c.y == 0.f && c.z == 0.f)) {
-                    const uint32_t lo_ = ldq(q.sh_id, io);
-                    char* Lb = reinterpret_cast<char*>(q.L);
-                    atomicAdd(reinterpret_cast<float*>(Lb + lo_), c.x);
-                    atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 4 + lo_), c.y);
-                    atomicAdd(reinterpret_cast<float*>(Lb + (size_t)p.cap * 8 + lo_), c.z);
+                    add_radiance(q.L, p.cap, ldq(q.sh_id, io), c, false);
                 }
                 if (arrived) t_lit++;
             }

@@ -7,7 +7,7 @@
 One "step" = one complete render of the workload: every owned pixel receives its samples through the
 generate/extend/shade/shadow/finalize stages (+ the tile all-gather when N > 1).  N = 1 workload = BASELINE
 configs[1]: cornell box, 512x512, 1024 spp, 8 bounces.  For N > 1 the film is sharded in interleaved column
-bands; `--scaling weak` (default) scales the sample count by N so that every GPU does the N = 1 amount of work,
+bands; `--scaling weak` (default, except c4 / c5) scales the sample count by N so that every GPU does the N = 1 amount of work,
 `--scaling strong` keeps film and samples fixed (what BASELINE configs 4 / 5 describe: one image split over 4 / 8
 GPUs).  The only collective is the all_gather of the tile framebuffers over RCCL.
 
@@ -137,7 +137,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="N > 1: weak = samples per step x N (per-GPU work fixed), strong = film and samples fixed")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="N > 1: weak = samples per step x N (per-GPU work fixed), strong = film and samples fixed; "
+                    "default: strong for c4 / c5 (BASELINE describes them as ONE image tiled over 4 / 8 GPUs), weak otherwise")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel per step")
     ap.add_argument("--spp-per-batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -189,6 +190,8 @@ def main():
     lanes = int(os.environ.get("APT_LANES", "3"))
     if args.spp > 0:
         spp = args.spp
+    if args.scaling is None:
+        args.scaling = "strong" if args.config in ("c4", "c5") else "weak"
     spp_step = spp * world if args.scaling == "weak" else spp       # weak: per-GPU samples stay at the N = 1 amount
     parsed = load_scene(sdir, sfile)
     rdr = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world,

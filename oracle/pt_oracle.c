@@ -1248,7 +1248,8 @@ static void prim_bound(const v3 p[3], int is_sphere, bvh_info_t* out) {     /* b
     } else {
         v3 lo = vminv(vminv(p[0], p[1]), p[2]), hi = vmaxv(vmaxv(p[0], p[1]), p[2]);
         float* l = &lo.x; float* h = &hi.x;
-        for (int i = 0; i < 3; i++) if (h[i] - l[i] < 1e-4f) { l[i] -= 1e-4f; h[i] += 1e-4f; }
+        /* bvh_helper.h:38-42: `diff(i) < 1e-4` compares the float difference with a double literal, `mini(i) -= 1e-4` moves the bound in double */
+        for (int i = 0; i < 3; i++) if ((double)(h[i] - l[i]) < 1e-4) { l[i] = (float)((double)l[i] - 1e-4); h[i] = (float)((double)h[i] + 1e-4); }
         out->bound.mini = lo; out->bound.maxi = hi;
         /* Eigen 3.4 rowwise().mean() = sum() / 3 (VectorwiseOp.h), and a fixed-size sum of three coefficients is unrolled as
          * x0 + (x1 + x2) (Redux.h, redux_novec_unroller: the range is halved recursively, 3 -> 1 + 2) */
