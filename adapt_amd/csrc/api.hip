@@ -189,6 +189,7 @@ struct apt_renderer {
     int grid_shadow = 0;
     int grid_vshadow = 0;         // volumetric transmittance walk (closest-hit LDS footprint, its own register budget)
     int vshadow_nt = BLOCK;       // its workgroup size and dynamic LDS
+    int vshadow_mode = 0;         // traversal mode of the volumetric transmittance walk (one closest-hit query per lane and pass: with the flat sweep's two-rays-per-lane loop half of every packed instruction would idle, so small scenes keep the tiled / wave sweep there)
     size_t vshadow_lds = 0;
     std::vector<EventPair> pending;
     std::vector<EventPair> free_events;
@@ -793,10 +794,16 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (r->trace_mode != 2) { r->lds_bytes_any = r->lds_bytes; r->grid_shadow = r->grid_trace; }
     if (const char* g = getenv("APT_GRID_SHADOW")) r->grid_shadow = cus * std::max(1, atoi(g));
     r->grid_vshadow = r->grid_trace; r->vshadow_nt = r->trace_nt; r->vshadow_lds = r->lds_bytes;
-    if (r->trace_mode == 2) {
+    r->vshadow_mode = r->trace_mode;
+    if (r->trace_mode == 3) {                            // measured: V2 530 -> 500, V3 543 -> 499 Msamples/s with the walk on the flat sweep's one-ray adapter
+        r->vshadow_mode = (tile_ok && sc->max_obj_prims >= APT_SWEEP_LIST_MIN) ? 2 : 1;
+        if (r->vshadow_mode == 1) { int occ = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kVShadow[1], BLOCK, 0) != hipSuccess || occ < 1) occ = 4; r->grid_vshadow = cus * std::min(occ, 8) * 2; r->vshadow_lds = 0; }
+    }
+    if (r->vshadow_mode == 2) {
         r->vshadow_nt = APT_VSHADOW_NT;
         r->vshadow_lds = APT_TILE_LDS_BYTES(APT_VSHADOW_NT, sc->n_objects);
         r->grid_vshadow = cus * std::max(1, std::min((int)((160 * 1024) / r->vshadow_lds), (APT_VSHADOW_WAVES * 4) / (APT_VSHADOW_NT / 64)));
+        if (r->vshadow_lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kVShadow[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->vshadow_lds));
     }
     if (const char* g = getenv("APT_GRID_VSHADOW")) r->grid_vshadow = cus * std::max(1, atoi(g));
     r->grid_vshadow = ((r->grid_vshadow + nq - 1) / nq) * nq;
@@ -918,7 +925,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
                     const int n_pass = r->scene->has_null_surface ? 7 : 1;       // track_ray walks at most seven segments (vpt.py:113)
                     for (int pass = 0; pass < n_pass; pass++) {
                         LaunchTimer t(r, 3, st);
-                        hipLaunchKernelGGL(kVShadow[r->trace_mode], dim3(grid_for(is.total * (size_t)is.p.S, r->grid_vshadow, nq, r->vshadow_nt)), dim3(r->vshadow_nt), r->vshadow_lds, st, sc, is.p, q, cnt, lane_plan, pass);
+                        hipLaunchKernelGGL(kVShadow[r->vshadow_mode], dim3(grid_for(is.total * (size_t)is.p.S, r->grid_vshadow, nq, r->vshadow_nt)), dim3(r->vshadow_nt), r->vshadow_lds, st, sc, is.p, q, cnt, lane_plan, pass);
                     }
                 }
                 is.cur ^= 1;

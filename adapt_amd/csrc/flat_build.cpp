@@ -1,8 +1,8 @@
 // flat_build.cpp — host side of the flat sweep (traverse.hpp "Flat sweep"): the scene's primitives as precomputed-transform records.
 //
 // Replaces, for small scenes in the fast build, the data the reference's brute-force intersector reads per ray: `prims` / `precom_vec`
-// (tracer/tracer_base.py:117-134, 184-212).  Per planar primitive the rows U, V, T of [e1 e2 n]^-1 (n = e1 x e2) with the translation
-// folded into a fourth column, so that for a point x:  u = U . (x, 1), v = V . (x, 1), height over the plane = T . (x, 1)
+// (tracer/tracer_base.py:117-134, 184-212).  Per planar primitive its corner p0 and the rows U, V, T of [e1 e2 n]^-1 (n = e1 x e2), so
+// that for a point x:  u = U . (x - p0), v = V . (x - p0), height over the plane = T . (x - p0)
 // (Baldwin & Weber, "Fast Ray-Triangle Intersections by Coordinate Transformation", JCGT 5(3), 2016).  Computed in double, stored as
 // float.  Two triangles of one object that form a parallelogram become ONE record in the basis (corner, edge, edge); which triangle a
 // hit belongs to is u + v <= 1, and each triangle's own barycentrics are an affine map of the record's (u, v) with coefficients in

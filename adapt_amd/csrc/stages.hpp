@@ -603,10 +603,11 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_
                 thr = ld3q(in.thr, p.cap, io);
                 id = ldq(in.id, io);
                 uint32_t meta = ldq(in.meta, io);
-                ray_pdf = ldq(in.pdf, io);
+                if (SM & 2) ray_pdf = ldq(in.pdf, io);          // (its only reader is the emission MIS weight: scenes without area lights never look at it)
                 was_spec = (meta >> 24) & 1u;
                 f3 rec_kd;
-                build_hit(sc, prim, ldq(in.t, io), ldq(in.u, io), ldq(in.v, io), o, d, it, hit_light, rec_kd);
+                const bool need_uv = sc.has_vn || (TEX && sc.tex_i != nullptr);      // otherwise nobody reads the barycentrics (and the flat extend kernel does not write them)
+                build_hit(sc, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
                 if (BM == 0x002) bx.k_d = rec_kd;               // Lambertian-only scenes: type 1, not delta, not a BSDF (the defaults above), colour from the record
                 else bx = sc.bxdf[it.obj_id];
                 if (TEX && sc.tex_i != nullptr) {                // the scene declares image textures (TEX kernels only, see below)
@@ -746,7 +747,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_
             st3q(q.thr[nxt], p.cap, so, thr);
             stq(q.id[nxt], so, id);
             stq(q.meta[nxt], so, pack_meta(rng.draw, (uint32_t)(bounce + 1), is_spec));
-            stq(q.pdf[nxt], so, new_pdf);
+            if (SM & 2) stq(q.pdf[nxt], so, new_pdf);
         }
         SH_TICK(5);
     }
@@ -900,10 +901,12 @@ __global__ void __launch_bounds__(BLOCK) k_extend_flat(DevScene sc, Params p, Qu
         int c0, c1;
         flat_closest2(sc.flat, sc.sweep, sc.prim_class, o0, d0, o1, d1, r0, r1, c0, c1);
         if (!SORTED) {
+            // barycentrics only travel when somebody reads them: vertex normals, textures, or the unit-test entry (apt_intersect: cnt == nullptr)
+            const bool need_uv = sc.has_vn || sc.tex_i != nullptr || cnt == nullptr;
             if (v1) {
                 st2q<v2f>(q.hit_t, io, mk2(r0.t, r1.t)); v2i pr; pr.x = r0.prim; pr.y = r1.prim; st2q<v2i>(q.hit_prim, io, pr);
-                st2q<v2f>(q.hit_u, io, mk2(r0.u, r1.u)); st2q<v2f>(q.hit_v, io, mk2(r0.v, r1.v));
-            } else if (v0) { stq(q.hit_t, io, r0.t); stq(q.hit_prim, io, r0.prim); stq(q.hit_u, io, r0.u); stq(q.hit_v, io, r0.v); }
+                if (need_uv) { st2q<v2f>(q.hit_u, io, mk2(r0.u, r1.u)); st2q<v2f>(q.hit_v, io, mk2(r0.v, r1.v)); }
+            } else if (v0) { stq(q.hit_t, io, r0.t); stq(q.hit_prim, io, r0.prim); if (need_uv) { stq(q.hit_u, io, r0.u); stq(q.hit_v, io, r0.v); } }
         } else {
             // sort by material class (see k_extend): the tails of all class queues move with ONE atomic instruction per tile row
             const v2f tx = ld2q<v2f>(q.thr[cur], io), ty = ld2q<v2f>(q.thr[cur], io + cs), tz = ld2q<v2f>(q.thr[cur], io + 2u * cs);

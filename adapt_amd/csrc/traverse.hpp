@@ -662,51 +662,62 @@ struct FlatHit2 { v2f t; int idx0, idx1, run0, run1; };   // closest record per 
 // candidate within FLAT_TIE_EPS of the running minimum; flat_tie_break() then lets the reference's own arithmetic decide between the two.
 #define FLAT_TIE_REL 1e-5f
 #define FLAT_TIE_ABS 1e-6f
-template <bool ANY, bool TIE>
-APT_D void flat_candidate(bool inside, float t, int idx, float& best, int& bidx, int& runner, bool& occ) {
+struct FlatBest { float t; int idx, runner; };               // running closest hit of one ray: distance (or the search limit), record (-1: none), near-tied runner-up (-1: none)
+// (passed and returned BY VALUE: with reference parameters the backend kept the four indices of a lane in scratch memory)
+template <bool TIE>
+APT_D FlatBest flat_candidate(FlatBest b, bool inside, float t, int idx) {
     const bool valid = inside && t > 1e-4f;
-    if (ANY) { occ = occ || (valid && t < best); return; }
     if (TIE) {
-        const float gap = FLAT_TIE_REL * best + FLAT_TIE_ABS;
-        if (valid && t < best) { runner = (best - t <= gap) ? bidx : -1; best = t; bidx = idx; }
-        else if (valid && t - best <= gap) runner = idx;
-    } else if (valid && t < best) { best = t; bidx = idx; }
+        const float gap = FLAT_TIE_REL * b.t + FLAT_TIE_ABS;
+        const bool better = valid && t < b.t, near_behind = valid && !better && (t - b.t <= gap);
+        const int run_new = (b.t - t <= gap) ? b.idx : -1;
+        b.runner = better ? run_new : (near_behind ? idx : b.runner);
+        b.idx = better ? idx : b.idx;
+        b.t = better ? t : b.t;
+    } else {
+        const bool better = valid && t < b.t;
+        b.idx = better ? idx : b.idx;
+        b.t = better ? t : b.t;
+    }
+    return b;
 }
+APT_D bool flat_blocks(bool inside, float t, float lim) { return inside && t > 1e-4f && t < lim; }
 // Both rays against every record.  ANY = false: closest hit below `lim` per ray.  ANY = true: occ0 / occ1 = something lies in (1e-4, lim).
 template <bool ANY>
 APT_D void flat_loop(const FlatScene& fl, const FlatRays& q, v2f lim, FlatHit2& h, bool& occ0, bool& occ1) {
     cf_ptr at = (cf_ptr)fl.stream;
-    float best0 = lim.x, best1 = lim.y;
-    int b0 = -1, b1 = -1, r0 = -1, r1 = -1;
-    occ0 = false; occ1 = false;
+    FlatBest x, y; x.t = lim.x; y.t = lim.y; x.idx = y.idx = -1; x.runner = y.runner = -1;
+    bool o0 = false, o1 = false;
     int idx = 0;                                           // wave-uniform record index
     // parallelograms: inside <=> |u - 1/2| <= 1/2 and |v - 1/2| <= 1/2
     const int nq_plain = ANY ? fl.n_quads + fl.n_quads_tie : fl.n_quads;
     for (int j = 0; j < nq_plain; j++, idx++, at += 12) {
         v2f t, u, v; planar_solve(at, q, t, u, v);
         const v2f a = u - sp2(0.5f), b = v - sp2(0.5f);
-        flat_candidate<ANY, false>(fmaxf(fabsf(a.x), fabsf(b.x)) <= 0.5f, t.x, idx, best0, b0, r0, occ0);
-        flat_candidate<ANY, false>(fmaxf(fabsf(a.y), fabsf(b.y)) <= 0.5f, t.y, idx, best1, b1, r1, occ1);
+        const bool i0 = fmaxf(fabsf(a.x), fabsf(b.x)) <= 0.5f, i1 = fmaxf(fabsf(a.y), fabsf(b.y)) <= 0.5f;
+        if (ANY) { o0 = o0 || flat_blocks(i0, t.x, lim.x); o1 = o1 || flat_blocks(i1, t.y, lim.y); }
+        else { x = flat_candidate<false>(x, i0, t.x, idx); y = flat_candidate<false>(y, i1, t.y, idx); }
     }
     if (!ANY) for (int j = 0; j < fl.n_quads_tie; j++, idx++, at += 12) {
         v2f t, u, v; planar_solve(at, q, t, u, v);
         const v2f a = u - sp2(0.5f), b = v - sp2(0.5f);
-        flat_candidate<ANY, true>(fmaxf(fabsf(a.x), fabsf(b.x)) <= 0.5f, t.x, idx, best0, b0, r0, occ0);
-        flat_candidate<ANY, true>(fmaxf(fabsf(a.y), fabsf(b.y)) <= 0.5f, t.y, idx, best1, b1, r1, occ1);
+        x = flat_candidate<true>(x, fmaxf(fabsf(a.x), fabsf(b.x)) <= 0.5f, t.x, idx);
+        y = flat_candidate<true>(y, fmaxf(fabsf(a.y), fabsf(b.y)) <= 0.5f, t.y, idx);
     }
     // triangles: inside <=> min(u, v, 1 - u - v) >= 0
     const int nt_plain = ANY ? fl.n_tris + fl.n_tris_tie : fl.n_tris;
     for (int j = 0; j < nt_plain; j++, idx++, at += 12) {
         v2f t, u, v; planar_solve(at, q, t, u, v);
         const v2f w = (sp2(1.0f) - u) - v;
-        flat_candidate<ANY, false>(fminf(fminf(u.x, v.x), w.x) >= 0.f, t.x, idx, best0, b0, r0, occ0);
-        flat_candidate<ANY, false>(fminf(fminf(u.y, v.y), w.y) >= 0.f, t.y, idx, best1, b1, r1, occ1);
+        const bool i0 = fminf(fminf(u.x, v.x), w.x) >= 0.f, i1 = fminf(fminf(u.y, v.y), w.y) >= 0.f;
+        if (ANY) { o0 = o0 || flat_blocks(i0, t.x, lim.x); o1 = o1 || flat_blocks(i1, t.y, lim.y); }
+        else { x = flat_candidate<false>(x, i0, t.x, idx); y = flat_candidate<false>(y, i1, t.y, idx); }
     }
     if (!ANY) for (int j = 0; j < fl.n_tris_tie; j++, idx++, at += 12) {
         v2f t, u, v; planar_solve(at, q, t, u, v);
         const v2f w = (sp2(1.0f) - u) - v;
-        flat_candidate<ANY, true>(fminf(fminf(u.x, v.x), w.x) >= 0.f, t.x, idx, best0, b0, r0, occ0);
-        flat_candidate<ANY, true>(fminf(fminf(u.y, v.y), w.y) >= 0.f, t.y, idx, best1, b1, r1, occ1);
+        x = flat_candidate<true>(x, fminf(fminf(u.x, v.x), w.x) >= 0.f, t.x, idx);
+        y = flat_candidate<true>(y, fminf(fminf(u.y, v.y), w.y) >= 0.f, t.y, idx);
     }
     // spheres: the reference's test operation for operation (tracer_base.py:184-199; un-fused products, IEEE square root) - a grazing hit is a
     // difference of two nearly equal squares, and on the mirror and glass balls of the Cornell scenes every digit of it is amplified by
@@ -720,10 +731,12 @@ APT_D void flat_loop(const FlatScene& fl, const FlatRays& q, v2f lim, FlatHit2& 
         const v2f disc = r2 - c2ray;
         const float cut0 = sqrtf(disc.x), cut1 = sqrtf(disc.y);
         const float ta = proj.x + ((cn2.x > r2.x + 1e-4f) ? -cut0 : cut0), tb = proj.y + ((cn2.y > r2.y + 1e-4f) ? -cut1 : cut1);
-        flat_candidate<ANY, false>(c2ray.x < r2.x, ta, idx, best0, b0, r0, occ0);
-        flat_candidate<ANY, false>(c2ray.y < r2.y, tb, idx, best1, b1, r1, occ1);
+        const bool i0 = c2ray.x < r2.x, i1 = c2ray.y < r2.y;
+        if (ANY) { o0 = o0 || flat_blocks(i0, ta, lim.x); o1 = o1 || flat_blocks(i1, tb, lim.y); }
+        else { x = flat_candidate<false>(x, i0, ta, idx); y = flat_candidate<false>(y, i1, tb, idx); }
     }
-    h.t = mk2(best0, best1); h.idx0 = b0; h.idx1 = b1; h.run0 = r0; h.run1 = r1;
+    h.t = mk2(x.t, y.t); h.idx0 = x.idx; h.idx1 = y.idx; h.run0 = x.runner; h.run1 = y.runner;
+    occ0 = o0; occ1 = o1;
 }
 // the winning record's own triangle, barycentrics and material class: hit point -> (u, v) of the record, then the triangle's affine map
 APT_D void flat_resolve(const FlatScene& fl, int idx, float t, f3 o, f3 d, HitRec& rec, int& cls) {

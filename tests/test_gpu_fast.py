@@ -316,3 +316,56 @@ def test_the_two_builds_agree_bit_for_bit_where_they_run_the_same_code():
         finally:
             r.close()
     assert np.array_equal(imgs[False], imgs[True]) and imgs[True].max() > 0
+
+
+@pytest.mark.parametrize("tag,scene", [("c2", "cbox"), ("c3", "balls_mono")])
+def test_full_frame_c2_c3_against_the_oracle_statistics(tag, scene, renderer):
+    """BASELINE configs[1] / [2] at their FULL film size (512 x 512, all bounces; 64 of the 1024 spp) against the oracle's render of the
+    same samples (tests/golden/fullsize_*.npz, tests/golden/gen/gen_fullsize_stats.py): path statistics, the 8 x 8 grid of tile means, and
+    the image at 1/8 resolution."""
+    g = golden(f"fullsize_{tag}.npz")
+    w, h, spp = int(g["width"]), int(g["height"]), int(g["spp"])
+    r = renderer(scene, width=w, height=h, max_bounce=int(g["max_bounce"]))
+    r.render(n_spp=spp)
+    st = r.stats()
+    assert st["n_samples"] == int(g["n_samples"]) == w * h * spp
+    for k in ("n_shade", "n_shadow", "n_draws"):
+        assert abs(st[k] - int(g[k])) <= 1e-4 * int(g[k]), (k, st[k], int(g[k]))
+    img = r.pixels.to_numpy().astype(np.float64)
+    img[~np.isfinite(img).all(axis=2)] = 0.0
+    tiles = img.reshape(w // 64, 64, h // 64, 64, 3).mean(axis=(1, 3))
+    small = img.reshape(w // 8, 8, h // 8, 8, 3).mean(axis=(1, 3))
+    assert np.abs(tiles - g["tiles"]).max() <= 2e-3 * g["tiles"].mean(), float(np.abs(tiles - g["tiles"]).max() / g["tiles"].mean())
+    m = image_metrics(small, g["small"].astype(np.float64))
+    assert m["relMSE"] <= 1e-5 and m["frac_within"] >= 0.99, m
+
+
+def test_two_gpu_rccl_bench_equals_the_single_gpu_image(tmp_path):
+    """bench.py exactly as the driver launches it on a multi-GPU node - torch.distributed.run, one rank per GPU, backend "nccl" (= RCCL over
+    xGMI), the device-resident all_gather of tiles - with a world of TWO: the gathered image equals the one-GPU image bit for bit (the Philox
+    key is the global pixel).  Needs two visible devices: skipped on the one-GPU test boxes, runs wherever the scaling runs do."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    imgs = {}
+    for n in (1, 2):
+        img = str(tmp_path / f"n{n}.npy")
+        common = ["bench.py", "--gpus", str(n), "--config", "c1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-exclusive-pass", "--scaling", "strong", "--spp", "8", "--dump-image", img]
+        if n > 1:
+            sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port)] + common
+        else:
+            cmd = [sys.executable] + common
+        res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-2000:]
+        line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == n and line["value"] > 0
+        imgs[n] = np.load(img)
+    assert np.array_equal(imgs[1], imgs[2])

@@ -402,6 +402,28 @@ def test_full_size_parity_c2_c3(tag, spp, renderer, parsed, oracle_scene, capsys
 
 
 # ---------------------------------------------------------------- large scenes: BVH traversal path
+@pytest.mark.parametrize("tag,scene", [("c2", "cbox"), ("c3", "balls_mono")])
+def test_full_frame_c2_c3_against_the_oracle_statistics(tag, scene, renderer):
+    """BASELINE configs[1] / [2] at their FULL film size (512 x 512, all bounces; 64 of the 1024 spp) against the oracle's render of the
+    same samples (tests/golden/fullsize_*.npz, generated by tests/golden/gen/gen_fullsize_stats.py): path statistics, the 8 x 8 grid of
+    tile means, the image at 1/8 resolution.  Un-gated twin of test_full_size_parity_c2_c3, which compares every pixel at 1024 spp."""
+    g = golden(f"fullsize_{tag}.npz")
+    w, h, spp = int(g["width"]), int(g["height"]), int(g["spp"])
+    r = renderer(scene, width=w, height=h, max_bounce=int(g["max_bounce"]))
+    r.render(n_spp=spp)
+    st = r.stats()
+    assert st["n_samples"] == int(g["n_samples"]) == w * h * spp
+    for k in ("n_shade", "n_shadow", "n_draws"):
+        assert abs(st[k] - int(g[k])) <= 2e-6 * int(g[k]), (k, st[k], int(g[k]))          # an ulp in a transcendental can flip a branch: 81 of 1.2e9 vertices at 1024 spp
+    img = r.pixels.to_numpy().astype(np.float64)
+    img[~np.isfinite(img).all(axis=2)] = 0.0
+    tiles = img.reshape(w // 64, 64, h // 64, 64, 3).mean(axis=(1, 3))
+    small = img.reshape(w // 8, 8, h // 8, 8, 3).mean(axis=(1, 3))
+    assert np.abs(tiles - g["tiles"]).max() <= 2e-5 * g["tiles"].mean(), float(np.abs(tiles - g["tiles"]).max() / g["tiles"].mean())
+    m = image_metrics(small, g["small"].astype(np.float64))
+    assert m["relMSE"] <= 1e-9 and m["frac_within"] >= 0.9999, m
+
+
 @pytest.fixture(scope="module")
 def bunnies_small():
     from adapt_amd.synth import three_bunnies

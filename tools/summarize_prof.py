@@ -17,6 +17,10 @@ def short(name):
         return "k_extend_dyn<bvh, dynamic fetch" + (", sorted>" if "ILi1E" in name else ">")
     if "k_shadow_dyn" in name:
         return "k_shadow_dyn<bvh, dynamic fetch>"
+    if "k_extend_flat" in name:
+        return "k_extend_flat<flat sweep, 2 rays / lane" + (", sorted>" if "ILi1E" in name else ">")
+    if "k_shadow_flat" in name:
+        return "k_shadow_flat<flat sweep, 2 rays / lane>"
     for k in ("k_generate", "k_extend", "k_vshade", "k_vshadow", "k_shade", "k_shadow", "k_finalize", "k_divide"):
         if k in name:
             tag = k
