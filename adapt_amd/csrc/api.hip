@@ -607,7 +607,24 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     p.use_rr = c.use_rr; p.use_mis = c.use_mis; p.anti_alias = c.anti_alias; p.stratified = c.stratified; p.two_sides = c.brdf_two_sides;
     p.rr_bounce_th = c.rr_bounce_th; p.rr_threshold = c.rr_threshold; p.seed = c.seed; p.cap = (uint32_t)cap; p.subcap = (uint32_t)subcap; p.nq = nq;
     p.inv_ns = 1.f / (float)sc->n_sources; p.inv_ns1 = (sc->n_sources > 1) ? 1.f / (float)(sc->n_sources - 1) : 1.f;
-    p.l_planes = (!c.volumetric && S >= 2 && S <= 4) ? S : 1;        // stages.hpp APT_EXCLUSIVE_L: one radiance plane per light sample of a vertex
+    // traversal mode: small scenes sweep all primitives wave-uniformly in the reference's brute-force order
+    // the tiled sweep pays off once some object has enough primitives that skipping it per ray matters;
+    // scenes of spheres and quads only are as fast in the plain wave sweep
+    const bool tile_ok = sc->has_aabb && sc->has_sweep && sc->n_objects <= APT_TILE_MAX_OBJECTS && sc->n_prims < 65536 &&
+                         APT_TILE_LDS_BYTES(APT_TILE_NT, sc->n_objects) <= 160 * 1024;      // the per-object lists of a tile must fit the CU's LDS (34 objects at 512 threads)
+    r->trace_mode = (sc->n_prims <= APT_SWEEP_MAX_PRIMS && sc->has_aabb && sc->has_sweep) ? ((tile_ok && sc->max_obj_prims >= APT_SWEEP_LIST_MIN) ? 2 : 1) : 0;
+    if (sc->has_flat) r->trace_mode = 3;                 // fast build: the flat sweep serves every scene small enough to have its records
+    if (const char* force = getenv("APT_TRAVERSAL")) {
+        if (!strcmp(force, "bvh")) r->trace_mode = 0;
+        else if (!strcmp(force, "flat") && sc->has_flat) r->trace_mode = 3;
+        else if (!strcmp(force, "sweep") && sc->has_aabb && sc->has_sweep) r->trace_mode = 1;
+        else if (!strcmp(force, "tile") && tile_ok) r->trace_mode = 2;
+    }
+    // flat sweep with several light samples per vertex: the samples are queued by vertex and the shadow kernel adds a vertex's samples with
+    // one read-modify-write (stages.hpp k_shadow_flat); otherwise 2-4 samples per vertex add into one radiance plane each
+    p.nee_vm = (!c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
+    if (const char* f = getenv("APT_NEE_VM")) p.nee_vm = (atoi(f) != 0 && !c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
+    p.l_planes = (!c.volumetric && !p.nee_vm && S >= 2 && S <= 4) ? S : 1;        // stages.hpp APT_EXCLUSIVE_L: one radiance plane per light sample of a vertex
     p.pix_bits = 0; while ((1u << p.pix_bits) < (uint32_t)r->npix) p.pix_bits++;
     if (((uint64_t)B << p.pix_bits) > (1ull << 32)) { return fail(APT_E_INVALID, "apt_renderer_create: spp_per_batch x pixels does not fit the 32-bit path id"); }
     {   // local pixel -> RNG key (global pixel index), same mapping as local_to_global in stages.hpp
@@ -714,19 +731,6 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c.device));
     int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    // traversal mode: small scenes sweep all primitives wave-uniformly in the reference's brute-force order
-    // the tiled sweep pays off once some object has enough primitives that skipping it per ray matters;
-    // scenes of spheres and quads only are as fast in the plain wave sweep
-    const bool tile_ok = sc->has_aabb && sc->has_sweep && sc->n_objects <= APT_TILE_MAX_OBJECTS && sc->n_prims < 65536 &&
-                         APT_TILE_LDS_BYTES(APT_TILE_NT, sc->n_objects) <= 160 * 1024;      // the per-object lists of a tile must fit the CU's LDS (34 objects at 512 threads)
-    r->trace_mode = (sc->n_prims <= APT_SWEEP_MAX_PRIMS && sc->has_aabb && sc->has_sweep) ? ((tile_ok && sc->max_obj_prims >= APT_SWEEP_LIST_MIN) ? 2 : 1) : 0;
-    if (sc->has_flat) r->trace_mode = 3;                 // fast build: the flat sweep serves every scene small enough to have its records
-    if (const char* force = getenv("APT_TRAVERSAL")) {
-        if (!strcmp(force, "bvh")) r->trace_mode = 0;
-        else if (!strcmp(force, "flat") && sc->has_flat) r->trace_mode = 3;
-        else if (!strcmp(force, "sweep") && sc->has_aabb && sc->has_sweep) r->trace_mode = 1;
-        else if (!strcmp(force, "tile") && tile_ok) r->trace_mode = 2;
-    }
     // LDS plan of the BVH walk: the per-lane stack of 8-byte groups.  A node visit leaves at most one group behind (the rest of its
     // hit children), so the stack never holds more groups than the tree has levels.
     {

@@ -95,6 +95,7 @@ struct Params {
     uint32_t pix_bits;
     const uint32_t* pix_key;  // local pixel -> global pixel index x * H + y = the RNG key (host-built; band mapping folded in)
     float inv_ns, inv_ns1;    // 1 / n_sources, 1 / (n_sources - 1): sample_light's pdfs (path_tracer.py:537-554)
+    int nee_vm;               // 1: light samples are queued BY VERTEX (one slot per vertex and sub-queue, sample s in plane s of the sub-queue's region, unwanted samples marked tmax < 0), so that the flat shadow kernel adds a vertex's samples with ONE read-modify-write and the shade kernel moves the queue tail once per tile row (flat sweep, S > 1)
     int l_planes;             // radiance planes of L: light sample s of a vertex adds into plane s (2 <= S <= 4), so that no two entries of a shadow launch share a slot; 1 otherwise
     float w_min[3], w_max[3]; // world box = (objects U camera) +- 0.1 (path_tracer.py:130-138); volumetric tracer only
 };
@@ -190,6 +191,15 @@ APT_D uint32_t wave_append(bool flag, uint32_t* counter) {
     if (lane_id() == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m));
     base = __shfl(base, 0);
     return base + rank_in(m);
+}
+
+// the same for blocks of `k` consecutive entries per flagged lane; returns the position of this lane's block
+APT_D uint32_t wave_append_n(bool flag, uint32_t* counter, uint32_t k) {
+    unsigned long long m = __ballot(flag);
+    uint32_t base = 0;
+    if (lane_id() == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m) * k);
+    base = __shfl(base, 0);
+    return base + rank_in(m) * k;
 }
 
 // Queue addressing.  Every queue array is indexed by a 32-bit slot whose BYTE offset also fits 32 bits (the host
@@ -653,6 +663,9 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_
         bool break_flag = false;
         DevSrc src_only;                                      // the scene's only light, read once through the scalar path
         if (sc.n_sources == 1) src_only = ld_src_uniform(sc.src);
+        // light samples by vertex: ONE queue-tail atomic per tile row for all S samples of every vertex
+        uint32_t vbase = 0;
+        if (p.nee_vm) vbase = wave_append(alive, shadow_counter);
         for (int s = 0; s < p.S; s++) {
             bool want = false, sampled = false, poisoned = false;
             f3 light_dir = splat3(0.f), contrib = splat3(0.f);
@@ -705,14 +718,25 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_
             }
             SH_TICK(2);
             t_shadow += wave_count(sampled); t_poison += wave_count(poisoned);
-            uint32_t spos = wave_append(want, shadow_counter);
-            if (want && spos < q.sh_subcap) {
-                const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
-                st3q(q.sh_o, sc_, so, hit_point);
-                st3q(q.sh_d, sc_, so, light_dir);
-                stq(q.sh_tmax, so, emitter_d);
-                st3q(q.sh_c, sc_, so, contrib);
-                stq(q.sh_id, so, l_off | ((p.l_planes > 1) ? (uint32_t)s : 0u));
+            if (p.nee_vm) {
+                const uint32_t so = (sh_qbase + (uint32_t)s * p.subcap + vbase) << 2, sc_ = q.sh_cap;        // plane s of the sub-queue's region: consecutive lanes, consecutive entries
+                if (want) {
+                    st3q(q.sh_o, sc_, so, hit_point);
+                    st3q(q.sh_d, sc_, so, light_dir);
+                    stq(q.sh_tmax, so, emitter_d);
+                    st3q(q.sh_c, sc_, so, contrib);
+                } else if (alive) stq(q.sh_tmax, so, -1.0f);                   // the vertex has no sample s worth tracing
+                if (alive && s == 0) stq(q.sh_id, so, l_off);                   // one radiance slot per vertex, kept with its first entry
+            } else {
+                uint32_t spos = wave_append(want, shadow_counter);
+                if (want && spos < q.sh_subcap) {
+                    const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
+                    st3q(q.sh_o, sc_, so, hit_point);
+                    st3q(q.sh_d, sc_, so, light_dir);
+                    stq(q.sh_tmax, so, emitter_d);
+                    st3q(q.sh_c, sc_, so, contrib);
+                    stq(q.sh_id, so, l_off | ((p.l_planes > 1) ? (uint32_t)s : 0u));
+                }
             }
         }
 
@@ -949,11 +973,44 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_flat(DevScene sc, Params p, Qu
     const SubLoop sl = sub_loop(p.nq, FLAT_NT);
     const uint32_t n = min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
     if (sl.first == 0 && threadIdx.x == 0) {
-        cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
+        if (!p.nee_vm) cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
         for (int c = 0; c < q.n_classes; c++) cnt->n_cls[c][sl.q * CNT_PAD] = 0;      // every shade of this bounce is done
     }
     const uint32_t qbase = (uint32_t)sl.q * q.sh_subcap, cs = q.sh_cap * 4u;
-    uint32_t t_lit = 0;
+    uint32_t t_lit = 0, t_traced = 0;
+    if (p.nee_vm) {
+        // Light samples by vertex (S > 1; `n` counts VERTICES): a lane owns one vertex and walks its sample planes two at a time - the two
+        // rays of a packed test then share their origin.  The samples are summed in sample order, as upstream sums direct_int, and the
+        // vertex's radiance slot takes ONE read-modify-write, which no other lane of the launch touches.  (tmax < 0: a sample the shade
+        // kernel found not worth tracing.)  An occluded sample still enters the sum as 0 * contribution - NaN for a non-finite one (see k_shadow).
+        const SubLoop sv = sub_loop(p.nq, BLOCK);
+        for (uint32_t base = sv.first; base < n; base += sv.stride) {
+            const uint32_t pos = base + threadIdx.x;
+            const bool valid = pos < n;
+            const uint32_t io = (qbase + (valid ? pos : n - 1u)) << 2;
+            const uint32_t slot = ldq(q.sh_id, io);
+            f3 sum = splat3(0.f); bool any = false;
+            for (int smp = 0; smp < p.S; smp += 2) {
+                const bool two = smp + 1 < p.S;
+                const uint32_t ia = io + ((uint32_t)smp * p.subcap << 2), ib = io + ((uint32_t)(two ? smp + 1 : smp) * p.subcap << 2);
+                const float ta = ldq(q.sh_tmax, ia), tb = ldq(q.sh_tmax, ib);
+                const bool la = valid && !(ta < 0.0f), lb = valid && two && !(tb < 0.0f);
+                const f3 o = ld3q(q.sh_o, q.sh_cap, la ? ia : ib);                 // (the origin is written with every wanted sample)
+                const f3 da = ld3q(q.sh_d, q.sh_cap, ia), db = ld3q(q.sh_d, q.sh_cap, ib);
+                bool oa, ob;
+                flat_any2(sc.flat, sc.sweep, o, da, o, db, la ? ((ta > 0.0f) ? ta - 1e-4f : 1e7f) : -1.0f, lb ? ((tb > 0.0f) ? tb - 1e-4f : 1e7f) : -1.0f, oa, ob);
+                f3 ca = ld3q(q.sh_c, q.sh_cap, ia), cb = ld3q(q.sh_c, q.sh_cap, ib);
+                const bool wa = !(isfinite(ca.x) && isfinite(ca.y) && isfinite(ca.z)), wb = !(isfinite(cb.x) && isfinite(cb.y) && isfinite(cb.z));
+                if (la && (!oa || wa)) { if (oa) ca = ca * 0.f; sum = any ? sum + ca : ca; any = true; }
+                if (lb && (!ob || wb)) { if (ob) cb = cb * 0.f; sum = any ? sum + cb : cb; any = true; }
+                t_traced += (la ? 1u : 0u) + (lb ? 1u : 0u); t_lit += (la && !oa ? 1u : 0u) + (lb && !ob ? 1u : 0u);
+            }
+            if (any) add_radiance(q.L, p.cap, slot & ~3u, sum, true);
+        }
+        flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);
+        flush_stat(t_traced, &cnt->stats[sl.q][ST_SHADOW_TRACED]);
+        return;
+    }
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
         const uint32_t pos = base + 2u * threadIdx.x;
         const bool v0 = pos < n, v1 = pos + 1u < n;
