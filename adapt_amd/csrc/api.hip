@@ -432,14 +432,14 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
             FlatScene& fl = s->dev.flat;
             std::vector<uint8_t> trans((size_t)O);
             for (int o = 0; o < O; o++) trans[(size_t)o] = bx[(size_t)o].is_bsdf ? 1 : 0;
-            int fc[5];
+            int fc[7];
             if (apt::build_flat(d->prims, N, d->obj_info, O, pcls.data(), trans.data(), fr, ft, fc) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: flat records: obj_info range outside the primitive array"); }
-            fl.n_quads = fc[0]; fl.n_quads_tie = fc[1]; fl.n_tris = fc[2]; fl.n_tris_tie = fc[3]; fl.n_spheres = fc[4];
+            fl.n_quads = fc[0]; fl.n_quads_tie = fc[1]; fl.n_gquads = fc[2]; fl.n_gquads_tie = fc[3]; fl.n_tris = fc[4]; fl.n_tris_tie = fc[5]; fl.n_spheres = fc[6];
             hipError_t e1_ = upload(s->flat_recs, fr), e2_ = (e1_ == hipSuccess) ? upload(s->flat_tab, ft) : e1_;
             if (e2_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload flat records: ") + hipGetErrorString(e2_)); }
             fl.stream = s->flat_recs.as<float>(); fl.tab = s->flat_tab.as<float4>();
             s->has_flat = true;
-            if (timing) fprintf(stderr, "[scene timing] flat records: %d + %d parallelograms, %d + %d triangles (plain + coplanar groups), %d spheres of %d primitives\n", fc[0], fc[1], fc[2], fc[3], fc[4], N);
+            if (timing) fprintf(stderr, "[scene timing] flat records: %d + %d parallelograms, %d + %d convex quads, %d + %d triangles (plain + coplanar groups), %d spheres of %d primitives\n", fc[0], fc[1], fc[2], fc[3], fc[4], fc[5], fc[6], N);
             tick("flat records");
         }
 #endif

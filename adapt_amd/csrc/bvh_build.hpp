@@ -67,5 +67,5 @@ int build_linear_bvh(const float* prims, int n_prims, const int32_t* obj_prim_cn
 // flat_build.cpp: the records of the flat sweep (traverse.hpp FlatScene): precomputed-transform planar primitives (parallelograms merged),
 // spheres, and the per-record table that maps a winning record back to its triangle and barycentrics
 int build_flat(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, const int32_t* prim_class, const uint8_t* transmissive,
-               std::vector<float>& stream, std::vector<float>& tab, int counts[5]);      // counts: quads, quads in coplanar groups, triangles, triangles in coplanar groups, spheres
+               std::vector<float>& stream, std::vector<float>& tab, int counts[7]);      // counts: parallelograms, convex quads, triangles - each plain, then in coplanar groups - and spheres
 }  // namespace apt

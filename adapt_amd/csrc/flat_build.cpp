@@ -4,9 +4,10 @@
 // (tracer/tracer_base.py:117-134, 184-212).  Per planar primitive its corner p0 and the rows U, V, T of [e1 e2 n]^-1 (n = e1 x e2), so
 // that for a point x:  u = U . (x - p0), v = V . (x - p0), height over the plane = T . (x - p0)
 // (Baldwin & Weber, "Fast Ray-Triangle Intersections by Coordinate Transformation", JCGT 5(3), 2016).  Computed in double, stored as
-// float.  Two triangles of one object that form a parallelogram become ONE record in the basis (corner, edge, edge); which triangle a
-// hit belongs to is u + v <= 1, and each triangle's own barycentrics are an affine map of the record's (u, v) with coefficients in
-// {-1, 0, 1}.  Degenerate triangles get a record no ray can hit (upstream: det = 0 -> non-finite barycentrics -> never accepted).
+// float.  Two coplanar triangles of one object that share an edge and form a convex outline become ONE record in the basis (corner opposite
+// the shared edge, edge, edge): a parallelogram (inside <=> u, v in [0, 1]) or a general convex quadrilateral (u, v >= 0 and two more edge
+// functions of (u, v)); which triangle a hit belongs to is u + v <= 1, and each triangle's own barycentrics are an affine map of the
+// record's (u, v) (coefficients in {-1, 0, 1} for a parallelogram).  Degenerate triangles get a record no ray can hit (upstream: det = 0 -> non-finite barycentrics -> never accepted).
 #include <cmath>
 #include <cstring>
 
@@ -21,7 +22,7 @@ inline D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b
 inline double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline D3 vtx(const float* prims, int k, int v) { const float* p = prims + 9 * (size_t)k + 3 * v; return {p[0], p[1], p[2]}; }
 
-struct Planar { float P0[3], U[4], V[4], T[4]; int prim_a, prim_b; float map_a[6], map_b[6]; bool ok; int obj; bool tie; float lo[3], hi[3]; };
+struct Planar { float P0[3], U[4], V[4], T[4]; int prim_a, prim_b; float map_a[6], map_b[6]; bool ok; int obj; bool tie; float lo[3], hi[3]; float far_edges[6]; };
 
 // rows of [e1 e2 n]^-1 applied to (x - p0)
 bool make_rows(D3 p0, D3 e1, D3 e2, Planar& r) {
@@ -51,23 +52,20 @@ bool make_rows(D3 p0, D3 e1, D3 e2, Planar& r) {
     r.T[0] = (float)T.x; r.T[1] = (float)T.y; r.T[2] = (float)T.z; r.T[3] = (float)tw;
     return true;
 }
-// triangle k's own barycentrics as an affine map of the record's (u, v): coefficients must be integers (else: not a parallelogram half)
-bool bary_map(const float* prims, int k, D3 p0, D3 e1, D3 e2, double tol, float m[6]) {
+// triangle k's own barycentrics as an affine map of the record's (u, v) - k lies in the record's plane, so the map is exact: evaluate
+// k's barycentrics at the record's corner and edge ends.  (For a parallelogram half the coefficients come out in {-1, 0, 1}.)
+bool bary_map(const float* prims, int k, D3 p0, D3 e1, D3 e2, float m[6]) {
     const D3 q0 = vtx(prims, k, 0), f1 = sub(vtx(prims, k, 1), q0), f2 = sub(vtx(prims, k, 2), q0);
-    // coordinates of q0, f1, f2 in the (e1, e2) basis
-    const D3 n = cross(e1, e2); const double det = dot(n, n);
-    auto coord = [&](D3 w, double& a, double& b) { a = dot(cross(w, e2), n) / det; b = dot(cross(e1, w), n) / det; };
+    const D3 n = cross(f1, f2); const double det = dot(n, n);
+    if (!(det > 0.0) || !std::isfinite(det)) return false;
+    auto bary = [&](D3 x, double& a, double& b) { const D3 w = sub(x, q0); a = dot(cross(w, f2), n) / det; b = dot(cross(f1, w), n) / det; };
     double a0, b0, a1, b1, a2, b2;
-    coord(sub(q0, p0), a0, b0); coord(f1, a1, b1); coord(f2, a2, b2);
-    const double c[6] = {a0, b0, a1, b1, a2, b2};
-    double r[6];
-    for (int i = 0; i < 6; i++) { r[i] = std::nearbyint(c[i]); if (std::fabs(c[i] - r[i]) > tol) return false; }
-    // (u', v') = (a0, b0) + [[a1, a2], [b1, b2]] (uk, vk)  ->  invert the 2 x 2 integer matrix
-    const double d2 = r[2] * r[5] - r[4] * r[3];
-    if (std::fabs(std::fabs(d2) - 1.0) > 1e-9) return false;
-    const double i00 = r[5] / d2, i01 = -r[4] / d2, i10 = -r[3] / d2, i11 = r[2] / d2;
-    m[1] = (float)i00; m[2] = (float)i01; m[0] = (float)(-(i00 * r[0] + i01 * r[1]));
-    m[4] = (float)i10; m[5] = (float)i11; m[3] = (float)(-(i10 * r[0] + i11 * r[1]));
+    bary(p0, a0, b0); bary(add(p0, e1), a1, b1); bary(add(p0, e2), a2, b2);
+    const double c[6] = {a0, a1 - a0, a2 - a0, b0, b1 - b0, b2 - b0};
+    for (int i = 0; i < 6; i++) {
+        const double r = std::nearbyint(c[i]);
+        m[i] = (float)((std::fabs(c[i] - r) < 1e-9) ? r + 0.0 : c[i]);
+    }
     return true;
 }
 
@@ -97,15 +95,16 @@ bool convex_overlap(const Poly& A, const Poly& B, const float plane[4]) {
 }
 }  // namespace
 
-// stream: [quads][quads of coplanar groups][triangles][triangles of coplanar groups] x 12 floats, [spheres] x 4; a planar record = corner
-// p0, rows U, V, T (3 floats each).  tab: 28 floats per record, in stream order (7 float4: (U, p0.x), (V, p0.y), (prim_a, prim_b, class_a,
+// stream: [parallelograms][same, of coplanar groups] x 12 floats, [convex quads][same, of coplanar groups] x 18, [triangles][same, of
+// coplanar groups] x 12, [spheres] x 4; a planar record = corner p0, rows U, V, T (3 floats each); a convex quad appends its two far
+// edges as functions a u + b v + c of the record's (u, v) that are >= 0 inside.  tab: 28 floats per record, in stream order (7 float4: (U, p0.x), (V, p0.y), (prim_a, prim_b, class_a,
 // class_b), map_a, map_b, (p0.z, -, -, -)).
 // prim_class: material class per primitive (sorted shading) or null.  transmissive: per object, 1 when rays can travel inside it (a BSDF).
 // A record joins a coplanar group when another record lies in the same plane (to 2e-5) and their outlines overlap - the configurations in
 // which upstream's answer hangs on the last bit of two distances (traverse.hpp flat_tie_break): a glass box resting on the floor, a decal on a wall.
 int build_flat(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, const int32_t* prim_class, const uint8_t* transmissive,
-               std::vector<float>& stream, std::vector<float>& tab, int counts[5]) {
-    std::vector<Planar> quads, tris;
+               std::vector<float>& stream, std::vector<float>& tab, int counts[7]) {
+    std::vector<Planar> quads, gquads, tris;
     std::vector<int> spheres;
     std::vector<uint8_t> used((size_t)n_prims, 0);
     const float ident[6] = {0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
@@ -124,23 +123,37 @@ int build_flat(const float* prims, int n_prims, const int32_t* obj_info, int n_o
             used[(size_t)k] = 1;
             const D3 A = vtx(prims, k, 0), B = vtx(prims, k, 1), C = vtx(prims, k, 2);
             const double ext = std::sqrt(std::max(dot(sub(B, A), sub(B, A)), dot(sub(C, A), sub(C, A)))), tol = 1e-6 * ext + 1e-12;
-            // a partner in the same object that shares an edge and closes the parallelogram: its third vertex = sum of the shared edge's ends - this triangle's opposite vertex
+            // a partner in the same object that shares an edge, lies in the same plane and makes a convex outline with this triangle.  In this
+            // triangle's frame (corner = the vertex opposite the shared edge) the partner's third vertex sits at (ud, vd): (1, 1) closes a
+            // parallelogram; any other point with ud > 0, vd > 0, ud + vd > 1 a convex quadrilateral.
             bool paired = false;
             const D3 tv[3] = {A, B, C};
             for (int k2 = k + 1; k2 < first + count && !paired; k2++) {
                 if (used[(size_t)k2]) continue;
                 const D3 w[3] = {vtx(prims, k2, 0), vtx(prims, k2, 1), vtx(prims, k2, 2)};
                 for (int opp = 0; opp < 3 && !paired; opp++) {            // this triangle's vertex opposite the shared edge
-                    const D3 s1 = tv[(opp + 1) % 3], s2 = tv[(opp + 2) % 3], far = sub(add(s1, s2), tv[opp]);
+                    const D3 s1 = tv[(opp + 1) % 3], s2 = tv[(opp + 2) % 3];
                     auto same = [&](D3 a, D3 b) { const D3 d = sub(a, b); return dot(d, d) <= tol * tol; };
-                    int hit_s1 = -1, hit_s2 = -1, hit_far = -1;
-                    for (int j = 0; j < 3; j++) { if (same(w[j], s1)) hit_s1 = j; else if (same(w[j], s2)) hit_s2 = j; else if (same(w[j], far)) hit_far = j; }
-                    if (hit_s1 < 0 || hit_s2 < 0 || hit_far < 0) continue;
+                    int hit_s1 = -1, hit_s2 = -1;
+                    for (int j = 0; j < 3; j++) { if (same(w[j], s1)) hit_s1 = j; else if (same(w[j], s2)) hit_s2 = j; }
+                    if (hit_s1 < 0 || hit_s2 < 0 || hit_s1 == hit_s2) continue;
+                    const D3 far = w[3 - hit_s1 - hit_s2];
+                    const D3 p0 = tv[opp], e1 = sub(s1, p0), e2 = sub(s2, p0), n = cross(e1, e2);
+                    const double det = dot(n, n);
+                    if (!(det > 0.0)) continue;
+                    const D3 fd = sub(far, p0);
+                    if (std::fabs(dot(fd, n)) / std::sqrt(det) > tol) continue;                                  // not in this triangle's plane
+                    const double ud = dot(cross(fd, e2), n) / det, vd = dot(cross(e1, fd), n) / det;
+                    if (!(ud > 1e-4 && vd > 1e-4 && ud + vd > 1.0 + 1e-4)) continue;                             // the outline would not be convex
                     Planar q{}; q.prim_a = k; q.prim_b = k2; q.obj = o;
-                    const D3 p0 = tv[opp], e1 = sub(s1, p0), e2 = sub(s2, p0);
                     if (!make_rows(p0, e1, e2, q)) continue;
-                    if (!bary_map(prims, k, p0, e1, e2, 1e-5, q.map_a) || !bary_map(prims, k2, p0, e1, e2, 1e-5, q.map_b)) continue;
-                    q.ok = true; bounds(q); quads.push_back(q); used[(size_t)k2] = 1; paired = true;
+                    if (!bary_map(prims, k, p0, e1, e2, q.map_a) || !bary_map(prims, k2, p0, e1, e2, q.map_b)) continue;
+                    q.ok = true; bounds(q); used[(size_t)k2] = 1; paired = true;
+                    if (std::fabs(ud - 1.0) <= 1e-6 && std::fabs(vd - 1.0) <= 1e-6) { quads.push_back(q); break; }
+                    // the far edges (1, 0) -> (ud, vd) and (ud, vd) -> (0, 1) as functions that are >= 0 inside
+                    const double fe[6] = {-vd, ud - 1.0, vd, vd - 1.0, -ud, ud};
+                    for (int i = 0; i < 6; i++) q.far_edges[i] = (float)fe[i];
+                    gquads.push_back(q);
                 }
             }
             if (paired) continue;
@@ -171,6 +184,7 @@ int build_flat(const float* prims, int n_prims, const int32_t* obj_info, int n_o
     {   // coplanar groups
         std::vector<Planar*> all;
         for (Planar& p : quads) all.push_back(&p);
+        for (Planar& p : gquads) all.push_back(&p);
         for (Planar& p : tris) all.push_back(&p);
         for (size_t i = 0; i < all.size(); i++) for (size_t j = i + 1; j < all.size(); j++) {
             Planar &a = *all[i], &b = *all[j];
@@ -192,14 +206,15 @@ int build_flat(const float* prims, int n_prims, const int32_t* obj_info, int n_o
         v = plain; v.insert(v.end(), tie.begin(), tie.end());
         return n_tie;
     };
-    const int nq_tie = split(quads), nt_tie = split(tris);
-    counts[0] = (int)quads.size() - nq_tie; counts[1] = nq_tie; counts[2] = (int)tris.size() - nt_tie; counts[3] = nt_tie; counts[4] = (int)spheres.size();
-    const int n_quads = (int)quads.size(), n_tris = (int)tris.size(), n_spheres = (int)spheres.size();
-    stream.assign((size_t)(n_quads + n_tris) * 12 + (size_t)n_spheres * 4 + 4, 0.f);
-    tab.assign((size_t)(n_quads + n_tris + n_spheres) * 28, 0.f);
+    const int nq_tie = split(quads), ng_tie = split(gquads), nt_tie = split(tris);
+    counts[0] = (int)quads.size() - nq_tie; counts[1] = nq_tie; counts[2] = (int)gquads.size() - ng_tie; counts[3] = ng_tie;
+    counts[4] = (int)tris.size() - nt_tie; counts[5] = nt_tie; counts[6] = (int)spheres.size();
+    const int n_quads = (int)quads.size(), n_gquads = (int)gquads.size(), n_tris = (int)tris.size(), n_spheres = (int)spheres.size();
+    stream.assign((size_t)(n_quads + n_tris) * 12 + (size_t)n_gquads * 18 + (size_t)n_spheres * 4 + 4, 0.f);
+    tab.assign((size_t)(n_quads + n_gquads + n_tris + n_spheres) * 28, 0.f);
     size_t at = 0, rec = 0;
     auto cls_of = [&](int k) -> int32_t { return (prim_class && k >= 0) ? prim_class[k] : -1; };
-    auto put_planar = [&](const std::vector<Planar>& v) {
+    auto put_planar = [&](const std::vector<Planar>& v, int stride) {
         for (const Planar& p : v) {
             float* r = stream.data() + at;
             float* e = tab.data() + 28 * rec;
@@ -208,13 +223,15 @@ int build_flat(const float* prims, int n_prims, const int32_t* obj_info, int n_o
                 for (int c = 0; c < 3; c++) { r[c] = p.P0[c]; r[3 + c] = p.U[c]; r[6 + c] = p.V[c]; r[9 + c] = p.T[c]; e[c] = p.U[c]; e[4 + c] = p.V[c]; }
                 e[3] = p.P0[0]; e[7] = p.P0[1]; e[24] = p.P0[2];
                 memcpy(e + 12, p.map_a, 24); memcpy(e + 18, p.map_b, 24);
+                if (stride == 18) memcpy(r + 12, p.far_edges, 24);
             }                                                    // a degenerate triangle keeps its slot with all-zero rows: t = -0 / 0 = NaN, which no comparison accepts
             memcpy(e + 8, ids, 16);
-            at += 12; rec++;
+            at += (size_t)stride; rec++;
         }
     };
-    put_planar(quads);
-    put_planar(tris);
+    put_planar(quads, 12);
+    put_planar(gquads, 18);
+    put_planar(tris, 12);
     for (int k : spheres) {
         float* r = stream.data() + at;
         float* e = tab.data() + 28 * rec;

@@ -625,10 +625,10 @@ APT_D bool sweep_any(const SweepScene& sc, f3 o, f3 d, HitRec& rec) { return swe
 #define APT_FLAT_MAX_PRIMS 96
 #endif
 struct FlatScene {
-    const float* stream;      // [quads][quads in a coplanar group][triangles][triangles in a coplanar group] x 12 floats (corner p0, rows U, V, T) | [spheres] x 4 (centre, r^2)
+    const float* stream;      // [parallelograms][same, in a coplanar group] x 12 floats (corner p0, rows U, V, T) | [convex quads][same, coplanar group] x 18 (+ the two far edges' functions of (u, v)) | [triangles][same, coplanar group] x 12 | [spheres] x 4 (centre, r^2)
     const float4* tab;        // per record, 7 float4: (U, p0.x) (V, p0.y) | prim_a prim_b class_a class_b | map_a (u0 uu uv v0 vu vv) map_b (same) | (p0.z, -, -, -)
     const float* precom;      // n_prims * 9: (e1, e2, p0) per triangle - the reference's own test decides between near-tied coplanar candidates
-    int n_quads, n_quads_tie, n_tris, n_tris_tie, n_spheres;
+    int n_quads, n_quads_tie, n_gquads, n_gquads_tie, n_tris, n_tris_tie, n_spheres;
 };
 #if APT_FAST
 APT_D v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -703,6 +703,23 @@ APT_D void flat_loop(const FlatScene& fl, const FlatRays& q, v2f lim, FlatHit2& 
         const v2f a = u - sp2(0.5f), b = v - sp2(0.5f);
         x = flat_candidate<true>(x, fmaxf(fabsf(a.x), fabsf(b.x)) <= 0.5f, t.x, idx);
         y = flat_candidate<true>(y, fmaxf(fabsf(a.y), fabsf(b.y)) <= 0.5f, t.y, idx);
+    }
+    // convex quadrilaterals (two coplanar triangles sharing an edge that do NOT close a parallelogram: the slanted faces of a sheared box):
+    // in the frame of the first triangle (corner opposite the shared edge) the outline is u >= 0, v >= 0 and the two far edges, each an
+    // affine function of (u, v) stored behind the rows: inside <=> min(u, v, e1, e2) >= 0.  One plane solve instead of two.
+    const int ng_plain = ANY ? fl.n_gquads + fl.n_gquads_tie : fl.n_gquads;
+    for (int j = 0; j < ng_plain; j++, idx++, at += 18) {
+        v2f t, u, v; planar_solve(at, q, t, u, v);
+        const v2f e1 = fma2(sp2(at[12]), u, fma2(sp2(at[13]), v, sp2(at[14]))), e2 = fma2(sp2(at[15]), u, fma2(sp2(at[16]), v, sp2(at[17])));
+        const bool i0 = fminf(fminf(u.x, v.x), fminf(e1.x, e2.x)) >= 0.f, i1 = fminf(fminf(u.y, v.y), fminf(e1.y, e2.y)) >= 0.f;
+        if (ANY) { o0 = o0 || flat_blocks(i0, t.x, lim.x); o1 = o1 || flat_blocks(i1, t.y, lim.y); }
+        else { x = flat_candidate<false>(x, i0, t.x, idx); y = flat_candidate<false>(y, i1, t.y, idx); }
+    }
+    if (!ANY) for (int j = 0; j < fl.n_gquads_tie; j++, idx++, at += 18) {
+        v2f t, u, v; planar_solve(at, q, t, u, v);
+        const v2f e1 = fma2(sp2(at[12]), u, fma2(sp2(at[13]), v, sp2(at[14]))), e2 = fma2(sp2(at[15]), u, fma2(sp2(at[16]), v, sp2(at[17])));
+        x = flat_candidate<true>(x, fminf(fminf(u.x, v.x), fminf(e1.x, e2.x)) >= 0.f, t.x, idx);
+        y = flat_candidate<true>(y, fminf(fminf(u.y, v.y), fminf(e1.y, e2.y)) >= 0.f, t.y, idx);
     }
     // triangles: inside <=> min(u, v, 1 - u - v) >= 0
     const int nt_plain = ANY ? fl.n_tris + fl.n_tris_tie : fl.n_tris;
