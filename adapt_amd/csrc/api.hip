@@ -158,7 +158,7 @@ struct apt_scene {
     bool has_sweep = false;              // the sweep stream exists (scenes small enough that a sweep could ever be asked for)
 };
 
-struct EventPair { hipEvent_t a, b; int kernel; };
+struct EventPair { hipEvent_t a, b; int kernel; bool own_a; };       // own_a = false: `a` is the previous launch's `b` (back-to-back launches on one stream share the event)
 
 struct apt_renderer {
     const apt_scene* scene = nullptr;
@@ -192,7 +192,8 @@ struct apt_renderer {
     int vshadow_mode = 0;         // traversal mode of the volumetric transmittance walk (one closest-hit query per lane and pass: with the flat sweep's two-rays-per-lane loop half of every packed instruction would idle, so small scenes keep the tiled / wave sweep there)
     size_t vshadow_lds = 0;
     std::vector<EventPair> pending;
-    std::vector<EventPair> free_events;
+    std::vector<hipEvent_t> free_events;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> chain;      // per stream: the end event of a timed launch nothing has followed yet
     double kernel_ms[APT_N_KERNELS] = {0, 0, 0, 0, 0};
     int64_t launches[APT_N_KERNELS] = {0, 0, 0, 0, 0};
     double render_ms = 0.0;
@@ -792,7 +793,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)k_shadow_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
     }
-    r->grid_small = cus * 8;       // streaming stages: up to 8 x 256-thread workgroups per CU
+    r->grid_small = cus * (r->volumetric ? 8 : 4);       // streaming stages, persistent grid in 256-thread workgroups per CU.  Measured (tools/grid_sweep.sh, 2 / 3 / 4 / 5 / 8 per CU): C2 3 385 / 3 350 / 3 378 / 3 312 / 3 279 Msamples/s (a shade kernel holds 4 workgroups per CU; a second round of workgroups only adds a tail), C1 / C3 / C4 / C5 within 1 %, V1 823 / 838 / 842 / 840 / 858
     if (const char* g = getenv("APT_GRID_SMALL")) r->grid_small = cus * std::max(1, atoi(g));       // tuning knobs: workgroups per CU
     if (const char* g = getenv("APT_GRID_TRACE")) r->grid_trace = cus * std::max(1, atoi(g));
     if (r->trace_mode != 2) { r->lds_bytes_any = r->lds_bytes; r->grid_shadow = r->grid_trace; }
@@ -836,8 +837,8 @@ APT_EXPORT void apt_renderer_destroy(apt_renderer* r) {
     for (auto& ln : r->extra) { if (ln.stream) { (void)hipStreamSynchronize(ln.stream); (void)hipStreamDestroy(ln.stream); } if (ln.fin) (void)hipEventDestroy(ln.fin); }
     if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
     if (r->fin0) (void)hipEventDestroy(r->fin0);
-    for (auto& ev : r->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    for (auto& ev : r->free_events) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto& ev : r->pending) { if (ev.own_a) (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto& ev : r->free_events) (void)hipEventDestroy(ev);
     if (r->ev_r0) (void)hipEventDestroy(r->ev_r0);
     if (r->ev_r1) (void)hipEventDestroy(r->ev_r1);
     delete r;
@@ -851,17 +852,37 @@ static int grid_for(size_t n, int cap_blocks, int nq, int nt = BLOCK) {
     return (int)(b < (size_t)cap_blocks ? b : (size_t)cap_blocks);
 }
 
+// Per-launch timing (cfg.profile): a launch is bracketed by two events on its stream.  Launches that follow each other directly on one
+// stream share the event between them - one hipEventRecord per launch instead of two (each costs the stream a few microseconds: 52 of them
+// per 7 ms lane-batch were 4 % of C2's rate) - so a duration then includes the gap to the previous kernel's end, i.e. errs on the long side.
+// Anything else enqueued on the stream (a memset, a wait on another lane's event) must call unchain() first, or its time is charged to the
+// next kernel.
+static void unchain(apt_renderer* r, hipStream_t st) {
+    for (auto& c : r->chain) if (c.first == st) c.second = nullptr;
+}
+static hipEvent_t take_event(apt_renderer* r) {
+    hipEvent_t e = nullptr;
+    if (!r->free_events.empty()) { e = r->free_events.back(); r->free_events.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+}
 struct LaunchTimer {      // brackets one kernel launch with events when profiling is on
     apt_renderer* r; int kernel; EventPair ev{}; bool on; hipStream_t st;
     LaunchTimer(apt_renderer* r_, int k, hipStream_t stream = nullptr) : r(r_), kernel(k), on(r_->cfg.profile != 0), st(stream ? stream : r_->stream) {
         r->launches[k]++;
         if (!on) return;
-        if (!r->free_events.empty()) { ev = r->free_events.back(); r->free_events.pop_back(); }
-        else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
-        ev.kernel = k;
-        (void)hipEventRecord(ev.a, st);
+        ev.kernel = k; ev.a = nullptr; ev.own_a = false;
+        for (auto& c : r->chain) if (c.first == st) ev.a = c.second;
+        if (!ev.a) { ev.a = take_event(r); ev.own_a = true; (void)hipEventRecord(ev.a, st); }
+        ev.b = take_event(r);
     }
-    ~LaunchTimer() { if (on) { (void)hipEventRecord(ev.b, st); r->pending.push_back(ev); } }
+    ~LaunchTimer() {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, st); r->pending.push_back(ev);
+        bool found = false;
+        for (auto& c : r->chain) if (c.first == st) { c.second = ev.b; found = true; }
+        if (!found) r->chain.push_back({st, ev.b});
+    }
 };
 
 static int resolve_events(apt_renderer* r) {
@@ -870,9 +891,10 @@ static int resolve_events(apt_renderer* r) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
         r->kernel_ms[ev.kernel] += ms;
-        r->free_events.push_back(ev);
     }
+    for (auto& ev : r->pending) { if (ev.own_a) r->free_events.push_back(ev.a); r->free_events.push_back(ev.b); }
     r->pending.clear();
+    r->chain.clear();
     if (r->render_pending) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, r->ev_r0, r->ev_r1));
@@ -900,7 +922,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
             const Queues& q = li ? r->extra[(size_t)li - 1].q : r->q;
             Counters* cnt = li ? r->extra[(size_t)li - 1].counters.as<Counters>() : r->counters.as<Counters>();
             Issued is; is.li = li; is.cur = 0; is.p = r->par; is.p.cnt_base = r->cnt; is.p.spp_batch = B; is.total = (size_t)r->npix * (size_t)B;
-            HIP_TRY(hipMemsetAsync(cnt, 0, offsetof(Counters, stats), st));
+            unchain(r, st); HIP_TRY(hipMemsetAsync(cnt, 0, offsetof(Counters, stats), st));
             { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate, dim3(grid_for(is.total, r->grid_small, 1)), dim3(BLOCK), 0, st, is.p, q, cnt); }
             round.push_back(is);
             r->cnt += B; done += B;
@@ -911,7 +933,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
             Counters* cnt = is.li ? r->extra[(size_t)is.li - 1].counters.as<Counters>() : r->counters.as<Counters>();
             const LdsPlan& lane_plan = is.li ? r->extra[(size_t)is.li - 1].plan : r->plan;
             for (int b = 0; b < n_iter; b++) {
-                if (r->dyn_fetch) HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st));
+                if (r->dyn_fetch) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st)); }
                 { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
                 if (!r->sorted) {
                     ShadeIn in = {q.ray_o[is.cur], q.ray_d[is.cur], q.thr[is.cur], q.id[is.cur], q.meta[is.cur], q.pdf[is.cur],
@@ -923,7 +945,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
                         ShadeIn in = {k.ray_o, k.ray_d, k.thr, k.id, k.meta, k.pdf, k.t, k.prim, k.u, k.v, (const uint32_t*)cnt->n_cls[c]};
                         LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vclass_fn[c], dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, in, is.cur);
                     }
-                    if (is.p.S <= 0) HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st));     // normally k_vshadow's first pass recycles these
+                    if (is.p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }     // normally k_vshadow's first pass recycles these
                 }
                 if (is.p.S > 0) {
                     const int n_pass = r->scene->has_null_surface ? 7 : 1;       // track_ray walks at most seven segments (vpt.py:113)
@@ -947,7 +969,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
             if (r->scene->has_null_surface) {
                 unsigned long long live = 0;
                 for (int k = 0; k < 4096; k++) {
-                    HIP_TRY(hipMemcpyAsync(r->host_counters.n_active[is.cur], cnt->n_active[is.cur], sizeof(cnt->n_active[is.cur]), hipMemcpyDeviceToHost, st));
+                    unchain(r, st); HIP_TRY(hipMemcpyAsync(r->host_counters.n_active[is.cur], cnt->n_active[is.cur], sizeof(cnt->n_active[is.cur]), hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipStreamSynchronize(st));
                     live = 0;
                     for (int sq = 0; sq < nq; sq++) live += r->host_counters.n_active[is.cur][sq * CNT_PAD];
@@ -956,7 +978,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
                 }
                 if (live) return fail(APT_E_STATE, "apt_render: paths still crossing null surfaces after 8192 extra iterations (a closed loop of null surfaces?)");
             }
-            if (prev_fin && r->n_lanes > 1) HIP_TRY(hipStreamWaitEvent(st, prev_fin, 0));
+            if (prev_fin && r->n_lanes > 1) { unchain(r, st); HIP_TRY(hipStreamWaitEvent(st, prev_fin, 0)); }
             { LaunchTimer t(r, 4, st); hipLaunchKernelGGL(k_finalize, dim3(grid_for((size_t)r->npix, r->grid_small, 1)), dim3(BLOCK), 0, st, is.p, q, r->accum.as<float>()); }
             HIP_TRY(hipEventRecord(fin, st));
             prev_fin = fin;
@@ -986,10 +1008,10 @@ APT_EXPORT int apt_render(apt_renderer* r, int32_t n_spp) {
 static int render_impl(apt_renderer* r, int32_t n_spp) {
     const DevScene& sc = r->scene->dev;
     HIP_TRY(hipEventRecord(r->ev_r0, r->stream));
-    for (auto& ln : r->extra) HIP_TRY(hipStreamWaitEvent(ln.stream, r->ev_r0, 0));     // lanes start after whatever the main stream did before
+    for (auto& ln : r->extra) { unchain(r, ln.stream); HIP_TRY(hipStreamWaitEvent(ln.stream, r->ev_r0, 0)); }     // lanes start after whatever the main stream did before
     if (r->volumetric) {
         if (int rc = render_volumetric(r, n_spp)) return rc;
-        for (auto& ln : r->extra) { HIP_TRY(hipEventRecord(ln.fin, ln.stream)); HIP_TRY(hipStreamWaitEvent(r->stream, ln.fin, 0)); }
+        for (auto& ln : r->extra) { unchain(r, r->stream); HIP_TRY(hipEventRecord(ln.fin, ln.stream)); HIP_TRY(hipStreamWaitEvent(r->stream, ln.fin, 0)); }
         HIP_TRY(hipEventRecord(r->ev_r1, r->stream));
         r->render_pending = true;
         return APT_OK;
@@ -1008,12 +1030,12 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
         const LdsPlan& lane_plan = li ? r->extra[(size_t)li - 1].plan : r->plan;
         Params p = r->par; p.cnt_base = r->cnt; p.spp_batch = B;
         const size_t total = (size_t)r->npix * (size_t)B;
-        HIP_TRY(hipMemsetAsync(cnt, 0, offsetof(Counters, stats), st));   // queue counters only; statistics keep accumulating
+        unchain(r, st); HIP_TRY(hipMemsetAsync(cnt, 0, offsetof(Counters, stats), st));   // queue counters only; statistics keep accumulating
         const int nq = r->nq;
         { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, p, q, cnt); }
         int cur = 0;
         for (int b = 0; b < p.max_bounce; b++) {
-            if (r->dyn_fetch) HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st));
+            if (r->dyn_fetch) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st)); }
             { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
             if (!r->sorted) {
                 ShadeIn in = {q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.id[cur], q.meta[cur], q.pdf[cur],
@@ -1025,23 +1047,23 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
                     ShadeIn in = {k.ray_o, k.ray_d, k.thr, k.id, k.meta, k.pdf, k.t, k.prim, k.u, k.v, (const uint32_t*)cnt->n_cls[c]};
                     LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->class_fn[c], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
                 }
-                if (p.S <= 0) HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st));      // normally k_shadow recycles these
+                if (p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }      // normally k_shadow recycles these
             }
             if (p.S > 0 && r->dyn_fetch) {
-                HIP_TRY(hipMemsetAsync(cnt->n_work[1], 0, sizeof(cnt->n_work[1]), st));
+                unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[1], 0, sizeof(cnt->n_work[1]), st));
                 LaunchTimer t(r, 3, st); hipLaunchKernelGGL(k_shadow_dyn, dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan);
             } else if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan); }
             cur ^= 1;
         }
         // the framebuffer is shared: batch k's samples are added after batch k-1's, whichever lanes they ran on
-        if (prev_fin && r->n_lanes > 1) HIP_TRY(hipStreamWaitEvent(st, prev_fin, 0));
+        if (prev_fin && r->n_lanes > 1) { unchain(r, st); HIP_TRY(hipStreamWaitEvent(st, prev_fin, 0)); }
         { LaunchTimer t(r, 4, st); hipLaunchKernelGGL(k_finalize, dim3(grid_for((size_t)r->npix, r->grid_small, 1)), dim3(BLOCK), 0, st, p, q, r->accum.as<float>()); }
         HIP_TRY(hipEventRecord(fin, st));
         prev_fin = fin;
         HIP_TRY(hipGetLastError());
         r->cnt += B; done += B; batch++;
     }
-    for (auto& ln : r->extra) { HIP_TRY(hipEventRecord(ln.fin, ln.stream)); HIP_TRY(hipStreamWaitEvent(r->stream, ln.fin, 0)); }   // join
+    for (auto& ln : r->extra) { unchain(r, r->stream); HIP_TRY(hipEventRecord(ln.fin, ln.stream)); HIP_TRY(hipStreamWaitEvent(r->stream, ln.fin, 0)); }   // join
     HIP_TRY(hipEventRecord(r->ev_r1, r->stream));
     r->render_pending = true;
     return APT_OK;
