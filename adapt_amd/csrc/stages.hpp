@@ -253,6 +253,9 @@ APT_D SubLoop sub_loop(int nq, int nt = BLOCK) {
 #endif
 // occupancy targets (waves per SIMD the register allocator must allow): the stages are latency-bound on dependent
 // table lookups and LDS round trips, so more resident waves beat a few spilled registers (measured)
+#ifndef APT_LAMBERT_WAVES
+#define APT_LAMBERT_WAVES 1
+#endif
 #ifndef APT_SHADE_WAVES
 #define APT_SHADE_WAVES 1
 #endif
@@ -460,17 +463,27 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
         if (!SORTED) {
             if (fin) { stq(q.hit_t, io, rec.t); stq(q.hit_prim, io, rec.prim); stq(q.hit_u, io, rec.u); stq(q.hit_v, io, rec.v); }
         } else if (__any(fin)) {
+            // (as in k_extend: the rest of the record is requested first, the queue tails of all classes move with ONE atomic instruction)
+            f3 st_thr = splat3(0.f); uint32_t st_id = 0, st_meta = 0; float st_pdf = 0.f;
+            if (fin) { st_thr = ld3q(q.thr[cur_q], p.cap, io); st_id = ldq(q.id[cur_q], io); st_meta = ldq(q.meta[cur_q], io); st_pdf = ldq(q.pdf[cur_q], io); }
             const int cls = !fin ? -1 : ((rec.prim >= 0) ? sc.prim_class[rec.prim] : q.miss_class);
+            uint32_t my_rank = 0, cnt_vec = 0;
             for (int c = 0; c < q.n_classes; c++) {
-                const bool mine = cls == c;
-                const uint32_t cpos = wave_append(mine, &cnt->n_cls[c][sq * CNT_PAD]);
-                if (mine) {
+                const unsigned long long m = __ballot(cls == c);
+                if (cls == c) my_rank = rank_in(m);
+                if ((int)lane_id() == c) cnt_vec = (uint32_t)__popcll(m);
+            }
+            uint32_t tail = 0;
+            if ((int)lane_id() < q.n_classes && cnt_vec) tail = atomicAdd(&cnt->n_cls[lane_id()][sq * CNT_PAD], cnt_vec);
+            const uint32_t cpos = (uint32_t)__shfl((int)tail, cls < 0 ? 0 : cls) + my_rank;
+            const uint32_t so = (qbase + cpos) << 2;
+            for (int c = 0; c < q.n_classes; c++) {
+                if (cls == c) {
                     const Queues::ClassQ& k = q.cls[c];
-                    const uint32_t so = (qbase + cpos) << 2;
                     st3q(k.ray_o, p.cap, so, r.o);
                     st3q(k.ray_d, p.cap, so, r.d);
-                    st3q(k.thr, p.cap, so, ld3q(q.thr[cur_q], p.cap, io));
-                    stq(k.id, so, ldq(q.id[cur_q], io)); stq(k.meta, so, ldq(q.meta[cur_q], io)); stq(k.pdf, so, ldq(q.pdf[cur_q], io));
+                    st3q(k.thr, p.cap, so, st_thr);
+                    stq(k.id, so, st_id); stq(k.meta, so, st_meta); stq(k.pdf, so, st_pdf);
                     stq(k.t, so, rec.t); stq(k.prim, so, rec.prim); stq(k.u, so, rec.u); stq(k.v, so, rec.v);
                 }
             }
@@ -567,7 +580,7 @@ APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3
 // it): inlined into the specialised kernels the lookup costs e.g. the mod-Phong class kernel its fourth wave per SIMD
 // (126 -> 129 VGPRs) in every scene WITHOUT textures, and out of line it costs a call frame in scratch.
 template <int BM, int SM, int TEX = 0>
-__global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : APT_SHADE_WAVES)) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
+__global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_LAMBERT_WAVES : APT_SHADE_WAVES))) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
     const uint32_t n = in.counts[sl.q * CNT_PAD];
