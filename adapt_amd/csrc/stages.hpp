@@ -189,7 +189,7 @@ APT_D uint32_t wave_append(bool flag, uint32_t* counter) {
     unsigned long long m = __ballot(flag);
     uint32_t base = 0;
     if (lane_id() == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, 0);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);      // v_readlane: lane 0's value as a scalar (a shuffle would go through the LDS crossbar)
     return base + rank_in(m);
 }
 
@@ -198,7 +198,7 @@ APT_D uint32_t wave_append_n(bool flag, uint32_t* counter, uint32_t k) {
     unsigned long long m = __ballot(flag);
     uint32_t base = 0;
     if (lane_id() == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m) * k);
-    base = __shfl(base, 0);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);      // v_readlane: lane 0's value as a scalar (a shuffle would go through the LDS crossbar)
     return base + rank_in(m) * k;
 }
 
@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
             const unsigned long long m = __ballot(need);
             uint32_t base = 0;
             if (lane_id() == 0 && m) base = atomicAdd(work, (uint32_t)__popcll(m));
-            base = __shfl(base, 0);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);      // v_readlane: lane 0's value as a scalar (a shuffle would go through the LDS crossbar)
             const uint32_t pos = base + rank_in(m);
             if (need && pos < n) {
                 io = (qbase + pos) << 2;
@@ -879,7 +879,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
             const unsigned long long m = __ballot(need);
             uint32_t base = 0;
             if (lane_id() == 0 && m) base = atomicAdd(work, (uint32_t)__popcll(m));
-            base = __shfl(base, 0);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);      // v_readlane: lane 0's value as a scalar (a shuffle would go through the LDS crossbar)
             const uint32_t pos = base + rank_in(m);
             if (need && pos < n) {
                 io = (qbase + pos) << 2;

@@ -445,7 +445,7 @@ APT_D bool sweep_wg(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active, 
             const unsigned long long m = __ballot(need);
             int base = 0;
             if (lane == 0 && m) base = atomicAdd(&s_count[n_lists], (int)__popcll(m));
-            base = __shfl(base, 0);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);      // v_readlane: lane 0's value as a scalar (a shuffle would go through the LDS crossbar)
             if (need) {
                 s_list[base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = tid;
                 s_t[tid] = rec.t; s_prim[tid] = -1;
