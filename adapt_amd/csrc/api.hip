@@ -623,6 +623,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     }
     // flat sweep with several light samples per vertex: the samples are queued by vertex and the shadow kernel adds a vertex's samples with
     // one read-modify-write (stages.hpp k_shadow_flat); otherwise 2-4 samples per vertex add into one radiance plane each
+    p.keep_order = c.volumetric ? 1 : 0;
     p.nee_vm = (!c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
     if (const char* f = getenv("APT_NEE_VM")) p.nee_vm = (atoi(f) != 0 && !c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
     p.l_planes = (!c.volumetric && !p.nee_vm && S >= 2 && S <= 4) ? S : 1;        // stages.hpp APT_EXCLUSIVE_L: one radiance plane per light sample of a vertex
@@ -812,6 +813,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     }
     if (const char* g = getenv("APT_GRID_VSHADOW")) r->grid_vshadow = cus * std::max(1, atoi(g));
     r->grid_vshadow = ((r->grid_vshadow + nq - 1) / nq) * nq;
+    if (getenv("APT_DEBUG_GRID")) fprintf(stderr, "[grid] trace mode %d grid %d nt %d lds %zu | shadow grid %d lds %zu | vshadow mode %d grid %d nt %d lds %zu | small %d\n", r->trace_mode, r->grid_trace, r->trace_nt, r->lds_bytes, r->grid_shadow, r->lds_bytes_any, r->vshadow_mode, r->grid_vshadow, r->vshadow_nt, r->vshadow_lds, r->grid_small);
     r->grid_trace = ((r->grid_trace + nq - 1) / nq) * nq;          // persistent grids are multiples of nq
     r->grid_shadow = ((r->grid_shadow + nq - 1) / nq) * nq;
     r->grid_small = ((r->grid_small + nq - 1) / nq) * nq;
