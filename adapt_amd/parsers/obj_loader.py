@@ -11,9 +11,12 @@ itself and produces the same four arrays:
     uvs     (N,3,2) float32   per-face-vertex uvs,     or None if the file has no `vt`
 
 Polygons are fan-triangulated (0, i, i+1), the order pywavefront emits.  Like the reference, which reads the vertex stream of the
-FIRST material of the file only (`for wrapper in obj.materials.values(): ...; break`, obj_loader.py:35-37), faces that belong to a
-second `usemtl` group are dropped - with a warning here, silently upstream; faces before any `usemtl` form the first group.
-None of the bundled meshes has more than one group.  `apply_transform` /
+FIRST material of the file only (`for wrapper in obj.materials.values(): ...; break`, obj_loader.py:35-37), faces of every other
+material are dropped - with a warning here, silently upstream.  "First" is pywavefront's (1.3) order of `obj.materials`: the `newmtl`
+entries of a `mtllib` in definition order, entered when the `mtllib` line is read; then materials first met in a `usemtl` line; faces
+before any `usemtl` belong to a default material entered when the first such face is read.  So an OBJ whose .mtl defines [B, A] and
+whose faces use A first loads B's faces, upstream and here.  (A `mtllib` file that cannot be read is skipped here; pywavefront raises.)
+None of the bundled meshes has more than one material.  `apply_transform` /
 `calculate_surface_area` follow reference obj_loader.py:82-122 including the
 float32/float64 mixing of numpy (rotation matrices are float64, so a rotated
 mesh is float64 until the final pack casts it back).
@@ -38,24 +41,33 @@ def _resolve(idx: int, count: int) -> int:
 def read_obj(path: str):
     """Parse `v`/`vt`/`vn`/`f` records.  Returns (positions, uvs|None, normals|None)
     as per-face-vertex float32 arrays of shape (N,3,k)."""
+    import os
     pos, tex, nrm = [], [], []
-    tri_p, tri_t, tri_n = [], [], []
-    group, first_group, dropped = None, None, 0          # `usemtl` groups: only the first one that owns a face is kept (see above)
+    faces = {}                                   # material key -> (tri_p, tri_t, tri_n); key None = faces before any `usemtl`
+    order = []                                   # pywavefront's `obj.materials` order (module docstring)
+    group = None
     with open(path, "r") as fh:
         for raw in fh:
             line = raw.strip()
             if not line or line[0] == "#":
                 continue
             head, _, rest = line.partition(" ")
+            if head == "mtllib":
+                for name in rest.split():
+                    try:
+                        with open(os.path.join(os.path.dirname(path), name), "r") as mf:
+                            for ml in mf:
+                                mh, _, mr = ml.strip().partition(" ")
+                                if mh == "newmtl" and mr.strip() not in order:
+                                    order.append(mr.strip())
+                    except OSError:
+                        pass
+                continue
             if head == "usemtl":
                 group = rest.strip()
+                if group not in order:
+                    order.append(group)
                 continue
-            if head == "f":
-                if first_group is None:
-                    first_group = (group,)
-                elif first_group != (group,):
-                    dropped += 1
-                    continue
             if head == "v":
                 pos.append([float(x) for x in rest.split()[:3]])
             elif head == "vt":
@@ -63,6 +75,9 @@ def read_obj(path: str):
             elif head == "vn":
                 nrm.append([float(x) for x in rest.split()[:3]])
             elif head == "f":
+                if group not in order:
+                    order.append(group)          # (only the default material can get here)
+                tri_p, tri_t, tri_n = faces.setdefault(group, ([], [], []))
                 corners = []
                 for tok in rest.split():
                     parts = tok.split("/")
@@ -75,11 +90,19 @@ def read_obj(path: str):
                     tri_p.append([pos[c[0]] for c in tri])
                     tri_t.append([tex[c[1]] if c[1] >= 0 else [0., 0.] for c in tri])
                     tri_n.append([nrm[c[2]] if c[2] >= 0 else [0., 0., 0.] for c in tri])
+    if not faces:
+        raise ValueError(f"OBJ file '{path}' contains no faces")
+    first = order[0]
+    if first not in faces:
+        raise ValueError(f"OBJ file '{path}': its first material '{first}' owns no faces - the reference reads that material's (empty) "
+                         "vertex stream (parsers/obj_loader.py:35-37); put the used material first in the .mtl")
+    tri_p, tri_t, tri_n = faces[first]
+    dropped = sum(len(v[0]) for k, v in faces.items() if k != first)
     if not tri_p:
         raise ValueError(f"OBJ file '{path}' contains no faces")
     if dropped:
         import warnings
-        warnings.warn(f"{path}: {dropped} faces of further `usemtl` groups ignored - the reference loads the first material's faces only "
+        warnings.warn(f"{path}: {dropped} triangles of other materials ignored - the reference loads the first material's faces only "
                       "(parsers/obj_loader.py:35-37)", RuntimeWarning)
     meshes = np.float32(tri_p).reshape(-1, 3, 3)
     uvs = np.float32(tri_t).reshape(-1, 3, 2) if tex else None

@@ -111,6 +111,28 @@ def test_obj_reader(tmp_path):
     assert abs(calculate_surface_area(np.float32([[[0, 0, 0], [0.5] * 3, [0] * 3]]), 1) - np.pi) < 1e-6
 
 
+def test_obj_reader_keeps_the_first_material_in_pywavefront_order(tmp_path):
+    """The reference reads the vertex stream of the FIRST entry of pywavefront's `obj.materials` (obj_loader.py:35-37): .mtl definition
+    order first, then materials first met in `usemtl`, then the default material of faces without one."""
+    v = "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0 0 1\n"
+    (tmp_path / "two.mtl").write_text("newmtl B\nKd 1 0 0\nnewmtl A\nKd 0 1 0\n")
+    (tmp_path / "two.obj").write_text("mtllib two.mtl\n" + v + "usemtl A\nf 1 2 3\nusemtl B\nf 1 3 4\nf 1 4 5\n")
+    with pytest.warns(RuntimeWarning):
+        meshes, _, _ = read_obj(str(tmp_path / "two.obj"))
+    assert meshes.shape[0] == 2                                             # B's two faces (defined first), not A's one (used first)
+    np.testing.assert_array_equal(meshes[0], np.float32([[0, 0, 0], [1, 1, 0], [0, 1, 0]]))
+    (tmp_path / "nomtl.obj").write_text(v + "usemtl A\nf 1 2 3\nusemtl B\nf 1 3 4\nf 1 4 5\n")
+    with pytest.warns(RuntimeWarning):
+        assert read_obj(str(tmp_path / "nomtl.obj"))[0].shape[0] == 1     # no .mtl: order of first use
+    (tmp_path / "default.obj").write_text(v + "f 1 2 3\nusemtl A\nf 1 3 4\n")
+    with pytest.warns(RuntimeWarning):
+        assert read_obj(str(tmp_path / "default.obj"))[0].shape[0] == 1   # faces before any usemtl: the default material comes first
+    (tmp_path / "unused.mtl").write_text("newmtl X\nnewmtl A\n")
+    (tmp_path / "unused.obj").write_text("mtllib unused.mtl\n" + v + "usemtl A\nf 1 2 3\n")
+    with pytest.raises(ValueError):                                         # the first material owns no faces: upstream reads an empty stream
+        read_obj(str(tmp_path / "unused.obj"))
+
+
 def test_transform_dtype_flow_and_aabb():
     m = np.float32([[[0, 0, 0], [1, 0, 0], [0, 0, 1]]])
     out, _ = apply_transform(m.copy(), None, None, np.float32([0, -0.001, 0]), None)
