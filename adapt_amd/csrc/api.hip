@@ -586,6 +586,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (B <= 0) { B = (int)((16u << 20) / (uint32_t)r->npix); if (B < 1) B = 1; if (B > 1024) B = 1024; }   // ~16 Mi paths per lane (2.7 GB of queues each, of 288 GB) whatever the tile size: an 8-GPU rank owns 1/8 of the pixels and takes 8x the samples per batch
     r->spp_batch = B;
     const int S = c.num_shadow_ray;
+    if (const char* e = getenv("APT_NQ")) r->nq = std::min(APT_MAX_NQ, std::max(1, atoi(e)));      // tuning knob: sub-queues per queue
     const int nq = r->nq;
     const size_t n_waves = ((size_t)r->npix * (size_t)B + 63) / 64;
     const size_t subcap = ((n_waves + nq - 1) / nq) * 64;            // generate: wave w -> sub-queue w % nq

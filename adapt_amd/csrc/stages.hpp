@@ -194,6 +194,16 @@ APT_D uint32_t wave_append(bool flag, uint32_t* counter) {
     return base + rank_in(m);
 }
 
+// The same in two halves, for appends whose position is needed later than the flag is known: append_issue() sends the tail atomic on its
+// way, append_pos() waits for it.  (vmcnt counts in order: waiting for a returning atomic also waits for every load issued before it.)
+struct Append { unsigned long long m; uint32_t raw; };
+APT_D Append append_issue(bool flag, uint32_t* counter) {
+    Append a; a.m = __ballot(flag); a.raw = 0;
+    if (lane_id() == 0 && a.m) a.raw = atomicAdd(counter, (uint32_t)__popcll(a.m));
+    return a;
+}
+APT_D uint32_t append_pos(const Append& a) { return (uint32_t)__builtin_amdgcn_readlane((int)a.raw, 0) + rank_in(a.m); }
+
 // the same for blocks of `k` consecutive entries per flagged lane; returns the position of this lane's block
 APT_D uint32_t wave_append_n(bool flag, uint32_t* counter, uint32_t k) {
     unsigned long long m = __ballot(flag);
@@ -256,6 +266,12 @@ APT_D SubLoop sub_loop(int nq, int nt = BLOCK) {
 // table lookups and LDS round trips, so more resident waves beat a few spilled registers (measured)
 #ifndef APT_LAMBERT_WAVES
 #define APT_LAMBERT_WAVES 1
+#endif
+#ifndef APT_SHADE_PREFETCH
+#define APT_SHADE_PREFETCH 1
+#endif
+#ifndef APT_SHADE_LATE_SHADOW
+#define APT_SHADE_LATE_SHADOW 0      // measured: the deferred shadow entry costs the kernel its fourth wave per SIMD (120 -> 130 VGPRs: C2 shade 10.6 -> 13.1 ms)
 #endif
 #ifndef APT_SHADE_WAVES
 #define APT_SHADE_WAVES 1
@@ -552,8 +568,11 @@ APT_D bool get_uv_item(const DevScene& sc, int map, int obj, int prim, float bu,
 }
 
 // -------------------------------------------------------------------- shade
+APT_D void build_hit_rec(const DevScene& sc, float4 ra, float4 rb, int prim, float t, float u, float v, f3 o, f3 d, Hit& it, int& hit_light, f3& k_d, bool with_vn = true);
 APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3 o, f3 d, Hit& it, int& hit_light, f3& k_d) {
-    const float4 ra = sc.prim_shade[2 * prim], rb = sc.prim_shade[2 * prim + 1];
+    build_hit_rec(sc, sc.prim_shade[2 * prim], sc.prim_shade[2 * prim + 1], prim, t, u, v, o, d, it, hit_light, k_d);
+}
+APT_D void build_hit_rec(const DevScene& sc, float4 ra, float4 rb, int prim, float t, float u, float v, f3 o, f3 d, Hit& it, int& hit_light, f3& k_d, bool with_vn) {
     const int code = __float_as_int(ra.w);
     it.prim_id = prim; it.min_depth = t;
     it.obj_id = (code < 0) ? ~code : code;
@@ -565,7 +584,7 @@ APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3
         it.n_s = it.n_g;
     } else {
         it.n_g = mk3(ra.x, ra.y, ra.z);
-        if (sc.has_vn) {
+        if (with_vn && sc.has_vn) {
             const float* vn = sc.vnormals + 9 * prim;
             // interpolated vertex normal, NOT re-normalised (tracer_base.py:228-230)
             it.n_s = (ld3(vn) * (1.f - u - v) + ld3(vn + 3) * u) + ld3(vn + 6) * v;
@@ -600,6 +619,21 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
 #else
 #define SH_TICK(k) do { } while (0)
 #endif
+    // Software prefetch (the Lambertian / point-light kernel, which has the registers for it: C1 / C2).  A stage that only streams its
+    // queues with k_shade's pattern and occupancy reaches 3.2 TB/s (tools/probes/stream_probe.hip): with 4 waves per SIMD and a wave's
+    // loads in flight only between its tile rows, the bytes in flight are what bounds it, not the arithmetic.  So the next row's record is
+    // requested at the top of this row - after this row's shading record, so that waiting for that one (vmcnt counts in order) does not
+    // wait for the prefetch - and lands while this row is shaded.
+    constexpr bool PF = (APT_SHADE_PREFETCH != 0) && BM == 0x002 && SM == 0x1 && TEX == 0;
+    int pf_prim = -1; float pf_t = 0.f; f3 pf_o = splat3(0.f), pf_d = splat3(0.f), pf_thr = splat3(0.f); uint32_t pf_id = 0, pf_meta = 0;
+    auto prefetch = [&](uint32_t b) {            // straight-line loads (lanes past the end re-read the last entry: never used), so that no wait lands at the end of a branch
+        const uint32_t ps = min(b + threadIdx.x, n - 1u);
+        const uint32_t pio = (qbase + ps) << 2;
+        pf_prim = ldq(in.prim, pio); pf_t = ldq(in.t, pio);
+        pf_o = ld3q(in.ray_o, p.cap, pio); pf_d = ld3q(in.ray_d, p.cap, pio); pf_thr = ld3q(in.thr, p.cap, pio);
+        pf_id = ldq(in.id, pio); pf_meta = ldq(in.meta, pio);
+    };
+    if (PF && n > 0) prefetch(sl.first);
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
 #ifdef APT_SHADE_PROF
         unsigned long long stick_ = __builtin_readcyclecounter();
@@ -608,6 +642,17 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         const uint32_t pos = base + threadIdx.x;
         const uint32_t idx = qbase + pos;
         bool alive = pos < n;
+        const int cu_prim = pf_prim; const float cu_t = pf_t; const f3 cu_o = pf_o, cu_d = pf_d, cu_thr = pf_thr; const uint32_t cu_id = pf_id, cu_meta = pf_meta;
+        float4 cu_ra = make_float4(0.f, 0.f, 0.f, 0.f), cu_rb = cu_ra; uint32_t cu_key = 0;
+        if (PF) {
+            const int rp = max(cu_prim, 0);
+            cu_ra = sc.prim_shade[2 * rp]; cu_rb = sc.prim_shade[2 * rp + 1];
+            cu_key = cu_id & ((1u << p.pix_bits) - 1u);
+            if (p.world != 1) cu_key = ldq(p.pix_key, cu_key << 2);     // (multi-GPU: the pixel's global key; requested here for the same reason)
+            __builtin_amdgcn_sched_barrier(0);                 // the record first, then the prefetch: the wait for the record must not include the prefetch
+            prefetch(base + sl.stride);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), thr = splat3(0.f), hit_point = splat3(0.f);
         uint32_t id = 0, draw0 = 0, l_off = 0;                 // l_off: byte offset of this path's radiance slot
         float ray_pdf = 1.f;
@@ -619,19 +664,30 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
         if (alive) {
             const uint32_t io = idx << 2;
-            int prim = ldq(in.prim, io);
+            int prim = PF ? cu_prim : ldq(in.prim, io);
             if (prim < 0) alive = false;                         // nothing hit: path ends (vanilla_renderer.py:49)
             else {
-                o = ld3q(in.ray_o, p.cap, io);
-                d = ld3q(in.ray_d, p.cap, io);
-                thr = ld3q(in.thr, p.cap, io);
-                id = ldq(in.id, io);
-                uint32_t meta = ldq(in.meta, io);
+                uint32_t meta;
+                if (PF) { o = cu_o; d = cu_d; thr = cu_thr; id = cu_id; meta = cu_meta; }
+                else {
+                    o = ld3q(in.ray_o, p.cap, io);
+                    d = ld3q(in.ray_d, p.cap, io);
+                    thr = ld3q(in.thr, p.cap, io);
+                    id = ldq(in.id, io);
+                    meta = ldq(in.meta, io);
+                }
                 if (SM & 2) ray_pdf = ldq(in.pdf, io);          // (its only reader is the emission MIS weight: scenes without area lights never look at it)
                 was_spec = (meta >> 24) & 1u;
                 f3 rec_kd;
                 const bool need_uv = sc.has_vn || (TEX && sc.tex_i != nullptr);      // otherwise nobody reads the barycentrics (and the flat extend kernel does not write them)
-                build_hit(sc, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
+                if (PF) {
+                    build_hit_rec(sc, cu_ra, cu_rb, prim, cu_t, 0.f, 0.f, o, d, it, hit_light, rec_kd, false);
+                    if (sc.has_vn && __float_as_int(cu_ra.w) >= 0) {       // vertex normals: the barycentrics are fetched (and waited for) inside this branch only
+                        const float* vn = sc.vnormals + 9 * prim; const float bu = ldq(in.u, io), bv = ldq(in.v, io);
+                        it.n_s = (ld3(vn) * (1.f - bu - bv) + ld3(vn + 3) * bu) + ld3(vn + 6) * bv;
+                    }
+                }
+                else build_hit(sc, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
                 if (BM == 0x002) bx.k_d = rec_kd;               // Lambertian-only scenes: type 1, not delta, not a BSDF (the defaults above), colour from the record
                 else bx = sc.bxdf[it.obj_id];
                 if (TEX && sc.tex_i != nullptr) {                // the scene declares image textures (TEX kernels only, see below)
@@ -649,7 +705,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                 const uint32_t lp = id & ((1u << p.pix_bits) - 1u), s = id >> p.pix_bits;
                 l_off = (s * (uint32_t)p.npix + lp) << 2;
                 draw0 = meta & 0xffffu;
-                rng_init(rng, (p.world == 1) ? lp : ldq(p.pix_key, lp << 2), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
+                rng_init(rng, PF ? cu_key : ((p.world == 1) ? lp : ldq(p.pix_key, lp << 2)), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
                 // tail of the previous iteration: emission MIS weight for this hit (vanilla_renderer.py:111-117)
                 if (bounce > 0 && p.use_mis) {
                     float e_pdf = 0.0f;
@@ -671,6 +727,11 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         if (alive) {
             hit_point = d * it.min_depth + o;
         }
+        // prefetching kernel: both queue-tail atomics of the row are sent early and awaited once, at the end of the row, so that the only
+        // full wait of a row comes after all of its arithmetic - by then the next row's record has long arrived
+        const bool cont_early = alive && (bounce + 1) < p.max_bounce;
+        Append next_app; next_app.m = 0ull; next_app.raw = 0u;
+        if (PF) next_app = append_issue(cont_early, next_counter);
         SH_TICK(1);
 
         // ---- next-event estimation: one shadow-queue entry per useful light sample
@@ -680,6 +741,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         // light samples by vertex: ONE queue-tail atomic per tile row for all S samples of every vertex
         uint32_t vbase = 0;
         if (p.nee_vm) vbase = wave_append(alive, shadow_counter);
+        bool late_want = false; f3 late_dir = splat3(0.f), late_c = splat3(0.f); float late_tmax = 0.f; Append late_app; late_app.m = 0ull; late_app.raw = 0u;
         for (int s = 0; s < p.S; s++) {
             bool want = false, sampled = false, poisoned = false;
             f3 light_dir = splat3(0.f), contrib = splat3(0.f);
@@ -741,6 +803,9 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                     st3q(q.sh_c, sc_, so, contrib);
                 } else if (alive) stq(q.sh_tmax, so, -1.0f);                   // the vertex has no sample s worth tracing
                 if (alive && s == 0) stq(q.sh_id, so, l_off);                   // one radiance slot per vertex, kept with its first entry
+            } else if (PF && APT_SHADE_LATE_SHADOW && s == p.S - 1) {
+                late_app = append_issue(want, shadow_counter);
+                late_want = want; late_dir = light_dir; late_c = contrib; late_tmax = emitter_d;
             } else {
                 uint32_t spos = wave_append(want, shadow_counter);
                 if (want && spos < q.sh_subcap) {
@@ -777,7 +842,18 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         }
         if (rng.draw != draw0) atomicAdd(&s_draws[threadIdx.x >> 6], rng.draw - draw0);      // also paths that died in the roulette
         SH_TICK(4);
-        uint32_t npos = wave_append(cont, next_counter);
+        if (PF && APT_SHADE_LATE_SHADOW && !p.nee_vm && p.S > 0) {
+            const uint32_t spos = append_pos(late_app);
+            if (late_want && spos < q.sh_subcap) {
+                const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
+                st3q(q.sh_o, sc_, so, hit_point);
+                st3q(q.sh_d, sc_, so, late_dir);
+                stq(q.sh_tmax, so, late_tmax);
+                st3q(q.sh_c, sc_, so, late_c);
+                stq(q.sh_id, so, l_off | ((p.l_planes > 1) ? (uint32_t)(p.S - 1) : 0u));
+            }
+        }
+        uint32_t npos = PF ? append_pos(next_app) : wave_append(cont, next_counter);
         if (cont) {
             const uint32_t so = (qbase + npos) << 2;
             st3q(q.ray_o[nxt], p.cap, so, hit_point);
