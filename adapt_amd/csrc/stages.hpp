@@ -619,12 +619,12 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
 #else
 #define SH_TICK(k) do { } while (0)
 #endif
-    // Software prefetch (the Lambertian / point-light kernel, which has the registers for it: C1 / C2).  A stage that only streams its
-    // queues with k_shade's pattern and occupancy reaches 3.2 TB/s (tools/probes/stream_probe.hip): with 4 waves per SIMD and a wave's
-    // loads in flight only between its tile rows, the bytes in flight are what bounds it, not the arithmetic.  So the next row's record is
-    // requested at the top of this row - after this row's shading record, so that waiting for that one (vmcnt counts in order) does not
-    // wait for the prefetch - and lands while this row is shaded.
-    constexpr bool PF = (APT_SHADE_PREFETCH != 0) && BM == 0x002 && SM == 0x1 && TEX == 0;
+    // Software prefetch (the Lambertian / point-light kernel, which has the registers for it: C1 / C2).  A kernel that only streams
+    // k_shade's queues (13 SoA reads, 22 SoA writes per entry, same grid) moves 5.1 TB/s (tools/probes/stream_probe.hip), k_shade ~3:
+    // with 4 waves per SIMD each wave's loads are in flight only between its tile rows, and every row starts with two dependent round
+    // trips.  So the next row's record is requested at the top of this row - after this row's shading record, so that waiting for that
+    // one (vmcnt counts in order) does not wait for the prefetch - and lands while this row is shaded.
+    constexpr bool PF = ((APT_SHADE_PREFETCH != 0) && BM == 0x002 && SM == 0x1 && TEX == 0) || (APT_SHADE_PREFETCH == 2 && TEX == 0);
     int pf_prim = -1; float pf_t = 0.f; f3 pf_o = splat3(0.f), pf_d = splat3(0.f), pf_thr = splat3(0.f); uint32_t pf_id = 0, pf_meta = 0;
     auto prefetch = [&](uint32_t b) {            // straight-line loads (lanes past the end re-read the last entry: never used), so that no wait lands at the end of a branch
         const uint32_t ps = min(b + threadIdx.x, n - 1u);
