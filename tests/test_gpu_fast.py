@@ -90,6 +90,76 @@ def _check_hits(prim, t, uv, prim_o, t_o, uv_o, is_tri, d, normals):
     assert np.abs(uv[tri] - uv_o[tri]).max() <= 5e-5 if tri.any() else True
 
 
+def _quad_soup(seed):
+    """A scene of planar shapes for the flat sweep's record builder (csrc/flat_build.cpp): convex quadrilaterals, parallelograms, concave
+    quadrilaterals (their two triangles must NOT be merged into a convex-quad record), slightly folded quads (not coplanar: not merged),
+    triangle fans, coplanar triangles that share no edge, lone triangles - every triangle with a random vertex rotation."""
+    from adapt_amd import synth
+    rs = np.random.RandomState(seed)
+    b = synth._Builder()
+    white = synth._brdf("lambertian", "#BDBDBD")
+
+    def frame():
+        n = rs.normal(size=3); n /= np.linalg.norm(n)
+        a = np.cross(n, rs.normal(size=3)); a /= np.linalg.norm(a)
+        return rs.uniform(1.0, 4.5, 3), a, np.cross(n, a), n
+
+    def rot(tri):
+        k = rs.randint(3)
+        return np.roll(tri, k, axis=0)
+
+    def emit(tris):
+        b.mesh(np.float32([rot(np.asarray(t)) for t in tris]), white)
+
+    for kind in ["convex"] * 6 + ["para"] * 3 + ["concave"] * 3 + ["folded"] * 2:
+        c, a, bb, n = frame()
+        if kind == "convex":
+            ang = np.sort(rs.uniform(0, 2 * np.pi, 4)); ang += np.float64([0.0, 0.3, 0.6, 0.9])      # four points around a centre, in order
+            rad = rs.uniform(0.5, 1.2, 4)
+            pts = [c + r * (np.cos(t) * a + np.sin(t) * bb) for r, t in zip(rad, ang)]
+            hull_ok = all(np.dot(np.cross(pts[(i + 1) % 4] - pts[i], pts[(i + 2) % 4] - pts[(i + 1) % 4]), n) > 0 for i in range(4))
+            if not hull_ok:
+                pts = [c + 0.8 * (np.cos(t) * a + np.sin(t) * bb) for t in (0.2, 1.9, 3.3, 4.9)]
+        elif kind == "para":
+            e1, e2 = rs.uniform(0.5, 1.2) * a + rs.uniform(-0.3, 0.3) * bb, rs.uniform(0.5, 1.2) * bb
+            pts = [c, c + e1, c + e1 + e2, c + e2]
+        elif kind == "concave":
+            pts = [c + 1.0 * a, c + 0.15 * (a + bb), c + 1.0 * bb, c - 0.8 * (a + bb)]                # reflex corner at pts[1]: split along 1-3
+            emit([[pts[1], pts[2], pts[3]], [pts[1], pts[3], pts[0]]])
+            continue
+        else:
+            pts = [c, c + a, c + a + bb + 2e-3 * n, c + bb]
+        emit([[pts[0], pts[1], pts[2]], [pts[0], pts[2], pts[3]]])
+    c, a, bb, n = frame()                                                                            # a fan of five coplanar triangles
+    ring = [c + 0.9 * (np.cos(t) * a + np.sin(t) * bb) for t in np.linspace(0, 2 * np.pi, 6)[:-1]]
+    emit([[c, ring[i], ring[(i + 1) % 5]] for i in range(5)])
+    c, a, bb, n = frame()                                                                            # coplanar, no shared edge
+    emit([[c, c + a, c + bb], [c + 1.5 * a, c + 2.5 * a, c + 1.5 * a + bb]])
+    emit([[rs.uniform(0.5, 5.0, 3) for _ in range(3)] for _ in range(10)])                           # lone triangles
+    em = [synth._spot("6.0, 6.0, 6.0", "100.0", (2.7, 5.0, 2.7), (0.0, -1.0, 0.0), 40.0, "s")]
+    return b.finish(em, synth._sensor(64, 64, 4, 1))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_flat_records_of_merged_triangle_pairs_answer_as_the_exact_build(seed):
+    """The record builder merges coplanar triangle pairs with a convex outline into one record (parallelogram or convex quadrilateral) and
+    must leave every other pair alone: random quad soups, product build against the exact build on the same rays."""
+    from adapt_amd.renderer import Renderer
+    tup = _quad_soup(seed)
+    o, d, tmax = _rays(200000, 40 + seed)
+    f = Renderer(*tup, width=32, height=32)
+    e = Renderer(*tup, width=32, height=32, exact=True)
+    try:
+        assert f.info()["traversal"] == "flat" and f.info()["arithmetic"] == "fast" and e.info()["arithmetic"] == "exact"
+        prim, t, uv = f.intersect(o, d)
+        prim_o, t_o, uv_o = e.intersect(o, d)
+        assert (prim_o >= 0).mean() > 0.2
+        _check_hits(prim, t, uv, prim_o, t_o, uv_o, np.ones(len(prim), bool), d, f.flat.normals)
+        assert (f.occluded(o, d, tmax) != e.occluded(o, d, tmax)).sum() <= 3
+    finally:
+        f.close(); e.close()
+
+
 @pytest.mark.parametrize("tag", ["cbox", "balls_mono", "glass_box", "features_a", "features_c"])
 def test_flat_sweep_hits_vs_oracle_and_exact_build(tag, renderer, oracle_scene):
     n = 100000
