@@ -270,6 +270,9 @@ APT_D SubLoop sub_loop(int nq, int nt = BLOCK) {
 #ifndef APT_SHADE_PREFETCH
 #define APT_SHADE_PREFETCH 1
 #endif
+#ifndef APT_SHADE_PREFETCH_PRIM
+#define APT_SHADE_PREFETCH_PRIM 1
+#endif
 #ifndef APT_SHADE_LATE_SHADOW
 #define APT_SHADE_LATE_SHADOW 0      // measured: the deferred shadow entry costs the kernel its fourth wave per SIMD (120 -> 130 VGPRs: C2 shade 10.6 -> 13.1 ms)
 #endif
@@ -633,7 +636,11 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         pf_o = ld3q(in.ray_o, p.cap, pio); pf_d = ld3q(in.ray_d, p.cap, pio); pf_thr = ld3q(in.thr, p.cap, pio);
         pf_id = ldq(in.id, pio); pf_meta = ldq(in.meta, pio);
     };
+    // the kernels without registers for that (material classes: 124-128 VGPRs) prefetch only the hit primitive - one register - so that a
+    // row's shading record can be requested together with its queue record instead of a round trip after it
+    constexpr bool PFP = !PF && (APT_SHADE_PREFETCH_PRIM != 0) && TEX == 0;
     if (PF && n > 0) prefetch(sl.first);
+    if (PFP && n > 0) pf_prim = ldq(in.prim, (qbase + min(sl.first + threadIdx.x, n - 1u)) << 2);
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
 #ifdef APT_SHADE_PROF
         unsigned long long stick_ = __builtin_readcyclecounter();
@@ -644,6 +651,11 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         bool alive = pos < n;
         const int cu_prim = pf_prim; const float cu_t = pf_t; const f3 cu_o = pf_o, cu_d = pf_d, cu_thr = pf_thr; const uint32_t cu_id = pf_id, cu_meta = pf_meta;
         float4 cu_ra = make_float4(0.f, 0.f, 0.f, 0.f), cu_rb = cu_ra; uint32_t cu_key = 0;
+        if (PFP) {
+            const int rp = max(cu_prim, 0);
+            cu_ra = sc.prim_shade[2 * rp]; cu_rb = sc.prim_shade[2 * rp + 1];
+            pf_prim = ldq(in.prim, (qbase + min(base + sl.stride + threadIdx.x, n - 1u)) << 2);
+        }
         if (PF) {
             const int rp = max(cu_prim, 0);
             cu_ra = sc.prim_shade[2 * rp]; cu_rb = sc.prim_shade[2 * rp + 1];
@@ -664,7 +676,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
         if (alive) {
             const uint32_t io = idx << 2;
-            int prim = PF ? cu_prim : ldq(in.prim, io);
+            int prim = (PF || PFP) ? cu_prim : ldq(in.prim, io);
             if (prim < 0) alive = false;                         // nothing hit: path ends (vanilla_renderer.py:49)
             else {
                 uint32_t meta;
@@ -687,6 +699,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                         it.n_s = (ld3(vn) * (1.f - bu - bv) + ld3(vn + 3) * bu) + ld3(vn + 6) * bv;
                     }
                 }
+                else if (PFP) build_hit_rec(sc, cu_ra, cu_rb, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
                 else build_hit(sc, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
                 if (BM == 0x002) bx.k_d = rec_kd;               // Lambertian-only scenes: type 1, not delta, not a BSDF (the defaults above), colour from the record
                 else bx = sc.bxdf[it.obj_id];
