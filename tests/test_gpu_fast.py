@@ -13,6 +13,8 @@ reference's loop operation for operation.  The shading arithmetic is the same in
   * statistical cross-check against a CPU render with another seed.
 Scenes too large for the flat sweep walk the same 8-wide tree in both builds: there the two builds must agree bit for bit.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -88,6 +90,32 @@ def _check_hits(prim, t, uv, prim_o, t_o, uv_o, is_tri, d, normals):
     tied = np.abs(t[diff] - t_o[diff]) <= 1e-5 * np.maximum(np.abs(t_o[diff]), 1e-2)
     assert diff.mean() <= 5e-3 and (~tied).sum() <= max(3, int(2e-5 * len(prim))), (diff.sum(), (~tied).sum())
     assert np.abs(uv[tri] - uv_o[tri]).max() <= 5e-5 if tri.any() else True
+
+
+FULL_SIZE = os.environ.get("APT_FULL_SIZE_PARITY") == "1"
+
+
+@pytest.mark.skipif(not FULL_SIZE, reason="minutes of host time for the oracle: APT_FULL_SIZE_PARITY=1 (the run of record is profiles/r0N_full_size_parity.log)")
+@pytest.mark.parametrize("tag,spp", [("cbox", 1024), ("balls_mono", 1024)])
+def test_full_size_parity_c2_c3_product_build(tag, spp, renderer, parsed, oracle_scene, capsys):
+    """BASELINE configs[1] and [2] at their FULL size, product build against the oracle on the same Philox stream, every pixel, held to
+    SURVEY 8(d)'s tolerance (the exact build's twin in test_gpu_parity.py is held to 1e-7)."""
+    r = renderer(tag)
+    assert (r.w, r.h) == (512, 512) and r.info()["arithmetic"] == "fast" and r.info()["traversal"] == "flat"
+    r.render(n_spp=spp)
+    acc = r.color.to_numpy()
+    st = r.stats()
+    rc = make_config(parsed(tag)[3])
+    ref, cnt, ost = oracle_scene(tag).render(rc, spp, threads=0)
+    fin = np.isfinite(acc).all(axis=2) & np.isfinite(ref).all(axis=2)
+    a, b = np.where(fin[..., None], acc, 0) / spp, np.where(fin[..., None], ref, 0) / spp
+    m = image_metrics(a, b)
+    with capsys.disabled():
+        print(f"\n[full size, product build] {tag}: 512x512x{spp} spp  relMSE {m['relMSE']:.3e}  max|diff| {m['max_abs']:.3e}  pixels within 1e-3(1+x) {100 * m['frac_within']:.4f} %  "
+              f"non-finite pixels {int((~fin).sum())}  n_shade {st['n_shade']} / {ost['n_shade']}  n_shadow {st['n_shadow']} / {ost['n_shadow']}  n_draws {st['n_draws']} / {ost['n_draws']}")
+    assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-4, m
+    for k in ("n_shade", "n_shadow", "n_draws"):
+        assert abs(st[k] - ost[k]) <= 5e-4 * ost[k], (k, st[k], ost[k])
 
 
 def _quad_soup(seed):
