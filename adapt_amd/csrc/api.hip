@@ -245,6 +245,17 @@ APT_EXPORT int apt_bvh_export(const apt_bvh* b, float* nodes, int32_t* prim_orde
     memcpy(prim_order, b->data.prim_order.data(), b->data.prim_order.size() * sizeof(int32_t));
     return APT_OK;
 }
+APT_EXPORT int apt_flat_records(const float* prims, int32_t n_prims, const int32_t* obj_info, int32_t n_objects, int32_t counts[7],
+                                float* stream, int32_t stream_cap, float* tab, int32_t tab_cap, int32_t* n_stream, int32_t* n_tab) {
+    if (!prims || !obj_info || !counts || n_prims <= 0 || n_objects <= 0 || !n_stream || !n_tab) return fail(APT_E_INVALID, "apt_flat_records: bad argument");
+    std::vector<float> st, tb; int c[7];
+    if (apt::build_flat(prims, n_prims, obj_info, n_objects, nullptr, nullptr, st, tb, c) != 0) return fail(APT_E_INVALID, "apt_flat_records: obj_info range outside the primitive array");
+    for (int k = 0; k < 7; k++) counts[k] = c[k];
+    *n_stream = (int32_t)st.size(); *n_tab = (int32_t)tb.size();
+    if (stream) { if (stream_cap < (int32_t)st.size()) return fail(APT_E_INVALID, "apt_flat_records: stream buffer too small"); memcpy(stream, st.data(), st.size() * 4); }
+    if (tab) { if (tab_cap < (int32_t)tb.size()) return fail(APT_E_INVALID, "apt_flat_records: table buffer too small"); memcpy(tab, tb.data(), tb.size() * 4); }
+    return APT_OK;
+}
 APT_EXPORT int apt_bvh_wide_counts(const apt_bvh* b, int32_t* n_nodes, int32_t* n_levels) {
     if (!b) return fail(APT_E_INVALID, "apt_bvh_wide_counts: null handle");
     if (n_nodes) *n_nodes = b->wide.n_nodes();

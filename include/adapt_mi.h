@@ -7,6 +7,7 @@
  *   apt_bvh_build_linear / apt_linear_bvh_*   tracer/bvh/bvh.cpp:274-296  bvh_cpp.bvh_build(...) (pybind11 module), called from
  *                                   tracer/path_tracer.py:143-179 (bvh_process): the same four arrays in the same layout
  *   apt_bvh_build / apt_bvh_*      the same builder's role for this library's own kernels (binary SAH tree -> 8-wide quantised tree)
+ *   apt_flat_records               tracer/tracer_base.py:117-134,184-212: the data of the brute-force intersector, as the flat sweep wants it
  *   apt_scene_create               tracer/tracer_base.py:117-134 (load_primitives) +
  *                                   tracer/path_tracer.py:245-274 (initialze): numpy -> device fields
  *   apt_renderer_create            renderer/vanilla_renderer.py:26-30 / tracer_base.py:36-102 (film, crop, camera,
@@ -128,6 +129,17 @@ int apt_bvh_export(const apt_bvh*, float* nodes, int32_t* prim_order);
 int apt_bvh_wide_counts(const apt_bvh*, int32_t* n_nodes, int32_t* n_levels);
 int apt_bvh_wide_export(const apt_bvh*, uint32_t* nodes /* n_nodes*20 */, int32_t* prim_order /* n_prims */);
 void apt_bvh_free(apt_bvh*);
+
+/* ---- records of the flat sweep (host; csrc/flat_build.cpp).  What the product build's small-scene intersector reads instead of the
+ * reference's `prims` / `precom_vec` (tracer/tracer_base.py:117-134,184-212): per planar primitive its corner and the rows of
+ * [e1 e2 n]^-1; two coplanar triangles of an object that share an edge and have a convex outline are one record.  apt_scene_create
+ * builds them internally; this entry exposes the builder so that it can be checked without a device.
+ * counts[7]: parallelograms, parallelograms in coplanar groups, convex quads, convex quads in groups, triangles, triangles in groups,
+ * spheres.  stream (may be NULL): counts-ordered records, 12 floats each (corner p0, rows U, V, T), 18 for convex quads (+ the two far
+ * edges as a u + b v + c), 4 per sphere (centre, r^2); tab (may be NULL): 28 floats per record (U, p0.x | V, p0.y | prim_a prim_b
+ * class_a class_b as int32 | map_a[6] | map_b[6] | p0.z ...).  n_stream / n_tab: floats needed (always written). */
+int apt_flat_records(const float* prims /* n_prims*9 */, int32_t n_prims, const int32_t* obj_info /* n_objects*3 */, int32_t n_objects,
+                     int32_t counts[7], float* stream, int32_t stream_cap, float* tab, int32_t tab_cap, int32_t* n_stream, int32_t* n_tab);
 
 /* ---- BVH build, reference layout: the drop-in for the pybind11 module itself.
  * Replaces bvh_cpp.bvh_build(obj_array, obj_info, world_min, world_max) (tracer/bvh/bvh.cpp:274-296), whose four flat arrays
