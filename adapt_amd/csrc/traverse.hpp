@@ -633,7 +633,8 @@ struct FlatScene {
 #if APT_FAST
 APT_D v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 struct FlatRays { v2f ox, oy, oz, dx, dy, dz; };           // two rays: .x = entry 2k, .y = entry 2k + 1
-// (t, u, v) of both rays against one planar record: 12 wave-uniform floats at r = corner p0, rows U, V, T of [e1 e2 n]^-1.
+// (t, u, v) of both rays against one planar record: 12 wave-uniform floats at r = corner p0, rows U, V, T of [e1 e2 n]^-1:
+// t = -T.s / T.d, then u = U.P, v = V.P at P = s + t d.
 // The origin enters as s = o - p0, exactly the reference's first operation (tracer_base.py:206): for a ray that STARTS on the primitive
 // (every continuation and shadow ray does, on one) the height T . s is then a sum of small products, and its rounding noise - which decides
 // whether a grazing ray re-hits its own surface beyond the 1e-4 threshold - stays at the reference's level.  (With the translation folded
@@ -647,12 +648,11 @@ APT_D void planar_solve(cf_ptr r, const FlatRays& q, v2f& t, v2f& u, v2f& v) {
     const v2f t_d = fma2(tx, q.dx, fma2(ty, q.dy, tz * q.dz));
     v2f inv; inv.x = __builtin_amdgcn_rcpf(t_d.x); inv.y = __builtin_amdgcn_rcpf(t_d.y);
     t = -t_o * inv;
-    const v2f u_o = fma2(ux, sx, fma2(uy, sy, uz * sz));
-    const v2f u_d = fma2(ux, q.dx, fma2(uy, q.dy, uz * q.dz));
-    const v2f v_o = fma2(vx, sx, fma2(vy, sy, vz * sz));
-    const v2f v_d = fma2(vx, q.dx, fma2(vy, q.dy, vz * q.dz));
-    u = fma2(t, u_d, u_o);
-    v = fma2(t, v_d, v_o);
+    // (u, v) from the hit point relative to the corner, P = s + t d - what flat_resolve() does for the winner, so the inside test and the
+    // reported barycentrics are one formula - 9 packed operations instead of the 14 of U.s + t (U.d), V.s + t (V.d)
+    const v2f px = fma2(t, q.dx, sx), py = fma2(t, q.dy, sy), pz = fma2(t, q.dz, sz);
+    u = fma2(ux, px, fma2(uy, py, uz * pz));
+    v = fma2(vx, px, fma2(vy, py, vz * pz));
 }
 struct FlatHit2 { v2f t; int idx0, idx1, run0, run1; };   // closest record per ray (-1: none), its distance (or the search limit), and a near-tied runner-up (-1: none)
 // Coplanar primitives (a glass box resting on the floor): which of two faces at the SAME distance a ray "hits" is decided upstream by
@@ -759,7 +759,7 @@ APT_D void flat_loop(const FlatScene& fl, const FlatRays& q, v2f lim, FlatHit2& 
 APT_D void flat_resolve(const FlatScene& fl, int idx, float t, f3 o, f3 d, HitRec& rec, int& cls) {
     const float4* e = fl.tab + 7 * idx;
     const float4 U = e[0], V = e[1], ids = e[2], ma0 = e[3], mab = e[4], mb1 = e[5], pz = e[6];      // U.w, V.w, pz.x = the record's corner p0
-    const f3 P = mk3(__builtin_fmaf(t, d.x, o.x) - U.w, __builtin_fmaf(t, d.y, o.y) - V.w, __builtin_fmaf(t, d.z, o.z) - pz.x);
+    const f3 P = mk3(__builtin_fmaf(t, d.x, o.x - U.w), __builtin_fmaf(t, d.y, o.y - V.w), __builtin_fmaf(t, d.z, o.z - pz.x));      // s + t d, as planar_solve()
     const float u = __builtin_fmaf(U.x, P.x, __builtin_fmaf(U.y, P.y, U.z * P.z));
     const float v = __builtin_fmaf(V.x, P.x, __builtin_fmaf(V.y, P.y, V.z * P.z));
     const int prim_b = __float_as_int(ids.y);

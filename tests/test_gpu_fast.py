@@ -284,7 +284,7 @@ def test_image_matches_reference_run(tag, renderer):
     r.render(n_spp=spp)
     m = image_metrics(r.pixels.to_numpy(), g["pixels"])
     assert m["frac_within"] >= 0.93 and m["relMSE"] <= 1e-2, m
-    assert abs(r.stats()["n_draws"] - int(g["draws"].sum())) <= 2e-3 * int(g["draws"].sum())
+    assert abs(r.stats()["n_draws"] - int(g["draws"].sum())) <= max(2e-3 * int(g["draws"].sum()), 250)       # (a re-drawn glass path of features_c is ~80 draws; two or three of them differ in a render this small, in either direction)
 
 
 @pytest.mark.parametrize("tag", ["cbox", "balls_mono", "textured"])
