@@ -86,9 +86,12 @@ typedef void (*occluded_fn)(DevScene, uint32_t, const float*, const float*, cons
 #define APT_FLAT_FN(...) nullptr          // the flat sweep exists in the fast build only (traverse.hpp)
 #endif
 static const extend_fn kExtend[4][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_extend<1, 0>, k_extend<1, 1>}, {k_extend<2, 0>, k_extend<2, 1>},
-                                        {APT_FLAT_FN(k_extend_flat<0>), APT_FLAT_FN(k_extend_flat<1>)}};   // [mode][sorted]
+                                        {APT_FLAT_FN(k_extend_flat<0, 0>), APT_FLAT_FN(k_extend_flat<1, 0>)}};   // [mode][sorted] (flat: the self-contained variant, for explicit rays)
+// flat sweep inside a render: the hot variant and its fix-up launch (stages.hpp "fix-up lists"), [sorted]
+static const extend_fn kExtendFlatHot[2] = {APT_FLAT_FN(k_extend_flat<0, 1>), APT_FLAT_FN(k_extend_flat<1, 1>)};
+static const extend_fn kFixFlat[2] = {APT_FLAT_FN(k_fix_flat<0>), APT_FLAT_FN(k_fix_flat<1>)};
 static const extend_fn kExtendDyn[2] = {k_extend_dyn<0>, k_extend_dyn<1>};      // BVH walk with dynamic ray fetch [sorted]
-static const shadow_fn kShadow[4] = {k_shadow<0>, k_shadow<1>, k_shadow<2>, APT_FLAT_FN(k_shadow_flat)};
+static const shadow_fn kShadow[4] = {k_shadow<0>, k_shadow<1>, k_shadow<2>, APT_FLAT_FN(k_shadow_flat<1>)};      // (flat: the hot variant; its list is served by the next kFixFlat launch)
 static const occluded_fn kOccluded[4] = {k_occluded<0>, k_occluded<1>, k_occluded<2>, APT_FLAT_FN(k_occluded_flat)};
 typedef void (*vshade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int);
 struct VShadeVariant { int bm, sm; vshade_fn fn; const char* name; };
@@ -187,6 +190,7 @@ struct apt_renderer {
     LdsPlan plan{};
     size_t lds_bytes = 0, lds_bytes_any = 0;     // dynamic LDS of the closest-hit / any-hit trace kernels
     int grid_shadow = 0;
+    int grid_fix = 0;             // flat sweep: grid of the fix-up launches (a few workgroups per sub-queue: their lists are all but empty)
     int grid_vshadow = 0;         // volumetric transmittance walk (closest-hit LDS footprint, its own register budget)
     int vshadow_nt = BLOCK;       // its workgroup size and dynamic LDS
     int vshadow_mode = 0;         // traversal mode of the volumetric transmittance walk (one closest-hit query per lane and pass: with the flat sweep's two-rays-per-lane loop half of every packed instruction would idle, so small scenes keep the tiled / wave sweep there)
@@ -635,7 +639,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     }
     // flat sweep with several light samples per vertex: the samples are queued by vertex and the shadow kernel adds a vertex's samples with
     // one read-modify-write (stages.hpp k_shadow_flat); otherwise 2-4 samples per vertex add into one radiance plane each
-    p.keep_order = c.volumetric ? 1 : 0;
+    p.keep_order = c.volumetric ? 1 : 0; p.volumetric_flat = c.volumetric ? 1 : 0; p.fix_par = 0;
     p.nee_vm = (!c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
     if (const char* f = getenv("APT_NEE_VM")) p.nee_vm = (atoi(f) != 0 && !c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
     p.l_planes = (!c.volumetric && !p.nee_vm && S >= 2 && S <= 4) ? S : 1;        // stages.hpp APT_EXCLUSIVE_L: one radiance plane per light sample of a vertex
@@ -700,7 +704,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     // one pool per lane, carved into the SoA arrays (all 4-byte lanes)
     const bool walk_lists = r->volumetric && sc->has_null_surface;      // light samples that cross null surfaces are re-queued by slot
     const size_t l_planes = (size_t)p.l_planes;
-    const size_t words = cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
+    const size_t words = (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
         hipError_t e_ = pool.alloc(words * 4);
         if (e_ != hipSuccess) return e_;
@@ -708,6 +712,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         auto take = [&](size_t n) { float* x = w; w += n; return x; };
         for (int k = 0; k < 2; k++) { q.ray_o[k] = take(3 * cap); q.ray_d[k] = take(3 * cap); }
         q.hit_t = take(cap); q.hit_prim = (int*)take(cap); q.hit_u = take(cap); q.hit_v = take(cap);
+        q.fix_ext = (r->trace_mode == 3) ? (uint32_t*)take(cap) : nullptr; q.fix_sh = (r->trace_mode == 3) ? (uint32_t*)take(sh_cap) : nullptr;
         for (int k = 0; k < 2; k++) { q.thr[k] = take(3 * cap); q.id[k] = (uint32_t*)take(cap); q.meta[k] = (uint32_t*)take(cap); q.pdf[k] = take(cap); }
         q.L = take(4 * cap * l_planes);
         q.sh_o = take(3 * sh_cap); q.sh_d = take(3 * sh_cap); q.sh_tmax = take(sh_cap); q.sh_c = take(3 * sh_cap); q.sh_id = (uint32_t*)take(sh_cap);
@@ -825,6 +830,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     }
     if (const char* g = getenv("APT_GRID_VSHADOW")) r->grid_vshadow = cus * std::max(1, atoi(g));
     r->grid_vshadow = ((r->grid_vshadow + nq - 1) / nq) * nq;
+    r->grid_fix = nq * 8;
     if (getenv("APT_DEBUG_GRID")) fprintf(stderr, "[grid] trace mode %d grid %d nt %d lds %zu | shadow grid %d lds %zu | vshadow mode %d grid %d nt %d lds %zu | small %d\n", r->trace_mode, r->grid_trace, r->trace_nt, r->lds_bytes, r->grid_shadow, r->lds_bytes_any, r->vshadow_mode, r->grid_vshadow, r->vshadow_nt, r->vshadow_lds, r->grid_small);
     r->grid_trace = ((r->grid_trace + nq - 1) / nq) * nq;          // persistent grids are multiples of nq
     r->grid_shadow = ((r->grid_shadow + nq - 1) / nq) * nq;
@@ -882,8 +888,8 @@ static hipEvent_t take_event(apt_renderer* r) {
 }
 struct LaunchTimer {      // brackets one kernel launch with events when profiling is on
     apt_renderer* r; int kernel; EventPair ev{}; bool on; hipStream_t st;
-    LaunchTimer(apt_renderer* r_, int k, hipStream_t stream = nullptr) : r(r_), kernel(k), on(r_->cfg.profile != 0), st(stream ? stream : r_->stream) {
-        r->launches[k]++;
+    LaunchTimer(apt_renderer* r_, int k, hipStream_t stream = nullptr, bool count = true) : r(r_), kernel(k), on(r_->cfg.profile != 0), st(stream ? stream : r_->stream) {
+        if (count) r->launches[k]++;                         // (a fix-up launch adds its time to its stage's bucket, not a launch to its count)
         if (!on) return;
         ev.kernel = k; ev.a = nullptr; ev.own_a = false;
         for (auto& c : r->chain) if (c.first == st) ev.a = c.second;
@@ -948,7 +954,8 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
             const LdsPlan& lane_plan = is.li ? r->extra[(size_t)is.li - 1].plan : r->plan;
             for (int b = 0; b < n_iter; b++) {
                 if (r->dyn_fetch) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st)); }
-                { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(is.total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
+                { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : (r->trace_mode == 3 ? kExtendFlatHot[r->sorted] : kExtend[r->trace_mode][r->sorted]), dim3(grid_for(is.total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
+                if (r->trace_mode == 3) { LaunchTimer t(r, 1, st, false); hipLaunchKernelGGL(kFixFlat[r->sorted], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
                 if (!r->sorted) {
                     ShadeIn in = {q.ray_o[is.cur], q.ray_d[is.cur], q.thr[is.cur], q.id[is.cur], q.meta[is.cur], q.pdf[is.cur],
                                   q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[is.cur]};
@@ -1050,7 +1057,8 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
         int cur = 0;
         for (int b = 0; b < p.max_bounce; b++) {
             if (r->dyn_fetch) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st)); }
-            { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : kExtend[r->trace_mode][r->sorted], dim3(grid_for(total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
+            { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : (r->trace_mode == 3 ? kExtendFlatHot[r->sorted] : kExtend[r->trace_mode][r->sorted]), dim3(grid_for(total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
+            if (r->trace_mode == 3) { LaunchTimer t(r, 1, st, false); hipLaunchKernelGGL(kFixFlat[r->sorted], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
             if (!r->sorted) {
                 ShadeIn in = {q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.id[cur], q.meta[cur], q.pdf[cur],
                               q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur]};
@@ -1066,8 +1074,14 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             if (p.S > 0 && r->dyn_fetch) {
                 unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[1], 0, sizeof(cnt->n_work[1]), st));
                 LaunchTimer t(r, 3, st); hipLaunchKernelGGL(k_shadow_dyn, dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan);
-            } else if (p.S > 0) { LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan); }
+            } else if (p.S > 0) {
+                p.fix_par = cur;
+                LaunchTimer t(r, 3, st); hipLaunchKernelGGL(kShadow[r->trace_mode], dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan);
+            }
             cur ^= 1;
+        }
+        if (r->trace_mode == 3 && p.S > 0 && p.max_bounce > 0) {     // the last bounce's shadow list (the extend list of this parity is empty)
+            LaunchTimer t(r, 3, st, false); hipLaunchKernelGGL(kFixFlat[r->sorted], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan);
         }
         // the framebuffer is shared: batch k's samples are added after batch k-1's, whichever lanes they ran on
         if (prev_fin && r->n_lanes > 1) { unchain(r, st); HIP_TRY(hipStreamWaitEvent(st, prev_fin, 0)); }

@@ -96,6 +96,8 @@ struct Params {
     const uint32_t* pix_key;  // local pixel -> global pixel index x * H + y = the RNG key (host-built; band mapping folded in)
     float inv_ns, inv_ns1;    // 1 / n_sources, 1 / (n_sources - 1): sample_light's pdfs (path_tracer.py:537-554)
     int keep_order;           // 1: the flat extend kernel's class appends keep the queue's entry order (volumetric renders: the transmittance walk's wave-wide culls want neighbouring rays in a wave)
+    int fix_par;              // flat sweep: queue parity of the current bounce (which shadow fix-up list the hot shadow kernel appends to); set per launch
+    int volumetric_flat;      // 1: volumetric render (the flat shadow kernels never run: the fix-up launch has no shadow list)
     int nee_vm;               // 1: light samples are queued BY VERTEX (one slot per vertex and sub-queue, sample s in plane s of the sub-queue's region, unwanted samples marked tmax < 0), so that the flat shadow kernel adds a vertex's samples with ONE read-modify-write and the shade kernel moves the queue tail once per tile row (flat sweep, S > 1)
     int l_planes;             // radiance planes of L: light sample s of a vertex adds into plane s (2 <= S <= 4), so that no two entries of a shadow launch share a slot; 1 otherwise
     float w_min[3], w_max[3]; // world box = (objects U camera) +- 0.1 (path_tracer.py:130-138); volumetric tracer only
@@ -105,6 +107,7 @@ struct Params {
 struct Queues {
     float* ray_o[2]; float* ray_d[2];           // 3 components each
     float* hit_t; int* hit_prim; float* hit_u; float* hit_v;
+    uint32_t* fix_ext; uint32_t* fix_sh;         // flat sweep: fix-up lists, sub-queue-local entry indices (null elsewhere)
     float* thr[2]; uint32_t* id[2]; uint32_t* meta[2]; float* pdf[2];
     float* sh_o; float* sh_d; float* sh_tmax; float* sh_c; uint32_t* sh_id;
     uint32_t* sh_walk[2];                        // volumetric, scenes with null surfaces: slot lists of the samples that walk on (ping-pong)
@@ -137,6 +140,8 @@ struct Counters {
     uint32_t n_shadow[APT_MAX_NQ * CNT_PAD];
     uint32_t n_walk[8][APT_MAX_NQ * CNT_PAD];     // volumetric: light samples still walking after pass p-1 (pass p reads list p, fills list p + 1)
     uint32_t n_cls[8][APT_MAX_NQ * CNT_PAD];
+    uint32_t n_fix_ext[2][APT_MAX_NQ * CNT_PAD];  // flat sweep: entries handed to the fix-up launch of the extend stage (by queue parity) ...
+    uint32_t n_fix_sh[2][APT_MAX_NQ * CNT_PAD];   // ... and of the shadow stage, by the parity of the bounce that listed them (stages.hpp "fix-up lists")
     uint32_t n_work[2][APT_MAX_NQ * CNT_PAD];     // BVH walk with dynamic fetch: next unclaimed queue position (0 extend, 1 shadow); zeroed by the host before the launch
     unsigned long long stats[APT_MAX_NQ][16];    // [q][ST_*], 128 bytes per sub-queue
 #ifdef APT_SHADE_PROF
@@ -1006,39 +1011,69 @@ template <typename T2> APT_D T2 ld2q(const void* base, uint32_t off) { return *r
 template <typename T2> APT_D void st2q(void* base, uint32_t off, T2 v) { *reinterpret_cast<T2*>(reinterpret_cast<char*>(base) + off) = v; }
 #define FLAT_NT (2 * BLOCK)
 
-template <int SORTED>
-__global__ void __launch_bounds__(BLOCK) k_extend_flat(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
-    const SubLoop sl = sub_loop(p.nq, FLAT_NT);
-    const uint32_t n = n_src[sl.q * CNT_PAD];
-    if (cnt && sl.first == 0 && threadIdx.x == 0) {
+// Fix-up lists.  Two kinds of rays need the reference's own arithmetic (traverse.hpp flat_closest2): they are a handful per million, but
+// the code that serves them - prim_test(), the reference-order sweep() - inlined into the stage kernels set their register allocation
+// (k_extend_flat 79 VGPRs, k_shadow_flat 85: 5-6 waves per SIMD).  So the kernels come in three variants: VAR 1, the hot one, resolves
+// every other ray and appends the entries it cannot settle to a per-sub-queue list (52 / 44 VGPRs); VAR 2 runs right after it on the same
+// stream with a small grid, takes its entries from that list - one per lane - and does the full work for them, including the class
+// appends of the sorted pipeline; VAR 0 is the self-contained kernel for explicit rays (apt_intersect), where no lists exist.
+APT_D void fix_append(bool f0, bool f1, uint32_t pos, uint32_t* counter, uint32_t* list, uint32_t qbase) {
+    if (!__any(f0 || f1)) return;
+    const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+    uint32_t tail = 0;
+    if (lane_id() == 0) tail = atomicAdd(counter, (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1));
+    const uint32_t at = (qbase + (uint32_t)__builtin_amdgcn_readlane((int)tail, 0) + rank_in(m0) + rank_in(m1)) << 2;
+    if (f0) stq(list, at, pos);
+    if (f1) stq(list, at + (f0 ? 4u : 0u), pos + 1u);
+}
+template <int SORTED, int VAR>
+APT_D void extend_flat_body(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, int cur, const uint32_t* n_src) {
+    const SubLoop sl = sub_loop(p.nq, VAR == 2 ? BLOCK : FLAT_NT);
+    const uint32_t n = (VAR == 2) ? cnt->n_fix_ext[cur][sl.q * CNT_PAD] : n_src[sl.q * CNT_PAD];
+    if (VAR != 2 && cnt && sl.first == 0 && threadIdx.x == 0) {
         cnt->n_shadow[sl.q * CNT_PAD] = 0; cnt->n_active[cur ^ 1][sl.q * CNT_PAD] = 0;
         for (int w = 0; w < 8; w++) cnt->n_walk[w][sl.q * CNT_PAD] = 0;
+        cnt->n_fix_ext[cur ^ 1][sl.q * CNT_PAD] = 0; cnt->n_fix_sh[cur][sl.q * CNT_PAD] = 0;   // (both lists were consumed by fix-up launches that have finished)
         cnt->stats[sl.q][ST_EXTEND] += n;
     }
     const float* ro = q.ray_o[cur]; const float* rd = q.ray_d[cur];
     const uint32_t qbase = (uint32_t)sl.q * p.subcap, cs = p.cap * 4u;             // component stride in bytes
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
-        const uint32_t pos = base + 2u * threadIdx.x;
-        const bool v0 = pos < n, v1 = pos + 1u < n;
-        const uint32_t io = (qbase + (v0 ? pos : ((n - 1u) & ~1u))) << 2;           // idle lanes re-read the last pair (never written back)
-        const v2f ox = ld2q<v2f>(ro, io), oy = ld2q<v2f>(ro, io + cs), oz = ld2q<v2f>(ro, io + 2u * cs);
-        const v2f dx = ld2q<v2f>(rd, io), dy = ld2q<v2f>(rd, io + cs), dz = ld2q<v2f>(rd, io + 2u * cs);
+        uint32_t pos; bool v0, v1; uint32_t io; bool odd = false;
+        if (VAR == 2) {                                                            // one listed entry per lane, as "entry 0" of its pair
+            const uint32_t li = base + threadIdx.x;
+            v0 = li < n; v1 = false;
+            pos = ldq(q.fix_ext, (qbase + (v0 ? li : n - 1u)) << 2);
+            odd = (pos & 1u) != 0u; io = (qbase + (pos & ~1u)) << 2;
+        } else {
+            pos = base + 2u * threadIdx.x;
+            v0 = pos < n; v1 = pos + 1u < n;
+            io = (qbase + (v0 ? pos : ((n - 1u) & ~1u))) << 2;                      // idle lanes re-read the last pair (never written back)
+        }
+        v2f ox = ld2q<v2f>(ro, io), oy = ld2q<v2f>(ro, io + cs), oz = ld2q<v2f>(ro, io + 2u * cs);
+        v2f dx = ld2q<v2f>(rd, io), dy = ld2q<v2f>(rd, io + cs), dz = ld2q<v2f>(rd, io + 2u * cs);
+        if (VAR == 2 && odd) { ox = mk2(ox.y, ox.x); oy = mk2(oy.y, oy.x); oz = mk2(oz.y, oz.x); dx = mk2(dx.y, dx.x); dy = mk2(dy.y, dy.x); dz = mk2(dz.y, dz.x); }
+        const uint32_t io0 = (VAR == 2) ? (qbase + pos) << 2 : io;                  // byte offset of entry 0's own slot
         const f3 o0 = mk3(ox.x, oy.x, oz.x), d0 = mk3(dx.x, dy.x, dz.x), o1 = mk3(ox.y, oy.y, oz.y), d1 = mk3(dx.y, dy.y, dz.y);
         HitRec r0, r1; r0.t = r1.t = 1e7f; r0.prim = r1.prim = -1; r0.u = r0.v = r1.u = r1.v = 0.f;
-        int c0, c1;
-        flat_closest2(sc.flat, sc.sweep, sc.prim_class, o0, d0, o1, d1, r0, r1, c0, c1);
+        int c0, c1; bool sp0, sp1;
+        flat_closest2<VAR == 1>(sc.flat, sc.sweep, sc.prim_class, o0, d0, o1, d1, r0, r1, c0, c1, sp0, sp1);
+        if (VAR == 1) { sp0 = sp0 && v0; sp1 = sp1 && v1; fix_append(sp0, sp1, pos, &cnt->n_fix_ext[cur][sl.q * CNT_PAD], q.fix_ext, qbase); }
         if (!SORTED) {
             // barycentrics only travel when somebody reads them: vertex normals, textures, or the unit-test entry (apt_intersect: cnt == nullptr)
             const bool need_uv = sc.has_vn || sc.tex_i != nullptr || cnt == nullptr;
             if (v1) {
                 st2q<v2f>(q.hit_t, io, mk2(r0.t, r1.t)); v2i pr; pr.x = r0.prim; pr.y = r1.prim; st2q<v2i>(q.hit_prim, io, pr);
                 if (need_uv) { st2q<v2f>(q.hit_u, io, mk2(r0.u, r1.u)); st2q<v2f>(q.hit_v, io, mk2(r0.v, r1.v)); }
-            } else if (v0) { stq(q.hit_t, io, r0.t); stq(q.hit_prim, io, r0.prim); if (need_uv) { stq(q.hit_u, io, r0.u); stq(q.hit_v, io, r0.v); } }
+            } else if (v0) { stq(q.hit_t, io0, r0.t); stq(q.hit_prim, io0, r0.prim); if (need_uv) { stq(q.hit_u, io0, r0.u); stq(q.hit_v, io0, r0.v); } }
+            // (VAR 1 writes a provisional record for a deferred entry; the fix-up launch overwrites it before anybody reads it)
         } else {
             // sort by material class (see k_extend): the tails of all class queues move with ONE atomic instruction per tile row
-            const v2f tx = ld2q<v2f>(q.thr[cur], io), ty = ld2q<v2f>(q.thr[cur], io + cs), tz = ld2q<v2f>(q.thr[cur], io + 2u * cs);
-            const v2u pid = ld2q<v2u>(q.id[cur], io), pmeta = ld2q<v2u>(q.meta[cur], io); const v2f ppdf = ld2q<v2f>(q.pdf[cur], io);
-            const int cls0 = !v0 ? -1 : ((r0.prim >= 0) ? c0 : q.miss_class), cls1 = !v1 ? -1 : ((r1.prim >= 0) ? c1 : q.miss_class);
+            v2f tx = ld2q<v2f>(q.thr[cur], io), ty = ld2q<v2f>(q.thr[cur], io + cs), tz = ld2q<v2f>(q.thr[cur], io + 2u * cs);
+            v2u pid = ld2q<v2u>(q.id[cur], io), pmeta = ld2q<v2u>(q.meta[cur], io); v2f ppdf = ld2q<v2f>(q.pdf[cur], io);
+            if (VAR == 2 && odd) { tx = mk2(tx.y, tx.x); ty = mk2(ty.y, ty.x); tz = mk2(tz.y, tz.x); ppdf = mk2(ppdf.y, ppdf.x); v2u t_; t_.x = pid.y; t_.y = pid.x; pid = t_; t_.x = pmeta.y; t_.y = pmeta.x; pmeta = t_; }
+            // (a deferred entry joins its class queue in the fix-up launch)
+            const int cls0 = (!v0 || sp0) ? -1 : ((r0.prim >= 0) ? c0 : q.miss_class), cls1 = (!v1 || sp1) ? -1 : ((r1.prim >= 0) ? c1 : q.miss_class);
             uint32_t rank0 = 0, rank1 = 0, cnt_vec = 0;
             for (int c = 0; c < q.n_classes; c++) {
                 const unsigned long long m0 = __ballot(cls0 == c), m1 = __ballot(cls1 == c);
@@ -1068,21 +1103,31 @@ __global__ void __launch_bounds__(BLOCK) k_extend_flat(DevScene sc, Params p, Qu
                 }
             }
             if (q.miss_rr_draw) {
-                if (v0 && r0.prim < 0) count_dropped_miss(p, q, cnt, cur, io, sl.q);
-                if (v1 && r1.prim < 0) count_dropped_miss(p, q, cnt, cur, io + 4u, sl.q);
+                if (v0 && !sp0 && r0.prim < 0) count_dropped_miss(p, q, cnt, cur, io0, sl.q);
+                if (v1 && !sp1 && r1.prim < 0) count_dropped_miss(p, q, cnt, cur, io + 4u, sl.q);
             }
         }
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) k_shadow_flat(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
-    const SubLoop sl = sub_loop(p.nq, FLAT_NT);
-    const uint32_t n = min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
-    if (sl.first == 0 && threadIdx.x == 0) {
+template <int SORTED, int VAR>
+__global__ void __launch_bounds__(BLOCK) k_extend_flat(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
+    extend_flat_body<SORTED, VAR>(sc, p, q, cnt, cur, n_src);
+}
+
+// par: parity of the shadow fix-up list this launch appends to (VAR 1: the bounce's queue parity, Params::fix_par) or consumes (VAR 2)
+template <int VAR>
+APT_D void shadow_flat_body(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, int par) {
+    // VAR 1 / 2: hot variant and the fix-up pass (see k_extend_flat); an entry whose ray needs the reference-order sweep is listed by
+    // VAR 1 - untouched: no radiance, no statistics - and done in full by VAR 2.
+    const SubLoop sl = sub_loop(p.nq, VAR == 2 ? BLOCK : FLAT_NT);
+    const uint32_t n = (VAR == 2) ? cnt->n_fix_sh[par][sl.q * CNT_PAD] : min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
+    if (VAR != 2 && sl.first == 0 && threadIdx.x == 0) {
         if (!p.nee_vm) cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
         for (int c = 0; c < q.n_classes; c++) cnt->n_cls[c][sl.q * CNT_PAD] = 0;      // every shade of this bounce is done
     }
     const uint32_t qbase = (uint32_t)sl.q * q.sh_subcap, cs = q.sh_cap * 4u;
+    uint32_t* fix_counter = &cnt->n_fix_sh[par][sl.q * CNT_PAD];
     uint32_t t_lit = 0, t_traced = 0;
     if (p.nee_vm) {
         // Light samples by vertex (S > 1; `n` counts VERTICES): a lane owns one vertex and walks its sample planes two at a time - the two
@@ -1091,11 +1136,13 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_flat(DevScene sc, Params p, Qu
         // kernel found not worth tracing.)  An occluded sample still enters the sum as 0 * contribution - NaN for a non-finite one (see k_shadow).
         const SubLoop sv = sub_loop(p.nq, BLOCK);
         for (uint32_t base = sv.first; base < n; base += sv.stride) {
-            const uint32_t pos = base + threadIdx.x;
-            const bool valid = pos < n;
-            const uint32_t io = (qbase + (valid ? pos : n - 1u)) << 2;
+            const uint32_t li = base + threadIdx.x;
+            const bool valid = li < n;
+            const uint32_t pos = (VAR == 2) ? ldq(q.fix_sh, (qbase + (valid ? li : n - 1u)) << 2) : (valid ? li : n - 1u);
+            const uint32_t io = (qbase + pos) << 2;
             const uint32_t slot = ldq(q.sh_id, io);
-            f3 sum = splat3(0.f); bool any = false;
+            f3 sum = splat3(0.f); bool any = false, defer = false;
+            uint32_t v_traced = 0, v_lit = 0;
             for (int smp = 0; smp < p.S; smp += 2) {
                 const bool two = smp + 1 < p.S;
                 const uint32_t ia = io + ((uint32_t)smp * p.subcap << 2), ib = io + ((uint32_t)(two ? smp + 1 : smp) * p.subcap << 2);
@@ -1103,33 +1150,56 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_flat(DevScene sc, Params p, Qu
                 const bool la = valid && !(ta < 0.0f), lb = valid && two && !(tb < 0.0f);
                 const f3 o = ld3q(q.sh_o, q.sh_cap, la ? ia : ib);                 // (the origin is written with every wanted sample)
                 const f3 da = ld3q(q.sh_d, q.sh_cap, ia), db = ld3q(q.sh_d, q.sh_cap, ib);
-                bool oa, ob;
-                flat_any2(sc.flat, sc.sweep, o, da, o, db, la ? ((ta > 0.0f) ? ta - 1e-4f : 1e7f) : -1.0f, lb ? ((tb > 0.0f) ? tb - 1e-4f : 1e7f) : -1.0f, oa, ob);
+                bool oa, ob, spa, spb;
+                flat_any2<VAR == 1>(sc.flat, sc.sweep, o, da, o, db, la ? ((ta > 0.0f) ? ta - 1e-4f : 1e7f) : -1.0f, lb ? ((tb > 0.0f) ? tb - 1e-4f : 1e7f) : -1.0f, oa, ob, spa, spb);
+                if (VAR == 1) defer = defer || (la && spa) || (lb && spb);
                 f3 ca = ld3q(q.sh_c, q.sh_cap, ia), cb = ld3q(q.sh_c, q.sh_cap, ib);
                 const bool wa = !(isfinite(ca.x) && isfinite(ca.y) && isfinite(ca.z)), wb = !(isfinite(cb.x) && isfinite(cb.y) && isfinite(cb.z));
                 if (la && (!oa || wa)) { if (oa) ca = ca * 0.f; sum = any ? sum + ca : ca; any = true; }
                 if (lb && (!ob || wb)) { if (ob) cb = cb * 0.f; sum = any ? sum + cb : cb; any = true; }
-                t_traced += (la ? 1u : 0u) + (lb ? 1u : 0u); t_lit += (la && !oa ? 1u : 0u) + (lb && !ob ? 1u : 0u);
+                v_traced += (la ? 1u : 0u) + (lb ? 1u : 0u); v_lit += (la && !oa ? 1u : 0u) + (lb && !ob ? 1u : 0u);
             }
-            if (any) add_radiance(q.L, p.cap, slot & ~3u, sum, true);
+            if (VAR == 1) fix_append(defer, false, pos, fix_counter, q.fix_sh, qbase);      // the whole vertex goes to the fix-up launch
+            if (!defer) {
+                if (any) add_radiance(q.L, p.cap, slot & ~3u, sum, true);
+                t_traced += v_traced; t_lit += v_lit;
+            }
         }
         flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);
         flush_stat(t_traced, &cnt->stats[sl.q][ST_SHADOW_TRACED]);
         return;
     }
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
-        const uint32_t pos = base + 2u * threadIdx.x;
-        const bool v0 = pos < n, v1 = pos + 1u < n;
-        const uint32_t io = (qbase + (v0 ? pos : ((n - 1u) & ~1u))) << 2;
-        const v2f ox = ld2q<v2f>(q.sh_o, io), oy = ld2q<v2f>(q.sh_o, io + cs), oz = ld2q<v2f>(q.sh_o, io + 2u * cs);
-        const v2f dx = ld2q<v2f>(q.sh_d, io), dy = ld2q<v2f>(q.sh_d, io + cs), dz = ld2q<v2f>(q.sh_d, io + 2u * cs);
-        const v2f dist = ld2q<v2f>(q.sh_tmax, io);
+        uint32_t pos; bool v0, v1; uint32_t io; bool odd = false;
+        if (VAR == 2) {
+            const uint32_t li = base + threadIdx.x;
+            v0 = li < n; v1 = false;
+            pos = ldq(q.fix_sh, (qbase + (v0 ? li : n - 1u)) << 2);
+            odd = (pos & 1u) != 0u; io = (qbase + (pos & ~1u)) << 2;
+        } else {
+            pos = base + 2u * threadIdx.x;
+            v0 = pos < n; v1 = pos + 1u < n;
+            io = (qbase + (v0 ? pos : ((n - 1u) & ~1u))) << 2;
+        }
+        v2f ox = ld2q<v2f>(q.sh_o, io), oy = ld2q<v2f>(q.sh_o, io + cs), oz = ld2q<v2f>(q.sh_o, io + 2u * cs);
+        v2f dx = ld2q<v2f>(q.sh_d, io), dy = ld2q<v2f>(q.sh_d, io + cs), dz = ld2q<v2f>(q.sh_d, io + 2u * cs);
+        v2f dist = ld2q<v2f>(q.sh_tmax, io);
         // the radiance slots are requested with the rays, so that after the sweep ONE round trip fetches contribution and radiance of both entries
-        const v2u slot = ld2q<v2u>(q.sh_id, io);
-        bool occ0, occ1;
-        flat_any2(sc.flat, sc.sweep, mk3(ox.x, oy.x, oz.x), mk3(dx.x, dy.x, dz.x), mk3(ox.y, oy.y, oz.y), mk3(dx.y, dy.y, dz.y),
-                  (dist.x > 0.0f) ? dist.x - 1e-4f : 1e7f, (dist.y > 0.0f) ? dist.y - 1e-4f : 1e7f, occ0, occ1);
-        const v2f cx = ld2q<v2f>(q.sh_c, io), cy = ld2q<v2f>(q.sh_c, io + cs), cz = ld2q<v2f>(q.sh_c, io + 2u * cs);
+        v2u slot = ld2q<v2u>(q.sh_id, io);
+        if (VAR == 2 && odd) {
+            ox = mk2(ox.y, ox.x); oy = mk2(oy.y, oy.x); oz = mk2(oz.y, oz.x); dx = mk2(dx.y, dx.x); dy = mk2(dy.y, dy.x); dz = mk2(dz.y, dz.x);
+            dist = mk2(dist.y, dist.x); v2u t_; t_.x = slot.y; t_.y = slot.x; slot = t_;
+        }
+        bool occ0, occ1, sp0, sp1;
+        flat_any2<VAR == 1>(sc.flat, sc.sweep, mk3(ox.x, oy.x, oz.x), mk3(dx.x, dy.x, dz.x), mk3(ox.y, oy.y, oz.y), mk3(dx.y, dy.y, dz.y),
+                            (dist.x > 0.0f) ? dist.x - 1e-4f : 1e7f, (dist.y > 0.0f) ? dist.y - 1e-4f : 1e7f, occ0, occ1, sp0, sp1);
+        if (VAR == 1) {
+            sp0 = sp0 && v0; sp1 = sp1 && v1;
+            fix_append(sp0, sp1, pos, fix_counter, q.fix_sh, qbase);
+            v0 = v0 && !sp0; v1 = v1 && !sp1;                                    // a listed entry is left alone here
+        }
+        v2f cx = ld2q<v2f>(q.sh_c, io), cy = ld2q<v2f>(q.sh_c, io + cs), cz = ld2q<v2f>(q.sh_c, io + 2u * cs);
+        if (VAR == 2 && odd) { cx = mk2(cx.y, cx.x); cy = mk2(cy.y, cy.x); cz = mk2(cz.y, cz.x); }
         const bool excl = APT_EXCLUSIVE_L(p);
 #ifdef APT_PROBE_NO_L      // measurement only (tools/build_variant.sh nol -DAPT_PROBE_NO_L=1): how much of the stage is the radiance read-modify-write
         if (cx.x == 123.456f) stL(q.L, p.cap, slot.x, ldL(q.L, p.cap, slot.x));
@@ -1156,6 +1226,18 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_flat(DevScene sc, Params p, Qu
         t_lit += (v0 && !occ0 ? 1u : 0u) + (v1 && !occ1 ? 1u : 0u);
     }
     flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);
+}
+template <int VAR>
+__global__ void __launch_bounds__(BLOCK) k_shadow_flat(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
+    shadow_flat_body<VAR>(sc, p, q, cnt, p.fix_par);
+}
+// The fix-up launch of a bounce, right after its hot extend kernel: the entries that kernel listed, and the shadow entries the PREVIOUS
+// bounce's hot shadow kernel listed (one extra launch per bounce instead of two: every launch boundary is a pipeline drain; a last one
+// after the final bounce, with an empty extend list, serves that bounce's shadow list).
+template <int SORTED>
+__global__ void __launch_bounds__(BLOCK) k_fix_flat(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
+    extend_flat_body<SORTED, 2>(sc, p, q, cnt, cur, n_src);
+    if (p.S > 0 && !p.volumetric_flat) shadow_flat_body<2>(sc, p, q, cnt, cur ^ 1);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_occluded_flat(DevScene sc, uint32_t n, const float* o_, const float* d_, const float* tmax, int* occ, LdsPlan plan) {

@@ -802,8 +802,14 @@ APT_D bool flat_needs_cull(const FlatScene& fl, f3 d) {
     return d.x == 0.f || d.y == 0.f || d.z == 0.f || (fl.n_spheres > 0 && fabsf(((d.x * d.x + d.y * d.y) + d.z * d.z) - 1.0f) > 1e-4f);
 }
 
-// Closest hits of the lane's two rays (search limits in rec0.t / rec1.t); cls0 / cls1 = material class of the hit primitive (-1: miss)
-APT_D void flat_closest2(const FlatScene& fl, const SweepScene& sw, const int* prim_class, f3 o0, f3 d0, f3 o1, f3 d1, HitRec& rec0, HitRec& rec1, int& cls0, int& cls1) {
+// Closest hits of the lane's two rays (search limits in rec0.t / rec1.t); cls0 / cls1 = material class of the hit primitive (-1: miss).
+// DEFER = true (the stage kernels' hot variant): the two rare cases whose answer needs the reference's own arithmetic - a near-tied
+// coplanar runner-up, a ray for which upstream's slab cull is part of the result - are NOT settled here: sp0 / sp1 report them and the
+// caller hands those entries to a follow-up launch (stages.hpp "fix-up lists").  Inlined, prim_test() and the reference-order sweep()
+// set the register allocation of the whole kernel: k_extend_flat 79 -> 52 VGPRs, k_shadow_flat 85 -> 44 without them - and the register
+// file, not issue slots or bandwidth, is what the three-lane pipeline runs out of.
+template <bool DEFER>
+APT_D void flat_closest2(const FlatScene& fl, const SweepScene& sw, const int* prim_class, f3 o0, f3 d0, f3 o1, f3 d1, HitRec& rec0, HitRec& rec1, int& cls0, int& cls1, bool& sp0, bool& sp1) {
     FlatRays q; q.ox = mk2(o0.x, o1.x); q.oy = mk2(o0.y, o1.y); q.oz = mk2(o0.z, o1.z); q.dx = mk2(d0.x, d1.x); q.dy = mk2(d0.y, d1.y); q.dz = mk2(d0.z, d1.z);
     FlatHit2 h; bool x0, x1;
     const float lim0 = rec0.t, lim1 = rec1.t;
@@ -811,6 +817,8 @@ APT_D void flat_closest2(const FlatScene& fl, const SweepScene& sw, const int* p
     cls0 = -1; cls1 = -1;
     if (h.idx0 >= 0) flat_resolve(fl, h.idx0, h.t.x, o0, d0, rec0, cls0);
     if (h.idx1 >= 0) flat_resolve(fl, h.idx1, h.t.y, o1, d1, rec1, cls1);
+    sp0 = sp1 = false;
+    if (DEFER) { sp0 = h.run0 >= 0 || flat_needs_cull(fl, d0); sp1 = h.run1 >= 0 || flat_needs_cull(fl, d1); return; }
     if (__any(h.run0 >= 0 || h.run1 >= 0)) {                 // only scenes with reachable coplanar faces ever get here
         if (h.run0 >= 0) flat_tie_break(fl, h.idx0, h.run0, h.t.x, lim0, o0, d0, rec0, cls0);
         if (h.run1 >= 0) flat_tie_break(fl, h.idx1, h.run1, h.t.y, lim1, o1, d1, rec1, cls1);
@@ -821,17 +829,26 @@ APT_D void flat_closest2(const FlatScene& fl, const SweepScene& sw, const int* p
         if (z1) { rec1.t = lim1; rec1.prim = -1; rec1.u = rec1.v = 0.f; sweep<false>(sw, o1, d1, rec1); cls1 = rec1.prim >= 0 ? prim_class[rec1.prim] : -1; }
     }
 }
-// Occlusion of the lane's two rays below lim0 / lim1
-APT_D void flat_any2(const FlatScene& fl, const SweepScene& sw, f3 o0, f3 d0, f3 o1, f3 d1, float lim0, float lim1, bool& occ0, bool& occ1) {
+APT_D void flat_closest2(const FlatScene& fl, const SweepScene& sw, const int* prim_class, f3 o0, f3 d0, f3 o1, f3 d1, HitRec& rec0, HitRec& rec1, int& cls0, int& cls1) {
+    bool a, b; flat_closest2<false>(fl, sw, prim_class, o0, d0, o1, d1, rec0, rec1, cls0, cls1, a, b);
+}
+// Occlusion of the lane's two rays below lim0 / lim1 (DEFER: see flat_closest2)
+template <bool DEFER>
+APT_D void flat_any2(const FlatScene& fl, const SweepScene& sw, f3 o0, f3 d0, f3 o1, f3 d1, float lim0, float lim1, bool& occ0, bool& occ1, bool& sp0, bool& sp1) {
     FlatRays q; q.ox = mk2(o0.x, o1.x); q.oy = mk2(o0.y, o1.y); q.oz = mk2(o0.z, o1.z); q.dx = mk2(d0.x, d1.x); q.dy = mk2(d0.y, d1.y); q.dz = mk2(d0.z, d1.z);
     FlatHit2 h;
     flat_loop<true>(fl, q, mk2(lim0, lim1), h, occ0, occ1);
     const bool z0 = flat_needs_cull(fl, d0), z1 = flat_needs_cull(fl, d1);
+    sp0 = sp1 = false;
+    if (DEFER) { sp0 = z0; sp1 = z1; return; }
     if (__any(z0 || z1)) {
         HitRec r; r.prim = -1; r.u = r.v = 0.f;
         if (z0) { r.t = lim0; occ0 = sweep<true>(sw, o0, d0, r); }
         if (z1) { r.t = lim1; occ1 = sweep<true>(sw, o1, d1, r); }
     }
+}
+APT_D void flat_any2(const FlatScene& fl, const SweepScene& sw, f3 o0, f3 d0, f3 o1, f3 d1, float lim0, float lim1, bool& occ0, bool& occ1) {
+    bool a, b; flat_any2<false>(fl, sw, o0, d0, o1, d1, lim0, lim1, occ0, occ1, a, b);
 }
 // one-ray adapters (volumetric transmittance walk, which keeps its one-entry-per-lane loop): the ray rides in both halves
 template <bool ANY>
