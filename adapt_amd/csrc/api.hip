@@ -450,6 +450,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
             for (int o = 0; o < O; o++) trans[(size_t)o] = bx[(size_t)o].is_bsdf ? 1 : 0;
             int fc[7];
             if (apt::build_flat(d->prims, N, d->obj_info, O, pcls.data(), trans.data(), fr, ft, fc) != 0) { delete s; return fail(APT_E_INVALID, "apt_scene_create: flat records: obj_info range outside the primitive array"); }
+            fl.defer_all = getenv("APT_FLAT_DEFER_ALL") ? atoi(getenv("APT_FLAT_DEFER_ALL")) : 0;
             fl.n_quads = fc[0]; fl.n_quads_tie = fc[1]; fl.n_gquads = fc[2]; fl.n_gquads_tie = fc[3]; fl.n_tris = fc[4]; fl.n_tris_tie = fc[5]; fl.n_spheres = fc[6];
             hipError_t e1_ = upload(s->flat_recs, fr), e2_ = (e1_ == hipSuccess) ? upload(s->flat_tab, ft) : e1_;
             if (e2_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload flat records: ") + hipGetErrorString(e2_)); }

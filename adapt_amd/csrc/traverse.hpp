@@ -629,6 +629,7 @@ struct FlatScene {
     const float4* tab;        // per record, 7 float4: (U, p0.x) (V, p0.y) | prim_a prim_b class_a class_b | map_a (u0 uu uv v0 vu vv) map_b (same) | (p0.z, -, -, -)
     const float* precom;      // n_prims * 9: (e1, e2, p0) per triangle - the reference's own test decides between near-tied coplanar candidates
     int n_quads, n_quads_tie, n_gquads, n_gquads_tie, n_tris, n_tris_tie, n_spheres;
+    int defer_all;            // test switch (APT_FLAT_DEFER_ALL=1 at scene creation): every ray takes the reference-order path - in the stage kernels, through the fix-up lists
 };
 #if APT_FAST
 APT_D v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
@@ -799,7 +800,7 @@ APT_D void flat_tie_break(const FlatScene& fl, int idx_win, int idx_run, float t
 //    18 % more energy in that picture when the cull was left out).
 // These rays re-run the reference-order sweep() after the flat loop.
 APT_D bool flat_needs_cull(const FlatScene& fl, f3 d) {
-    return d.x == 0.f || d.y == 0.f || d.z == 0.f || (fl.n_spheres > 0 && fabsf(((d.x * d.x + d.y * d.y) + d.z * d.z) - 1.0f) > 1e-4f);
+    return d.x == 0.f || d.y == 0.f || d.z == 0.f || (fl.n_spheres > 0 && fabsf(((d.x * d.x + d.y * d.y) + d.z * d.z) - 1.0f) > 1e-4f) || fl.defer_all != 0;
 }
 
 // Closest hits of the lane's two rays (search limits in rec0.t / rec1.t); cls0 / cls1 = material class of the hit primitive (-1: miss).

@@ -92,6 +92,28 @@ def _check_hits(prim, t, uv, prim_o, t_o, uv_o, is_tri, d, normals):
     assert np.abs(uv[tri] - uv_o[tri]).max() <= 5e-5 if tri.any() else True
 
 
+@pytest.mark.parametrize("tag,kw", [("cbox", {}), ("glass_box", {}), ("balls_mono", {}), ("balls_mono", {"num_shadow_ray": 1}), ("features_b", {}), ("textured", {"num_shadow_ray": 3})])
+def test_fix_up_lists_carry_every_ray_when_asked_to(tag, kw, renderer, monkeypatch):
+    """The hot flat kernels hand the rays they cannot settle to fix-up launches (stages.hpp "Fix-up lists").  APT_FLAT_DEFER_ALL=1 makes
+    EVERY ray such a ray: extend and shadow entries of all bounces then travel through the lists - unsorted and class-sorted, one light
+    sample per vertex and samples queued by vertex - and are resolved by the reference-order sweep, i.e. with the exact build's
+    arithmetic.  Where the exact build itself sweeps in reference order (every scene without a 6-primitive object takes its `sweep`
+    mode; the others its tiled twin, which returns the same hits), path statistics must then be the exact build's to the last count, and images
+    bit for bit (one light sample per vertex) or to the last bit of a differently associated sum (several)."""
+    w, h, spp = 48, 40, 6
+    e = renderer(tag, width=w, height=h, exact=True, **kw)
+    e.render(n_spp=spp); ref = e.color.to_numpy(); est = e.stats()
+    monkeypatch.setenv("APT_FLAT_DEFER_ALL", "1")
+    f = renderer(tag, width=w, height=h, **kw)
+    assert f.info()["traversal"] == "flat" and f.info()["arithmetic"] == "fast"
+    f.render(n_spp=spp); img = f.color.to_numpy(); st = f.stats()
+    for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"):
+        assert st[k] == est[k], (k, st[k], est[k])
+    if f.num_shadow_ray == 1: assert np.array_equal(img, ref, equal_nan=True)
+    else:                                     # several light samples per vertex: the product build adds a vertex's samples first, then the vertex to the slot
+        assert np.allclose(img, ref, rtol=1e-6, atol=1e-6 * float(np.nanmax(np.abs(ref))), equal_nan=True)     # (the exact build keeps one radiance plane per sample): the last bit of a sum
+
+
 FULL_SIZE = os.environ.get("APT_FULL_SIZE_PARITY") == "1"
 
 
