@@ -133,7 +133,8 @@ def load(variant: str | None = None):
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype, fn.argtypes = res, args
     tag = lib.apt_version()
-    if f"arithmetic: {v}".encode() not in tag and not os.environ.get("ADAPT_MI_LIB"):
+    overridden = os.environ.get("ADAPT_MI_LIB" if v == "fast" else "ADAPT_MI_LIB_EXACT")      # only the variant whose path was replaced skips the check
+    if f"arithmetic: {v}".encode() not in tag and not overridden:
         raise AptError(f"{path} reports {tag!r}: not the {v} build")
     _libs[v] = lib
     return lib

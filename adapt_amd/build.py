@@ -64,11 +64,17 @@ def build(force: bool = False, extra_flags=(), verbose: bool = False, variants=(
         if verbose:
             print(" ".join(cmd))
         procs.append((v, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
-    for v, pr in procs:
+    failures = []
+    for v, pr in procs:                      # every compile is waited for before anything is raised: no orphan hipcc, no half-written .tmp left behind
         out, err = pr.communicate()
         if pr.returncode != 0:
-            raise RuntimeError(f"hipcc failed for the {v} build ({pr.returncode}):\n{out}\n{err}")
-        os.replace(VARIANT_LIB[v] + ".tmp", VARIANT_LIB[v])
+            failures.append(f"hipcc failed for the {v} build ({pr.returncode}):\n{out}\n{err}")
+            if os.path.exists(VARIANT_LIB[v] + ".tmp"):
+                os.remove(VARIANT_LIB[v] + ".tmp")
+        else:
+            os.replace(VARIANT_LIB[v] + ".tmp", VARIANT_LIB[v])
+    if failures:
+        raise RuntimeError("\n".join(failures))
     return LIB
 
 

@@ -709,6 +709,9 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
         hipError_t e_ = pool.alloc(words * 4);
         if (e_ != hipSuccess) return e_;
+        // zero-filled once: some queue arrays are only written when somebody reads them (the flat extend kernel skips hit_u / hit_v unless
+        // vertex normals or textures need the barycentrics), and a kernel that loads them anyway must not see a previous renderer's bytes
+        if ((e_ = hipMemset(pool.p, 0, words * 4)) != hipSuccess) return e_;
         float* w = pool.as<float>();
         auto take = [&](size_t n) { float* x = w; w += n; return x; };
         for (int k = 0; k < 2; k++) { q.ray_o[k] = take(3 * cap); q.ray_d[k] = take(3 * cap); }

@@ -854,6 +854,11 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                 }
             }
             f3 spec;
+            // (pdf == 0 - a cosine-hemisphere draw of exactly 0, one in 2^24 - makes this spec / 0: +inf when the rounding residue of n_s . out is
+            // positive, NaN when it is not; upstream lets +inf through to the pixel and zeroes NaN.  The residue hangs on the last bits of the
+            // un-normalised interpolated vertex normal, i.e. of the barycentrics, which the product build's intersectors return to 1e-6 and not
+            // to the bit: DESIGN.md section 5 "non-finite pixels".  Re-sampling such a vertex here with the reference's own triangle test was
+            // measured: it costs the Lambertian kernel its fourth wave per SIMD, 122 -> 130 / 158 VGPRs inline / as a loop.)
             new_d = surface_sample<BM>(bx, it, d, sc.world_ior, p.two_sides, rng, spec, new_pdf, is_spec);
             thr = thr * (spec / new_pdf);
             cont = (bounce + 1) < p.max_bounce;

@@ -753,6 +753,16 @@ APT_D void flat_loop(const FlatScene& fl, const FlatRays& q, v2f lim, FlatHit2& 
         if (ANY) { o0 = o0 || flat_blocks(i0, ta, lim.x); o1 = o1 || flat_blocks(i1, tb, lim.y); }
         else { x = flat_candidate<false>(x, i0, ta, idx); y = flat_candidate<false>(y, i1, tb, idx); }
     }
+    // A runner-up only means something next to a winner from a coplanar-group section: the plain sections that run after a tie section
+    // (convex quads, triangles, spheres) replace the winner without looking at the runner, so a sphere or a plain face in front of a coplanar
+    // pair would otherwise end with the pair's stale runner and be "tie-broken" against a face far behind it.  Checked once per ray here
+    // instead of once per record in flat_candidate<false> (the hot loop of scenes without any coplanar group stays as it is).
+    if (!ANY && (fl.n_quads_tie | fl.n_gquads_tie | fl.n_tris_tie) != 0) {
+        const int a0 = fl.n_quads, a1 = a0 + fl.n_quads_tie, b0 = a1 + fl.n_gquads, b1 = b0 + fl.n_gquads_tie, c0 = b1 + fl.n_tris, c1 = c0 + fl.n_tris_tie;
+        const bool tx = (x.idx >= a0 && x.idx < a1) || (x.idx >= b0 && x.idx < b1) || (x.idx >= c0 && x.idx < c1);
+        const bool ty = (y.idx >= a0 && y.idx < a1) || (y.idx >= b0 && y.idx < b1) || (y.idx >= c0 && y.idx < c1);
+        x.runner = tx ? x.runner : -1; y.runner = ty ? y.runner : -1;
+    }
     h.t = mk2(x.t, y.t); h.idx0 = x.idx; h.idx1 = y.idx; h.run0 = x.runner; h.run1 = y.runner;
     occ0 = o0; occ1 = o1;
 }
@@ -776,6 +786,8 @@ APT_D void flat_resolve(const FlatScene& fl, int idx, float t, f3 o, f3 d, HitRe
 // the reference's order (primitive index) with its strict `t < min_depth` - i.e. what upstream's loop would have kept.
 APT_D void flat_tie_break(const FlatScene& fl, int idx_win, int idx_run, float t_flat, float lim, f3 o, f3 d, HitRec& rec, int& cls) {
     HitRec ra, rb; int ca, cb;
+    const int n_planar = fl.n_quads + fl.n_quads_tie + fl.n_gquads + fl.n_gquads_tie + fl.n_tris + fl.n_tris_tie;
+    if (idx_win >= n_planar || idx_run >= n_planar) { flat_resolve(fl, idx_win, t_flat, o, d, rec, cls); return; }     // (a sphere is never part of a coplanar group: flat_loop clears such runners; kept as a guard - prim_test below reads triangle records)
     flat_resolve(fl, idx_win, t_flat, o, d, ra, ca);
     flat_resolve(fl, idx_run, t_flat, o, d, rb, cb);          // (the runner-up's plane is the winner's: the same hit point picks its triangle)
     if (rb.prim < ra.prim) { const HitRec tr = ra; ra = rb; rb = tr; const int tc = ca; ca = cb; cb = tc; }     // ra: the earlier primitive

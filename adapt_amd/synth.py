@@ -80,6 +80,16 @@ class _Builder:
         self.objs: List[ObjDescriptor] = []
         self.prims, self.ng, self.ns, self.uvs = [], [], [], []
         self.area_of = {}
+        self.sphere_rows: List[int] = []
+
+    def sphere(self, centre, radius, material):
+        """one analytic sphere (packed as the parser packs it: centre, (r, r, r), 0 - xml_parser.parse_wavefront)"""
+        rec = np.zeros((1, 3, 3), np.float32)
+        rec[0, 0] = np.float32(centre); rec[0, 1] = np.float32(radius)
+        self.sphere_rows.append(sum(p.shape[0] for p in self.prims))
+        self.prims.append(rec); self.ng.append(np.float32([[0, 1, 0]])); self.ns.append(np.zeros((1, 3, 3), np.float32)); self.uvs.append(np.zeros((1, 3, 2), np.float32))
+        self.objs.append(ObjDescriptor(rec, np.float32([[0, 1, 0]]), material, None, None, {"albedo": None, "normal": None, "bump": None, "roughness": None},
+                                       None, None, -1, 1))
 
     def mesh(self, tris, material, vns=None, emitter=-1):
         tris = np.ascontiguousarray(tris, np.float32)
@@ -115,7 +125,7 @@ class _Builder:
             if i in self.area_of:
                 em.inv_area = 1. / self.area_of[i]
                 em.attached = True
-        arr = {"primitives": np.concatenate(self.prims).astype(np.float32), "indices": None,
+        arr = {"primitives": np.concatenate(self.prims).astype(np.float32), "indices": np.int64(self.sphere_rows) if self.sphere_rows else None,
                "n_g": np.concatenate(self.ng).astype(np.float32), "n_s": np.concatenate(self.ns).astype(np.float32),
                "uvs": np.concatenate(self.uvs).astype(np.float32)}
         return emitters, arr, self.objs, cfg

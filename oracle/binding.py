@@ -173,6 +173,28 @@ class OracleScene:
                                C.byref(ne), C.byref(nd))
         return col, ev[:ne.value].copy(), nd.value
 
+    def explain_non_finite(self, rc, a, b, n_spp: int, max_pixels: int = 16):
+        """Pixels whose finiteness differs between a HIP render `a` and this oracle's render `b` of the same samples: for each, the samples
+        whose throughput stops being finite at a path vertex - a sampled direction with pdf == 0 (a cosine-hemisphere draw of exactly 0,
+        one in 2^24), after which the throughput is spec / 0: +inf if the rounding residue of n_s . out is positive, NaN (zeroed at the end,
+        vanilla_renderer.py:119) if it is not.  That residue hangs on the last bits of the barycentrics the un-normalised vertex normal is
+        interpolated with, which the product build's intersectors return to 1e-6 relative, not to the bit: a
+        knife-edge the stated intersector tolerance cannot pin.  Returns (explained, findings): explained = every mismatching pixel has
+        such a vertex among its samples."""
+        bad = np.argwhere(np.isfinite(a).all(axis=2) != np.isfinite(b).all(axis=2))
+        findings, explained = [], True
+        for i, j in bad[:max_pixels]:
+            hits = []
+            for cnt in range(1, int(n_spp) + 1):
+                col, ev, nd = self.trace_sample(rc, int(i), int(j), cnt)
+                fin = np.isfinite(ev[:, 9:12]).all(axis=1) if len(ev) else np.zeros(0, bool)
+                k = np.flatnonzero(~fin)
+                if len(k) and k[0] > 0:
+                    hits.append({"sample": cnt, "vertex": int(k[0]) - 1, "throughput_after": [float(x) for x in ev[k[0], 9:12]], "sample_colour_finite": bool(np.isfinite(col).all())})
+            findings.append({"pixel": [int(i), int(j)], "zero_pdf_vertices": hits})
+            explained = explained and len(hits) > 0
+        return bool(explained and len(bad) <= max_pixels), findings
+
     def intersect(self, o, d, use_bvh=False):
         o, d = _f3(o).reshape(-1, 3), _f3(d).reshape(-1, 3)
         n = o.shape[0]

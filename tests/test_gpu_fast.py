@@ -138,6 +138,47 @@ def test_full_size_parity_c2_c3_product_build(tag, spp, renderer, parsed, oracle
     assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-4, m
     for k in ("n_shade", "n_shadow", "n_draws"):
         assert abs(st[k] - ost[k]) <= 5e-4 * ost[k], (k, st[k], ost[k])
+    # non-finite pixels (upstream lets +inf through, vanilla_renderer.py:119): the oracle's, or zero-pdf knife-edges and nothing else
+    if not np.array_equal(np.isfinite(acc), np.isfinite(ref)):
+        ok, findings = oracle_scene(tag).explain_non_finite(rc, acc, ref, spp)
+        assert ok, findings
+
+
+def test_the_one_non_finite_pixel_of_c2_is_a_zero_pdf_knife_edge(renderer, parsed, oracle_scene):
+    """BENCH_r03's parity leg: pixel (215, 277) of C2 is inf in the oracle's 512-spp render and finite in the product build's.  Sample 508
+    of that pixel draws a cosine-hemisphere variate of exactly 0 at its first vertex (Philox word 0x000000a9 >> 8): pdf = 0, throughput =
+    spec / 0 = +inf or NaN by the sign of the rounding residue of n_s . out, which hangs on the last bits of the barycentrics the
+    un-normalised vertex normal is interpolated with.  The exact build computes them with the reference's arithmetic and reproduces the
+    oracle's inf; the product build's intersector returns them to 1e-6 and may land on either side - the mismatch class
+    bench.py accepts (and the only one: oracle/binding.py explain_non_finite).  Rendered here as a one-pixel crop with the sample counter
+    set to 507, so that the one sample rendered IS sample 508."""
+    from adapt_amd.renderer import Renderer
+    from oracle import binding as ob
+    i, j, cnt = 215, 277, 508
+    words = ob.rng_stream(i * 512 + j, 0, cnt, 4)
+    assert int(words[3]) >> 8 == 0                                                  # the draw behind it: jitter x, jitter y, light pick, THEN the cosine variate
+    em, arr, objs, cfg = parsed("cbox")
+    cfg = dict(cfg); cfg["film"] = {"width": 512, "height": 512, "crop_x": i, "crop_y": j, "crop_rx": 1, "crop_ry": 1}
+    rc = make_config(cfg)
+    assert rc.do_crop and rc.start_x <= i < rc.end_x and rc.start_y <= j < rc.end_y
+    col, ev, nd = oracle_scene("cbox").trace_sample(rc, i, j, cnt)
+    assert np.isinf(col).all() and np.isfinite(ev[0, 9:12]).all() and np.isinf(ev[1, 9:12]).all()      # throughput 1 at the first vertex, +inf after its sample
+    out = {}
+    for exact in (True, False):
+        r = Renderer(em, arr, objs, cfg, exact=exact)
+        try:
+            r.cnt[None] = cnt - 1
+            r.render(n_spp=1)
+            out[exact] = r.color.to_numpy()[i, j].copy()
+            assert r.stats()["n_samples"] == (rc.end_x - rc.start_x) * (rc.end_y - rc.start_y)
+        finally:
+            r.close()
+    assert np.isinf(out[True]).all()                                                 # exact build: the reference's barycentrics, the reference's inf
+    assert np.isinf(out[False]).all() or np.isfinite(out[False]).all()              # product build: either side of the knife-edge, never a NaN in the framebuffer
+    a = np.zeros((512, 512, 3), np.float32); b = a.copy(); b[i, j] = col; a[i, j] = out[False]
+    if not np.isinf(out[False]).all():
+        ok, findings = oracle_scene("cbox").explain_non_finite(rc, a, b, cnt)
+        assert ok and findings[0]["zero_pdf_vertices"][-1]["sample"] == cnt and findings[0]["zero_pdf_vertices"][-1]["vertex"] == 0, findings
 
 
 def _quad_soup(seed):
@@ -206,6 +247,57 @@ def test_flat_records_of_merged_triangle_pairs_answer_as_the_exact_build(seed):
         assert (prim_o >= 0).mean() > 0.2
         _check_hits(prim, t, uv, prim_o, t_o, uv_o, np.ones(len(prim), bool), d, f.flat.normals)
         assert (f.occluded(o, d, tmax) != e.occluded(o, d, tmax)).sum() <= 3
+    finally:
+        f.close(); e.close()
+
+
+def _decal_scene():
+    """A floor with a decal lying exactly in its plane (a coplanar group: both quads sit in the flat sweep's tie sections), and in FRONT of
+    the pair a ball, a lone triangle and a convex quad - records of the plain sections that run after the tie sections."""
+    from adapt_amd import synth
+    b = synth._Builder()
+    white, red = synth._brdf("lambertian", "#BDBDBD"), synth._brdf("lambertian", "#DD2525")
+
+    def quad(p0, e1, e2):
+        p0, e1, e2 = np.float64(p0), np.float64(e1), np.float64(e2)
+        return np.float32([[p0, p0 + e1, p0 + e1 + e2], [p0, p0 + e1 + e2, p0 + e2]])
+    b.mesh(quad((0.5, 0.0, 0.5), (4.5, 0, 0), (0, 0, 4.5)), white)                       # floor
+    b.mesh(quad((1.5, 0.0, 1.5), (2.5, 0, 0), (0, 0, 2.5)), red)                         # decal, same plane
+    b.sphere((2.7, 1.0, 2.7), 0.7, white)
+    b.mesh(np.float32([[(1.0, 0.6, 1.0), (2.2, 0.6, 1.1), (1.3, 0.6, 2.4)]]), red)      # lone triangle over the decal's corner
+    p = np.float64([(3.2, 0.5, 3.1), (4.4, 0.5, 3.3), (4.6, 0.5, 4.5), (3.0, 0.5, 4.0)])  # convex quadrilateral, not a parallelogram
+    b.mesh(np.float32([[p[0], p[1], p[2]], [p[0], p[2], p[3]]]), white)
+    em = [synth._spot("6.0, 6.0, 6.0", "100.0", (2.7, 5.0, 2.7), (0.0, -1.0, 0.0), 40.0, "s")]
+    return b.finish(em, synth._sensor(64, 64, 4, 1))
+
+
+def test_a_sphere_or_plain_face_in_front_of_a_coplanar_pair_keeps_its_hit():
+    """the plain record sections run after the coplanar-group sections and used to leave the pair's runner-up behind; the fix-up
+    pass then 'tie-broke' the ball against the decal far behind it and the ray went through the ball."""
+    from adapt_amd.renderer import Renderer
+    tup = _decal_scene()
+    rs = np.random.RandomState(11)
+    n = 100000
+    o = rs.uniform([0.6, 2.0, 0.6], [4.9, 4.0, 4.9], size=(n, 3)).astype(np.float32)
+    tgt = rs.uniform([0.6, 0.0, 0.6], [4.9, 0.0, 4.9], size=(n, 3)).astype(np.float32)
+    d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tmax = rs.uniform(0.5, 6.0, n).astype(np.float32)
+    f = Renderer(*tup, width=32, height=32)
+    e = Renderer(*tup, width=32, height=32, exact=True)
+    try:
+        assert f.info()["traversal"] == "flat" and e.info()["arithmetic"] == "exact"
+        prim, t, uv = f.intersect(o, d)
+        prim_o, t_o, uv_o = e.intersect(o, d)
+        is_tri = prim_o != 4                                                            # primitive 4 is the ball
+        assert (prim_o == 4).mean() > 0.05 and (prim_o == 5).mean() > 0.01              # the ball (primitive 4) and the lone triangle are in front of the pair often enough
+        assert np.array_equal(prim == 4, prim_o == 4)                                     # no ray passes through the ball
+        _check_hits(prim, t, uv, prim_o, t_o, uv_o, is_tri, d, f.flat.normals)
+        assert (f.occluded(o, d, tmax) != e.occluded(o, d, tmax)).sum() <= 3
+        # and through the render pipeline (hot kernel + fix-up lists): same path statistics as the exact build
+        f.render(n_spp=8); e.render(n_spp=8)
+        sf, se = f.stats(), e.stats()
+        for k in ("n_shade", "n_shadow", "n_draws"):
+            assert abs(sf[k] - se[k]) <= max(5e-4 * se[k], 20), (k, sf[k], se[k])
     finally:
         f.close(); e.close()
 
@@ -329,6 +421,33 @@ def test_statistical_cross_check_other_seed(tag, renderer, parsed, oracle_scene)
     assert rel(hip, cpu[0]) <= (1e-4 if tag != "textured" else 1e-2 * noise) < noise              # and on the SAME seed it is the same image, far below the noise floor
 
 
+@pytest.mark.parametrize("tag,spp", [("textured", 1024), ("features_a", 2048), ("cbox", 2048), ("glass_box", 1024)])
+def test_no_systematic_difference_between_the_builds(tag, spp, renderer):
+    """The bias probe of round 3 (tools/gpu_bias_probe.py, profiles/r03_bias_probe.log) as a test: at a sample count where the per-pixel
+    chaos of ulp-level hit differences averages out, the product build shades the same number of vertices as the exact build on the same
+    stream to 3e-4 (measured: textured -2.3e-4, features_a +1.6e-4 - the share of rays that re-hit the surface they start on moves with
+    the intersector's last bits - everything else below 6e-5), carries the same energy to 1e-3, and its image differs from the exact
+    build's by far less than two seeds of the exact build differ from each other."""
+    w, h = 64, 48
+    res = {}
+    for key, exact, seed in (("fast", False, 0), ("exact", True, 0), ("exact1", True, 1)):
+        r = renderer(tag, width=w, height=h, exact=exact, seed=seed)
+        r.render(n_spp=spp)
+        img = r.pixels.to_numpy().astype(np.float64)
+        img[~np.isfinite(img).all(axis=2)] = 0.0
+        res[key] = (img, r.stats())
+        r.close()
+    (f, sf), (e, se), (e1, _) = res["fast"], res["exact"], res["exact1"]
+    for k in ("n_shade", "n_shadow", "n_draws"):
+        assert abs(sf[k] - se[k]) <= 3e-4 * se[k], (tag, k, sf[k], se[k], (sf[k] - se[k]) / se[k])
+    assert abs(f.mean() - e.mean()) <= 1e-3 * e.mean(), (f.mean(), e.mean())
+
+    def rel(a, b):
+        return float(np.mean((a - b) ** 2 / (b ** 2 + 1e-2)))
+    noise = rel(e, e1)
+    assert rel(f, e) <= 0.02 * noise, (rel(f, e), noise)
+
+
 def test_determinism_batches_lanes_and_partitions(renderer, parsed, monkeypatch):
     """the product build is bit-reproducible, and its image does not depend on batch size, render lanes or the rank partition"""
     from adapt_amd.tiles import assemble
@@ -419,6 +538,57 @@ def test_volumetric_tracer_through_the_flat_sweep(parsed, oracle_scene):
             assert abs(st[k] - ost[k]) <= 1e-3 * ost[k], (k, st[k], ost[k])
     finally:
         r.close()
+
+
+# ---- product-build twins of the exact module's volumetric and large-scene cases (tests/gpu_cases.py: same bodies, this build's tolerances)
+from conftest import VPT_SCENE_TAGS  # noqa: E402
+
+
+@pytest.mark.parametrize("tag", VPT_SCENE_TAGS)
+def test_volumetric_product_build_vs_reference_run_and_oracle(tag):
+    """`render.py --type vpt` and `bench.py --config v1..v3` run THIS build: its closest-hit queries go through the flat sweep (hot kernel +
+    fix-up lists) where the exact build runs the reference's loop.  All five vpt scenes against the reference-run fixtures and the oracle."""
+    from gpu_cases import volumetric_scene_vs_reference_run_and_oracle
+    info = volumetric_scene_vs_reference_run_and_oracle(tag, within=0.97, rel=2e-3, draws_tol=3e-3, stat_tol=1e-3)
+    assert info["arithmetic"] == "fast"
+
+
+@pytest.mark.parametrize("name", ["volgrid_a", "volgrid_b"])
+def test_grid_volume_product_build_vs_reference_run_and_oracle(name):
+    from gpu_cases import grid_volume_vs_reference_run_and_oracle
+    info = grid_volume_vs_reference_run_and_oracle(name, within=0.97, rel=3e-3, draws_tol=4e-3, stat_tol=3e-3)
+    assert info["arithmetic"] == "fast"
+
+
+def test_full_size_c4_crop_product_build_vs_brute_force_oracle():
+    """BASELINE configs[3] at full geometry on the build bench.py measures (its BVH walk may differ from the exact build's inside SURVEY
+    8(d)'s intersector tolerance: this is the test that holds it to the oracle, not a tie to the exact build on a toy scene)."""
+    from gpu_cases import c4_crop_vs_brute_force_oracle
+    assert c4_crop_vs_brute_force_oracle(within=0.985, rel=3e-4)["arithmetic"] == "fast"
+
+
+@pytest.mark.parametrize("cx,cy", [(640, 360), (330, 250), (930, 200)])
+def test_full_size_c5_crop_product_build_vs_brute_force_oracle(cx, cy):
+    from gpu_cases import c5_crop_vs_brute_force_oracle
+    assert c5_crop_vs_brute_force_oracle(cx, cy, within=0.985, rel=3e-4)["arithmetic"] == "fast"
+
+
+@pytest.mark.parametrize("tag,mode", [("cbox", "tile"), ("balls_mono", "sweep"), ("features_b", "tile"), ("glass_box", "bvh"), ("features_a", "sweep")])
+def test_shipped_library_is_bit_checked_where_it_runs_the_reference_arithmetic(tag, mode, renderer, monkeypatch):
+    """the bit-exact parity tests run on libadapt_mi_exact.so, the library that ships is libadapt_mi.so.  With APT_TRAVERSAL forced
+    to one of the exact build's intersectors the shipped library executes the same arithmetic in every stage - queues, class sorting, shading,
+    radiance slots, finalize - so its image and path statistics must be the exact build's bit for bit (one light sample per vertex or
+    radiance planes; more than four samples would be float atomics)."""
+    w, h, spp = 64, 48, 5
+    monkeypatch.setenv("APT_TRAVERSAL", mode)
+    e = renderer(tag, width=w, height=h, exact=True)
+    f = renderer(tag, width=w, height=h)
+    assert f.info()["arithmetic"] == "fast" and f.info()["traversal"] == mode == e.info()["traversal"], (f.info(), e.info())
+    e.render(n_spp=spp); f.render(n_spp=spp)
+    se, sf = e.stats(), f.stats()
+    for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"):
+        assert sf[k] == se[k], (k, sf[k], se[k])
+    assert np.array_equal(f.color.to_numpy(), e.color.to_numpy(), equal_nan=True)
 
 
 def test_the_two_builds_agree_bit_for_bit_where_they_run_the_same_code():

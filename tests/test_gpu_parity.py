@@ -547,34 +547,9 @@ def test_rccl_gather_path_on_one_gpu(renderer):
 
 
 def test_full_size_c4_crop_matches_brute_force_oracle():
-    """Full 95 050-triangle scene, a cropped window, HIP (BVH traversal) vs the oracle's BRUTE-FORCE intersector: the
-    HIP tree returns the brute-force hit.  (The reference's own BVH, as restated in the oracle, drops ~2e-4 of the hits
-    on this scene — its node boxes are unpadded — so it is compared statistically below, not per pixel.)"""
-    from adapt_amd.renderer import Renderer
-    from adapt_amd.scene_pack import pack_scene
-    from adapt_amd.synth import three_bunnies
-    from oracle import binding as ob
-    em, arr, objs, cfg = three_bunnies()
-    cfg = dict(cfg); cfg["film"] = {"width": 800, "height": 800, "crop_x": 330, "crop_y": 250, "crop_rx": 20, "crop_ry": 14}
-    r = Renderer(em, arr, objs, cfg)
-    r.render(n_spp=2)
-    img = r.color.to_numpy()[310:350, 236:264]
-    rc = make_config(cfg)
-    assert rc.do_crop and rc.use_bvh
-    sc = ob.OracleScene(pack_scene(em, arr, objs, cfg), rc.cam_t, build_bvh=True)
-    rc.use_bvh = False
-    ref, _, ost = sc.render(rc, 2)
-    m = image_metrics(img / 2, ref[310:350, 236:264] / 2)
-    st = r.stats()
-    assert st["n_samples"] == ost["n_samples"] == 2 * 40 * 28
-    assert m["frac_within"] >= 0.99 and m["relMSE"] <= 2e-4, m
-    assert abs(st["n_draws"] - ost["n_draws"]) <= 2e-3 * ost["n_draws"]
-    # reference-layout BVH in the oracle: same picture up to its rare lost hits
-    rc.use_bvh = True
-    ref_bvh, _, _ = sc.render(rc, 2)
-    mb = image_metrics(img / 2, ref_bvh[310:350, 236:264] / 2)
-    assert mb["frac_within"] >= 0.97, mb
-    r.close()
+    """tests/gpu_cases.py c4_crop_vs_brute_force_oracle on the exact build"""
+    from gpu_cases import c4_crop_vs_brute_force_oracle
+    assert c4_crop_vs_brute_force_oracle()["arithmetic"] == "exact"
 
 
 def test_full_size_c5_scene_properties():
@@ -607,30 +582,9 @@ def test_full_size_c5_scene_properties():
 
 @pytest.mark.parametrize("cx,cy", [(640, 360), (330, 250), (930, 200)])
 def test_full_size_c5_crop_matches_brute_force_oracle(cx, cy):
-    """Full 285 134-triangle scene, cropped windows of 96 x 64 pixels x 4 spp, 16 bounces: HIP (own BVH) vs the oracle's BRUTE-FORCE
-    intersector on the same Philox stream - per pixel, plus exact sample counts and path statistics to 2e-3."""
-    from adapt_amd.renderer import Renderer
-    from adapt_amd.scene_pack import pack_scene
-    from adapt_amd.synth import bunny_field
-    from oracle import binding as ob
-    em, arr, objs, cfg = bunny_field()
-    cfg = dict(cfg); cfg["film"] = {"width": 1280, "height": 720, "crop_x": cx, "crop_y": cy, "crop_rx": 48, "crop_ry": 32}
-    r = Renderer(em, arr, objs, cfg)
-    r.render(n_spp=4)
-    rc = make_config(cfg)
-    assert rc.do_crop and rc.use_bvh and (rc.end_x - rc.start_x, rc.end_y - rc.start_y) == (96, 64)
-    win = (slice(rc.start_x, rc.end_x), slice(rc.start_y, rc.end_y))
-    img = r.color.to_numpy()[win]
-    sc = ob.OracleScene(pack_scene(em, arr, objs, cfg), rc.cam_t, build_bvh=False)
-    rc.use_bvh = False
-    ref, _, ost = sc.render(rc, 4)
-    m = image_metrics(img / 4, ref[win] / 4)
-    st = r.stats()
-    assert st["n_samples"] == ost["n_samples"] == 4 * 96 * 64
-    assert m["frac_within"] >= 0.99 and m["relMSE"] <= 2e-4, m
-    for k in ("n_shade", "n_shadow", "n_draws"):
-        assert abs(st[k] - ost[k]) <= 2e-3 * ost[k], (k, st[k], ost[k])
-    r.close()
+    """tests/gpu_cases.py c5_crop_vs_brute_force_oracle on the exact build"""
+    from gpu_cases import c5_crop_vs_brute_force_oracle
+    assert c5_crop_vs_brute_force_oracle(cx, cy)["arithmetic"] == "exact"
 
 
 def test_full_size_properties_c3(renderer):
@@ -761,34 +715,9 @@ from conftest import VPT_SCENE_TAGS  # noqa: E402
 
 @pytest.mark.parametrize("tag", VPT_SCENE_TAGS)
 def test_volumetric_hip_vs_reference_run_and_oracle(tag):
-    """The reference's three vpt scenes + the two media coverage scenes of this repo: (a) against the image the reference's own
-    VolumeRenderer.render produced on the same Philox stream (fixture), (b) against the oracle at more samples, where the path
-    structure has to agree too: vertices shaded, light samples taken and random numbers drawn."""
-    from adapt_amd.renderer import VolumeRenderer
-    from adapt_amd.scene_pack import make_config, pack_scene
-    from oracle import binding as ob
-    tup, g = scene_from_golden(tag, "vptscene")
-    w, h, spp = int(g["width"]), int(g["height"]), int(g["spp"])
-    r = VolumeRenderer(*tup, width=w, height=h)
-    try:
-        assert r.info()["shade_variant"].startswith("volumetric")
-        r.render(n_spp=spp)
-        m = image_metrics(r.color.to_numpy() / spp, g["accum"] / spp)
-        assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-3, (tag, m)
-        assert abs(r.stats()["n_draws"] - int(g["draws"].sum())) <= 2e-3 * int(g["draws"].sum())
-        r.clear(); r.render(n_spp=16)
-        rc = make_config(tup[3], width=w, height=h, volumetric=True)
-        ref, _, ost = ob.OracleScene(pack_scene(*tup), rc.cam_t).render(rc, 16)
-        m = image_metrics(r.color.to_numpy() / 16, ref / 16)
-        assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-3, (tag, m)
-        st = r.stats()
-        for k in ("n_shade", "n_shadow", "n_draws"):
-            assert abs(st[k] - ost[k]) <= 5e-4 * ost[k], (tag, k, st[k], ost[k])
-        assert st["n_samples"] == ost["n_samples"] == w * h * 16
-        # the walk only follows light samples that can contribute, the reference follows all of them
-        assert 0 < st["n_track"] <= ost["n_track"] and st["n_lit"] <= ost["n_lit"]
-    finally:
-        r.close()
+    """tests/gpu_cases.py volumetric_scene_vs_reference_run_and_oracle on the exact build"""
+    from gpu_cases import volumetric_scene_vs_reference_run_and_oracle
+    assert volumetric_scene_vs_reference_run_and_oracle(tag)["arithmetic"] == "exact"
 
 
 @pytest.mark.parametrize("mode", ["bvh", "sweep", "tile"])
@@ -900,40 +829,9 @@ def test_volumetric_tracer_on_scenes_without_media(tag, renderer, parsed, oracle
 
 @pytest.mark.parametrize("name", ["volgrid_a", "volgrid_b"])
 def test_grid_volume_hip_vs_reference_run_and_oracle(name):
-    """Grid volumes on the device: delta tracking in the free-path step and ratio tracking inside the light sampling draw from the
-    path's own Philox stream in the reference's order, so image, vertices shaded, light samples and draw counts follow the oracle
-    (and the reference-run fixture) like every other scene."""
-    import os
-    from conftest import ROOT
-    from adapt_amd.parsers.xml_parser import scene_parsing
-    from adapt_amd.renderer import VolumeRenderer
-    from adapt_amd.scene_pack import pack_scene
-    from oracle import binding as ob
-    g = golden(f"vptrun_{name}.npz")
-    cwd = os.getcwd(); os.chdir(ROOT)
-    try:
-        tup = scene_parsing(os.path.join(ROOT, "scenes", "test"), name + ".xml")
-        w, h, spp = int(g["width"]), int(g["height"]), int(g["spp"])
-        r = VolumeRenderer(*tup, width=w, height=h)
-        fs = pack_scene(*tup)
-    finally:
-        os.chdir(cwd)
-    try:
-        assert "grid volume" in r.info()["shade_variant"]
-        r.render(n_spp=spp)
-        m = image_metrics(r.color.to_numpy() / spp, g["accum"] / spp)
-        assert m["frac_within"] >= 0.985 and m["relMSE"] <= 2e-3, (name, m)
-        assert abs(r.stats()["n_draws"] - int(g["draws"].sum())) <= 3e-3 * int(g["draws"].sum())
-        r.clear(); r.render(n_spp=16)
-        rc = make_config(tup[3], width=w, height=h, volumetric=True)
-        ref, _, ost = ob.OracleScene(fs, rc.cam_t).render(rc, 16)
-        m = image_metrics(r.color.to_numpy() / 16, ref / 16)
-        assert m["frac_within"] >= 0.985 and m["relMSE"] <= 2e-3, (name, m)
-        st = r.stats()
-        for k in ("n_shade", "n_shadow", "n_draws"):
-            assert abs(st[k] - ost[k]) <= 2e-3 * ost[k], (name, k, st[k], ost[k])
-    finally:
-        r.close()
+    """tests/gpu_cases.py grid_volume_vs_reference_run_and_oracle on the exact build"""
+    from gpu_cases import grid_volume_vs_reference_run_and_oracle
+    assert grid_volume_vs_reference_run_and_oracle(name)["arithmetic"] == "exact"
 
 
 def test_full_size_properties_volumetric_fog_box():
