@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -140,7 +141,7 @@ struct apt_scene {
     DevScene dev{};
     apt::BvhData bvh;                    // binary SAH tree (leaves of <= 3 primitives): the intermediate of the build
     apt::WideBvhData wide;               // 8-wide quantised tree: what the kernels walk
-    DevBuf nodes, prims, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
+    DevBuf nodes, prims, slot_prim, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
     DevBuf flat_recs, flat_tab;          // flat sweep (fast build, small scenes): records and the per-record table (traverse.hpp FlatScene)
     bool has_flat = false;
     DevBuf uvs, tex_i, tex_f, atlas[3];      // image textures (empty when the scene has none)
@@ -318,7 +319,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     s->device = device;
     const int N = d->n_prims, O = d->n_objects, S = d->n_sources;
     // the walk addresses primitive (48 B) and node (80 B, at most one per primitive) records with 32-bit byte offsets (traverse.hpp)
-    if ((uint64_t)N * 80ull >= (1ull << 32)) { delete s; return fail(APT_E_INVALID, "apt_scene_create: more than 53 687 091 primitives (32-bit record offsets)"); }
+    if ((uint64_t)N * (uint64_t)APT_NODE_BYTES >= (1ull << 32)) { delete s; return fail(APT_E_INVALID, "apt_scene_create: more than 53 687 091 primitives (32-bit record offsets)"); }
     s->n_prims = N; s->n_objects = O; s->n_sources = S;
     const bool timing = getenv("APT_SCENE_TIMING") != nullptr;      // stderr: where apt_scene_create spends its time
     auto t_prev = std::chrono::steady_clock::now();
@@ -368,9 +369,16 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         int k = s->wide.prim_order[(size_t)slot];
         const float* v = d->prims + 9 * (size_t)k; const float* pc = prec.data() + 9 * (size_t)k; float* r = recs.data() + 12 * (size_t)slot;
         int32_t kid = k, flag = sphere[(size_t)k] ? 1 : 0;
+#if APT_FAST
+        // product build: precomputed-transform records without an id (traverse.hpp tri_two; the walk reports leaf slots, DevBvh::slot_prim)
+        (void)pc; (void)kid;
+        if (flag) { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = std::numeric_limits<float>::quiet_NaN(); r[4] = v[3]; }
+        else apt::planar_rows(v, r);
+#else
         if (flag) { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; }
         else { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = pc[0]; r[4] = pc[1]; r[5] = pc[2]; r[6] = pc[3]; r[7] = pc[4]; r[8] = pc[5]; }
         memcpy(&r[9], &kid, 4); memcpy(&r[10], &flag, 4);
+#endif
     });
     tick("primitive records");
     // sweep stream in scene order (layout: traverse.hpp SweepScene); the t-row cofactors of [e1 e2 .] are
@@ -476,10 +484,10 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     if (d->v_normals) vn.assign(d->v_normals, d->v_normals + (size_t)N * 9);
     std::vector<int> oi(d->obj_info, d->obj_info + (size_t)O * 3), ei(d->emitter_id, d->emitter_id + (size_t)O);
 #define UP(buf, vec) do { hipError_t e_ = upload(s->buf, vec); if (e_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload " #buf ": ") + hipGetErrorString(e_)); } } while (0)
-    UP(nodes, s->wide.nodes); UP(prims, recs); UP(normals, nrm); UP(vnormals, vn); UP(precom, prec); UP(prim_obj, prim_obj);
+    UP(nodes, s->wide.nodes); UP(prims, recs); UP(slot_prim, s->wide.prim_order); UP(normals, nrm); UP(vnormals, vn); UP(precom, prec); UP(prim_obj, prim_obj);
     UP(obj_info, oi); UP(emitter_id, ei); UP(bxdf, bx); UP(src, sr); UP(sweep_recs, sw); UP(sweep_tab, sw_tab); UP(obj_aabb, aabb);
     DevScene& ds = s->dev;
-    ds.bvh.nodes = s->nodes.as<uint4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.n_nodes = s->wide.n_nodes(); ds.bvh.n_prims = N;
+    ds.bvh.nodes = s->nodes.as<uint4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.slot_prim = s->slot_prim.as<int>(); ds.bvh.n_nodes = s->wide.n_nodes(); ds.bvh.n_prims = N;
     ds.sweep.stream = s->sweep_recs.as<float>(); ds.sweep.obj_tab = s->sweep_tab.as<int>(); ds.sweep.prim_obj = s->prim_obj.as<int>(); ds.sweep.n_objects = O;
     s->has_aabb = d->obj_aabb != nullptr;
     ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float>(); ds.precom = s->precom.as<float>();
@@ -711,6 +719,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         if (e_ != hipSuccess) return e_;
         // zero-filled once: some queue arrays are only written when somebody reads them (the flat extend kernel skips hit_u / hit_v unless
         // vertex normals or textures need the barycentrics), and a kernel that loads them anyway must not see a previous renderer's bytes
+        // (hipMemset runs on the null stream and does not wait on the host; the render lanes are non-blocking streams that do not
+        // synchronise with it: the hipDeviceSynchronize() after the last pool is carved is what orders the fill before the first launch)
         if ((e_ = hipMemset(pool.p, 0, words * 4)) != hipSuccess) return e_;
         float* w = pool.as<float>();
         auto take = [&](size_t n) { float* x = w; w += n; return x; };
@@ -738,6 +748,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     for (auto& ln : r->extra) {
         if ((e = carve(ln.pool, ln.q)) != hipSuccess || (e = ln.counters.alloc(sizeof(Counters))) != hipSuccess) { return fail(APT_E_NOMEM, std::string("queue pool (lane): ") + hipGetErrorString(e)); }
     }
+    HIP_TRY(hipDeviceSynchronize());
     if ((e = r->counters.alloc(sizeof(Counters))) != hipSuccess || (e = r->accum.alloc((size_t)r->npix * 12)) != hipSuccess ||
         (e = r->scratch.alloc((size_t)r->npix * 12)) != hipSuccess) { return fail(APT_E_NOMEM, std::string("framebuffer: ") + hipGetErrorString(e)); }
     HIP_TRY(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));

@@ -6,6 +6,10 @@
 #include <thread>
 #include <vector>
 
+#ifndef APT_NODE_BYTES
+#define APT_NODE_BYTES 80u
+#endif
+#define APT_NODE_DWORDS (APT_NODE_BYTES / 4u)
 namespace apt {
 // Host threads for the per-primitive and per-node loops of scene creation (tree build, collapse, record packing): the machine's, at most
 // 32, or APT_HOST_THREADS.  Results never depend on the count.
@@ -45,10 +49,10 @@ int build_bvh_gpu(const float* prims, int n_prims, const int32_t* obj_info, int 
 
 // 8-wide tree with quantised child boxes, what the traversal kernels walk (bvh_wide.cpp; layout in traverse.hpp).
 struct WideBvhData {
-    std::vector<uint32_t> nodes;       // 20 dwords (80 bytes) per node, node 0 = root, breadth-first
+    std::vector<uint32_t> nodes;       // APT_NODE_DWORDS (20 = 80 bytes; the first 20 carry the node) per node, node 0 = root, breadth-first
     std::vector<int32_t> prim_order;   // leaf-order slot -> original primitive index
     int max_depth = 0;                 // levels of 8-wide nodes
-    int n_nodes() const { return (int)(nodes.size() / 20); }
+    int n_nodes() const { return (int)(nodes.size() / APT_NODE_DWORDS); }
 };
 int build_wide_bvh(const BvhData& bvh2, WideBvhData& out);
 
@@ -66,6 +70,7 @@ int build_linear_bvh(const float* prims, int n_prims, const int32_t* obj_prim_cn
 
 // flat_build.cpp: the records of the flat sweep (traverse.hpp FlatScene): precomputed-transform planar primitives (parallelograms merged),
 // spheres, and the per-record table that maps a winning record back to its triangle and barycentrics
+void planar_rows(const float* tri9, float out12[12]);      // one triangle: corner + rows U, V, T of [e1 e2 n]^-1 (the product build's BVH leaf record)
 int build_flat(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, const int32_t* prim_class, const uint8_t* transmissive,
                std::vector<float>& stream, std::vector<float>& tab, int counts[7]);      // counts: parallelograms, convex quads, triangles - each plain, then in coplanar groups - and spheres
 }  // namespace apt

@@ -156,7 +156,7 @@ int emit_node(const BvhData& bvh2, const Work& wk, uint32_t* nodes, int32_t* pri
     w[4] = (uint32_t)wk.child_base; w[5] = (uint32_t)wk.tri_base;
     std::memcpy(&w[6], meta, 8);
     for (int g = 0; g < 6; g++) std::memcpy(&w[8 + 2 * g], q[g], 8);
-    std::memcpy(nodes + 20 * (size_t)wk.node8, w, sizeof(w));
+    std::memcpy(nodes + APT_NODE_DWORDS * (size_t)wk.node8, w, sizeof(w));
     return 0;
 }
 
@@ -177,7 +177,7 @@ int build_wide_bvh(const BvhData& bvh2, WideBvhData& out) {
     size_t work_cap = 0;
     std::vector<int> next_at, rc;
     int n_nodes8 = 1, n_slots = 0;
-    out.nodes.resize(20, 0u);
+    out.nodes.resize(APT_NODE_DWORDS, 0u);
     while (!level.empty()) {
         const int n = (int)level.size();
         out.max_depth = std::max(out.max_depth, level[0].depth);
@@ -197,7 +197,7 @@ int build_wide_bvh(const BvhData& bvh2, WideBvhData& out) {
             n_nodes8 += w.n_inner; n_slots += w.n_tris;
         }
         if ((size_t)n_slots > out.prim_order.size()) return -4;
-        out.nodes.resize((size_t)n_nodes8 * 20);
+        out.nodes.resize((size_t)n_nodes8 * APT_NODE_DWORDS);
         next.resize((size_t)(n_nodes8 - first_child));
         rc.assign((size_t)n, 0);
         parallel_for(n, threads, [&](int i) {

@@ -95,6 +95,17 @@ bool convex_overlap(const Poly& A, const Poly& B, const float plane[4]) {
 }
 }  // namespace
 
+// One triangle as the BVH walk of the product build reads it (traverse.hpp tri_two): corner p0, rows U, V, T of [e1 e2 n]^-1, 12 floats.
+// A degenerate triangle gets all-zero rows: T . d = 0 -> t is NaN or inf -> never accepted (upstream: det = 0 -> NaN barycentrics).
+void planar_rows(const float* tri9, float out12[12]) {
+    const D3 p0 = {tri9[0], tri9[1], tri9[2]}, e1 = sub({tri9[3], tri9[4], tri9[5]}, p0), e2 = sub({tri9[6], tri9[7], tri9[8]}, p0);
+    Planar r;
+    for (int a = 0; a < 12; a++) out12[a] = 0.f;
+    out12[0] = tri9[0]; out12[1] = tri9[1]; out12[2] = tri9[2];
+    if (!make_rows(p0, e1, e2, r)) return;
+    for (int a = 0; a < 3; a++) { out12[3 + a] = r.U[a]; out12[6 + a] = r.V[a]; out12[9 + a] = r.T[a]; }
+}
+
 // stream: [parallelograms][same, of coplanar groups] x 12 floats, [convex quads][same, of coplanar groups] x 18, [triangles][same, of
 // coplanar groups] x 12, [spheres] x 4; a planar record = corner p0, rows U, V, T (3 floats each); a convex quad appends its two far
 // edges as functions a u + b v + c of the record's (u, v) that are >= 0 inside.  tab: 28 floats per record, in stream order (7 float4: (U, p0.x), (V, p0.y), (prim_a, prim_b, class_a,

@@ -485,6 +485,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
     for (;;) {
         // ---- hand in finished rays (all lanes take part: the class appends are ballot-compacted)
         const bool fin = state == 2;
+        if (fin) rec.prim = walk_prim(sc.bvh, rec.prim);        // (product build: the walk reports the winner's leaf slot)
         if (!SORTED) {
             if (fin) { stq(q.hit_t, io, rec.t); stq(q.hit_prim, io, rec.prim); stq(q.hit_u, io, rec.u); stq(q.hit_v, io, rec.v); }
         } else if (__any(fin)) {

@@ -22,10 +22,16 @@
 struct DevBvh {
     const uint4* nodes;      // 5 uint4 (80 bytes) per node, layout in bvh_wide.cpp
     const float4* prims;     // 3 float4 per primitive, leaf order
+    const int* slot_prim;    // leaf-order slot -> primitive index (product build: its records carry no id, the walk reports the slot and the winner is looked up once per ray)
     int n_nodes, n_prims;
 };
-// primitive record: triangle q0=(p0, e1.x) q1=(e1.yz, e2.xy) q2=(e2.z, prim_id, 0, -)
-//                   sphere   q0=(centre, r)                  q2=(-, prim_id, 1, -)
+// primitive record, exact build:   triangle q0=(p0, e1.x) q1=(e1.yz, e2.xy) q2=(e2.z, prim_id, 0, -)
+//                                  sphere   q0=(centre, r)                  q2=(-, prim_id, 1, -)
+// primitive record, product build: triangle q0=(p0, U.x)  q1=(U.yz, V.xy)   q2=(V.z, T.xyz)      rows U, V, T of [e1 e2 n]^-1 (flat_build.cpp planar_rows)
+//                                  sphere   q0=(centre, NaN) q1=(r, -, -, -)
+#ifndef APT_NODE_BYTES
+#define APT_NODE_BYTES 80u     // node stride (bvh_wide.cpp emits APT_NODE_BYTES / 4 dwords per node; 128: one node per cache line, measurement only)
+#endif
 
 struct HitRec { float t; int prim; float u, v; };
 
@@ -53,19 +59,20 @@ APT_D WalkRay make_walk_ray(f3 o, f3 d) {
 }
 
 // One primitive against the ray.  Returns the reference's ray_t (or -1) and barycentrics.
+// sphere: tracer_base.py:184-199 (the reference's arithmetic in both builds: a grazing hit is a difference of two nearly equal squares)
+APT_D float sphere_test_t(f3 c, float radius, f3 o, f3 d) {
+    float r2 = radius * radius;
+    f3 s2c = c - o;
+    float cn2 = norm2(s2c);
+    float proj = dot(d, s2c);
+    float c2ray = cn2 - proj * proj;
+    if (c2ray >= r2) return -1.f;
+    float cut = sqrtf(r2 - c2ray);
+    return proj + ((cn2 > r2 + 1e-4f) ? -cut : cut);
+}
 APT_D float prim_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float& u, float& v) {
     u = 0.f; v = 0.f;
-    if (__float_as_int(q2.z) != 0) {          // sphere: tracer_base.py:184-199
-        f3 c = mk3(q0.x, q0.y, q0.z);
-        float r2 = q0.w * q0.w;
-        f3 s2c = c - o;
-        float cn2 = norm2(s2c);
-        float proj = dot(d, s2c);
-        float c2ray = cn2 - proj * proj;
-        if (c2ray >= r2) return -1.f;
-        float cut = sqrtf(r2 - c2ray);
-        return proj + ((cn2 > r2 + 1e-4f) ? -cut : cut);
-    }
+    if (__float_as_int(q2.z) != 0) return sphere_test_t(mk3(q0.x, q0.y, q0.z), q0.w, o, d);
     // triangle: columns (e1, e2, -d); inverse = adjugate * (1/det), Taichi's 3x3 formula
     float a00 = q0.w, a10 = q1.x, a20 = q1.y;      // e1
     float a01 = q1.z, a11 = q1.w, a21 = q2.x;      // e2
@@ -113,7 +120,7 @@ APT_D float ubyte_f(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu);
 // Out: hit mask - bits 31..24 the INNER children that are hit, at position 24 + (slot ^ (7 - ray octant)) so that "highest bit
 // first" is front to back; bits 23..0 the primitives of the hit leaf children, by offset from tri_base.
 APT_D uint32_t node8_test(const DevBvh& b, uint32_t idx, const WalkRay& r, float tmax, uint32_t& child_base, uint32_t& tri_base, uint32_t& imask) {
-    const char* base = reinterpret_cast<const char*>(b.nodes) + idx * 80u;          // wave-uniform base + 32-bit offset
+    const char* base = reinterpret_cast<const char*>(b.nodes) + idx * APT_NODE_BYTES;          // wave-uniform base + 32-bit offset
     const uint4 n0 = *reinterpret_cast<const uint4*>(base), n1 = *reinterpret_cast<const uint4*>(base + 16), n2 = *reinterpret_cast<const uint4*>(base + 32),
                 n3 = *reinterpret_cast<const uint4*>(base + 48), n4 = *reinterpret_cast<const uint4*>(base + 64);
     child_base = n1.x; tri_base = n1.y; imask = n0.w >> 24;
@@ -148,6 +155,82 @@ APT_D uint32_t node8_test(const DevBvh& b, uint32_t idx, const WalkRay& r, float
     return hitmask;
 }
 
+#if APT_FAST
+// Product build: the leaf test of the flat sweep (planar_solve below) on the tree's primitives, two of a lane's pending primitives in the
+// halves of packed f32 instructions.  Record = corner p0 and the rows U, V, T of [e1 e2 n]^-1 (Baldwin & Weber, JCGT 2016; computed in
+// double on the host): s = o - p0 (the reference's own first operation, tracer_base.py:206: a ray that STARTS on the primitive keeps its
+// height T . s a sum of small products), t = -T.s / T.d with ONE reciprocal, then (u, v) = (U.P, V.P) at the hit point P = s + t d -
+// ~40 instructions per pair where the adjugate solve with its IEEE division takes ~95.  Inside SURVEY 8(d): t within 1e-5 relative of the
+// exact build's, same primitive unless tied (tests/test_gpu_fast.py).  Of two primitives at the same distance to the last bit - a ray
+// through a shared edge that both inside tests accept: a strip about 1e-7 of the edge length wide - the first one tested wins (the exact
+// build reproduces upstream's "lower index"; under different arithmetic the two distances are no longer equal to the bit anyway).
+// Records carry no primitive id: rec.prim is the LEAF SLOT while a ray walks, the callers translate the winner (DevBvh::slot_prim).
+APT_D v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+APT_D float walk_scalar_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float& u, float& v) {      // one record, either kind (lanes that meet a sphere)
+    u = 0.f; v = 0.f;
+    if (q0.w != q0.w) return sphere_test_t(mk3(q0.x, q0.y, q0.z), q1.x, o, d);
+    const f3 s = o - mk3(q0.x, q0.y, q0.z);
+    const float t_o = __builtin_fmaf(q2.y, s.x, __builtin_fmaf(q2.z, s.y, q2.w * s.z));
+    const float t_d = __builtin_fmaf(q2.y, d.x, __builtin_fmaf(q2.z, d.y, q2.w * d.z));
+    const float t = -t_o * __builtin_amdgcn_rcpf(t_d);
+    const f3 P = mk3(__builtin_fmaf(t, d.x, s.x), __builtin_fmaf(t, d.y, s.y), __builtin_fmaf(t, d.z, s.z));
+    u = __builtin_fmaf(q0.w, P.x, __builtin_fmaf(q1.x, P.y, q1.y * P.z));
+    v = __builtin_fmaf(q1.z, P.x, __builtin_fmaf(q1.w, P.y, q2.x * P.z));
+    return (fminf(fminf(u, v), (1.0f - u) - v) >= 0.f) ? t : -1.f;
+}
+template <bool ANY>
+APT_D bool tri_one(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
+    const uint32_t k = 31u - (uint32_t)__clz((int)tg.y);
+    tg.y &= ~(1u << k);
+    const char* base = reinterpret_cast<const char*>(b.prims) + (tg.x + k) * 48u;
+    const float4 p0 = *reinterpret_cast<const float4*>(base), p1 = *reinterpret_cast<const float4*>(base + 16), p2 = *reinterpret_cast<const float4*>(base + 32);
+    float u, v;
+    const float t = walk_scalar_test(p0, p1, p2, r.o, r.d, u, v);
+    WALK_COUNT(ws.prims);
+    if (ANY) return t > 1e-4f && t < rec.t;
+    if (t > 1e-4f && t < rec.t) { rec.t = t; rec.prim = (int)(tg.x + k); rec.u = u; rec.v = v; }
+    return false;
+}
+template <bool ANY>
+APT_D bool tri_two(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
+    const uint32_t k0 = 31u - (uint32_t)__clz((int)tg.y);
+    const uint32_t rest = tg.y & ~(1u << k0);
+    const bool two = rest != 0u;
+    const uint32_t k1 = two ? 31u - (uint32_t)__clz((int)rest) : k0;
+    tg.y = two ? (rest & ~(1u << k1)) : 0u;
+    const char* ba = reinterpret_cast<const char*>(b.prims) + (tg.x + k0) * 48u;
+    const char* bb = reinterpret_cast<const char*>(b.prims) + (tg.x + k1) * 48u;
+    const float4 a0 = *reinterpret_cast<const float4*>(ba), a1 = *reinterpret_cast<const float4*>(ba + 16), a2 = *reinterpret_cast<const float4*>(ba + 32);
+    const float4 b0 = *reinterpret_cast<const float4*>(bb), b1 = *reinterpret_cast<const float4*>(bb + 16), b2 = *reinterpret_cast<const float4*>(bb + 32);
+    WALK_COUNT(ws.prims); if (two) WALK_COUNT(ws.prims);
+    v2f t, u, v;
+    if (a0.w != a0.w || b0.w != b0.w) {                                          // a sphere among the two (NaN marker): scalar tests
+        float uu, vv;
+        t.x = walk_scalar_test(a0, a1, a2, r.o, r.d, uu, vv); u.x = uu; v.x = vv;
+        t.y = walk_scalar_test(b0, b1, b2, r.o, r.d, uu, vv); u.y = uu; v.y = vv;
+    } else {
+        const v2f sx = sp2(r.o.x) - mk2(a0.x, b0.x), sy = sp2(r.o.y) - mk2(a0.y, b0.y), sz = sp2(r.o.z) - mk2(a0.z, b0.z);
+        const v2f dx = sp2(r.d.x), dy = sp2(r.d.y), dz = sp2(r.d.z);
+        const v2f tx = mk2(a2.y, b2.y), ty = mk2(a2.z, b2.z), tz = mk2(a2.w, b2.w);
+        const v2f t_o = fma2(tx, sx, fma2(ty, sy, tz * sz));
+        const v2f t_d = fma2(tx, dx, fma2(ty, dy, tz * dz));
+        v2f inv; inv.x = __builtin_amdgcn_rcpf(t_d.x); inv.y = __builtin_amdgcn_rcpf(t_d.y);
+        t = -t_o * inv;
+        const v2f px = fma2(t, dx, sx), py = fma2(t, dy, sy), pz = fma2(t, dz, sz);
+        u = fma2(mk2(a0.w, b0.w), px, fma2(mk2(a1.x, b1.x), py, mk2(a1.y, b1.y) * pz));
+        v = fma2(mk2(a1.z, b1.z), px, fma2(mk2(a1.w, b1.w), py, mk2(a2.x, b2.x) * pz));
+        const v2f w = (sp2(1.0f) - u) - v;
+        t.x = (fminf(fminf(u.x, v.x), w.x) >= 0.f) ? t.x : -1.f;
+        t.y = (fminf(fminf(u.y, v.y), w.y) >= 0.f) ? t.y : -1.f;
+    }
+    if (ANY) return (t.x > 1e-4f && t.x < rec.t) || (t.y > 1e-4f && t.y < rec.t);
+    if (t.x > 1e-4f && t.x < rec.t) { rec.t = t.x; rec.prim = (int)(tg.x + k0); rec.u = u.x; rec.v = v.x; }
+    if (t.y > 1e-4f && t.y < rec.t) { rec.t = t.y; rec.prim = (int)(tg.x + k1); rec.u = u.y; rec.v = v.y; }
+    return false;
+}
+// leaf slot -> primitive index of a finished closest-hit walk
+APT_D int walk_prim(const DevBvh& b, int slot) { return slot >= 0 ? b.slot_prim[slot] : -1; }
+#else
 // One primitive of a triangle group (the highest pending bit).  Closest hit: strictly nearer wins, and of two primitives at
 // EXACTLY the same t the lower original index - the reference's brute-force loop keeps the first strictly-closer hit in index
 // order (tracer_base.py:208), so the answer does not depend on the order in which the tree presents the primitives.
@@ -211,6 +294,8 @@ APT_D bool tri_two(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, Wa
     if (t.y > 1e-4f && (t.y < rec.t || (t.y == rec.t && kb < rec.prim))) { rec.t = t.y; rec.prim = kb; rec.u = u.y; rec.v = v.y; }
     return false;
 }
+APT_D int walk_prim(const DevBvh&, int prim) { return prim; }      // exact build: the records carry the primitive index
+#endif
 template <bool ANY>
 APT_D bool tri_group(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
 #ifdef APT_TRI_SINGLE
@@ -258,6 +343,7 @@ APT_D bool traverse(const DevBvh& bvh, const TravStack& ts, f3 o, f3 d, HitRec& 
             ng = tpop(ts, sp);
         }
     }
+    if (!ANY) rec.prim = walk_prim(bvh, rec.prim);
     return false;
 }
 
@@ -632,7 +718,6 @@ struct FlatScene {
     int defer_all;            // test switch (APT_FLAT_DEFER_ALL=1 at scene creation): every ray takes the reference-order path - in the stage kernels, through the fix-up lists
 };
 #if APT_FAST
-APT_D v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 struct FlatRays { v2f ox, oy, oz, dx, dy, dz; };           // two rays: .x = entry 2k, .y = entry 2k + 1
 // (t, u, v) of both rays against one planar record: 12 wave-uniform floats at r = corner p0, rows U, V, T of [e1 e2 n]^-1:
 // t = -T.s / T.d, then u = U.P, v = V.P at P = s + t d.
