@@ -319,7 +319,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     s->device = device;
     const int N = d->n_prims, O = d->n_objects, S = d->n_sources;
     // the walk addresses primitive (48 B) and node (80 B, at most one per primitive) records with 32-bit byte offsets (traverse.hpp)
-    if ((uint64_t)N * (uint64_t)APT_NODE_BYTES >= (1ull << 32)) { delete s; return fail(APT_E_INVALID, "apt_scene_create: more than 53 687 091 primitives (32-bit record offsets)"); }
+    if (N >= (1 << 26) || (uint64_t)N * (uint64_t)APT_NODE_BYTES >= (1ull << 32)) { delete s; return fail(APT_E_INVALID, "apt_scene_create: more than 53 687 091 primitives (32-bit record offsets)"); }
     s->n_prims = N; s->n_objects = O; s->n_sources = S;
     const bool timing = getenv("APT_SCENE_TIMING") != nullptr;      // stderr: where apt_scene_create spends its time
     auto t_prev = std::chrono::steady_clock::now();
@@ -369,7 +369,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         int k = s->wide.prim_order[(size_t)slot];
         const float* v = d->prims + 9 * (size_t)k; const float* pc = prec.data() + 9 * (size_t)k; float* r = recs.data() + 12 * (size_t)slot;
         int32_t kid = k, flag = sphere[(size_t)k] ? 1 : 0;
-#if APT_FAST
+#if APT_FAST_LEAVES
         // product build: precomputed-transform records without an id (traverse.hpp tri_two; the walk reports leaf slots, DevBvh::slot_prim)
         (void)pc; (void)kid;
         if (flag) { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = std::numeric_limits<float>::quiet_NaN(); r[4] = v[3]; }
@@ -429,6 +429,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
             if (!lean) s->phong_no_lobe = false;
         }
     }
+    std::vector<int> pcls_host;
     // material classes present in this scene -> compact ids; per-primitive class table for the sorting extend.  Blinn-Phong objects
     // without a specular lobe (the diffuse walls of most scenes) get a class of their own, whose kernel carries no double-precision
     // pow - unless that would need more class queues than there are (APT_MAX_CLASSES), then they stay with the other Blinn-Phong objects
@@ -447,6 +448,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         }
         std::vector<int> pcls((size_t)N);
         for (int k = 0; k < N; k++) pcls[(size_t)k] = obj_cls[(size_t)prim_obj[(size_t)k]];
+        pcls_host = pcls;
         hipError_t e_ = upload(s->prim_class, pcls);
         if (e_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload prim_class: ") + hipGetErrorString(e_)); }
         memset(&s->dev.flat, 0, sizeof(s->dev.flat));
@@ -484,7 +486,11 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     if (d->v_normals) vn.assign(d->v_normals, d->v_normals + (size_t)N * 9);
     std::vector<int> oi(d->obj_info, d->obj_info + (size_t)O * 3), ei(d->emitter_id, d->emitter_id + (size_t)O);
 #define UP(buf, vec) do { hipError_t e_ = upload(s->buf, vec); if (e_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload " #buf ": ") + hipGetErrorString(e_)); } } while (0)
-    UP(nodes, s->wide.nodes); UP(prims, recs); UP(slot_prim, s->wide.prim_order); UP(normals, nrm); UP(vnormals, vn); UP(precom, prec); UP(prim_obj, prim_obj);
+    std::vector<int> slot_info((size_t)N);                // leaf slot -> primitive | material class << 28 (traverse.hpp walk_info)
+    {
+        for (int slot = 0; slot < N; slot++) { const int k = s->wide.prim_order[(size_t)slot]; slot_info[(size_t)slot] = k | (pcls_host[(size_t)k] << 28); }
+    }
+    UP(nodes, s->wide.nodes); UP(prims, recs); UP(slot_prim, slot_info); UP(normals, nrm); UP(vnormals, vn); UP(precom, prec); UP(prim_obj, prim_obj);
     UP(obj_info, oi); UP(emitter_id, ei); UP(bxdf, bx); UP(src, sr); UP(sweep_recs, sw); UP(sweep_tab, sw_tab); UP(obj_aabb, aabb);
     DevScene& ds = s->dev;
     ds.bvh.nodes = s->nodes.as<uint4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.slot_prim = s->slot_prim.as<int>(); ds.bvh.n_nodes = s->wide.n_nodes(); ds.bvh.n_prims = N;

@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 // dynamic fetch", re-cut for 64-wide waves and an LDS stack).  Per-ray arithmetic and the visiting order inside a ray are those of
 // traverse<false>; only the assignment of rays to lanes changes, and hits are written to the ray's own slot.
 #ifndef APT_DYN_MIN_ACTIVE
-#define APT_DYN_MIN_ACTIVE 40
+#define APT_DYN_MIN_ACTIVE 32      // measured 32 / 40 / 52 with the product build's leaf test: C4 extend 21.5 / 22.2 / 26.7 ms per 64 spp, C5 13.5 / 14.05 / 15.8 per 32
 #endif
 #ifdef APT_WALK_WAVES
 #define APT_WALK_ATTR __attribute__((amdgpu_waves_per_eu(APT_WALK_WAVES, APT_WALK_WAVES)))
@@ -485,14 +485,21 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
     for (;;) {
         // ---- hand in finished rays (all lanes take part: the class appends are ballot-compacted)
         const bool fin = state == 2;
-        if (fin) rec.prim = walk_prim(sc.bvh, rec.prim);        // (product build: the walk reports the winner's leaf slot)
+#if APT_FAST_LEAVES
+        int fin_cls = -1;                                      // product build: the walk reports the winner's leaf slot; one lookup yields primitive and class
+        if (fin) { const int info = walk_info(sc.bvh, rec.prim); rec.prim = info < 0 ? -1 : (info & 0x0fffffff); fin_cls = info < 0 ? -1 : (info >> 28); }
+#endif
         if (!SORTED) {
             if (fin) { stq(q.hit_t, io, rec.t); stq(q.hit_prim, io, rec.prim); stq(q.hit_u, io, rec.u); stq(q.hit_v, io, rec.v); }
         } else if (__any(fin)) {
             // (as in k_extend: the rest of the record is requested first, the queue tails of all classes move with ONE atomic instruction)
             f3 st_thr = splat3(0.f); uint32_t st_id = 0, st_meta = 0; float st_pdf = 0.f;
             if (fin) { st_thr = ld3q(q.thr[cur_q], p.cap, io); st_id = ldq(q.id[cur_q], io); st_meta = ldq(q.meta[cur_q], io); st_pdf = ldq(q.pdf[cur_q], io); }
+#if APT_FAST_LEAVES
+            const int cls = !fin ? -1 : ((rec.prim >= 0) ? fin_cls : q.miss_class);
+#else
             const int cls = !fin ? -1 : ((rec.prim >= 0) ? sc.prim_class[rec.prim] : q.miss_class);
+#endif
             uint32_t my_rank = 0, cnt_vec = 0;
             for (int c = 0; c < q.n_classes; c++) {
                 const unsigned long long m = __ballot(cls == c);

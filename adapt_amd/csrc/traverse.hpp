@@ -29,6 +29,12 @@ struct DevBvh {
 //                                  sphere   q0=(centre, r)                  q2=(-, prim_id, 1, -)
 // primitive record, product build: triangle q0=(p0, U.x)  q1=(U.yz, V.xy)   q2=(V.z, T.xyz)      rows U, V, T of [e1 e2 n]^-1 (flat_build.cpp planar_rows)
 //                                  sphere   q0=(centre, NaN) q1=(r, -, -, -)
+#ifndef APT_FLAT_UNFUSED_HEIGHT
+#define APT_FLAT_UNFUSED_HEIGHT 0
+#endif
+#ifndef APT_FAST_LEAVES
+#define APT_FAST_LEAVES APT_FAST     // product build: precomputed-transform leaf records (0: the exact build's records and test in the product build, measurement only)
+#endif
 #ifndef APT_NODE_BYTES
 #define APT_NODE_BYTES 80u     // node stride (bvh_wide.cpp emits APT_NODE_BYTES / 4 dwords per node; 128: one node per cache line, measurement only)
 #endif
@@ -156,6 +162,9 @@ APT_D uint32_t node8_test(const DevBvh& b, uint32_t idx, const WalkRay& r, float
 }
 
 #if APT_FAST
+APT_D v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+#if APT_FAST_LEAVES
 // Product build: the leaf test of the flat sweep (planar_solve below) on the tree's primitives, two of a lane's pending primitives in the
 // halves of packed f32 instructions.  Record = corner p0 and the rows U, V, T of [e1 e2 n]^-1 (Baldwin & Weber, JCGT 2016; computed in
 // double on the host): s = o - p0 (the reference's own first operation, tracer_base.py:206: a ray that STARTS on the primitive keeps its
@@ -165,7 +174,6 @@ APT_D uint32_t node8_test(const DevBvh& b, uint32_t idx, const WalkRay& r, float
 // through a shared edge that both inside tests accept: a strip about 1e-7 of the edge length wide - the first one tested wins (the exact
 // build reproduces upstream's "lower index"; under different arithmetic the two distances are no longer equal to the bit anyway).
 // Records carry no primitive id: rec.prim is the LEAF SLOT while a ray walks, the callers translate the winner (DevBvh::slot_prim).
-APT_D v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 APT_D float walk_scalar_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float& u, float& v) {      // one record, either kind (lanes that meet a sphere)
     u = 0.f; v = 0.f;
     if (q0.w != q0.w) return sphere_test_t(mk3(q0.x, q0.y, q0.z), q1.x, o, d);
@@ -228,8 +236,10 @@ APT_D bool tri_two(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, Wa
     if (t.y > 1e-4f && t.y < rec.t) { rec.t = t.y; rec.prim = (int)(tg.x + k1); rec.u = u.y; rec.v = v.y; }
     return false;
 }
-// leaf slot -> primitive index of a finished closest-hit walk
-APT_D int walk_prim(const DevBvh& b, int slot) { return slot >= 0 ? b.slot_prim[slot] : -1; }
+// leaf slot -> primitive index (low 28 bits) and material class (bits 28..30) of a finished closest-hit walk: ONE lookup at the hand-in,
+// where the exact build makes one too (prim_class[prim]) - a second dependent load there stalls the whole wave
+APT_D int walk_info(const DevBvh& b, int slot) { return slot >= 0 ? b.slot_prim[slot] : -1; }
+APT_D int walk_prim(const DevBvh& b, int slot) { return slot >= 0 ? (b.slot_prim[slot] & 0x0fffffff) : -1; }
 #else
 // One primitive of a triangle group (the highest pending bit).  Closest hit: strictly nearer wins, and of two primitives at
 // EXACTLY the same t the lower original index - the reference's brute-force loop keeps the first strictly-closer hit in index
@@ -295,6 +305,9 @@ APT_D bool tri_two(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, Wa
     return false;
 }
 APT_D int walk_prim(const DevBvh&, int prim) { return prim; }      // exact build: the records carry the primitive index
+#endif
+#if APT_FAST_LEAVES && !defined(APT_TRI_PAIR)
+#define APT_TRI_SINGLE 1     // with the cheap leaf test the walk is bound by its divergent 16-byte loads, not by arithmetic: the pair test fetches six per iteration whether or not the lane has a second primitive pending (measured: C4 extend 22.2 -> 21.1 ms per 64 spp, C5 14.05 -> 13.7 per 32)
 #endif
 template <bool ANY>
 APT_D bool tri_group(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
@@ -730,7 +743,17 @@ APT_D void planar_solve(cf_ptr r, const FlatRays& q, v2f& t, v2f& u, v2f& v) {
     const v2f ux = sp2(r[3]), uy = sp2(r[4]), uz = sp2(r[5]);
     const v2f vx = sp2(r[6]), vy = sp2(r[7]), vz = sp2(r[8]);
     const v2f tx = sp2(r[9]), ty = sp2(r[10]), tz = sp2(r[11]);
+#if APT_FLAT_UNFUSED_HEIGHT
+    // The height of the ray's origin over the plane is a small difference of large products - for a ray that starts ON the plane, pure
+    // rounding noise - and t = height / cosine exceeds the 1e-4 threshold for grazing rays only when that noise is large enough: the share of
+    // rays that "re-hit" the surface they start on scales with the noise.  Upstream's adjugate solve rounds every product and every sum
+    // (tracer_base.py:206-207); a fused chain rounds a third as often, carries less noise and produced fewer such re-hits: -2.3e-4 shaded
+    // vertices on scenes/test/textured.xml (normal-mapped directions graze their own wall), the same sign under every seed.  With the height
+    // rounded like upstream's - product, product, sum, product, sum - the noise has upstream's distribution.
+    const v2f t_o = (tx * sx + ty * sy) + tz * sz;
+#else
     const v2f t_o = fma2(tx, sx, fma2(ty, sy, tz * sz));
+#endif
     const v2f t_d = fma2(tx, q.dx, fma2(ty, q.dy, tz * q.dz));
     v2f inv; inv.x = __builtin_amdgcn_rcpf(t_d.x); inv.y = __builtin_amdgcn_rcpf(t_d.y);
     t = -t_o * inv;

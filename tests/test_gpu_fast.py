@@ -69,7 +69,7 @@ def _rays(n, seed):
     return o, d, tmax
 
 
-def _check_hits(prim, t, uv, prim_o, t_o, uv_o, is_tri, d, normals):
+def _check_hits(prim, t, uv, prim_o, t_o, uv_o, is_tri, d, normals, tris=None):
     """t within 1e-5 relative, same primitive unless tied.  A ray-plane distance is a quotient of a height over the plane and
     a cosine, and the height carries the rounding of coordinates of size ~5 (a few 1e-7) whatever formula computes it - upstream's
     included: where the height itself is small the RELATIVE error of t is unbounded, so such hits are held to the equivalent absolute
@@ -90,7 +90,15 @@ def _check_hits(prim, t, uv, prim_o, t_o, uv_o, is_tri, d, normals):
     diff = ~same
     tied = np.abs(t[diff] - t_o[diff]) <= 1e-5 * np.maximum(np.abs(t_o[diff]), 1e-2)
     assert diff.mean() <= 5e-3 and (~tied).sum() <= max(3, int(2e-5 * len(prim))), (diff.sum(), (~tied).sum())
-    assert np.abs(uv[tri] - uv_o[tri]).max() <= 5e-5 if tri.any() else True
+    if tris is None:                                                                # Cornell-sized primitives: the barycentrics themselves
+        assert np.abs(uv[tri] - uv_o[tri]).max() <= 5e-5 if tri.any() else True
+    elif tri.any():
+        # meshes of small triangles: a barycentric is a length divided by an edge, so the statement that does not depend on the triangle's
+        # size is the POINT the barycentrics name - it moves by no more than the hit point may move along the ray (1e-5 t, and the absolute
+        # floor above)
+        e1, e2 = (tris[prim_o[tri], 1] - tris[prim_o[tri], 0]).astype(np.float64), (tris[prim_o[tri], 2] - tris[prim_o[tri], 0]).astype(np.float64)
+        dP = (uv[tri, 0:1] - uv_o[tri, 0:1]).astype(np.float64) * e1 + (uv[tri, 1:2] - uv_o[tri, 1:2]).astype(np.float64) * e2
+        assert np.all(np.linalg.norm(dP, axis=1) <= 1e-5 * np.abs(t_o[tri]) + 5.5e-6), float(np.linalg.norm(dP, axis=1).max())
 
 
 @pytest.mark.parametrize("tag,kw", [("cbox", {}), ("glass_box", {}), ("balls_mono", {}), ("balls_mono", {"num_shadow_ray": 1}), ("features_b", {}), ("textured", {"num_shadow_ray": 3})])
@@ -614,7 +622,7 @@ def test_product_walk_hits_within_tolerance_of_the_exact_build(which, parsed, mo
         prim_o, t_o, uv_o = e.intersect(o, d)
         assert (prim_o >= 0).mean() > 0.5
         is_tri = f.flat.obj_info[np.searchsorted(f.flat.obj_info[:, 0], np.maximum(prim_o, 0), side="right") - 1, 2] == 0
-        _check_hits(prim, t, uv, prim_o, t_o, uv_o, is_tri, d, f.flat.normals)
+        _check_hits(prim, t, uv, prim_o, t_o, uv_o, is_tri, d, f.flat.normals, tris=f.flat.prims.reshape(-1, 3, 3))
         assert (f.occluded(o, d, tmax) != e.occluded(o, d, tmax)).sum() <= 3
         f.render(n_spp=4); e.render(n_spp=4)
         sf, se = f.stats(), e.stats()
