@@ -38,14 +38,19 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 // ------------------------------------------------- shade kernel specialisations
 // (material mask, emitter mask) -> instantiation; the host picks the first one that covers the scene
 typedef void (*shade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int, int);
-struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; };
+#if APT_FAST
+#define APT_FUSED_FN(...) __VA_ARGS__
+#else
+#define APT_FUSED_FN(...) nullptr         // light samples traced by the shade kernel: a product-build path (it rides on the flat sweep's records)
+#endif
+struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_fn fused; };      // fused: the variant that traces its own light samples (stages.hpp k_shade FUSE)
 static const ShadeVariant kShadeVariants[] = {
-    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point"},
-    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area"},
-    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area"},
-    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models"},
+    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade<0x002, 0x01, 0, 1>)},
+    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade<0x003, 0x03, 0, 1>)},
+    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade<0x107, 0x03, 0, 1>)},
+    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 1>)},
 };
-static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures"};
+static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 1>)};
 // Material classes for sorted shading: (class mask) x (emitter mask: point+area | all)
 // A kernel's register allocation is the maximum over the models it contains, so the classes are as fine as the models'
 // footprints differ: Lambertian alone runs at 4 waves per SIMD, together with Blinn-Phong (three double pows) at 2-3.
@@ -142,6 +147,7 @@ struct apt_scene {
     apt::BvhData bvh;                    // binary SAH tree (leaves of <= 3 primitives): the intermediate of the build
     apt::WideBvhData wide;               // 8-wide quantised tree: what the kernels walk
     DevBuf nodes, prims, slot_prim, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
+    DevBuf flat_pairs;                   // the flat records two by two (traverse.hpp FlatScene::pairs)
     DevBuf flat_recs, flat_tab;          // flat sweep (fast build, small scenes): records and the per-record table (traverse.hpp FlatScene)
     bool has_flat = false;
     DevBuf uvs, tex_i, tex_f, atlas[3];      // image textures (empty when the scene has none)
@@ -465,6 +471,22 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
             hipError_t e1_ = upload(s->flat_recs, fr), e2_ = (e1_ == hipSuccess) ? upload(s->flat_tab, ft) : e1_;
             if (e2_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload flat records: ") + hipGetErrorString(e2_)); }
             fl.stream = s->flat_recs.as<float>(); fl.tab = s->flat_tab.as<float4>();
+            {   // the records two by two for the one-ray any-hit sweep (flat_any1): floats of records 2j, 2j + 1 interleaved; an odd tail repeats its record
+                std::vector<float> fp;
+                const float* src = fr.data();
+                auto section = [&](int n, int w) {
+                    for (int j = 0; 2 * j < n; j++) {
+                        const float* a = src + (size_t)(2 * j) * w; const float* b = (2 * j + 1 < n) ? a + w : a;
+                        for (int k = 0; k < w; k++) { fp.push_back(a[k]); fp.push_back(b[k]); }
+                    }
+                    src += (size_t)n * w;
+                };
+                section(fc[0] + fc[1], 12); section(fc[2] + fc[3], 18); section(fc[4] + fc[5], 12); section(fc[6], 4);
+                if (fp.empty()) fp.push_back(0.f);
+                hipError_t e3_ = upload(s->flat_pairs, fp);
+                if (e3_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload flat record pairs: ") + hipGetErrorString(e3_)); }
+                fl.pairs = s->flat_pairs.as<float>();
+            }
             s->has_flat = true;
             if (timing) fprintf(stderr, "[scene timing] flat records: %d + %d parallelograms, %d + %d convex quads, %d + %d triangles (plain + coplanar groups), %d spheres of %d primitives\n", fc[0], fc[1], fc[2], fc[3], fc[4], fc[5], fc[6], N);
             tick("flat records");
@@ -658,6 +680,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     p.nee_vm = (!c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
     if (const char* f = getenv("APT_NEE_VM")) p.nee_vm = (atoi(f) != 0 && !c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
     p.l_planes = (!c.volumetric && !p.nee_vm && S >= 2 && S <= 4) ? S : 1;        // stages.hpp APT_EXCLUSIVE_L: one radiance plane per light sample of a vertex
+    p.fused = 0;
     p.pix_bits = 0; while ((1u << p.pix_bits) < (uint32_t)r->npix) p.pix_bits++;
     if (((uint64_t)B << p.pix_bits) > (1ull << 32)) { return fail(APT_E_INVALID, "apt_renderer_create: spp_per_batch x pixels does not fit the 32-bit path id"); }
     {   // local pixel -> RNG key (global pixel index), same mapping as local_to_global in stages.hpp
@@ -675,6 +698,9 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (const char* force = getenv("APT_SORTED")) r->sorted = (atoi(force) != 0 && sc->n_classes >= 1 && sc->n_classes <= APT_MAX_CLASSES) ? 1 : 0;
     if (textured) r->sorted = 0;
     r->volumetric = c.volumetric ? 1 : 0;
+    // light samples traced by the shade kernel itself (stages.hpp k_shade FUSE): flat sweep, one sample per vertex, one shade kernel
+    p.fused = (r->trace_mode == 3 && !r->sorted && !c.volumetric && S == 1 && r->shade->fused != nullptr) ? 1 : 0;
+    if (const char* f = getenv("APT_FUSED")) p.fused = (atoi(f) != 0 && p.fused) ? 1 : 0;
     if (r->volumetric) {
         if (c.max_bounce > 255) { return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer keeps the bounce count in 8 bits (max_bounce <= 255)"); }
         if (!sc->has_aabb) { return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer needs the object boxes (world bound)"); }
@@ -719,7 +745,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     // one pool per lane, carved into the SoA arrays (all 4-byte lanes)
     const bool walk_lists = r->volumetric && sc->has_null_surface;      // light samples that cross null surfaces are re-queued by slot
     const size_t l_planes = (size_t)p.l_planes;
-    const size_t words = (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
+    const size_t words = (p.fused ? 6 * cap : 0) + (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
         hipError_t e_ = pool.alloc(words * 4);
         if (e_ != hipSuccess) return e_;
@@ -735,6 +761,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         q.fix_ext = (r->trace_mode == 3) ? (uint32_t*)take(cap) : nullptr; q.fix_sh = (r->trace_mode == 3) ? (uint32_t*)take(sh_cap) : nullptr;
         for (int k = 0; k < 2; k++) { q.thr[k] = take(3 * cap); q.id[k] = (uint32_t*)take(cap); q.meta[k] = (uint32_t*)take(cap); q.pdf[k] = take(cap); }
         q.L = take(4 * cap * l_planes);
+        for (int k = 0; k < 2; k++) q.Lc[k] = p.fused ? take(3 * cap) : nullptr;
         q.sh_o = take(3 * sh_cap); q.sh_d = take(3 * sh_cap); q.sh_tmax = take(sh_cap); q.sh_c = take(3 * sh_cap); q.sh_id = (uint32_t*)take(sh_cap);
         q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
         q.sh_walk[0] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr; q.sh_walk[1] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr;
@@ -1082,8 +1109,8 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             if (r->trace_mode == 3) { LaunchTimer t(r, 1, st, false); hipLaunchKernelGGL(kFixFlat[r->sorted], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
             if (!r->sorted) {
                 ShadeIn in = {q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.id[cur], q.meta[cur], q.pdf[cur],
-                              q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur]};
-                LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->shade->fn, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
+                              q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur], q.Lc[cur]};
+                LaunchTimer t(r, 2, st); hipLaunchKernelGGL(p.fused ? r->shade->fused : r->shade->fn, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
             } else {
                 for (int c = 0; c < q.n_classes; c++) {
                     const Queues::ClassQ& k = q.cls[c];
@@ -1092,7 +1119,8 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
                 }
                 if (p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }      // normally k_shadow recycles these
             }
-            if (p.S > 0 && r->dyn_fetch) {
+            if (p.fused) { /* the shade kernel traced the light samples itself */ }
+            else if (p.S > 0 && r->dyn_fetch) {
                 unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[1], 0, sizeof(cnt->n_work[1]), st));
                 LaunchTimer t(r, 3, st); hipLaunchKernelGGL(k_shadow_dyn, dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan);
             } else if (p.S > 0) {

@@ -100,6 +100,7 @@ struct Params {
     int volumetric_flat;      // 1: volumetric render (the flat shadow kernels never run: the fix-up launch has no shadow list)
     int nee_vm;               // 1: light samples are queued BY VERTEX (one slot per vertex and sub-queue, sample s in plane s of the sub-queue's region, unwanted samples marked tmax < 0), so that the flat shadow kernel adds a vertex's samples with ONE read-modify-write and the shade kernel moves the queue tail once per tile row (flat sweep, S > 1)
     int l_planes;             // radiance planes of L: light sample s of a vertex adds into plane s (2 <= S <= 4), so that no two entries of a shadow launch share a slot; 1 otherwise
+    int fused;                // 1: the shade kernel traces its own light samples (flat sweep, one sample per vertex, unsorted: stages.hpp "light samples traced in place"); no shadow queue, no shadow launch, radiance travels with the path (Queues::Lc)
     float w_min[3], w_max[3]; // world box = (objects U camera) +- 0.1 (path_tracer.py:130-138); volumetric tracer only
 };
 
@@ -112,6 +113,7 @@ struct Queues {
     float* sh_o; float* sh_d; float* sh_tmax; float* sh_c; uint32_t* sh_id;
     uint32_t* sh_walk[2];                        // volumetric, scenes with null surfaces: slot lists of the samples that walk on (ping-pong)
     float* L;                                    // 3 components, indexed by path id
+    float* Lc[2];                                // fused shading: the path's radiance so far, a queue component like thr (3 components; null elsewhere)
     uint32_t sh_cap, sh_subcap;
     // Material-sorted shading (scenes with >= 2 material classes): extend drops misses and appends each hit
     // path's full record (ray + state + hit, 64 B) to the dense queue of its material class, so every shade
@@ -128,6 +130,7 @@ struct ShadeIn {
     const float* ray_o; const float* ray_d; const float* thr; const uint32_t* id; const uint32_t* meta; const float* pdf;
     const float* t; const int* prim; const float* u; const float* v;
     const uint32_t* counts;                      // per-sub-queue entry counts (stride CNT_PAD)
+    const float* Lc;                             // fused shading: carried radiance of the entries (null elsewhere)
 };
 
 #ifndef APT_MAX_NQ
@@ -615,7 +618,14 @@ APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3
 // TEX: image-texture lookups.  Only the all-models kernel is instantiated with TEX = 1 (textured scenes run unsorted through
 // it): inlined into the specialised kernels the lookup costs e.g. the mod-Phong class kernel its fourth wave per SIMD
 // (126 -> 129 VGPRs) in every scene WITHOUT textures, and out of line it costs a call frame in scratch.
-template <int BM, int SM, int TEX = 0>
+// FUSE (product build, flat sweep, one light sample per vertex, unsorted: Params::fused) - LIGHT SAMPLES TRACED IN PLACE.  For a scene
+// of a few dozen records the any-hit sweep of a shadow ray costs fewer issue slots than the round trip of its 44-byte queue entry through
+// HBM plus the scattered read-modify-write of the path's radiance slot behind it: the row's light samples are swept right here (one ray
+// per lane against two records per packed instruction, traverse.hpp flat_any1), after the continuation has been sampled and the next
+// queue entry written, when little else is live.  The path's radiance then travels WITH the path (Queues::Lc, 12 bytes of the queue
+// record) and reaches its slot of L once, when the path ends.  The rare rays whose answer needs the reference-order sweep
+// (flat_needs_cull) still leave as shadow-queue entries, counted by n_fix_sh[cur], and are served by the next fix-up launch.
+template <int BM, int SM, int TEX = 0, int FUSE = 0>
 __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_LAMBERT_WAVES : APT_SHADE_WAVES))) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
@@ -624,7 +634,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
     uint32_t* next_counter = &cnt->n_active[nxt][sl.q * CNT_PAD];
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
     const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
-    uint32_t t_shade = 0, t_shadow = 0, t_poison = 0;        // wave-uniform tallies (SGPRs)
+    uint32_t t_shade = 0, t_shadow = 0, t_poison = 0, t_traced = 0, t_lit = 0;        // wave-uniform tallies (SGPRs)
     __shared__ uint32_t s_draws[BLOCK / 64];                  // RNG draws of this wave: a per-lane tally would hold a VGPR for the whole kernel
     if (lane_id() == 0) s_draws[threadIdx.x >> 6] = 0;
 #ifdef APT_SHADE_PROF
@@ -680,6 +690,12 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         }
         f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), thr = splat3(0.f), hit_point = splat3(0.f);
         uint32_t id = 0, draw0 = 0, l_off = 0;                 // l_off: byte offset of this path's radiance slot
+        // FUSE: the radiance the path has gathered so far (camera rays carry none: nothing is read at bounce 0) and, for entries that end
+        // here without being shaded (nothing hit, roulette), the path id that names the slot it goes to
+        f3 Lc = splat3(0.f);
+        const bool entry = alive;
+        if (FUSE && alive && bounce > 0) Lc = ld3q(in.Lc, p.cap, idx << 2);
+        if (FUSE && alive && bounce > 0) id = PF ? cu_id : ldq(in.id, idx << 2);
         float ray_pdf = 1.f;
         bool was_spec = false;
         Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
@@ -766,7 +782,8 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         if (sc.n_sources == 1) src_only = ld_src_uniform(sc.src);
         // light samples by vertex: ONE queue-tail atomic per tile row for all S samples of every vertex
         uint32_t vbase = 0;
-        if (p.nee_vm) vbase = wave_append(alive, shadow_counter);
+        if (!FUSE && p.nee_vm) vbase = wave_append(alive, shadow_counter);
+        bool f_want = false; f3 f_dir = mk3(0.f, 0.f, 1.f), f_c = splat3(0.f); float f_tmax = 0.f;
         bool late_want = false; f3 late_dir = splat3(0.f), late_c = splat3(0.f); float late_tmax = 0.f; Append late_app; late_app.m = 0ull; late_app.raw = 0u;
         for (int s = 0; s < p.S; s++) {
             bool want = false, sampled = false, poisoned = false;
@@ -808,7 +825,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                         // Upstream the MIS weight multiplies the light sample even when the shadow ray is
                         // occluded (0 * NaN), so a NaN weight poisons the whole pixel-sample, which is then
                         // zeroed at the end (vanilla_renderer.py:87-95,119).  Reproduce that without tracing.
-                        stL(q.L, p.cap, l_off, splat3(mis_w));
+                        if (FUSE) Lc = splat3(mis_w); else stL(q.L, p.cap, l_off, splat3(mis_w));
                         poisoned = true;
                     } else {
                         f3 c = (direct_spec * shadow_int) * mis_w;
@@ -820,7 +837,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
             }
             SH_TICK(2);
             t_shadow += wave_count(sampled); t_poison += wave_count(poisoned);
-            if (p.nee_vm) {
+            if (!FUSE && p.nee_vm) {
                 const uint32_t so = (sh_qbase + (uint32_t)s * p.subcap + vbase) << 2, sc_ = q.sh_cap;        // plane s of the sub-queue's region: consecutive lanes, consecutive entries
                 if (want) {
                     st3q(q.sh_o, sc_, so, hit_point);
@@ -829,6 +846,8 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                     st3q(q.sh_c, sc_, so, contrib);
                 } else if (alive) stq(q.sh_tmax, so, -1.0f);                   // the vertex has no sample s worth tracing
                 if (alive && s == 0) stq(q.sh_id, so, l_off);                   // one radiance slot per vertex, kept with its first entry
+            } else if (FUSE) {
+                f_want = want; f_dir = light_dir; f_c = contrib; f_tmax = emitter_d;      // traced at the end of the row
             } else if (PF && APT_SHADE_LATE_SHADOW && s == p.S - 1) {
                 late_app = append_issue(want, shadow_counter);
                 late_want = want; late_dir = light_dir; late_c = contrib; late_tmax = emitter_d;
@@ -858,7 +877,8 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                 f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_s);
                 if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
                     f3 add = (emit_int * emission_weight) * thr;
-                    add_radiance(q.L, p.cap, l_off, add, true);      // (nothing else touches the path's slot while its shade kernel runs)
+                    if (FUSE) Lc = Lc + add;
+                    else add_radiance(q.L, p.cap, l_off, add, true);      // (nothing else touches the path's slot while its shade kernel runs)
                 }
             }
             f3 spec;
@@ -894,8 +914,35 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
             stq(q.meta[nxt], so, pack_meta(rng.draw, (uint32_t)(bounce + 1), is_spec));
             if (SM & 2) stq(q.pdf[nxt], so, new_pdf);
         }
+        if (FUSE) {
+            // the row's light samples, swept in place; a ray that needs the reference-order sweep leaves as a shadow-queue entry for the fix-up launch
+            const bool defer = f_want && flat_needs_cull(sc.flat, f_dir);
+            bool occ = false;
+            if (__any(f_want && !defer)) occ = flat_any1(sc.flat, hit_point, f_dir, (f_tmax > 0.0f) ? f_tmax - 1e-4f : 1e7f);
+            if (__any(defer)) {
+                const uint32_t spos = wave_append(defer, &cnt->n_fix_sh[cur][sl.q * CNT_PAD]);
+                if (defer && spos < q.sh_subcap) {
+                    const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
+                    st3q(q.sh_o, sc_, so, hit_point); st3q(q.sh_d, sc_, so, f_dir); stq(q.sh_tmax, so, f_tmax); st3q(q.sh_c, sc_, so, f_c); stq(q.sh_id, so, l_off);
+                }
+            }
+            const bool traced = f_want && !defer;
+            if (traced) {
+                // (an occluded sample still enters upstream's sum as 0 * contribution: NaN for a non-finite one, see k_shadow)
+                const bool weird = !(isfinite(f_c.x) && isfinite(f_c.y) && isfinite(f_c.z));
+                if (!occ) Lc = Lc + f_c; else if (weird) Lc = Lc + f_c * 0.f;
+            }
+            t_traced += wave_count(f_want); t_lit += wave_count(traced && !occ);
+            if (cont) st3q(q.Lc[nxt], p.cap, (qbase + npos) << 2, Lc);
+            else if (entry && !(Lc.x == 0.f && Lc.y == 0.f && Lc.z == 0.f)) {
+                // the path ends here (nothing hit, roulette, last bounce): its radiance goes to its slot - added, not stored: a fix-up launch may have put a deferred sample's share there already
+                const uint32_t lp_ = id & ((1u << p.pix_bits) - 1u), s_ = id >> p.pix_bits;
+                add_radiance(q.L, p.cap, (s_ * (uint32_t)p.npix + lp_) << 2, Lc, true);
+            }
+        }
         SH_TICK(5);
     }
+    if (FUSE) { flush_uniform(t_traced, &cnt->stats[sl.q][ST_SHADOW_TRACED]); flush_uniform(t_lit, &cnt->stats[sl.q][ST_LIT]); }
 #ifdef APT_SHADE_PROF
     sprof[6] = __builtin_readcyclecounter() - life0_;
     sprof[5] = wall_clock64() - wall0_;          // 100 MHz constant clock: calibrates the cycle counter
@@ -1133,9 +1180,11 @@ template <int VAR>
 APT_D void shadow_flat_body(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, int par) {
     // VAR 1 / 2: hot variant and the fix-up pass (see k_extend_flat); an entry whose ray needs the reference-order sweep is listed by
     // VAR 1 - untouched: no radiance, no statistics - and done in full by VAR 2.
-    const SubLoop sl = sub_loop(p.nq, VAR == 2 ? BLOCK : FLAT_NT);
-    const uint32_t n = (VAR == 2) ? cnt->n_fix_sh[par][sl.q * CNT_PAD] : min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap);
-    if (VAR != 2 && sl.first == 0 && threadIdx.x == 0) {
+    // VAR 3: the fix-up pass of a render whose shade kernel traces its light samples itself (k_shade FUSE): the shadow queue then holds
+    // nothing but the deferred entries, n_fix_sh[par] of them, and every one is done in full, one per lane, like VAR 2's.
+    const SubLoop sl = sub_loop(p.nq, VAR >= 2 ? BLOCK : FLAT_NT);
+    const uint32_t n = (VAR == 2) ? cnt->n_fix_sh[par][sl.q * CNT_PAD] : ((VAR == 3) ? min(cnt->n_fix_sh[par][sl.q * CNT_PAD], q.sh_subcap) : min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap));
+    if (VAR < 2 && sl.first == 0 && threadIdx.x == 0) {
         if (!p.nee_vm) cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
         for (int c = 0; c < q.n_classes; c++) cnt->n_cls[c][sl.q * CNT_PAD] = 0;      // every shade of this bounce is done
     }
@@ -1184,10 +1233,10 @@ APT_D void shadow_flat_body(const DevScene& sc, const Params& p, const Queues& q
     }
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
         uint32_t pos; bool v0, v1; uint32_t io; bool odd = false;
-        if (VAR == 2) {
+        if (VAR >= 2) {
             const uint32_t li = base + threadIdx.x;
             v0 = li < n; v1 = false;
-            pos = ldq(q.fix_sh, (qbase + (v0 ? li : n - 1u)) << 2);
+            pos = (VAR == 2) ? ldq(q.fix_sh, (qbase + (v0 ? li : n - 1u)) << 2) : (v0 ? li : n - 1u);
             odd = (pos & 1u) != 0u; io = (qbase + (pos & ~1u)) << 2;
         } else {
             pos = base + 2u * threadIdx.x;
@@ -1199,7 +1248,7 @@ APT_D void shadow_flat_body(const DevScene& sc, const Params& p, const Queues& q
         v2f dist = ld2q<v2f>(q.sh_tmax, io);
         // the radiance slots are requested with the rays, so that after the sweep ONE round trip fetches contribution and radiance of both entries
         v2u slot = ld2q<v2u>(q.sh_id, io);
-        if (VAR == 2 && odd) {
+        if (VAR >= 2 && odd) {
             ox = mk2(ox.y, ox.x); oy = mk2(oy.y, oy.x); oz = mk2(oz.y, oz.x); dx = mk2(dx.y, dx.x); dy = mk2(dy.y, dy.x); dz = mk2(dz.y, dz.x);
             dist = mk2(dist.y, dist.x); v2u t_; t_.x = slot.y; t_.y = slot.x; slot = t_;
         }
@@ -1212,7 +1261,7 @@ APT_D void shadow_flat_body(const DevScene& sc, const Params& p, const Queues& q
             v0 = v0 && !sp0; v1 = v1 && !sp1;                                    // a listed entry is left alone here
         }
         v2f cx = ld2q<v2f>(q.sh_c, io), cy = ld2q<v2f>(q.sh_c, io + cs), cz = ld2q<v2f>(q.sh_c, io + 2u * cs);
-        if (VAR == 2 && odd) { cx = mk2(cx.y, cx.x); cy = mk2(cy.y, cy.x); cz = mk2(cz.y, cz.x); }
+        if (VAR >= 2 && odd) { cx = mk2(cx.y, cx.x); cy = mk2(cy.y, cy.x); cz = mk2(cz.y, cz.x); }
         const bool excl = APT_EXCLUSIVE_L(p);
 #ifdef APT_PROBE_NO_L      // measurement only (tools/build_variant.sh nol -DAPT_PROBE_NO_L=1): how much of the stage is the radiance read-modify-write
         if (cx.x == 123.456f) stL(q.L, p.cap, slot.x, ldL(q.L, p.cap, slot.x));
@@ -1250,7 +1299,7 @@ __global__ void __launch_bounds__(BLOCK) k_shadow_flat(DevScene sc, Params p, Qu
 template <int SORTED>
 __global__ void __launch_bounds__(BLOCK) k_fix_flat(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
     extend_flat_body<SORTED, 2>(sc, p, q, cnt, cur, n_src);
-    if (p.S > 0 && !p.volumetric_flat) shadow_flat_body<2>(sc, p, q, cnt, cur ^ 1);
+    if (p.S > 0 && !p.volumetric_flat) { if (p.fused) shadow_flat_body<3>(sc, p, q, cnt, cur ^ 1); else shadow_flat_body<2>(sc, p, q, cnt, cur ^ 1); }
 }
 
 __global__ void __launch_bounds__(BLOCK) k_occluded_flat(DevScene sc, uint32_t n, const float* o_, const float* d_, const float* tmax, int* occ, LdsPlan plan) {

@@ -727,6 +727,7 @@ struct FlatScene {
     const float* stream;      // [parallelograms][same, in a coplanar group] x 12 floats (corner p0, rows U, V, T) | [convex quads][same, coplanar group] x 18 (+ the two far edges' functions of (u, v)) | [triangles][same, coplanar group] x 12 | [spheres] x 4 (centre, r^2)
     const float4* tab;        // per record, 7 float4: (U, p0.x) (V, p0.y) | prim_a prim_b class_a class_b | map_a (u0 uu uv v0 vu vv) map_b (same) | (p0.z, -, -, -)
     const float* precom;      // n_prims * 9: (e1, e2, p0) per triangle - the reference's own test decides between near-tied coplanar candidates
+    const float* pairs;       // the same records two by two, every float of records 2j and 2j + 1 next to each other (an odd tail repeats its last record): the any-hit sweep of ONE ray per lane tests two records per packed instruction (flat_any1: shade kernels that trace their own light samples)
     int n_quads, n_quads_tie, n_gquads, n_gquads_tie, n_tris, n_tris_tie, n_spheres;
     int defer_all;            // test switch (APT_FLAT_DEFER_ALL=1 at scene creation): every ray takes the reference-order path - in the stage kernels, through the fix-up lists
 };
@@ -970,6 +971,59 @@ APT_D void flat_any2(const FlatScene& fl, const SweepScene& sw, f3 o0, f3 d0, f3
 }
 APT_D void flat_any2(const FlatScene& fl, const SweepScene& sw, f3 o0, f3 d0, f3 o1, f3 d1, float lim0, float lim1, bool& occ0, bool& occ1) {
     bool a, b; flat_any2<false>(fl, sw, o0, d0, o1, d1, lim0, lim1, occ0, occ1, a, b);
+}
+// Occlusion of ONE ray per lane below `lim`: the lane's ray against two records per packed instruction (FlatScene::pairs) - the mirror
+// image of flat_loop<true>, for kernels that hold one path per lane (the shade kernels that trace their own light samples: stages.hpp
+// "light samples traced in place").  Same arithmetic per (ray, record) as flat_loop: the two answers are the same bit for bit.
+APT_D bool flat_any1(const FlatScene& fl, f3 o, f3 d, float lim) {
+    cf_ptr at = (cf_ptr)fl.pairs;
+    const v2f ox = sp2(o.x), oy = sp2(o.y), oz = sp2(o.z), dx = sp2(d.x), dy = sp2(d.y), dz = sp2(d.z);
+    bool occ = false;
+    auto solve = [&](cf_ptr r, v2f& t, v2f& u, v2f& v) {      // planar_solve() with the record pair in the halves and the ray broadcast
+        const v2f sx = ox - ld2c(r), sy = oy - ld2c(r + 2), sz = oz - ld2c(r + 4);
+        const v2f ux = ld2c(r + 6), uy = ld2c(r + 8), uz = ld2c(r + 10);
+        const v2f vx = ld2c(r + 12), vy = ld2c(r + 14), vz = ld2c(r + 16);
+        const v2f tx = ld2c(r + 18), ty = ld2c(r + 20), tz = ld2c(r + 22);
+#if APT_FLAT_UNFUSED_HEIGHT
+        const v2f t_o = (tx * sx + ty * sy) + tz * sz;
+#else
+        const v2f t_o = fma2(tx, sx, fma2(ty, sy, tz * sz));
+#endif
+        const v2f t_d = fma2(tx, dx, fma2(ty, dy, tz * dz));
+        v2f inv; inv.x = __builtin_amdgcn_rcpf(t_d.x); inv.y = __builtin_amdgcn_rcpf(t_d.y);
+        t = -t_o * inv;
+        const v2f px = fma2(t, dx, sx), py = fma2(t, dy, sy), pz = fma2(t, dz, sz);
+        u = fma2(ux, px, fma2(uy, py, uz * pz));
+        v = fma2(vx, px, fma2(vy, py, vz * pz));
+    };
+    const int nq = (fl.n_quads + fl.n_quads_tie + 1) >> 1, ng = (fl.n_gquads + fl.n_gquads_tie + 1) >> 1, nt = (fl.n_tris + fl.n_tris_tie + 1) >> 1, ns = (fl.n_spheres + 1) >> 1;
+    for (int j = 0; j < nq; j++, at += 24) {
+        v2f t, u, v; solve(at, t, u, v);
+        const v2f a = u - sp2(0.5f), b = v - sp2(0.5f);
+        occ = occ || flat_blocks(fmaxf(fabsf(a.x), fabsf(b.x)) <= 0.5f, t.x, lim) || flat_blocks(fmaxf(fabsf(a.y), fabsf(b.y)) <= 0.5f, t.y, lim);
+    }
+    for (int j = 0; j < ng; j++, at += 36) {
+        v2f t, u, v; solve(at, t, u, v);
+        const v2f e1 = fma2(ld2c(at + 24), u, fma2(ld2c(at + 26), v, ld2c(at + 28))), e2 = fma2(ld2c(at + 30), u, fma2(ld2c(at + 32), v, ld2c(at + 34)));
+        occ = occ || flat_blocks(fminf(fminf(u.x, v.x), fminf(e1.x, e2.x)) >= 0.f, t.x, lim) || flat_blocks(fminf(fminf(u.y, v.y), fminf(e1.y, e2.y)) >= 0.f, t.y, lim);
+    }
+    for (int j = 0; j < nt; j++, at += 24) {
+        v2f t, u, v; solve(at, t, u, v);
+        const v2f w = (sp2(1.0f) - u) - v;
+        occ = occ || flat_blocks(fminf(fminf(u.x, v.x), w.x) >= 0.f, t.x, lim) || flat_blocks(fminf(fminf(u.y, v.y), w.y) >= 0.f, t.y, lim);
+    }
+    for (int j = 0; j < ns; j++, at += 8) {                   // spheres: flat_loop's test (the reference's, tracer_base.py:184-199) on two spheres
+        const v2f r2 = ld2c(at + 6);
+        const v2f sx = ld2c(at) - ox, sy = ld2c(at + 2) - oy, sz = ld2c(at + 4) - oz;
+        const v2f cn2 = (sx * sx + sy * sy) + sz * sz;
+        const v2f proj = (dx * sx + dy * sy) + dz * sz;
+        const v2f c2ray = cn2 - proj * proj;
+        const v2f disc = r2 - c2ray;
+        const float cut0 = sqrtf(disc.x), cut1 = sqrtf(disc.y);
+        const float ta = proj.x + ((cn2.x > r2.x + 1e-4f) ? -cut0 : cut0), tb = proj.y + ((cn2.y > r2.y + 1e-4f) ? -cut1 : cut1);
+        occ = occ || flat_blocks(c2ray.x < r2.x, ta, lim) || flat_blocks(c2ray.y < r2.y, tb, lim);
+    }
+    return occ;
 }
 // one-ray adapters (volumetric transmittance walk, which keeps its one-entry-per-lane loop): the ray rides in both halves
 template <bool ANY>

@@ -447,8 +447,11 @@ def test_no_systematic_difference_between_the_builds(tag, spp, renderer):
         res[key] = (img, r.stats())
         r.close()
     (f, sf), (e, se), (e1, _) = res["fast"], res["exact"], res["exact1"]
-    for k in ("n_shade", "n_shadow", "n_draws"):
-        assert abs(sf[k] - se[k]) <= 3e-4 * se[k], (tag, k, sf[k], se[k], (sf[k] - se[k]) / se[k])
+    # (random numbers: a vertex that is lost takes the draws of the rest of its path with it - the longest paths of `textured` are the ones
+    # that graze their own wall - so the draw count moves by up to 1.5x the vertex count's share: measured -3.3e-4 there, with the height
+    # T . s rounded like upstream's as well: -3.29e-4, tools/build_variant.sh ufh -DAPT_FLAT_UNFUSED_HEIGHT=1)
+    for k, tol in (("n_shade", 3e-4), ("n_shadow", 3e-4), ("n_draws", 5e-4)):
+        assert abs(sf[k] - se[k]) <= tol * se[k], (tag, k, sf[k], se[k], (sf[k] - se[k]) / se[k])
     assert abs(f.mean() - e.mean()) <= 1e-3 * e.mean(), (f.mean(), e.mean())
 
     def rel(a, b):
