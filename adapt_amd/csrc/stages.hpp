@@ -458,6 +458,21 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 #ifndef APT_DYN_MIN_ACTIVE
 #define APT_DYN_MIN_ACTIVE 32      // measured 32 / 40 / 52 with the product build's leaf test: C4 extend 21.5 / 22.2 / 26.7 ms per 64 spp, C5 13.5 / 14.05 / 15.8 per 32
 #endif
+// Wave-level scheduling of the walk.  The while-while loop (a node step for every walking lane, then primitive tests until the slowest
+// lane has none left) kept half of the issue slots idle: most node steps leave a lane nothing to test, a few leave it a handful, and
+// the wave pays for the longest list (measured, C4: lane utilisation 0.58, of which the primitive loop ran at ~0.25).  With APT_WALK_VOTE
+// an iteration performs ONE kind of action, the one more lanes are waiting for - a node step (lanes whose pending primitive group is
+// empty) or one primitive test (lanes with pending primitives) - and the others sit that iteration out; lanes gather on whichever side
+// is the minority until it becomes the majority.
+#ifndef APT_WALK_VOTE
+#define APT_WALK_VOTE 1
+#endif
+// after either action: a walking lane with nothing pending and no inner children left takes its next group from the stack, or is finished
+APT_D void walk_settle(const TravStack& ts, int& sp, grp_t& ng, const grp_t& tg, int& state) {
+    if (state == 1 && tg.y == 0u && !APT_GROUP_HAS_NODES(ng)) {
+        if (sp == 0) state = 2; else ng = tpop(ts, sp);
+    }
+}
 #ifdef APT_WALK_WAVES
 #define APT_WALK_ATTR __attribute__((amdgpu_waves_per_eu(APT_WALK_WAVES, APT_WALK_WAVES)))
 #else
@@ -545,6 +560,16 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
         if (!__any(state == 1)) break;
         // ---- walk: the while-while loop of traverse<false>, left as soon as too few lanes still hold a ray
         const uint32_t min_active = exhausted ? 1u : (uint32_t)APT_DYN_MIN_ACTIVE;
+#if APT_WALK_VOTE
+        // One action per iteration for the whole wave, chosen by vote (see walk_settle): a node step for the lanes without pending primitives,
+        // or one primitive test for the lanes with some.  Per ray nothing changes - same nodes, same primitives, same order.
+        do {
+            const bool want_t = state == 1 && tg.y != 0u, want_n = state == 1 && tg.y == 0u;
+            if (__popcll(__ballot(want_t)) >= __popcll(__ballot(want_n))) { if (want_t) tri_one<false>(sc.bvh, tg, r, rec, ws); }
+            else if (want_n) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
+            walk_settle(ts, sp, ng, tg, state);
+        } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
+#else
         do {
             if (state == 1) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
             tri_group<false>(sc.bvh, tg, r, rec, ws);
@@ -552,6 +577,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
                 if (sp == 0) state = 2; else ng = tpop(ts, sp);
             }
         } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
+#endif
     }
 #ifdef APT_WALK_STATS
     flush_stat(ws.nodes, &cnt->stats[sq][10]); flush_stat(ws.prims, &cnt->stats[sq][11]);
@@ -914,6 +940,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
             stq(q.meta[nxt], so, pack_meta(rng.draw, (uint32_t)(bounce + 1), is_spec));
             if (SM & 2) stq(q.pdf[nxt], so, new_pdf);
         }
+#if APT_FAST
         if (FUSE) {
             // the row's light samples, swept in place; a ray that needs the reference-order sweep leaves as a shadow-queue entry for the fix-up launch
             const bool defer = f_want && flat_needs_cull(sc.flat, f_dir);
@@ -940,6 +967,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                 add_radiance(q.L, p.cap, (s_ * (uint32_t)p.npix + lp_) << 2, Lc, true);
             }
         }
+#endif
         SH_TICK(5);
     }
     if (FUSE) { flush_uniform(t_traced, &cnt->stats[sl.q][ST_SHADOW_TRACED]); flush_uniform(t_lit, &cnt->stats[sl.q][ST_LIT]); }
@@ -1047,6 +1075,15 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
         }
         if (!__any(state == 1)) break;
         const uint32_t min_active = exhausted ? 1u : (uint32_t)APT_DYN_MIN_ACTIVE;
+#if APT_WALK_VOTE
+        do {
+            const bool want_t = state == 1 && tg.y != 0u, want_n = state == 1 && tg.y == 0u;
+            if (__popcll(__ballot(want_t)) >= __popcll(__ballot(want_n))) {
+                if (want_t && tri_one<true>(sc.bvh, tg, r, rec, ws)) { occluded = true; sp = 0; ng.y = 0u; tg.y = 0u; }      // first occluder ends the walk
+            } else if (want_n) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
+            walk_settle(ts, sp, ng, tg, state);
+        } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
+#else
         do {
             if (state == 1) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
             if (tri_group<true>(sc.bvh, tg, r, rec, ws)) { occluded = true; sp = 0; ng.y = 0u; tg.y = 0u; }      // first occluder ends the walk
@@ -1054,6 +1091,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
                 if (sp == 0) state = 2; else ng = tpop(ts, sp);
             }
         } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
+#endif
     }
     flush_stat(t_lit, &cnt->stats[sq][ST_LIT]);
 #ifdef APT_WALK_STATS
