@@ -85,13 +85,20 @@ def kernel_bytes(st):
     shadow entry = o,d,tmax,contribution,id 44 B; radiance L = 12 B (24 B per read-modify-write)."""
     n_s, n_e, n_sh, n_lit = st["n_samples"], st["n_extend"], st["n_shadow_traced"], st["n_lit"]
     n_cont = n_e - n_s                       # queue entries written by shade for the next bounce
-    return {
+    kb = {
         "generate": 60 * n_s,                # ray 24 + state 24 + zeroed L 12
         "extend": 40 * n_e,                  # read ray 24, write hit 16
         "shade": 64 * n_e + 48 * n_cont + 44 * n_sh,     # read ray+hit+state, write next ray+state, write shadow entries
         "shadow": 44 * n_sh + 24 * n_lit,    # read entry, RMW radiance of unoccluded ones
         "finalize": 12 * n_s,                # read L (framebuffer RMW is 24 B per pixel per batch: negligible)
     }
+    if st.get("launches", {}).get("shadow", 1) == 0 and n_sh > 0:
+        # light samples traced in place (stages.hpp k_shade FUSE): the shade kernel does the shadow stage's work as well, so the UNIT of work
+        # it is credited with is SURVEY 8(d)'s for both stages - 88 B per shadow ray + 24 B per unoccluded one on top of its own - although
+        # the entries never travel through HBM (what it really moves is the `traffic` figure: 64 + 12 B read, 48 + 12 B written per entry)
+        kb["shade"] += kb["shadow"]
+        kb["shadow"] = 0
+    return kb
 
 
 def stage_units(st):
@@ -103,6 +110,8 @@ def region_roofline(stats, counters, n_simd, sclk_mhz):
     kb, kms, units = kernel_bytes(stats), stats["kernel_ms"], stage_units(stats)
     per = {}
     for k in kms:
+        if stats["launches"][k] == 0 and kb[k] == 0:
+            continue                                 # a stage this render does not launch (its fix-up time is in the bucket, nothing else)
         launches = max(1, stats["launches"][k])
         avg_ms = kms[k] / launches
         e = {"ms": round(kms[k], 3), "launches": int(stats["launches"][k]), "avg_launch_ms": round(avg_ms, 5), "alg_bytes": int(kb[k]),
