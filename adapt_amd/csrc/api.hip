@@ -43,14 +43,14 @@ typedef void (*shade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int, int)
 #else
 #define APT_FUSED_FN(...) nullptr         // light samples traced by the shade kernel: a product-build path (it rides on the flat sweep's records)
 #endif
-struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_fn fused; };      // fused: the variant that traces its own light samples (stages.hpp k_shade FUSE)
+struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_fn fused, traced; };      // fused: the variant that traces its own light samples (stages.hpp k_shade FUSE = 1); traced: ... and its continuation ray (FUSE = 2)
 static const ShadeVariant kShadeVariants[] = {
-    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade<0x002, 0x01, 0, 1>)},
-    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade<0x003, 0x03, 0, 1>)},
-    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade<0x107, 0x03, 0, 1>)},
-    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 1>)},
+    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade<0x002, 0x01, 0, 1>), APT_FUSED_FN(k_shade<0x002, 0x01, 0, 2>)},
+    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade<0x003, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x003, 0x03, 0, 2>)},
+    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade<0x107, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x107, 0x03, 0, 2>)},
+    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 2>)},
 };
-static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 1>)};
+static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 2>)};
 // Material classes for sorted shading: (class mask) x (emitter mask: point+area | all)
 // A kernel's register allocation is the maximum over the models it contains, so the classes are as fine as the models'
 // footprints differ: Lambertian alone runs at 4 waves per SIMD, together with Blinn-Phong (three double pows) at 2-3.
@@ -699,8 +699,9 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (textured) r->sorted = 0;
     r->volumetric = c.volumetric ? 1 : 0;
     // light samples traced by the shade kernel itself (stages.hpp k_shade FUSE): flat sweep, one sample per vertex, one shade kernel
-    p.fused = (r->trace_mode == 3 && !r->sorted && !c.volumetric && S == 1 && r->shade->fused != nullptr) ? 1 : 0;
-    if (const char* f = getenv("APT_FUSED")) p.fused = (atoi(f) != 0 && p.fused) ? 1 : 0;
+    // ... and, by default, its continuation ray too (FUSE = 2, "rays traced in place": no extend launch, no fix-up launch per bounce); APT_FUSED=0|1|2
+    p.fused = (r->trace_mode == 3 && !r->sorted && !c.volumetric && S == 1 && r->shade->fused != nullptr) ? 2 : 0;
+    if (const char* f = getenv("APT_FUSED")) p.fused = p.fused ? std::max(0, std::min(2, atoi(f))) : 0;
     if (r->volumetric) {
         if (c.max_bounce > 255) { return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer keeps the bounce count in 8 bits (max_bounce <= 255)"); }
         if (!sc->has_aabb) { return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer needs the object boxes (world bound)"); }
@@ -728,6 +729,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     }
     const int ncls = r->volumetric ? r->v_ncls : (r->sorted ? sc->n_classes : 0);
     r->shade_name = r->volumetric ? r->vshade->name : r->shade->name;
+    if (p.fused == 2) r->shade_name += " [rays traced in place]";
+    else if (p.fused == 1) r->shade_name += " [light samples traced in place]";
     if (r->sorted && r->volumetric) {
         r->shade_name = std::string(sc->has_volume ? "volumetric + grid volume, sorted:" : "volumetric, sorted:");
         for (int c = 0; c < sc->n_classes; c++) r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
@@ -745,7 +748,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     // one pool per lane, carved into the SoA arrays (all 4-byte lanes)
     const bool walk_lists = r->volumetric && sc->has_null_surface;      // light samples that cross null surfaces are re-queued by slot
     const size_t l_planes = (size_t)p.l_planes;
-    const size_t words = (p.fused ? 6 * cap : 0) + (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
+    const size_t words = (p.fused ? 6 * cap : 0) + (p.fused == 2 ? 4 * cap : 0) + (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
         hipError_t e_ = pool.alloc(words * 4);
         if (e_ != hipSuccess) return e_;
@@ -758,6 +761,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         auto take = [&](size_t n) { float* x = w; w += n; return x; };
         for (int k = 0; k < 2; k++) { q.ray_o[k] = take(3 * cap); q.ray_d[k] = take(3 * cap); }
         q.hit_t = take(cap); q.hit_prim = (int*)take(cap); q.hit_u = take(cap); q.hit_v = take(cap);
+        q.hit2_t = q.hit2_u = q.hit2_v = nullptr; q.hit2_prim = nullptr;
+        if (p.fused == 2) { q.hit2_t = take(cap); q.hit2_prim = (int*)take(cap); q.hit2_u = take(cap); q.hit2_v = take(cap); }
         q.fix_ext = (r->trace_mode == 3) ? (uint32_t*)take(cap) : nullptr; q.fix_sh = (r->trace_mode == 3) ? (uint32_t*)take(sh_cap) : nullptr;
         for (int k = 0; k < 2; k++) { q.thr[k] = take(3 * cap); q.id[k] = (uint32_t*)take(cap); q.meta[k] = (uint32_t*)take(cap); q.pdf[k] = take(cap); }
         q.L = take(4 * cap * l_planes);
@@ -1101,6 +1106,22 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
         const size_t total = (size_t)r->npix * (size_t)B;
         unchain(r, st); HIP_TRY(hipMemsetAsync(cnt, 0, offsetof(Counters, stats), st));   // queue counters only; statistics keep accumulating
         const int nq = r->nq;
+#if APT_FAST
+        if (p.fused == 2) {
+            // rays traced in place (stages.hpp): generate and every bounce are ONE launch each; the rare rays that need the reference-order code
+            // are served by the next launch's prologue, the last bounce's deferred light samples by one fix-up launch at the end
+            { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate_trace, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, sc, p, q, cnt); }
+            int cur = 0;
+            for (int b = 0; b < p.max_bounce; b++) {
+                ShadeIn in = {q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.id[cur], q.meta[cur], q.pdf[cur],
+                              cur ? q.hit2_t : q.hit_t, cur ? q.hit2_prim : q.hit_prim, cur ? q.hit2_u : q.hit_u, cur ? q.hit2_v : q.hit_v, (const uint32_t*)cnt->n_tr[b % 3], q.Lc[cur]};
+                LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->shade->traced, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
+                cur ^= 1;
+            }
+            if (p.max_bounce > 0) { LaunchTimer t(r, 3, st, false); hipLaunchKernelGGL(kFixFlat[0], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
+        } else
+#endif
+        {
         { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, p, q, cnt); }
         int cur = 0;
         for (int b = 0; b < p.max_bounce; b++) {
@@ -1131,6 +1152,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
         }
         if (r->trace_mode == 3 && p.S > 0 && p.max_bounce > 0) {     // the last bounce's shadow list (the extend list of this parity is empty)
             LaunchTimer t(r, 3, st, false); hipLaunchKernelGGL(kFixFlat[r->sorted], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan);
+        }
         }
         // the framebuffer is shared: batch k's samples are added after batch k-1's, whichever lanes they ran on
         if (prev_fin && r->n_lanes > 1) { unchain(r, st); HIP_TRY(hipStreamWaitEvent(st, prev_fin, 0)); }

@@ -101,6 +101,7 @@ struct Params {
     int nee_vm;               // 1: light samples are queued BY VERTEX (one slot per vertex and sub-queue, sample s in plane s of the sub-queue's region, unwanted samples marked tmax < 0), so that the flat shadow kernel adds a vertex's samples with ONE read-modify-write and the shade kernel moves the queue tail once per tile row (flat sweep, S > 1)
     int l_planes;             // radiance planes of L: light sample s of a vertex adds into plane s (2 <= S <= 4), so that no two entries of a shadow launch share a slot; 1 otherwise
     int fused;                // 1: the shade kernel traces its own light samples (flat sweep, one sample per vertex, unsorted: stages.hpp "light samples traced in place"); no shadow queue, no shadow launch, radiance travels with the path (Queues::Lc)
+                              // 2: ... and its continuation ray too (k_generate its camera rays): no extend launch, no fix-up launch per bounce, rays that hit nothing never enter a queue (stages.hpp "rays traced in place")
     float w_min[3], w_max[3]; // world box = (objects U camera) +- 0.1 (path_tracer.py:130-138); volumetric tracer only
 };
 
@@ -108,6 +109,7 @@ struct Params {
 struct Queues {
     float* ray_o[2]; float* ray_d[2];           // 3 components each
     float* hit_t; int* hit_prim; float* hit_u; float* hit_v;
+    float* hit2_t; int* hit2_prim; float* hit2_u; float* hit2_v;      // rays traced in place (Params::fused == 2): the hit records of queue parity 1 (hit_* serve parity 0; null elsewhere)
     uint32_t* fix_ext; uint32_t* fix_sh;         // flat sweep: fix-up lists, sub-queue-local entry indices (null elsewhere)
     float* thr[2]; uint32_t* id[2]; uint32_t* meta[2]; float* pdf[2];
     float* sh_o; float* sh_d; float* sh_tmax; float* sh_c; uint32_t* sh_id;
@@ -146,6 +148,9 @@ struct Counters {
     uint32_t n_fix_ext[2][APT_MAX_NQ * CNT_PAD];  // flat sweep: entries handed to the fix-up launch of the extend stage (by queue parity) ...
     uint32_t n_fix_sh[2][APT_MAX_NQ * CNT_PAD];   // ... and of the shadow stage, by the parity of the bounce that listed them (stages.hpp "fix-up lists")
     uint32_t n_work[2][APT_MAX_NQ * CNT_PAD];     // BVH walk with dynamic fetch: next unclaimed queue position (0 extend, 1 shadow); zeroed by the host before the launch
+    uint32_t n_tr[3][APT_MAX_NQ * CNT_PAD];       // rays traced in place: entries of the queue that launch k of the batch reads, at [k % 3] (launch k appends to [(k + 1) % 3] and zeroes [(k + 2) % 3], which launch k - 1 read: no launch in between has to reset a counter)
+    uint32_t fix_claim[APT_MAX_NQ * CNT_PAD];     // rays traced in place: which launch of the batch (1 + bounce) has had its fix-up lists claimed by a wave ...
+    uint32_t fix_done[APT_MAX_NQ * CNT_PAD];      // ... and served (stages.hpp fix_prologue)
     unsigned long long stats[APT_MAX_NQ][16];    // [q][ST_*], 128 bytes per sub-queue
 #ifdef APT_SHADE_PROF
     unsigned long long dbg[2 * 16384];           // per-wave (start, end) of the last k_shade launch, 100 MHz ticks
@@ -295,7 +300,10 @@ APT_D SubLoop sub_loop(int nq, int nt = BLOCK) {
 // ----------------------------------------------------------------- generate
 // wave w of the id space feeds sub-queue w % nq at position (w / nq) * 64 + lane: dense and
 // atomic-free unless a crop window makes some lanes inactive.
-__global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters* cnt) {
+// TRACE (rays traced in place, Params::fused == 2): the camera ray meets the scene's records here and the entry carries its hit record
+// (hit_* of queue parity 0; a ray that hits nothing keeps its dense, atomic-free slot with prim = -1); entries are counted in n_tr[0].
+template <bool TRACE>
+APT_D void generate_body(const DevScene* sc, const Params& p, const Queues& q, Counters* cnt) {
     const uint32_t total = (uint32_t)p.npix * (uint32_t)p.spp_batch;
     const uint32_t n_waves = (total + 63u) / 64u;
     const uint32_t wave_stride = gridDim.x * (BLOCK / 64);
@@ -334,12 +342,32 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
             }
         }
         uint32_t pos;
-        if (p.do_crop) pos = wave_append(alive, &cnt->n_active[0][sq * CNT_PAD]);
+        uint32_t* q0_counter = TRACE ? &cnt->n_tr[0][sq * CNT_PAD] : &cnt->n_active[0][sq * CNT_PAD];
+        if (p.do_crop) pos = wave_append(alive, q0_counter);
         else {
             pos = (w / (uint32_t)p.nq) * 64u + lane_id();
             unsigned long long m = __ballot(alive);
-            if (lane_id() == 0) atomicAdd(&cnt->n_active[0][sq * CNT_PAD], (uint32_t)__popcll(m));   // nq-way spread, ordered by w
+            if (lane_id() == 0) atomicAdd(q0_counter, (uint32_t)__popcll(m));   // nq-way spread, ordered by w
         }
+#if APT_FAST
+        if (TRACE) {
+            const f3 cam_o = mk3(p.cam_t[0], p.cam_t[1], p.cam_t[2]);
+            float tr_t = 0.f; int tr_run = -1, tr_idx = -1;
+            if (__any(alive)) tr_idx = flat_closest1(sc->flat, cam_o, dir, 1e7f, tr_t, tr_run);
+            const bool defer = alive && (tr_run >= 0 || flat_needs_cull(sc->flat, dir));
+            HitRec hr; hr.t = 1e7f; hr.prim = -1; hr.u = hr.v = 0.f;
+            if (alive && !defer && tr_idx >= 0) { int cls_; flat_resolve(sc->flat, tr_idx, tr_t, cam_o, dir, hr, cls_); }
+            if (alive) {
+                const uint32_t so = ((uint32_t)sq * p.subcap + pos) << 2;
+                stq(q.hit_t, so, hr.t); stq(q.hit_prim, so, hr.prim);
+                if (sc->has_vn || sc->tex_i != nullptr) { stq(q.hit_u, so, hr.u); stq(q.hit_v, so, hr.v); }
+            }
+            if (__any(defer)) {
+                const uint32_t lpos = wave_append(defer, &cnt->n_fix_ext[0][sq * CNT_PAD]);
+                if (defer) stq(q.fix_ext, ((uint32_t)sq * p.subcap + lpos) << 2, pos);
+            }
+        }
+#endif
         if (alive) {
             const uint32_t so = ((uint32_t)sq * p.subcap + pos) << 2;
             st3q(q.ray_o[0], p.cap, so, mk3(p.cam_t[0], p.cam_t[1], p.cam_t[2]));
@@ -354,8 +382,13 @@ __global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters
     }
     const int sq0 = (int)((blockIdx.x * (BLOCK / 64) + threadIdx.x / 64u) % (uint32_t)p.nq);
     flush_stat(t_samples, &cnt->stats[sq0][ST_SAMPLES]);
+    if (TRACE) flush_stat(t_samples, &cnt->stats[sq0][ST_EXTEND]);
     flush_stat(t_draws, &cnt->stats[sq0][ST_DRAWS]);
 }
+__global__ void __launch_bounds__(BLOCK) k_generate(Params p, Queues q, Counters* cnt) { generate_body<false>(nullptr, p, q, cnt); }
+#if APT_FAST
+__global__ void __launch_bounds__(BLOCK) k_generate_trace(DevScene sc, Params p, Queues q, Counters* cnt) { generate_body<true>(&sc, p, q, cnt); }
+#endif
 
 // ------------------------------------------------------------------- extend
 // closest hit for ray queue `cur`.  Also recycles the counters nobody reads any more: the
@@ -651,13 +684,78 @@ APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3
 // queue entry written, when little else is live.  The path's radiance then travels WITH the path (Queues::Lc, 12 bytes of the queue
 // record) and reaches its slot of L once, when the path ends.  The rare rays whose answer needs the reference-order sweep
 // (flat_needs_cull) still leave as shadow-queue entries, counted by n_fix_sh[cur], and are served by the next fix-up launch.
+#if APT_FAST
+// ---- rays traced in place (Params::fused == 2; product build, flat sweep, unsorted, one light sample per vertex)
+// The shade kernel sweeps its continuation ray against the scene's records itself (flat_closest1: one ray against two records per packed
+// instruction), as it already does with its light sample, and k_generate does the same for the camera rays: a bounce is ONE launch
+// instead of extend + fix-up + shade, the ray is never read back (24 + 8 bytes per segment), and a ray that hits nothing never enters a
+// queue - its path ends where it was sampled (18 % of C2's continuation rays: no record written, no idle lane in the next launch).
+// The rare rays that need the reference's own arithmetic (traverse.hpp flat_closest2: near-tied coplanar faces, directions for which
+// upstream's slab cull is part of the result) are queued with a provisional record and listed, as before - but the lists are served by
+// the NEXT launch itself instead of a fix-up launch per bounce (a launch boundary is a pipeline drain: ~20 us of a render lane each):
+// a wave that finds its sub-queue's lists non-empty claims them (one atomic), serves them - one entry per lane, the full reference-order
+// code - and publishes "done"; the sub-queue's other waves wait for that before they read a record.  The lists are empty in all but a few
+// launches per render, where the whole protocol is two scalar loads per wave; the serving code sits in front of the kernel's main loop,
+// where almost no register is live, so it costs the hot loop nothing (k_fix_flat alone allocates 84 VGPRs, the shade kernel 122).
+// Nothing depends on how workgroups are placed: whichever wave claims a list is running, hence the waiters cannot starve it.
+APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, const ShadeIn& in, int cur, int sq, uint32_t epoch) {
+    uint32_t* n_ext_p = &cnt->n_fix_ext[cur][sq * CNT_PAD]; uint32_t* n_sh_p = &cnt->n_fix_sh[cur ^ 1][sq * CNT_PAD];
+    const uint32_t n_ext = *n_ext_p, n_sh = min(*n_sh_p, q.sh_subcap);
+    if ((n_ext | n_sh) == 0u) return;
+    uint32_t old = 0;
+    if (lane_id() == 0) old = atomicMax(&cnt->fix_claim[sq * CNT_PAD], epoch);
+    old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);
+    if (old >= epoch) {                                       // somebody else serves (or has served) the lists of this launch
+        while (__hip_atomic_load(&cnt->fix_done[sq * CNT_PAD], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(16);
+        return;
+    }
+    const uint32_t qbase = (uint32_t)sq * p.subcap, sh_qbase = (uint32_t)sq * q.sh_subcap;
+    const bool need_uv = sc.has_vn || sc.tex_i != nullptr;
+    for (uint32_t base = 0; base < n_ext; base += 64u) {      // closest hits: the listed entries of queue `cur`, records written in place
+        const uint32_t li = base + lane_id(); const bool valid = li < n_ext;
+        const uint32_t pos = ldq(q.fix_ext, (qbase + (valid ? li : n_ext - 1u)) << 2);
+        const uint32_t io = (qbase + pos) << 2;
+        const f3 o = ld3q(in.ray_o, p.cap, io), d = ld3q(in.ray_d, p.cap, io);
+        HitRec r0, r1; r0.t = r1.t = 1e7f; r0.prim = r1.prim = -1; r0.u = r0.v = r1.u = r1.v = 0.f;
+        int c0, c1;
+        flat_closest2(sc.flat, sc.sweep, sc.prim_class, o, d, o, d, r0, r1, c0, c1);
+        if (valid) {
+            stq(const_cast<float*>(in.t), io, r0.t); stq(const_cast<int*>(in.prim), io, r0.prim);
+            if (need_uv) { stq(const_cast<float*>(in.u), io, r0.u); stq(const_cast<float*>(in.v), io, r0.v); }
+        }
+    }
+    uint32_t t_lit = 0;
+    for (uint32_t base = 0; base < n_sh; base += 64u) {       // light samples the previous launch could not settle (shadow_flat_body<3>)
+        const uint32_t li = base + lane_id(); const bool valid = li < n_sh;
+        const uint32_t io = (sh_qbase + (valid ? li : n_sh - 1u)) << 2;
+        const f3 o = ld3q(q.sh_o, q.sh_cap, io), d = ld3q(q.sh_d, q.sh_cap, io), c = ld3q(q.sh_c, q.sh_cap, io);
+        const float dist = ldq(q.sh_tmax, io); const uint32_t slot = ldq(q.sh_id, io);
+        bool occ, occ_b;
+        const float lim = (dist > 0.0f) ? dist - 1e-4f : 1e7f;
+        flat_any2(sc.flat, sc.sweep, o, d, o, d, lim, lim, occ, occ_b);
+        if (valid) {
+            const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
+            if (!occ) add_radiance(q.L, p.cap, slot, c, true);
+            else if (weird) add_radiance(q.L, p.cap, slot, c * 0.f, true);      // (k_shadow: an occluded sample enters upstream's sum as 0 * contribution)
+            t_lit += occ ? 0u : 1u;
+        }
+    }
+    flush_stat(t_lit, &cnt->stats[sq][ST_LIT]);
+    __threadfence();
+    if (lane_id() == 0) {
+        __hip_atomic_store(&cnt->fix_done[sq * CNT_PAD], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        *n_ext_p = 0u; *n_sh_p = 0u;                          // consumed (the launch after this one appends to these lists again)
+    }
+}
+#endif
 template <int BM, int SM, int TEX = 0, int FUSE = 0>
 __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_LAMBERT_WAVES : APT_SHADE_WAVES))) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
     const uint32_t n = in.counts[sl.q * CNT_PAD];
     const uint32_t qbase = (uint32_t)sl.q * p.subcap, sh_qbase = (uint32_t)sl.q * q.sh_subcap;
-    uint32_t* next_counter = &cnt->n_active[nxt][sl.q * CNT_PAD];
+    uint32_t* next_counter = (FUSE == 2) ? &cnt->n_tr[(bounce + 1) % 3][sl.q * CNT_PAD] : &cnt->n_active[nxt][sl.q * CNT_PAD];
+    if (FUSE == 2 && sl.first == 0 && threadIdx.x == 0) cnt->n_tr[(bounce + 2) % 3][sl.q * CNT_PAD] = 0;      // (read by the previous launch, appended to by the next one)
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
     const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
     uint32_t t_shade = 0, t_shadow = 0, t_poison = 0, t_traced = 0, t_lit = 0;        // wave-uniform tallies (SGPRs)
@@ -688,6 +786,11 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
     // the kernels without registers for that (material classes: 124-128 VGPRs) prefetch only the hit primitive - one register - so that a
     // row's shading record can be requested together with its queue record instead of a round trip after it
     constexpr bool PFP = !PF && (APT_SHADE_PREFETCH_PRIM != 0) && TEX == 0;
+    constexpr bool TRACE = FUSE == 2;                         // the continuation ray is traced in place too ("rays traced in place" above)
+    uint32_t t_extend = 0;
+#if APT_FAST
+    if (TRACE) fix_prologue(sc, p, q, cnt, in, cur, sl.q, (uint32_t)bounce + 1u);      // before the first record is requested
+#endif
     if (PF && n > 0) prefetch(sl.first);
     if (PFP && n > 0) pf_prim = ldq(in.prim, (qbase + min(sl.first + threadIdx.x, n - 1u)) << 2);
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
@@ -799,7 +902,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         // full wait of a row comes after all of its arithmetic - by then the next row's record has long arrived
         const bool cont_early = alive && (bounce + 1) < p.max_bounce;
         Append next_app; next_app.m = 0ull; next_app.raw = 0u;
-        if (PF) next_app = append_issue(cont_early, next_counter);
+        if (PF && !TRACE) next_app = append_issue(cont_early, next_counter);
         SH_TICK(1);
 
         // ---- next-event estimation: one shadow-queue entry per useful light sample
@@ -930,8 +1033,23 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                 stq(q.sh_id, so, l_off | ((p.l_planes > 1) ? (uint32_t)(p.S - 1) : 0u));
             }
         }
-        uint32_t npos = PF ? append_pos(next_app) : wave_append(cont, next_counter);
-        if (cont) {
+#if APT_FAST
+        // rays traced in place: the continuation ray meets the scene's records here.  Only rays that hit something (or whose answer is left
+        // to the reference-order code: listed, with a provisional record) enter the next queue; the tail atomic is on its way while the light
+        // sample is swept below.
+        float tr_t = 0.f; int tr_prim = -1; float tr_u = 0.f, tr_v = 0.f; bool tr_defer = false;
+        if (TRACE) {
+            int tr_idx = -1, tr_run = -1;
+            if (__any(cont)) tr_idx = flat_closest1(sc.flat, hit_point, new_d, 1e7f, tr_t, tr_run);
+            tr_defer = cont && (tr_run >= 0 || flat_needs_cull(sc.flat, new_d));
+            t_extend += wave_count(cont);
+            cont = cont && (tr_idx >= 0 || tr_defer);
+            next_app = append_issue(cont, next_counter);
+            if (cont && !tr_defer) { HitRec hr; int cls_; flat_resolve(sc.flat, tr_idx, tr_t, hit_point, new_d, hr, cls_); tr_prim = hr.prim; tr_u = hr.u; tr_v = hr.v; }
+        }
+#endif
+        uint32_t npos = (PF && !TRACE) ? append_pos(next_app) : (TRACE ? 0u : wave_append(cont, next_counter));
+        if (cont && !TRACE) {
             const uint32_t so = (qbase + npos) << 2;
             st3q(q.ray_o[nxt], p.cap, so, hit_point);
             st3q(q.ray_d[nxt], p.cap, so, new_d);
@@ -960,6 +1078,24 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                 if (!occ) Lc = Lc + f_c; else if (weird) Lc = Lc + f_c * 0.f;
             }
             t_traced += wave_count(f_want); t_lit += wave_count(traced && !occ);
+            if (TRACE) {
+                npos = append_pos(next_app);
+                if (cont) {
+                    const uint32_t so = (qbase + npos) << 2;
+                    st3q(q.ray_o[nxt], p.cap, so, hit_point);
+                    st3q(q.ray_d[nxt], p.cap, so, new_d);
+                    st3q(q.thr[nxt], p.cap, so, thr);
+                    stq(q.id[nxt], so, id);
+                    stq(q.meta[nxt], so, pack_meta(rng.draw, (uint32_t)(bounce + 1), is_spec));
+                    if (SM & 2) stq(q.pdf[nxt], so, new_pdf);
+                    stq(nxt ? q.hit2_t : q.hit_t, so, tr_t); stq(nxt ? q.hit2_prim : q.hit_prim, so, tr_prim);
+                    if (sc.has_vn || sc.tex_i != nullptr) { stq(nxt ? q.hit2_u : q.hit_u, so, tr_u); stq(nxt ? q.hit2_v : q.hit_v, so, tr_v); }
+                }
+                if (__any(tr_defer)) {                        // listed for the next launch's prologue (sub-queue-local position)
+                    const uint32_t lpos = wave_append(tr_defer, &cnt->n_fix_ext[nxt][sl.q * CNT_PAD]);
+                    if (tr_defer) stq(q.fix_ext, (qbase + lpos) << 2, npos);
+                }
+            }
             if (cont) st3q(q.Lc[nxt], p.cap, (qbase + npos) << 2, Lc);
             else if (entry && !(Lc.x == 0.f && Lc.y == 0.f && Lc.z == 0.f)) {
                 // the path ends here (nothing hit, roulette, last bounce): its radiance goes to its slot - added, not stored: a fix-up launch may have put a deferred sample's share there already
@@ -971,6 +1107,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         SH_TICK(5);
     }
     if (FUSE) { flush_uniform(t_traced, &cnt->stats[sl.q][ST_SHADOW_TRACED]); flush_uniform(t_lit, &cnt->stats[sl.q][ST_LIT]); }
+    if (TRACE) flush_uniform(t_extend, &cnt->stats[sl.q][ST_EXTEND]);
 #ifdef APT_SHADE_PROF
     sprof[6] = __builtin_readcyclecounter() - life0_;
     sprof[5] = wall_clock64() - wall0_;          // 100 MHz constant clock: calibrates the cycle counter

@@ -1025,6 +1025,105 @@ APT_D bool flat_any1(const FlatScene& fl, f3 o, f3 d, float lim) {
     }
     return occ;
 }
+// Closest hit of ONE ray per lane below `lim`, two records per packed instruction (FlatScene::pairs): flat_loop<false> for kernels that hold
+// one path per lane (the shade kernels that trace their continuation ray in place, k_generate's camera rays: stages.hpp "rays traced in
+// place").  Records are visited in flat_loop's order with flat_loop's arithmetic per (ray, record), so distance and winner are the same
+// bit for bit.  A pair that straddles the border between a plain section and its coplanar-group section is treated as a group pair: its
+// plain record may then be remembered as a runner-up, which only sends the ray to the reference-order arithmetic a little more often.
+// Returns the winner's record index (-1: none); t = its distance, runner = a near-tied runner-up from a coplanar group (-1: none).
+APT_D int flat_closest1(const FlatScene& fl, f3 o, f3 d, float lim, float& t_out, int& runner) {
+    cf_ptr at = (cf_ptr)fl.pairs;
+    const v2f ox = sp2(o.x), oy = sp2(o.y), oz = sp2(o.z), dx = sp2(d.x), dy = sp2(d.y), dz = sp2(d.z);
+    FlatBest b; b.t = lim; b.idx = -1; b.runner = -1;
+    auto solve = [&](cf_ptr r, v2f& t, v2f& u, v2f& v) {      // as in flat_any1
+        const v2f sx = ox - ld2c(r), sy = oy - ld2c(r + 2), sz = oz - ld2c(r + 4);
+        const v2f ux = ld2c(r + 6), uy = ld2c(r + 8), uz = ld2c(r + 10);
+        const v2f vx = ld2c(r + 12), vy = ld2c(r + 14), vz = ld2c(r + 16);
+        const v2f tx = ld2c(r + 18), ty = ld2c(r + 20), tz = ld2c(r + 22);
+#if APT_FLAT_UNFUSED_HEIGHT
+        const v2f t_o = (tx * sx + ty * sy) + tz * sz;
+#else
+        const v2f t_o = fma2(tx, sx, fma2(ty, sy, tz * sz));
+#endif
+        const v2f t_d = fma2(tx, dx, fma2(ty, dy, tz * dz));
+        v2f inv; inv.x = __builtin_amdgcn_rcpf(t_d.x); inv.y = __builtin_amdgcn_rcpf(t_d.y);
+        t = -t_o * inv;
+        const v2f px = fma2(t, dx, sx), py = fma2(t, dy, sy), pz = fma2(t, dz, sz);
+        u = fma2(ux, px, fma2(uy, py, uz * pz));
+        v = fma2(vx, px, fma2(vy, py, vz * pz));
+    };
+    int idx = 0;                                             // wave-uniform index of the pair's first record
+    {   // parallelograms
+        const int n = fl.n_quads + fl.n_quads_tie, n_plain = fl.n_quads >> 1;      // pairs whose records are both plain
+        int j = 0;
+        for (; j < n_plain; j++, idx += 2, at += 24) {
+            v2f t, u, v; solve(at, t, u, v);
+            const v2f a = u - sp2(0.5f), c = v - sp2(0.5f);
+            b = flat_candidate<false>(b, fmaxf(fabsf(a.x), fabsf(c.x)) <= 0.5f, t.x, idx);
+            b = flat_candidate<false>(b, fmaxf(fabsf(a.y), fabsf(c.y)) <= 0.5f, t.y, idx + 1);
+        }
+        for (; 2 * j < n; j++, idx += 2, at += 24) {
+            v2f t, u, v; solve(at, t, u, v);
+            const v2f a = u - sp2(0.5f), c = v - sp2(0.5f);
+            b = flat_candidate<true>(b, fmaxf(fabsf(a.x), fabsf(c.x)) <= 0.5f, t.x, idx);
+            b = flat_candidate<true>(b, 2 * j + 1 < n && fmaxf(fabsf(a.y), fabsf(c.y)) <= 0.5f, t.y, idx + 1);
+        }
+        idx = n;
+    }
+    {   // convex quadrilaterals
+        const int n = fl.n_gquads + fl.n_gquads_tie, n_plain = fl.n_gquads >> 1, first = idx;
+        int j = 0;
+        for (; j < n_plain; j++, idx += 2, at += 36) {
+            v2f t, u, v; solve(at, t, u, v);
+            const v2f e1 = fma2(ld2c(at + 24), u, fma2(ld2c(at + 26), v, ld2c(at + 28))), e2 = fma2(ld2c(at + 30), u, fma2(ld2c(at + 32), v, ld2c(at + 34)));
+            b = flat_candidate<false>(b, fminf(fminf(u.x, v.x), fminf(e1.x, e2.x)) >= 0.f, t.x, idx);
+            b = flat_candidate<false>(b, fminf(fminf(u.y, v.y), fminf(e1.y, e2.y)) >= 0.f, t.y, idx + 1);
+        }
+        for (; 2 * j < n; j++, idx += 2, at += 36) {
+            v2f t, u, v; solve(at, t, u, v);
+            const v2f e1 = fma2(ld2c(at + 24), u, fma2(ld2c(at + 26), v, ld2c(at + 28))), e2 = fma2(ld2c(at + 30), u, fma2(ld2c(at + 32), v, ld2c(at + 34)));
+            b = flat_candidate<true>(b, fminf(fminf(u.x, v.x), fminf(e1.x, e2.x)) >= 0.f, t.x, idx);
+            b = flat_candidate<true>(b, 2 * j + 1 < n && fminf(fminf(u.y, v.y), fminf(e1.y, e2.y)) >= 0.f, t.y, idx + 1);
+        }
+        idx = first + n;
+    }
+    {   // triangles
+        const int n = fl.n_tris + fl.n_tris_tie, n_plain = fl.n_tris >> 1, first = idx;
+        int j = 0;
+        for (; j < n_plain; j++, idx += 2, at += 24) {
+            v2f t, u, v; solve(at, t, u, v);
+            const v2f w = (sp2(1.0f) - u) - v;
+            b = flat_candidate<false>(b, fminf(fminf(u.x, v.x), w.x) >= 0.f, t.x, idx);
+            b = flat_candidate<false>(b, fminf(fminf(u.y, v.y), w.y) >= 0.f, t.y, idx + 1);
+        }
+        for (; 2 * j < n; j++, idx += 2, at += 24) {
+            v2f t, u, v; solve(at, t, u, v);
+            const v2f w = (sp2(1.0f) - u) - v;
+            b = flat_candidate<true>(b, fminf(fminf(u.x, v.x), w.x) >= 0.f, t.x, idx);
+            b = flat_candidate<true>(b, 2 * j + 1 < n && fminf(fminf(u.y, v.y), w.y) >= 0.f, t.y, idx + 1);
+        }
+        idx = first + n;
+    }
+    for (int j = 0; 2 * j < fl.n_spheres; j++, idx += 2, at += 8) {      // spheres: flat_loop's test (the reference's, tracer_base.py:184-199) on two spheres
+        const v2f r2 = ld2c(at + 6);
+        const v2f sx = ld2c(at) - ox, sy = ld2c(at + 2) - oy, sz = ld2c(at + 4) - oz;
+        const v2f cn2 = (sx * sx + sy * sy) + sz * sz;
+        const v2f proj = (dx * sx + dy * sy) + dz * sz;
+        const v2f c2ray = cn2 - proj * proj;
+        const v2f disc = r2 - c2ray;
+        const float cut0 = sqrtf(disc.x), cut1 = sqrtf(disc.y);
+        const float ta = proj.x + ((cn2.x > r2.x + 1e-4f) ? -cut0 : cut0), tb = proj.y + ((cn2.y > r2.y + 1e-4f) ? -cut1 : cut1);
+        b = flat_candidate<false>(b, c2ray.x < r2.x, ta, idx);
+        b = flat_candidate<false>(b, 2 * j + 1 < fl.n_spheres && c2ray.y < r2.y, tb, idx + 1);
+    }
+    if ((fl.n_quads_tie | fl.n_gquads_tie | fl.n_tris_tie) != 0) {      // a runner-up only means something next to a winner from a coplanar group (flat_loop)
+        const int a0 = fl.n_quads, a1 = a0 + fl.n_quads_tie, b0 = a1 + fl.n_gquads, b1 = b0 + fl.n_gquads_tie, c0 = b1 + fl.n_tris, c1 = c0 + fl.n_tris_tie;
+        const bool tie = (b.idx >= a0 && b.idx < a1) || (b.idx >= b0 && b.idx < b1) || (b.idx >= c0 && b.idx < c1);
+        b.runner = tie ? b.runner : -1;
+    } else b.runner = -1;
+    t_out = b.t; runner = b.runner;
+    return b.idx;
+}
 // one-ray adapters (volumetric transmittance walk, which keeps its one-entry-per-lane loop): the ray rides in both halves
 template <bool ANY>
 APT_D bool flat_sweep(const FlatScene& fl, const SweepScene& sw, f3 o, f3 d, HitRec& rec) {

@@ -98,6 +98,12 @@ def kernel_bytes(st):
         # the entries never travel through HBM (what it really moves is the `traffic` figure: 64 + 12 B read, 48 + 12 B written per entry)
         kb["shade"] += kb["shadow"]
         kb["shadow"] = 0
+    if st.get("launches", {}).get("extend", 1) == 0 and n_e > 0:
+        # rays traced in place (stages.hpp "rays traced in place"): k_generate sweeps the camera rays and the shade kernel its continuation ray,
+        # there is no extend launch - by the same rule the two kernels are credited with the extend stage's 40 B per ray they trace
+        kb["generate"] += 40 * n_s
+        kb["shade"] += 40 * n_cont
+        kb["extend"] = 0
     return kb
 
 

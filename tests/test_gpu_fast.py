@@ -123,6 +123,37 @@ def test_fix_up_lists_carry_every_ray_when_asked_to(tag, kw, renderer, monkeypat
         assert np.allclose(img, ref, rtol=1e-6, atol=1e-6 * float(np.nanmax(np.abs(ref))), equal_nan=True)     # (the exact build keeps one radiance plane per sample): the last bit of a sum
 
 
+@pytest.mark.parametrize("tag,kw", [("cbox", {}), ("cbox", {"max_bounce": 1}), ("glass_box", {"num_shadow_ray": 1}), ("balls_mono", {"num_shadow_ray": 1}), ("textured", {"num_shadow_ray": 1})])
+def test_rays_traced_in_place_render_the_staged_pipeline_s_image(tag, kw, renderer, monkeypatch):
+    """Unsorted flat-sweep renders with one light sample per vertex run ONE launch per bounce (stages.hpp "rays traced in place",
+    APT_FUSED=2, the default): the shade kernel sweeps its light sample and its continuation ray itself, k_generate the camera rays, and
+    the rays that need the reference-order code are served by the next launch's prologue.  Against the staged pipelines - APT_FUSED=1
+    (extend + fix-up + shade) and APT_FUSED=0 (+ shadow) - the ray, the records and the arithmetic per (ray, record) are the same, so
+    the image is the same up to the few rays the pair-wise sweep defers in addition (a plain record next to a coplanar group), and the
+    path statistics agree to 1e-4; rays that hit nothing are counted although they never enter a queue."""
+    w, h, spp = 64, 48, 16
+    out = {}
+    monkeypatch.setenv("APT_SORTED", "0")                       # (scenes of several material classes: one all-models kernel instead of class queues)
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("APT_FUSED", mode)
+        r = renderer(tag, width=w, height=h, **kw)
+        assert r.info()["traversal"] == "flat"
+        name = r.info()["shade_variant"]
+        assert ("rays traced in place" in name) == (mode == "2") and ("light samples traced in place" in name) == (mode == "1"), name
+        r.render(n_spp=spp)
+        out[mode] = (r.color.to_numpy(), r.stats())
+    img0, st0 = out["0"]
+    for mode in ("1", "2"):
+        img, st = out[mode]
+        assert st["n_samples"] == st0["n_samples"] and st["n_extend"] >= st["n_samples"]
+        for k in ("n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"):
+            assert abs(st[k] - st0[k]) <= max(2, 1e-4 * st0[k]), (mode, k, st[k], st0[k])
+        fin = np.isfinite(img0) & np.isfinite(img)
+        assert fin.mean() > 0.999
+        close = np.abs(img - img0)[fin] <= 1e-4 * (1.0 + np.abs(img0[fin]))
+        assert close.mean() >= 0.99, (mode, float(close.mean()))
+
+
 FULL_SIZE = os.environ.get("APT_FULL_SIZE_PARITY") == "1"
 
 
