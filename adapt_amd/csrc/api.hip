@@ -748,7 +748,10 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     // one pool per lane, carved into the SoA arrays (all 4-byte lanes)
     const bool walk_lists = r->volumetric && sc->has_null_surface;      // light samples that cross null surfaces are re-queued by slot
     const size_t l_planes = (size_t)p.l_planes;
-    const size_t words = (p.fused ? 6 * cap : 0) + (p.fused == 2 ? 4 * cap : 0) + (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
+    if (p.fused == 2 && cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (rays traced in place address 16-byte slots with 32-bit byte offsets: capacity must stay below 2^28)"); }
+    const bool tr_uv = p.fused == 2 && (sc->dev.has_vn || sc->dev.tex_i != nullptr);
+    // rays traced in place keep their path records in planes of their own (Queues::tr): the staged pipeline's second ray / state buffers are not carved
+    const size_t words = (p.fused == 1 ? 6 * cap : 0) + (p.fused == 2 ? (32 + (tr_uv ? 4 : 0)) * cap : 0) - (p.fused == 2 ? (6 + 12) * cap : 0) + (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
         hipError_t e_ = pool.alloc(words * 4);
         if (e_ != hipSuccess) return e_;
@@ -759,14 +762,17 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         if ((e_ = hipMemset(pool.p, 0, words * 4)) != hipSuccess) return e_;
         float* w = pool.as<float>();
         auto take = [&](size_t n) { float* x = w; w += n; return x; };
-        for (int k = 0; k < 2; k++) { q.ray_o[k] = take(3 * cap); q.ray_d[k] = take(3 * cap); }
+        const bool staged = p.fused != 2;      // (rays traced in place: parity 0 of the ray arrays and the hit arrays still serve apt_intersect)
+        for (int k = 0; k < 2; k++) { q.ray_o[k] = (k == 0 || staged) ? take(3 * cap) : nullptr; q.ray_d[k] = (k == 0 || staged) ? take(3 * cap) : nullptr; }
         q.hit_t = take(cap); q.hit_prim = (int*)take(cap); q.hit_u = take(cap); q.hit_v = take(cap);
-        q.hit2_t = q.hit2_u = q.hit2_v = nullptr; q.hit2_prim = nullptr;
-        if (p.fused == 2) { q.hit2_t = take(cap); q.hit2_prim = (int*)take(cap); q.hit2_u = take(cap); q.hit2_v = take(cap); }
+        for (int k = 0; k < 2; k++) {
+            for (int a = 0; a < 4; a++) q.tr[k][a] = (p.fused == 2) ? (float4*)take(4 * cap) : nullptr;
+            q.tr_uv[k] = tr_uv ? (float2*)take(2 * cap) : nullptr;
+        }
         q.fix_ext = (r->trace_mode == 3) ? (uint32_t*)take(cap) : nullptr; q.fix_sh = (r->trace_mode == 3) ? (uint32_t*)take(sh_cap) : nullptr;
-        for (int k = 0; k < 2; k++) { q.thr[k] = take(3 * cap); q.id[k] = (uint32_t*)take(cap); q.meta[k] = (uint32_t*)take(cap); q.pdf[k] = take(cap); }
+        for (int k = 0; k < 2; k++) { q.thr[k] = staged ? take(3 * cap) : nullptr; q.id[k] = staged ? (uint32_t*)take(cap) : nullptr; q.meta[k] = staged ? (uint32_t*)take(cap) : nullptr; q.pdf[k] = staged ? take(cap) : nullptr; }
         q.L = take(4 * cap * l_planes);
-        for (int k = 0; k < 2; k++) q.Lc[k] = p.fused ? take(3 * cap) : nullptr;
+        for (int k = 0; k < 2; k++) q.Lc[k] = (p.fused == 1) ? take(3 * cap) : nullptr;
         q.sh_o = take(3 * sh_cap); q.sh_d = take(3 * sh_cap); q.sh_tmax = take(sh_cap); q.sh_c = take(3 * sh_cap); q.sh_id = (uint32_t*)take(sh_cap);
         q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
         q.sh_walk[0] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr; q.sh_walk[1] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr;
@@ -1113,8 +1119,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate_trace, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, sc, p, q, cnt); }
             int cur = 0;
             for (int b = 0; b < p.max_bounce; b++) {
-                ShadeIn in = {q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.id[cur], q.meta[cur], q.pdf[cur],
-                              cur ? q.hit2_t : q.hit_t, cur ? q.hit2_prim : q.hit_prim, cur ? q.hit2_u : q.hit_u, cur ? q.hit2_v : q.hit_v, (const uint32_t*)cnt->n_tr[b % 3], q.Lc[cur]};
+                ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (const uint32_t*)cnt->n_tr[b % 3], nullptr};      // (the records are Queues::tr[cur])
                 LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->shade->traced, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
                 cur ^= 1;
             }

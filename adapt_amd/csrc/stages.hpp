@@ -109,7 +109,12 @@ struct Params {
 struct Queues {
     float* ray_o[2]; float* ray_d[2];           // 3 components each
     float* hit_t; int* hit_prim; float* hit_u; float* hit_v;
-    float* hit2_t; int* hit2_prim; float* hit2_u; float* hit2_v;      // rays traced in place (Params::fused == 2): the hit records of queue parity 1 (hit_* serve parity 0; null elsewhere)
+    // rays traced in place (Params::fused == 2): the path record as four 16-byte planes per queue parity - A = (ray origin, hit distance),
+    // B = (ray direction, pm), C = (throughput, path id), D = (radiance so far, pdf of the ray) - and, where somebody reads them, the hit's
+    // barycentrics; pm = hit primitive (8 bits, TR_NO_PRIM: nothing hit) | draw index << 8 | specular bit << 24.  Still SoA - a wave's 64
+    // entries of a plane are 1 KiB in a row - but a record is 4 loads and 4 stores instead of 16 and 18, and 8 base pointers instead of 30:
+    // the shade kernel's scalar registers no longer overflow into VGPR lanes (218 v_readlane per tile row before).  Null elsewhere.
+    float4* tr[2][4]; float2* tr_uv[2];
     uint32_t* fix_ext; uint32_t* fix_sh;         // flat sweep: fix-up lists, sub-queue-local entry indices (null elsewhere)
     float* thr[2]; uint32_t* id[2]; uint32_t* meta[2]; float* pdf[2];
     float* sh_o; float* sh_d; float* sh_tmax; float* sh_c; uint32_t* sh_id;
@@ -161,6 +166,10 @@ struct Counters {
 APT_D uint32_t pack_meta(uint32_t draw, uint32_t bounce, bool spec) { return (draw & 0xffffu) | ((bounce & 0xffu) << 16) | (spec ? (1u << 24) : 0u); }
 
 #define BLOCK 256
+#define TR_NO_PRIM 0xffu
+APT_D uint32_t tr_pack(int prim, uint32_t draw, bool spec) { return (prim < 0 ? TR_NO_PRIM : (uint32_t)prim) | ((draw & 0xffffu) << 8) | (spec ? (1u << 24) : 0u); }
+APT_D int tr_prim(uint32_t pm) { return ((pm & 0xffu) == TR_NO_PRIM) ? -1 : (int)(pm & 0xffu); }
+APT_D uint32_t tr_meta(uint32_t pm, uint32_t bounce) { return pack_meta(pm >> 8, bounce, ((pm >> 24) & 1u) != 0u); }      // the staged pipeline's meta word
 // One light sample per vertex, or one radiance plane per light sample (Params::l_planes): no two entries of a shadow launch add into the
 // same slot and the adds are plain read-modify-writes.  Measured on C3 (S = 4) with float atomics instead: k_shadow 17 % VALU-busy, 3.9x
 // its algorithmic HBM writes (every atomic is an L2 read-modify-write of a sector), and run-to-run differences in the last bit.
@@ -358,9 +367,13 @@ APT_D void generate_body(const DevScene* sc, const Params& p, const Queues& q, C
             HitRec hr; hr.t = 1e7f; hr.prim = -1; hr.u = hr.v = 0.f;
             if (alive && !defer && tr_idx >= 0) { int cls_; flat_resolve(sc->flat, tr_idx, tr_t, cam_o, dir, hr, cls_); }
             if (alive) {
-                const uint32_t so = ((uint32_t)sq * p.subcap + pos) << 2;
-                stq(q.hit_t, so, hr.t); stq(q.hit_prim, so, hr.prim);
-                if (sc->has_vn || sc->tex_i != nullptr) { stq(q.hit_u, so, hr.u); stq(q.hit_v, so, hr.v); }
+                const uint32_t slot = (uint32_t)sq * p.subcap + pos, so = slot << 4;
+                stq(q.tr[0][0], so, make_float4(cam_o.x, cam_o.y, cam_o.z, hr.t));
+                stq(q.tr[0][1], so, make_float4(dir.x, dir.y, dir.z, __uint_as_float(tr_pack(hr.prim, draws, false))));
+                stq(q.tr[0][2], so, make_float4(1.f, 1.f, 1.f, __uint_as_float(((idx / (uint32_t)p.npix) << p.pix_bits) | (idx % (uint32_t)p.npix))));
+                stq(q.tr[0][3], so, make_float4(0.f, 0.f, 0.f, 1.f));
+                if (sc->has_vn || sc->tex_i != nullptr) { float2 uv_; uv_.x = hr.u; uv_.y = hr.v; stq(q.tr_uv[0], slot << 3, uv_); }
+                t_samples++;
             }
             if (__any(defer)) {
                 const uint32_t lpos = wave_append(defer, &cnt->n_fix_ext[0][sq * CNT_PAD]);
@@ -368,7 +381,7 @@ APT_D void generate_body(const DevScene* sc, const Params& p, const Queues& q, C
             }
         }
 #endif
-        if (alive) {
+        if (alive && !TRACE) {
             const uint32_t so = ((uint32_t)sq * p.subcap + pos) << 2;
             st3q(q.ray_o[0], p.cap, so, mk3(p.cam_t[0], p.cam_t[1], p.cam_t[2]));
             st3q(q.ray_d[0], p.cap, so, dir);
@@ -714,14 +727,16 @@ APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Co
     for (uint32_t base = 0; base < n_ext; base += 64u) {      // closest hits: the listed entries of queue `cur`, records written in place
         const uint32_t li = base + lane_id(); const bool valid = li < n_ext;
         const uint32_t pos = ldq(q.fix_ext, (qbase + (valid ? li : n_ext - 1u)) << 2);
-        const uint32_t io = (qbase + pos) << 2;
-        const f3 o = ld3q(in.ray_o, p.cap, io), d = ld3q(in.ray_d, p.cap, io);
+        const uint32_t slot = qbase + pos, io = slot << 4;
+        const float4 ra = ldq(q.tr[cur][0], io), rb = ldq(q.tr[cur][1], io);
+        const f3 o = mk3(ra.x, ra.y, ra.z), d = mk3(rb.x, rb.y, rb.z);
         HitRec r0, r1; r0.t = r1.t = 1e7f; r0.prim = r1.prim = -1; r0.u = r0.v = r1.u = r1.v = 0.f;
         int c0, c1;
         flat_closest2(sc.flat, sc.sweep, sc.prim_class, o, d, o, d, r0, r1, c0, c1);
         if (valid) {
-            stq(const_cast<float*>(in.t), io, r0.t); stq(const_cast<int*>(in.prim), io, r0.prim);
-            if (need_uv) { stq(const_cast<float*>(in.u), io, r0.u); stq(const_cast<float*>(in.v), io, r0.v); }
+            stq(reinterpret_cast<float*>(q.tr[cur][0]), io + 12u, r0.t);
+            stq(reinterpret_cast<uint32_t*>(q.tr[cur][1]), io + 12u, (__float_as_uint(rb.w) & ~0xffu) | (r0.prim < 0 ? TR_NO_PRIM : (uint32_t)r0.prim));
+            if (need_uv) { float2 uv_; uv_.x = r0.u; uv_.y = r0.v; stq(q.tr_uv[cur], slot << 3, uv_); }
         }
     }
     uint32_t t_lit = 0;
@@ -775,9 +790,18 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
     // trips.  So the next row's record is requested at the top of this row - after this row's shading record, so that waiting for that
     // one (vmcnt counts in order) does not wait for the prefetch - and lands while this row is shaded.
     constexpr bool PF = ((APT_SHADE_PREFETCH != 0) && BM == 0x002 && SM == 0x1 && TEX == 0) || (APT_SHADE_PREFETCH == 2 && TEX == 0);
-    int pf_prim = -1; float pf_t = 0.f; f3 pf_o = splat3(0.f), pf_d = splat3(0.f), pf_thr = splat3(0.f); uint32_t pf_id = 0, pf_meta = 0;
+    constexpr bool TRACE = FUSE == 2;                         // the continuation ray is traced in place too ("rays traced in place" above)
+    static_assert(APT_FLAT_MAX_PRIMS < (int)TR_NO_PRIM, "the packed record keeps the hit primitive in 8 bits");
+    const float4* trA = TRACE ? q.tr[cur][0] : nullptr; const float4* trB = TRACE ? q.tr[cur][1] : nullptr; const float4* trC = TRACE ? q.tr[cur][2] : nullptr; const float4* trD = TRACE ? q.tr[cur][3] : nullptr;
+    int pf_prim = -1; float pf_t = 0.f; f3 pf_o = splat3(0.f), pf_d = splat3(0.f), pf_thr = splat3(0.f); uint32_t pf_id = 0, pf_meta = 0;      // (TRACE: pf_prim holds the packed word pm)
     auto prefetch = [&](uint32_t b) {            // straight-line loads (lanes past the end re-read the last entry: never used), so that no wait lands at the end of a branch
         const uint32_t ps = min(b + threadIdx.x, n - 1u);
+        if (TRACE) {
+            const uint32_t pio16 = (qbase + ps) << 4;
+            const float4 a = ldq(trA, pio16), b_ = ldq(trB, pio16), c = ldq(trC, pio16);
+            pf_o = mk3(a.x, a.y, a.z); pf_t = a.w; pf_d = mk3(b_.x, b_.y, b_.z); pf_prim = __float_as_int(b_.w); pf_thr = mk3(c.x, c.y, c.z); pf_id = __float_as_uint(c.w);
+            return;
+        }
         const uint32_t pio = (qbase + ps) << 2;
         pf_prim = ldq(in.prim, pio); pf_t = ldq(in.t, pio);
         pf_o = ld3q(in.ray_o, p.cap, pio); pf_d = ld3q(in.ray_d, p.cap, pio); pf_thr = ld3q(in.thr, p.cap, pio);
@@ -786,13 +810,16 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
     // the kernels without registers for that (material classes: 124-128 VGPRs) prefetch only the hit primitive - one register - so that a
     // row's shading record can be requested together with its queue record instead of a round trip after it
     constexpr bool PFP = !PF && (APT_SHADE_PREFETCH_PRIM != 0) && TEX == 0;
-    constexpr bool TRACE = FUSE == 2;                         // the continuation ray is traced in place too ("rays traced in place" above)
     uint32_t t_extend = 0;
 #if APT_FAST
     if (TRACE) fix_prologue(sc, p, q, cnt, in, cur, sl.q, (uint32_t)bounce + 1u);      // before the first record is requested
 #endif
     if (PF && n > 0) prefetch(sl.first);
-    if (PFP && n > 0) pf_prim = ldq(in.prim, (qbase + min(sl.first + threadIdx.x, n - 1u)) << 2);
+    auto prefetch_prim = [&](uint32_t b) {
+        const uint32_t ps = qbase + min(b + threadIdx.x, n - 1u);
+        pf_prim = TRACE ? ldq(reinterpret_cast<const int*>(trB), (ps << 4) + 12u) : ldq(in.prim, ps << 2);
+    };
+    if (PFP && n > 0) prefetch_prim(sl.first);
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
 #ifdef APT_SHADE_PROF
         unsigned long long stick_ = __builtin_readcyclecounter();
@@ -801,12 +828,13 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         const uint32_t pos = base + threadIdx.x;
         const uint32_t idx = qbase + pos;
         bool alive = pos < n;
-        const int cu_prim = pf_prim; const float cu_t = pf_t; const f3 cu_o = pf_o, cu_d = pf_d, cu_thr = pf_thr; const uint32_t cu_id = pf_id, cu_meta = pf_meta;
+        int cu_prim = pf_prim; const float cu_t = pf_t; const f3 cu_o = pf_o, cu_d = pf_d, cu_thr = pf_thr; const uint32_t cu_id = pf_id; uint32_t cu_meta = pf_meta;
+        if (TRACE && (PF || PFP)) { cu_meta = tr_meta((uint32_t)pf_prim, (uint32_t)bounce); cu_prim = tr_prim((uint32_t)pf_prim); }
         float4 cu_ra = make_float4(0.f, 0.f, 0.f, 0.f), cu_rb = cu_ra; uint32_t cu_key = 0;
         if (PFP) {
             const int rp = max(cu_prim, 0);
             cu_ra = sc.prim_shade[2 * rp]; cu_rb = sc.prim_shade[2 * rp + 1];
-            pf_prim = ldq(in.prim, (qbase + min(base + sl.stride + threadIdx.x, n - 1u)) << 2);
+            prefetch_prim(base + sl.stride);
         }
         if (PF) {
             const int rp = max(cu_prim, 0);
@@ -823,9 +851,14 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         // here without being shaded (nothing hit, roulette), the path id that names the slot it goes to
         f3 Lc = splat3(0.f);
         const bool entry = alive;
+        float ray_pdf = 1.f;
+        if (TRACE) {
+            if (alive && bounce > 0) { const float4 dd = ldq(trD, idx << 4); Lc = mk3(dd.x, dd.y, dd.z); if (SM & 2) ray_pdf = dd.w; }
+            if (alive && bounce > 0) id = PF ? cu_id : __float_as_uint(ldq(reinterpret_cast<const float*>(trC), (idx << 4) + 12u));
+        } else {
         if (FUSE && alive && bounce > 0) Lc = ld3q(in.Lc, p.cap, idx << 2);
         if (FUSE && alive && bounce > 0) id = PF ? cu_id : ldq(in.id, idx << 2);
-        float ray_pdf = 1.f;
+        }
         bool was_spec = false;
         Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
         Hit it; it.obj_id = -1; it.prim_id = -1; it.n_s = it.n_g = mk3(1.f, 0.f, 0.f); it.min_depth = 0.f;
@@ -834,35 +867,43 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
         if (alive) {
             const uint32_t io = idx << 2;
-            int prim = (PF || PFP) ? cu_prim : ldq(in.prim, io);
+            int prim = (PF || PFP) ? cu_prim : (TRACE ? tr_prim(__float_as_uint(ldq(reinterpret_cast<const float*>(trB), (idx << 4) + 12u))) : ldq(in.prim, io));
             if (prim < 0) alive = false;                         // nothing hit: path ends (vanilla_renderer.py:49)
             else {
-                uint32_t meta;
+                uint32_t meta; float tr_t_in = cu_t; float2 tr_uv_in; tr_uv_in.x = tr_uv_in.y = 0.f;
                 if (PF) { o = cu_o; d = cu_d; thr = cu_thr; id = cu_id; meta = cu_meta; }
-                else {
+                else if (TRACE) {
+                    const float4 a = ldq(trA, idx << 4), b_ = ldq(trB, idx << 4), c = ldq(trC, idx << 4);
+                    o = mk3(a.x, a.y, a.z); tr_t_in = a.w; d = mk3(b_.x, b_.y, b_.z); thr = mk3(c.x, c.y, c.z); id = __float_as_uint(c.w);
+                    meta = tr_meta(__float_as_uint(b_.w), (uint32_t)bounce);
+                } else {
                     o = ld3q(in.ray_o, p.cap, io);
                     d = ld3q(in.ray_d, p.cap, io);
                     thr = ld3q(in.thr, p.cap, io);
                     id = ldq(in.id, io);
                     meta = ldq(in.meta, io);
                 }
-                if (SM & 2) ray_pdf = ldq(in.pdf, io);          // (its only reader is the emission MIS weight: scenes without area lights never look at it)
+                if ((SM & 2) && !TRACE) ray_pdf = ldq(in.pdf, io);          // (its only reader is the emission MIS weight: scenes without area lights never look at it)
                 was_spec = (meta >> 24) & 1u;
                 f3 rec_kd;
                 const bool need_uv = sc.has_vn || (TEX && sc.tex_i != nullptr);      // otherwise nobody reads the barycentrics (and the flat extend kernel does not write them)
+                if (TRACE && need_uv && !PF) tr_uv_in = ldq(q.tr_uv[cur], idx << 3);
                 if (PF) {
                     build_hit_rec(sc, cu_ra, cu_rb, prim, cu_t, 0.f, 0.f, o, d, it, hit_light, rec_kd, false);
                     if (sc.has_vn && __float_as_int(cu_ra.w) >= 0) {       // vertex normals: the barycentrics are fetched (and waited for) inside this branch only
-                        const float* vn = sc.vnormals + 9 * prim; const float bu = ldq(in.u, io), bv = ldq(in.v, io);
+                        if (TRACE) tr_uv_in = ldq(q.tr_uv[cur], idx << 3);
+                        const float* vn = sc.vnormals + 9 * prim; const float bu = TRACE ? tr_uv_in.x : ldq(in.u, io), bv = TRACE ? tr_uv_in.y : ldq(in.v, io);
                         it.n_s = (ld3(vn) * (1.f - bu - bv) + ld3(vn + 3) * bu) + ld3(vn + 6) * bv;
                     }
                 }
+                else if (TRACE && PFP) build_hit_rec(sc, cu_ra, cu_rb, prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
+                else if (TRACE) build_hit(sc, prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
                 else if (PFP) build_hit_rec(sc, cu_ra, cu_rb, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
                 else build_hit(sc, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
                 if (BM == 0x002) bx.k_d = rec_kd;               // Lambertian-only scenes: type 1, not delta, not a BSDF (the defaults above), colour from the record
                 else bx = sc.bxdf[it.obj_id];
                 if (TEX && sc.tex_i != nullptr) {                // the scene declares image textures (TEX kernels only, see below)
-                    const float bu = ldq(in.u, io), bv = ldq(in.v, io);
+                    const float bu = TRACE ? tr_uv_in.x : ldq(in.u, io), bv = TRACE ? tr_uv_in.y : ldq(in.v, io);
                     f3 tx;
                     if (bounce == 0) {                           // PathTracer.process_ns, applied to the camera ray's hit only (vanilla_renderer.py:42)
                         if (get_uv_item(sc, 1, it.obj_id, prim, bu, bv, tx)) { m33 R; rotation_between(mk3(0.f, 1.f, 0.f), it.n_g, R); it.n_s = mul(R, tx); }
@@ -1037,7 +1078,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         // rays traced in place: the continuation ray meets the scene's records here.  Only rays that hit something (or whose answer is left
         // to the reference-order code: listed, with a provisional record) enter the next queue; the tail atomic is on its way while the light
         // sample is swept below.
-        float tr_t = 0.f; int tr_prim = -1; float tr_u = 0.f, tr_v = 0.f; bool tr_defer = false;
+        float tr_t = 0.f; int tr_hit = -1; float tr_u = 0.f, tr_v = 0.f; bool tr_defer = false;
         if (TRACE) {
             int tr_idx = -1, tr_run = -1;
             if (__any(cont)) tr_idx = flat_closest1(sc.flat, hit_point, new_d, 1e7f, tr_t, tr_run);
@@ -1045,7 +1086,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
             t_extend += wave_count(cont);
             cont = cont && (tr_idx >= 0 || tr_defer);
             next_app = append_issue(cont, next_counter);
-            if (cont && !tr_defer) { HitRec hr; int cls_; flat_resolve(sc.flat, tr_idx, tr_t, hit_point, new_d, hr, cls_); tr_prim = hr.prim; tr_u = hr.u; tr_v = hr.v; }
+            if (cont && !tr_defer) { HitRec hr; int cls_; flat_resolve(sc.flat, tr_idx, tr_t, hit_point, new_d, hr, cls_); tr_hit = hr.prim; tr_u = hr.u; tr_v = hr.v; }
         }
 #endif
         uint32_t npos = (PF && !TRACE) ? append_pos(next_app) : (TRACE ? 0u : wave_append(cont, next_counter));
@@ -1081,22 +1122,19 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
             if (TRACE) {
                 npos = append_pos(next_app);
                 if (cont) {
-                    const uint32_t so = (qbase + npos) << 2;
-                    st3q(q.ray_o[nxt], p.cap, so, hit_point);
-                    st3q(q.ray_d[nxt], p.cap, so, new_d);
-                    st3q(q.thr[nxt], p.cap, so, thr);
-                    stq(q.id[nxt], so, id);
-                    stq(q.meta[nxt], so, pack_meta(rng.draw, (uint32_t)(bounce + 1), is_spec));
-                    if (SM & 2) stq(q.pdf[nxt], so, new_pdf);
-                    stq(nxt ? q.hit2_t : q.hit_t, so, tr_t); stq(nxt ? q.hit2_prim : q.hit_prim, so, tr_prim);
-                    if (sc.has_vn || sc.tex_i != nullptr) { stq(nxt ? q.hit2_u : q.hit_u, so, tr_u); stq(nxt ? q.hit2_v : q.hit_v, so, tr_v); }
+                    const uint32_t slot = qbase + npos, so = slot << 4;
+                    stq(q.tr[nxt][0], so, make_float4(hit_point.x, hit_point.y, hit_point.z, tr_t));
+                    stq(q.tr[nxt][1], so, make_float4(new_d.x, new_d.y, new_d.z, __uint_as_float(tr_pack(tr_hit, rng.draw, is_spec))));
+                    stq(q.tr[nxt][2], so, make_float4(thr.x, thr.y, thr.z, __uint_as_float(id)));
+                    stq(q.tr[nxt][3], so, make_float4(Lc.x, Lc.y, Lc.z, new_pdf));
+                    if (sc.has_vn || sc.tex_i != nullptr) { float2 uv_; uv_.x = tr_u; uv_.y = tr_v; stq(q.tr_uv[nxt], slot << 3, uv_); }
                 }
                 if (__any(tr_defer)) {                        // listed for the next launch's prologue (sub-queue-local position)
                     const uint32_t lpos = wave_append(tr_defer, &cnt->n_fix_ext[nxt][sl.q * CNT_PAD]);
                     if (tr_defer) stq(q.fix_ext, (qbase + lpos) << 2, npos);
                 }
             }
-            if (cont) st3q(q.Lc[nxt], p.cap, (qbase + npos) << 2, Lc);
+            if (cont) { if (!TRACE) st3q(q.Lc[nxt], p.cap, (qbase + npos) << 2, Lc); }
             else if (entry && !(Lc.x == 0.f && Lc.y == 0.f && Lc.z == 0.f)) {
                 // the path ends here (nothing hit, roulette, last bounce): its radiance goes to its slot - added, not stored: a fix-up launch may have put a deferred sample's share there already
                 const uint32_t lp_ = id & ((1u << p.pix_bits) - 1u), s_ = id >> p.pix_bits;
