@@ -43,14 +43,25 @@ typedef void (*shade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int, int)
 #else
 #define APT_FUSED_FN(...) nullptr         // light samples traced by the shade kernel: a product-build path (it rides on the flat sweep's records)
 #endif
-struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_fn fused, traced; };      // fused: the variant that traces its own light samples (stages.hpp k_shade FUSE = 1); traced: ... and its continuation ray (FUSE = 2)
+// Rays traced in place by the class-sorted kernels and with several light samples per vertex (k_shade FUSE = 3) - measured on C3 and NOT
+// shipped (profiles/NOTES.md: the class kernels go from 124-128 to 147-168 VGPRs, four waves per SIMD to three, and take 108 ms per 256 spp
+// where extend + shade + shadow of the staged pipeline take 87: 970 -> 901 Msamples/s).  -DAPT_TRACE_MULTI=1 instantiates them (APT_FUSED=2 then selects them).
+#ifndef APT_TRACE_MULTI
+#define APT_TRACE_MULTI 0
+#endif
+#if APT_FAST && APT_TRACE_MULTI
+#define APT_MULTI_FN(...) __VA_ARGS__
+#else
+#define APT_MULTI_FN(...) nullptr
+#endif
+struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_fn fused, traced, traced_multi; };      // fused: the variant that traces its own light samples (stages.hpp k_shade FUSE = 1); traced: ... and its continuation ray (FUSE = 2: one light sample per vertex; traced_multi, FUSE = 3: any number)
 static const ShadeVariant kShadeVariants[] = {
-    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade<0x002, 0x01, 0, 1>), APT_FUSED_FN(k_shade<0x002, 0x01, 0, 2>)},
-    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade<0x003, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x003, 0x03, 0, 2>)},
-    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade<0x107, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x107, 0x03, 0, 2>)},
-    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 2>)},
+    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade<0x002, 0x01, 0, 1>), APT_FUSED_FN(k_shade<0x002, 0x01, 0, 2>), APT_MULTI_FN(k_shade<0x002, 0x01, 0, 3>)},
+    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade<0x003, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x003, 0x03, 0, 2>), APT_MULTI_FN(k_shade<0x003, 0x03, 0, 3>)},
+    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade<0x107, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x107, 0x03, 0, 2>), APT_MULTI_FN(k_shade<0x107, 0x03, 0, 3>)},
+    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 2>), APT_MULTI_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 3>)},
 };
-static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 2>)};
+static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 2>), APT_MULTI_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 3>)};
 // Material classes for sorted shading: (class mask) x (emitter mask: point+area | all)
 // A kernel's register allocation is the maximum over the models it contains, so the classes are as fine as the models'
 // footprints differ: Lambertian alone runs at 4 waves per SIMD, together with Blinn-Phong (three double pows) at 2-3.
@@ -74,6 +85,14 @@ static const shade_fn kClassShade[APT_N_CLASS_DEFS][2] = {
     {k_shade<0x010, 0x03>, k_shade<0x010, APT_SRC_ALL>}, {k_shade<0x020, 0x03>, k_shade<0x020, APT_SRC_ALL>},
     {k_shade<0x080, 0x03>, k_shade<0x080, APT_SRC_ALL>}, {k_shade<0x200, 0x03>, k_shade<0x200, APT_SRC_ALL>},
     {k_shade<0x008, 0x03>, k_shade<0x008, APT_SRC_ALL>}, {k_shade<0x801, 0x03>, k_shade<0x801, APT_SRC_ALL>},
+};
+// the same class kernels tracing their rays in place (stages.hpp "rays traced in place": product build, flat sweep)
+static const shade_fn kClassShadeTraced[APT_N_CLASS_DEFS][2] = {
+    {APT_MULTI_FN(k_shade<0x002, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x002, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x001, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x001, APT_SRC_ALL, 0, 3>)},
+    {APT_MULTI_FN(k_shade<0x040, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x040, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x504, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x504, APT_SRC_ALL, 0, 3>)},
+    {APT_MULTI_FN(k_shade<0x010, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x010, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x020, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x020, APT_SRC_ALL, 0, 3>)},
+    {APT_MULTI_FN(k_shade<0x080, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x080, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x200, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x200, APT_SRC_ALL, 0, 3>)},
+    {APT_MULTI_FN(k_shade<0x008, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x008, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x801, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x801, APT_SRC_ALL, 0, 3>)},
 };
 #define APT_CLASS_PHONG 1
 #define APT_CLASS_PHONG_NO_LOBE 9
@@ -193,6 +212,7 @@ struct apt_renderer {
     vshade_fn vclass_fn[APT_N_CLASS_DEFS + 1] = {};     // sorted volumetric shading: kernel per class queue (the miss class last)
     int v_ncls = 0;               // class queues in use (surface classes + the miss class when misses matter)
     shade_fn class_fn[APT_N_CLASS_DEFS] = {};
+    shade_fn class_fn_traced[APT_N_CLASS_DEFS] = {};      // ... tracing their rays in place (Params::fused == 2)
     std::string shade_name;
     LdsPlan plan{};
     size_t lds_bytes = 0, lds_bytes_any = 0;     // dynamic LDS of the closest-hit / any-hit trace kernels
@@ -700,8 +720,17 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     r->volumetric = c.volumetric ? 1 : 0;
     // light samples traced by the shade kernel itself (stages.hpp k_shade FUSE): flat sweep, one sample per vertex, one shade kernel
     // ... and, by default, its continuation ray too (FUSE = 2, "rays traced in place": no extend launch, no fix-up launch per bounce); APT_FUSED=0|1|2
-    p.fused = (r->trace_mode == 3 && !r->sorted && !c.volumetric && S == 1 && r->shade->fused != nullptr) ? 2 : 0;
-    if (const char* f = getenv("APT_FUSED")) p.fused = p.fused ? std::max(0, std::min(2, atoi(f))) : 0;
+    // - unsorted or sorted by material class, any number of light samples per vertex
+    {
+        const bool can1 = r->trace_mode == 3 && !r->sorted && !c.volumetric && S == 1 && r->shade->fused != nullptr;
+        bool can2 = can1 && r->shade->traced != nullptr;
+#if APT_TRACE_MULTI      // (measurement only: class-sorted queues and several light samples per vertex - those wait in LDS for the end of the tile row, 28 bytes each per thread)
+        can2 = r->trace_mode == 3 && !c.volumetric && r->shade->traced_multi != nullptr && S <= 8;
+#endif
+        p.fused = can2 ? 2 : (can1 ? 1 : 0);
+        if (const char* f = getenv("APT_FUSED")) { const int want = atoi(f); p.fused = (want >= 2 && can2) ? 2 : ((want >= 1 && can1) ? 1 : 0); }
+        if (p.fused == 2) { p.nee_vm = 0; p.l_planes = 1; }      // no shadow queue: a vertex's light samples are summed in registers
+    }
     if (r->volumetric) {
         if (c.max_bounce > 255) { return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer keeps the bounce count in 8 bits (max_bounce <= 255)"); }
         if (!sc->has_aabb) { return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer needs the object boxes (world bound)"); }
@@ -740,6 +769,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         r->shade_name = "sorted:";
         for (int c = 0; c < ncls; c++) {
             r->class_fn[c] = kClassShade[sc->class_def[c]][smi];
+            r->class_fn_traced[c] = kClassShadeTraced[sc->class_def[c]][smi];
             r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
         }
     }
@@ -751,7 +781,9 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (p.fused == 2 && cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (rays traced in place address 16-byte slots with 32-bit byte offsets: capacity must stay below 2^28)"); }
     const bool tr_uv = p.fused == 2 && (sc->dev.has_vn || sc->dev.tex_i != nullptr);
     // rays traced in place keep their path records in planes of their own (Queues::tr): the staged pipeline's second ray / state buffers are not carved
-    const size_t words = (p.fused == 1 ? 6 * cap : 0) + (p.fused == 2 ? (32 + (tr_uv ? 4 : 0)) * cap : 0) - (p.fused == 2 ? (6 + 12) * cap : 0) + (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + cap * 16 * (size_t)ncls + (walk_lists ? 2 * sh_cap : 0);
+    const size_t tr_q = (p.fused == 2) ? (size_t)(r->sorted ? ncls : 1) + 1 : 0;      // queues per plane: material classes (unsorted: one) + the staging queue
+    if (p.fused == 2 && tr_q * cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (rays traced in place: queues x capacity must stay below 2^28 slots)"); }
+    const size_t words = (p.fused == 1 ? 6 * cap : 0) + (p.fused == 2 ? (32 + (tr_uv ? 4 : 0)) * cap * tr_q : 0) - (p.fused == 2 ? (6 + 12) * cap : 0) + (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + (p.fused == 2 ? 0 : cap * 16 * (size_t)ncls) + (walk_lists ? 2 * sh_cap : 0);
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
         hipError_t e_ = pool.alloc(words * 4);
         if (e_ != hipSuccess) return e_;
@@ -766,9 +798,10 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         for (int k = 0; k < 2; k++) { q.ray_o[k] = (k == 0 || staged) ? take(3 * cap) : nullptr; q.ray_d[k] = (k == 0 || staged) ? take(3 * cap) : nullptr; }
         q.hit_t = take(cap); q.hit_prim = (int*)take(cap); q.hit_u = take(cap); q.hit_v = take(cap);
         for (int k = 0; k < 2; k++) {
-            for (int a = 0; a < 4; a++) q.tr[k][a] = (p.fused == 2) ? (float4*)take(4 * cap) : nullptr;
-            q.tr_uv[k] = tr_uv ? (float2*)take(2 * cap) : nullptr;
+            for (int a = 0; a < 4; a++) q.tr[k][a] = (p.fused == 2) ? (float4*)take(4 * cap * tr_q) : nullptr;
+            q.tr_uv[k] = tr_uv ? (float2*)take(2 * cap * tr_q) : nullptr;
         }
+        q.tr_ncls = (p.fused == 2) ? (int)tr_q - 1 : 0;
         q.fix_ext = (r->trace_mode == 3) ? (uint32_t*)take(cap) : nullptr; q.fix_sh = (r->trace_mode == 3) ? (uint32_t*)take(sh_cap) : nullptr;
         for (int k = 0; k < 2; k++) { q.thr[k] = staged ? take(3 * cap) : nullptr; q.id[k] = staged ? (uint32_t*)take(cap) : nullptr; q.meta[k] = staged ? (uint32_t*)take(cap) : nullptr; q.pdf[k] = staged ? take(cap) : nullptr; }
         q.L = take(4 * cap * l_planes);
@@ -779,7 +812,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         q.n_classes = ncls;
         q.miss_class = (r->volumetric && r->v_ncls > sc->n_classes) ? sc->n_classes : -1;
         q.miss_rr_draw = (r->volumetric && ncls > 0 && q.miss_class < 0) ? 1 : 0;
-        for (int c = 0; c < ncls; c++) {
+        for (int c = 0; c < ncls && p.fused != 2; c++) {
             Queues::ClassQ& k = q.cls[c];
             k.ray_o = take(3 * cap); k.ray_d = take(3 * cap); k.thr = take(3 * cap); k.id = (uint32_t*)take(cap); k.meta = (uint32_t*)take(cap);
             k.pdf = take(cap); k.t = take(cap); k.prim = (int*)take(cap); k.u = take(cap); k.v = take(cap);
@@ -1119,8 +1152,11 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate_trace, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, sc, p, q, cnt); }
             int cur = 0;
             for (int b = 0; b < p.max_bounce; b++) {
-                ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (const uint32_t*)cnt->n_tr[b % 3], nullptr};      // (the records are Queues::tr[cur])
-                LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->shade->traced, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
+                for (int c = 0; c < q.tr_ncls; c++) {       // (the records are Queues::tr[cur]: one queue per material class, or one for the scene)
+                    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c};
+                    const size_t park = (p.S > 1) ? (size_t)p.S * 7 * BLOCK * sizeof(float) : 0;      // k_shade: light samples parked in LDS
+                    LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->sorted ? r->class_fn_traced[c] : (p.S == 1 ? r->shade->traced : r->shade->traced_multi), dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), park, st, sc, p, q, cnt, in, cur, b);
+                }
                 cur ^= 1;
             }
             if (p.max_bounce > 0) { LaunchTimer t(r, 3, st, false); hipLaunchKernelGGL(kFixFlat[0], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }

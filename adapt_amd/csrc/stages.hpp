@@ -114,7 +114,10 @@ struct Queues {
     // barycentrics; pm = hit primitive (8 bits, TR_NO_PRIM: nothing hit) | draw index << 8 | specular bit << 24.  Still SoA - a wave's 64
     // entries of a plane are 1 KiB in a row - but a record is 4 loads and 4 stores instead of 16 and 18, and 8 base pointers instead of 30:
     // the shade kernel's scalar registers no longer overflow into VGPR lanes (218 v_readlane per tile row before).  Null elsewhere.
-    float4* tr[2][4]; float2* tr_uv[2];
+    // Every plane holds tr_ncls + 1 queues of `cap` slots each: one per material class (class-sorted shading: the shade kernel that traces a
+    // continuation ray appends the record to the queue of the HIT primitive's class - sorting costs no pass of its own) and a staging queue
+    // (index tr_ncls) for the rays whose hit is left to the reference-order code; slot = queue * cap + sub-queue * subcap + position.
+    float4* tr[2][4]; float2* tr_uv[2]; int tr_ncls;
     uint32_t* fix_ext; uint32_t* fix_sh;         // flat sweep: fix-up lists, sub-queue-local entry indices (null elsewhere)
     float* thr[2]; uint32_t* id[2]; uint32_t* meta[2]; float* pdf[2];
     float* sh_o; float* sh_d; float* sh_tmax; float* sh_c; uint32_t* sh_id;
@@ -138,6 +141,7 @@ struct ShadeIn {
     const float* t; const int* prim; const float* u; const float* v;
     const uint32_t* counts;                      // per-sub-queue entry counts (stride CNT_PAD)
     const float* Lc;                             // fused shading: carried radiance of the entries (null elsewhere)
+    int cls;                                     // rays traced in place: which of Queues::tr's queues this launch reads
 };
 
 #ifndef APT_MAX_NQ
@@ -153,7 +157,7 @@ struct Counters {
     uint32_t n_fix_ext[2][APT_MAX_NQ * CNT_PAD];  // flat sweep: entries handed to the fix-up launch of the extend stage (by queue parity) ...
     uint32_t n_fix_sh[2][APT_MAX_NQ * CNT_PAD];   // ... and of the shadow stage, by the parity of the bounce that listed them (stages.hpp "fix-up lists")
     uint32_t n_work[2][APT_MAX_NQ * CNT_PAD];     // BVH walk with dynamic fetch: next unclaimed queue position (0 extend, 1 shadow); zeroed by the host before the launch
-    uint32_t n_tr[3][APT_MAX_NQ * CNT_PAD];       // rays traced in place: entries of the queue that launch k of the batch reads, at [k % 3] (launch k appends to [(k + 1) % 3] and zeroes [(k + 2) % 3], which launch k - 1 read: no launch in between has to reset a counter)
+    uint32_t n_tr[3][8 + 1][APT_MAX_NQ * CNT_PAD];   // rays traced in place: entries of the queues (material classes, then the staging queue) that bounce k of the batch reads, at [k % 3] (bounce k appends to [(k + 1) % 3] and zeroes [(k + 2) % 3], which bounce k - 1 read: no launch in between has to reset a counter)
     uint32_t fix_claim[APT_MAX_NQ * CNT_PAD];     // rays traced in place: which launch of the batch (1 + bounce) has had its fix-up lists claimed by a wave ...
     uint32_t fix_done[APT_MAX_NQ * CNT_PAD];      // ... and served (stages.hpp fix_prologue)
     unsigned long long stats[APT_MAX_NQ][16];    // [q][ST_*], 128 bytes per sub-queue
@@ -180,6 +184,7 @@ APT_D uint32_t tr_meta(uint32_t pm, uint32_t bounce) { return pack_meta(pm >> 8,
 // LDS of the BVH-walk stages (dynamic, sized per scene by the host): the traversal stack, stack_depth * BLOCK 8-byte groups laid out [level][lane]
 struct LdsPlan { int lds_nodes, lds_prims, stack_depth; uint2* ovf; int ovf_stride; };     // stack_depth: levels kept in LDS; ovf: global spill columns (one per thread of the largest grid); lds_nodes / lds_prims: unused (nothing is staged)
 extern __shared__ float4 s_dyn[];
+typedef __attribute__((address_space(3))) float lds_f;
 APT_D TravStack make_stack(const LdsPlan& plan) {
     TravStack ts;
     ts.lds = (lds_u2*)(reinterpret_cast<grp_t*>(s_dyn)) + threadIdx.x;
@@ -234,6 +239,24 @@ APT_D uint32_t wave_append_n(bool flag, uint32_t* counter, uint32_t k) {
     base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);      // v_readlane: lane 0's value as a scalar (a shuffle would go through the LDS crossbar)
     return base + rank_in(m) * k;
 }
+
+// Append to one of several queues at once (rays traced in place: material classes + the staging queue, `nq_` of them; which = this lane's
+// queue, -1: none): the tails of all queues move with ONE atomic instruction (lane c carries queue c's count), as in k_extend's class
+// appends.  tr_append_issue sends it on its way, tr_append_pos waits for it.  `counters` = the first queue's tail of this sub-queue, queue c's
+// is `stride` words further per c.
+struct TrAppend { uint32_t raw, rank; };
+APT_D TrAppend tr_append_issue(int which, int nq_, uint32_t* counters, uint32_t stride) {
+    TrAppend a; a.raw = 0u; a.rank = 0u;
+    uint32_t cnt_vec = 0u;
+    for (int c = 0; c < nq_; c++) {
+        const unsigned long long m = __ballot(which == c);
+        if (which == c) a.rank = rank_in(m);
+        if ((int)lane_id() == c) cnt_vec = (uint32_t)__popcll(m);
+    }
+    if ((int)lane_id() < nq_ && cnt_vec) a.raw = atomicAdd(counters + (size_t)lane_id() * stride, cnt_vec);
+    return a;
+}
+APT_D uint32_t tr_append_pos(const TrAppend& a, int which) { return (uint32_t)__shfl((int)a.raw, which < 0 ? 0 : which) + a.rank; }
 
 // Queue addressing.  Every queue array is indexed by a 32-bit slot whose BYTE offset also fits 32 bits (the host
 // refuses batches with 12 * capacity >= 4 GiB), and every base pointer is wave-uniform.  Written as
@@ -310,7 +333,7 @@ APT_D SubLoop sub_loop(int nq, int nt = BLOCK) {
 // wave w of the id space feeds sub-queue w % nq at position (w / nq) * 64 + lane: dense and
 // atomic-free unless a crop window makes some lanes inactive.
 // TRACE (rays traced in place, Params::fused == 2): the camera ray meets the scene's records here and the entry carries its hit record
-// (hit_* of queue parity 0; a ray that hits nothing keeps its dense, atomic-free slot with prim = -1); entries are counted in n_tr[0].
+// (Queues::tr, parity 0, the queue of the hit primitive's class; counted in n_tr[0]); a ray that hits nothing is not queued at all.
 template <bool TRACE>
 APT_D void generate_body(const DevScene* sc, const Params& p, const Queues& q, Counters* cnt) {
     const uint32_t total = (uint32_t)p.npix * (uint32_t)p.spp_batch;
@@ -351,8 +374,9 @@ APT_D void generate_body(const DevScene* sc, const Params& p, const Queues& q, C
             }
         }
         uint32_t pos;
-        uint32_t* q0_counter = TRACE ? &cnt->n_tr[0][sq * CNT_PAD] : &cnt->n_active[0][sq * CNT_PAD];
-        if (p.do_crop) pos = wave_append(alive, q0_counter);
+        uint32_t* q0_counter = &cnt->n_active[0][sq * CNT_PAD];
+        if (TRACE) pos = 0;
+        else if (p.do_crop) pos = wave_append(alive, q0_counter);
         else {
             pos = (w / (uint32_t)p.nq) * 64u + lane_id();
             unsigned long long m = __ballot(alive);
@@ -365,19 +389,20 @@ APT_D void generate_body(const DevScene* sc, const Params& p, const Queues& q, C
             if (__any(alive)) tr_idx = flat_closest1(sc->flat, cam_o, dir, 1e7f, tr_t, tr_run);
             const bool defer = alive && (tr_run >= 0 || flat_needs_cull(sc->flat, dir));
             HitRec hr; hr.t = 1e7f; hr.prim = -1; hr.u = hr.v = 0.f;
-            if (alive && !defer && tr_idx >= 0) { int cls_; flat_resolve(sc->flat, tr_idx, tr_t, cam_o, dir, hr, cls_); }
-            if (alive) {
-                const uint32_t slot = (uint32_t)sq * p.subcap + pos, so = slot << 4;
+            int hit_cls = 0;
+            if (alive && !defer && tr_idx >= 0) flat_resolve(sc->flat, tr_idx, tr_t, cam_o, dir, hr, hit_cls);
+            // the entry joins the queue of the hit primitive's class (staging queue: hit left to the next launch's prologue); a camera ray that hits nothing ends here
+            const int ocls = !alive ? -1 : (defer ? q.tr_ncls : (hr.prim >= 0 ? (q.tr_ncls > 1 ? hit_cls : 0) : -1));
+            const TrAppend app = tr_append_issue(ocls, q.tr_ncls + 1, &cnt->n_tr[0][0][sq * CNT_PAD], APT_MAX_NQ * CNT_PAD);
+            pos = tr_append_pos(app, ocls);
+            if (alive) t_samples++;
+            if (ocls >= 0) {
+                const uint32_t slot = (uint32_t)ocls * p.cap + (uint32_t)sq * p.subcap + pos, so = slot << 4;
                 stq(q.tr[0][0], so, make_float4(cam_o.x, cam_o.y, cam_o.z, hr.t));
                 stq(q.tr[0][1], so, make_float4(dir.x, dir.y, dir.z, __uint_as_float(tr_pack(hr.prim, draws, false))));
                 stq(q.tr[0][2], so, make_float4(1.f, 1.f, 1.f, __uint_as_float(((idx / (uint32_t)p.npix) << p.pix_bits) | (idx % (uint32_t)p.npix))));
                 stq(q.tr[0][3], so, make_float4(0.f, 0.f, 0.f, 1.f));
                 if (sc->has_vn || sc->tex_i != nullptr) { float2 uv_; uv_.x = hr.u; uv_.y = hr.v; stq(q.tr_uv[0], slot << 3, uv_); }
-                t_samples++;
-            }
-            if (__any(defer)) {
-                const uint32_t lpos = wave_append(defer, &cnt->n_fix_ext[0][sq * CNT_PAD]);
-                if (defer) stq(q.fix_ext, ((uint32_t)sq * p.subcap + lpos) << 2, pos);
             }
         }
 #endif
@@ -711,36 +736,44 @@ APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3
 // launches per render, where the whole protocol is two scalar loads per wave; the serving code sits in front of the kernel's main loop,
 // where almost no register is live, so it costs the hot loop nothing (k_fix_flat alone allocates 84 VGPRs, the shade kernel 122).
 // Nothing depends on how workgroups are placed: whichever wave claims a list is running, hence the waiters cannot starve it.
-APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, const ShadeIn& in, int cur, int sq, uint32_t epoch) {
-    uint32_t* n_ext_p = &cnt->n_fix_ext[cur][sq * CNT_PAD]; uint32_t* n_sh_p = &cnt->n_fix_sh[cur ^ 1][sq * CNT_PAD];
-    const uint32_t n_ext = *n_ext_p, n_sh = min(*n_sh_p, q.sh_subcap);
-    if ((n_ext | n_sh) == 0u) return;
+APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, int cur, int sq, int bounce) {
+    const uint32_t epoch = (uint32_t)bounce + 1u;
+    const int ncls = q.tr_ncls;
+    uint32_t* n_def_p = &cnt->n_tr[bounce % 3][ncls][sq * CNT_PAD]; uint32_t* n_sh_p = &cnt->n_fix_sh[cur ^ 1][sq * CNT_PAD];
+    const uint32_t n_def = *n_def_p, n_sh = min(*n_sh_p, q.sh_subcap);
+    if ((n_def | n_sh) == 0u) return;
     uint32_t old = 0;
     if (lane_id() == 0) old = atomicMax(&cnt->fix_claim[sq * CNT_PAD], epoch);
     old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);
-    if (old >= epoch) {                                       // somebody else serves (or has served) the lists of this launch
+    if (old >= epoch) {                                       // somebody else serves (or has served) the lists of this bounce
         while (__hip_atomic_load(&cnt->fix_done[sq * CNT_PAD], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(16);
         return;
     }
     const uint32_t qbase = (uint32_t)sq * p.subcap, sh_qbase = (uint32_t)sq * q.sh_subcap;
     const bool need_uv = sc.has_vn || sc.tex_i != nullptr;
-    for (uint32_t base = 0; base < n_ext; base += 64u) {      // closest hits: the listed entries of queue `cur`, records written in place
-        const uint32_t li = base + lane_id(); const bool valid = li < n_ext;
-        const uint32_t pos = ldq(q.fix_ext, (qbase + (valid ? li : n_ext - 1u)) << 2);
-        const uint32_t slot = qbase + pos, io = slot << 4;
-        const float4 ra = ldq(q.tr[cur][0], io), rb = ldq(q.tr[cur][1], io);
+    for (uint32_t base = 0; base < n_def; base += 64u) {      // staged rays: closest hit by the reference-order code, then the record joins its class queue (or the path ends)
+        const uint32_t li = base + lane_id(); const bool valid = li < n_def;
+        const uint32_t io = ((uint32_t)ncls * p.cap + qbase + (valid ? li : n_def - 1u)) << 4;
+        const float4 ra = ldq(q.tr[cur][0], io), rb = ldq(q.tr[cur][1], io), rc = ldq(q.tr[cur][2], io), rd = ldq(q.tr[cur][3], io);
         const f3 o = mk3(ra.x, ra.y, ra.z), d = mk3(rb.x, rb.y, rb.z);
         HitRec r0, r1; r0.t = r1.t = 1e7f; r0.prim = r1.prim = -1; r0.u = r0.v = r1.u = r1.v = 0.f;
         int c0, c1;
         flat_closest2(sc.flat, sc.sweep, sc.prim_class, o, d, o, d, r0, r1, c0, c1);
-        if (valid) {
-            stq(reinterpret_cast<float*>(q.tr[cur][0]), io + 12u, r0.t);
-            stq(reinterpret_cast<uint32_t*>(q.tr[cur][1]), io + 12u, (__float_as_uint(rb.w) & ~0xffu) | (r0.prim < 0 ? TR_NO_PRIM : (uint32_t)r0.prim));
+        if (valid && r0.prim >= 0) {
+            const int oc = ncls > 1 ? c0 : 0;
+            const uint32_t pos = atomicAdd(&cnt->n_tr[bounce % 3][oc][sq * CNT_PAD], 1u);      // (one atomic per entry: this path is a handful of rays per million)
+            const uint32_t slot = (uint32_t)oc * p.cap + qbase + pos, so = slot << 4;
+            stq(q.tr[cur][0], so, make_float4(ra.x, ra.y, ra.z, r0.t));
+            stq(q.tr[cur][1], so, make_float4(rb.x, rb.y, rb.z, __uint_as_float((__float_as_uint(rb.w) & ~0xffu) | (uint32_t)r0.prim)));
+            stq(q.tr[cur][2], so, rc); stq(q.tr[cur][3], so, rd);
             if (need_uv) { float2 uv_; uv_.x = r0.u; uv_.y = r0.v; stq(q.tr_uv[cur], slot << 3, uv_); }
+        } else if (valid && !(rd.x == 0.f && rd.y == 0.f && rd.z == 0.f)) {      // nothing hit: the path ends, its radiance goes to its slot
+            const uint32_t id = __float_as_uint(rc.w), lp_ = id & ((1u << p.pix_bits) - 1u), s_ = id >> p.pix_bits;
+            add_radiance(q.L, p.cap, (s_ * (uint32_t)p.npix + lp_) << 2, mk3(rd.x, rd.y, rd.z), true);
         }
     }
     uint32_t t_lit = 0;
-    for (uint32_t base = 0; base < n_sh; base += 64u) {       // light samples the previous launch could not settle (shadow_flat_body<3>)
+    for (uint32_t base = 0; base < n_sh; base += 64u) {       // light samples the previous bounce could not settle (shadow_flat_body<3>)
         const uint32_t li = base + lane_id(); const bool valid = li < n_sh;
         const uint32_t io = (sh_qbase + (valid ? li : n_sh - 1u)) << 2;
         const f3 o = ld3q(q.sh_o, q.sh_cap, io), d = ld3q(q.sh_d, q.sh_cap, io), c = ld3q(q.sh_c, q.sh_cap, io);
@@ -748,18 +781,19 @@ APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Co
         bool occ, occ_b;
         const float lim = (dist > 0.0f) ? dist - 1e-4f : 1e7f;
         flat_any2(sc.flat, sc.sweep, o, d, o, d, lim, lim, occ, occ_b);
-        if (valid) {
-            const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
-            if (!occ) add_radiance(q.L, p.cap, slot, c, true);
-            else if (weird) add_radiance(q.L, p.cap, slot, c * 0.f, true);      // (k_shadow: an occluded sample enters upstream's sum as 0 * contribution)
-            t_lit += occ ? 0u : 1u;
+        // (several samples of one vertex may be listed - S > 1 - and share its slot: one entry at a time within the wave's 64)
+        const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
+        const bool add = valid && (!occ || weird);
+        for (unsigned long long m = __ballot(add); m != 0ull; m &= m - 1ull) {
+            if ((int)lane_id() == __ffsll((long long)m) - 1) add_radiance(q.L, p.cap, slot, occ ? c * 0.f : c, true);      // (k_shadow: an occluded non-finite sample enters upstream's sum as 0 * contribution)
         }
+        t_lit += (valid && !occ) ? 1u : 0u;
     }
     flush_stat(t_lit, &cnt->stats[sq][ST_LIT]);
     __threadfence();
     if (lane_id() == 0) {
         __hip_atomic_store(&cnt->fix_done[sq * CNT_PAD], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        *n_ext_p = 0u; *n_sh_p = 0u;                          // consumed (the launch after this one appends to these lists again)
+        *n_sh_p = 0u;                                         // consumed (the bounce after this one appends to this list again; the staging queue's counter rotates with the others)
     }
 }
 #endif
@@ -767,10 +801,13 @@ template <int BM, int SM, int TEX = 0, int FUSE = 0>
 __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_LAMBERT_WAVES : APT_SHADE_WAVES))) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
-    const uint32_t n = in.counts[sl.q * CNT_PAD];
+    uint32_t n = (FUSE >= 2) ? 0u : in.counts[sl.q * CNT_PAD];
     const uint32_t qbase = (uint32_t)sl.q * p.subcap, sh_qbase = (uint32_t)sl.q * q.sh_subcap;
-    uint32_t* next_counter = (FUSE == 2) ? &cnt->n_tr[(bounce + 1) % 3][sl.q * CNT_PAD] : &cnt->n_active[nxt][sl.q * CNT_PAD];
-    if (FUSE == 2 && sl.first == 0 && threadIdx.x == 0) cnt->n_tr[(bounce + 2) % 3][sl.q * CNT_PAD] = 0;      // (read by the previous launch, appended to by the next one)
+    uint32_t* next_counter = (FUSE >= 2) ? &cnt->n_tr[(bounce + 1) % 3][0][sl.q * CNT_PAD] : &cnt->n_active[nxt][sl.q * CNT_PAD];      // (FUSE == 2: the first queue's tail)
+    if (FUSE >= 2 && sl.first == 0 && threadIdx.x == 0) {      // (read by the previous bounce, appended to by the next one)
+        cnt->n_tr[(bounce + 2) % 3][in.cls][sl.q * CNT_PAD] = 0;
+        if (in.cls == 0) cnt->n_tr[(bounce + 2) % 3][q.tr_ncls][sl.q * CNT_PAD] = 0;
+    }
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
     const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
     uint32_t t_shade = 0, t_shadow = 0, t_poison = 0, t_traced = 0, t_lit = 0;        // wave-uniform tallies (SGPRs)
@@ -790,14 +827,16 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
     // trips.  So the next row's record is requested at the top of this row - after this row's shading record, so that waiting for that
     // one (vmcnt counts in order) does not wait for the prefetch - and lands while this row is shaded.
     constexpr bool PF = ((APT_SHADE_PREFETCH != 0) && BM == 0x002 && SM == 0x1 && TEX == 0) || (APT_SHADE_PREFETCH == 2 && TEX == 0);
-    constexpr bool TRACE = FUSE == 2;                         // the continuation ray is traced in place too ("rays traced in place" above)
+    constexpr bool TRACE = FUSE >= 2;                         // the continuation ray is traced in place too ("rays traced in place" above)
+    constexpr bool MULTI = FUSE == 3;                         // ... FUSE = 2: one queue (unsorted), one light sample per vertex - the kernel of C1 / C2, which carries nothing else; FUSE = 3: queues by material class, any number of light samples
     static_assert(APT_FLAT_MAX_PRIMS < (int)TR_NO_PRIM, "the packed record keeps the hit primitive in 8 bits");
+    const uint32_t in_base = TRACE ? (uint32_t)in.cls * p.cap + qbase : qbase;      // first slot of the queue this workgroup reads
     const float4* trA = TRACE ? q.tr[cur][0] : nullptr; const float4* trB = TRACE ? q.tr[cur][1] : nullptr; const float4* trC = TRACE ? q.tr[cur][2] : nullptr; const float4* trD = TRACE ? q.tr[cur][3] : nullptr;
     int pf_prim = -1; float pf_t = 0.f; f3 pf_o = splat3(0.f), pf_d = splat3(0.f), pf_thr = splat3(0.f); uint32_t pf_id = 0, pf_meta = 0;      // (TRACE: pf_prim holds the packed word pm)
     auto prefetch = [&](uint32_t b) {            // straight-line loads (lanes past the end re-read the last entry: never used), so that no wait lands at the end of a branch
         const uint32_t ps = min(b + threadIdx.x, n - 1u);
         if (TRACE) {
-            const uint32_t pio16 = (qbase + ps) << 4;
+            const uint32_t pio16 = (in_base + ps) << 4;
             const float4 a = ldq(trA, pio16), b_ = ldq(trB, pio16), c = ldq(trC, pio16);
             pf_o = mk3(a.x, a.y, a.z); pf_t = a.w; pf_d = mk3(b_.x, b_.y, b_.z); pf_prim = __float_as_int(b_.w); pf_thr = mk3(c.x, c.y, c.z); pf_id = __float_as_uint(c.w);
             return;
@@ -812,11 +851,14 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
     constexpr bool PFP = !PF && (APT_SHADE_PREFETCH_PRIM != 0) && TEX == 0;
     uint32_t t_extend = 0;
 #if APT_FAST
-    if (TRACE) fix_prologue(sc, p, q, cnt, in, cur, sl.q, (uint32_t)bounce + 1u);      // before the first record is requested
+    if (TRACE) {
+        fix_prologue(sc, p, q, cnt, cur, sl.q, bounce);       // before the queue's length is read: the prologue may append to it
+        n = __hip_atomic_load(&cnt->n_tr[bounce % 3][in.cls][sl.q * CNT_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #endif
     if (PF && n > 0) prefetch(sl.first);
     auto prefetch_prim = [&](uint32_t b) {
-        const uint32_t ps = qbase + min(b + threadIdx.x, n - 1u);
+        const uint32_t ps = in_base + min(b + threadIdx.x, n - 1u);
         pf_prim = TRACE ? ldq(reinterpret_cast<const int*>(trB), (ps << 4) + 12u) : ldq(in.prim, ps << 2);
     };
     if (PFP && n > 0) prefetch_prim(sl.first);
@@ -826,7 +868,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         sprof[7] += 1;
 #endif
         const uint32_t pos = base + threadIdx.x;
-        const uint32_t idx = qbase + pos;
+        const uint32_t idx = in_base + pos;
         bool alive = pos < n;
         int cu_prim = pf_prim; const float cu_t = pf_t; const f3 cu_o = pf_o, cu_d = pf_d, cu_thr = pf_thr; const uint32_t cu_id = pf_id; uint32_t cu_meta = pf_meta;
         if (TRACE && (PF || PFP)) { cu_meta = tr_meta((uint32_t)pf_prim, (uint32_t)bounce); cu_prim = tr_prim((uint32_t)pf_prim); }
@@ -954,6 +996,30 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         uint32_t vbase = 0;
         if (!FUSE && p.nee_vm) vbase = wave_append(alive, shadow_counter);
         bool f_want = false; f3 f_dir = mk3(0.f, 0.f, 1.f), f_c = splat3(0.f); float f_tmax = 0.f;
+        const bool alive_nee = alive;
+        f3 f_sum = splat3(0.f); bool f_any = false;            // FUSE: the vertex's unoccluded light samples, summed in sample order (as the by-vertex shadow kernel sums them), added to the path's radiance once
+#if APT_FAST
+        auto trace_light = [&](bool want, f3 dir, f3 c, float tmax) {
+            // a light sample swept in place; a ray that needs the reference-order sweep leaves as a shadow-queue entry for the next launch's prologue
+            const bool defer = want && flat_needs_cull(sc.flat, dir);
+            bool occ = false;
+            if (__any(want && !defer)) occ = flat_any1(sc.flat, hit_point, dir, (tmax > 0.0f) ? tmax - 1e-4f : 1e7f);
+            if (__any(defer)) {
+                const uint32_t spos = wave_append(defer, &cnt->n_fix_sh[cur][sl.q * CNT_PAD]);
+                if (defer && spos < q.sh_subcap) {
+                    const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
+                    st3q(q.sh_o, sc_, so, hit_point); st3q(q.sh_d, sc_, so, dir); stq(q.sh_tmax, so, tmax); st3q(q.sh_c, sc_, so, c); stq(q.sh_id, so, l_off);
+                }
+            }
+            const bool traced = want && !defer;
+            if (traced) {
+                // (an occluded sample still enters upstream's sum as 0 * contribution: NaN for a non-finite one, see k_shadow)
+                const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
+                if (!occ || weird) { const f3 a = occ ? c * 0.f : c; f_sum = f_any ? f_sum + a : a; f_any = true; }
+            }
+            t_traced += wave_count(want); t_lit += wave_count(traced && !occ);
+        };
+#endif
         bool late_want = false; f3 late_dir = splat3(0.f), late_c = splat3(0.f); float late_tmax = 0.f; Append late_app; late_app.m = 0ull; late_app.raw = 0u;
         for (int s = 0; s < p.S; s++) {
             bool want = false, sampled = false, poisoned = false;
@@ -1017,7 +1083,15 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                 } else if (alive) stq(q.sh_tmax, so, -1.0f);                   // the vertex has no sample s worth tracing
                 if (alive && s == 0) stq(q.sh_id, so, l_off);                   // one radiance slot per vertex, kept with its first entry
             } else if (FUSE) {
-                f_want = want; f_dir = light_dir; f_c = contrib; f_tmax = emitter_d;      // traced at the end of the row
+                // traced at the end of the row, when little else is live: one sample per vertex waits in registers, several are parked in LDS
+                // ([sample][component][thread]: conflict-free; a sample not worth tracing is marked by a negative distance)
+                if (!MULTI || p.S == 1) { f_want = want; f_dir = light_dir; f_c = contrib; f_tmax = emitter_d; }
+                else {
+                    lds_f* park = (lds_f*)reinterpret_cast<float*>(s_dyn) + ((uint32_t)s * 7u * BLOCK + threadIdx.x);
+                    park[0] = light_dir.x; park[BLOCK] = light_dir.y; park[2 * BLOCK] = light_dir.z;
+                    park[3 * BLOCK] = contrib.x; park[4 * BLOCK] = contrib.y; park[5 * BLOCK] = contrib.z;
+                    park[6 * BLOCK] = want ? emitter_d : -1.0f;
+                }
             } else if (PF && APT_SHADE_LATE_SHADOW && s == p.S - 1) {
                 late_app = append_issue(want, shadow_counter);
                 late_want = want; late_dir = light_dir; late_c = contrib; late_tmax = emitter_d;
@@ -1078,15 +1152,18 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         // rays traced in place: the continuation ray meets the scene's records here.  Only rays that hit something (or whose answer is left
         // to the reference-order code: listed, with a provisional record) enter the next queue; the tail atomic is on its way while the light
         // sample is swept below.
-        float tr_t = 0.f; int tr_hit = -1; float tr_u = 0.f, tr_v = 0.f; bool tr_defer = false;
+        float tr_t = 0.f; int tr_hit = -1; float tr_u = 0.f, tr_v = 0.f; int tr_q = -1;      // tr_q: the queue the record joins (-1: none)
+        TrAppend tr_app; tr_app.raw = 0u; tr_app.rank = 0u;
         if (TRACE) {
-            int tr_idx = -1, tr_run = -1;
+            int tr_idx = -1, tr_run = -1, hit_cls = 0;
             if (__any(cont)) tr_idx = flat_closest1(sc.flat, hit_point, new_d, 1e7f, tr_t, tr_run);
-            tr_defer = cont && (tr_run >= 0 || flat_needs_cull(sc.flat, new_d));
+            const bool tr_defer = cont && (tr_run >= 0 || flat_needs_cull(sc.flat, new_d));
             t_extend += wave_count(cont);
             cont = cont && (tr_idx >= 0 || tr_defer);
-            next_app = append_issue(cont, next_counter);
-            if (cont && !tr_defer) { HitRec hr; int cls_; flat_resolve(sc.flat, tr_idx, tr_t, hit_point, new_d, hr, cls_); tr_hit = hr.prim; tr_u = hr.u; tr_v = hr.v; }
+            if (cont && !tr_defer) { HitRec hr; flat_resolve(sc.flat, tr_idx, tr_t, hit_point, new_d, hr, hit_cls); tr_hit = hr.prim; tr_u = hr.u; tr_v = hr.v; }
+            tr_q = !cont ? -1 : (tr_defer ? q.tr_ncls : (q.tr_ncls > 1 ? hit_cls : 0));
+            if (MULTI) tr_app = tr_append_issue(tr_q, q.tr_ncls + 1, next_counter, APT_MAX_NQ * CNT_PAD);
+            else { const Append a_ = append_issue(tr_q == 0, next_counter); tr_app.raw = a_.raw; tr_app.rank = rank_in(a_.m); }      // (one queue; a staged ray - rare - moves the staging queue's tail by itself, below)
         }
 #endif
         uint32_t npos = (PF && !TRACE) ? append_pos(next_app) : (TRACE ? 0u : wave_append(cont, next_counter));
@@ -1101,42 +1178,33 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         }
 #if APT_FAST
         if (FUSE) {
-            // the row's light samples, swept in place; a ray that needs the reference-order sweep leaves as a shadow-queue entry for the fix-up launch
-            const bool defer = f_want && flat_needs_cull(sc.flat, f_dir);
-            bool occ = false;
-            if (__any(f_want && !defer)) occ = flat_any1(sc.flat, hit_point, f_dir, (f_tmax > 0.0f) ? f_tmax - 1e-4f : 1e7f);
-            if (__any(defer)) {
-                const uint32_t spos = wave_append(defer, &cnt->n_fix_sh[cur][sl.q * CNT_PAD]);
-                if (defer && spos < q.sh_subcap) {
-                    const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
-                    st3q(q.sh_o, sc_, so, hit_point); st3q(q.sh_d, sc_, so, f_dir); stq(q.sh_tmax, so, f_tmax); st3q(q.sh_c, sc_, so, f_c); stq(q.sh_id, so, l_off);
+            for (int s = 0; s < (MULTI ? p.S : 1); s++) {       // the row's light samples
+                if (MULTI && p.S > 1) {
+                    const lds_f* park = (const lds_f*)reinterpret_cast<const float*>(s_dyn) + ((uint32_t)s * 7u * BLOCK + threadIdx.x);
+                    f_dir = mk3(park[0], park[BLOCK], park[2 * BLOCK]); f_c = mk3(park[3 * BLOCK], park[4 * BLOCK], park[5 * BLOCK]);
+                    f_tmax = park[6 * BLOCK]; f_want = alive_nee && !(f_tmax < 0.0f);
                 }
+                trace_light(f_want, f_dir, f_c, f_tmax);
             }
-            const bool traced = f_want && !defer;
-            if (traced) {
-                // (an occluded sample still enters upstream's sum as 0 * contribution: NaN for a non-finite one, see k_shadow)
-                const bool weird = !(isfinite(f_c.x) && isfinite(f_c.y) && isfinite(f_c.z));
-                if (!occ) Lc = Lc + f_c; else if (weird) Lc = Lc + f_c * 0.f;
-            }
-            t_traced += wave_count(f_want); t_lit += wave_count(traced && !occ);
+            if (f_any) Lc = Lc + f_sum;
             if (TRACE) {
-                npos = append_pos(next_app);
+                if (MULTI) npos = tr_append_pos(tr_app, tr_q);
+                else {
+                    npos = (uint32_t)__builtin_amdgcn_readlane((int)tr_app.raw, 0) + tr_app.rank;
+                    if (__any(tr_q == 1)) { const uint32_t dpos = wave_append(tr_q == 1, next_counter + APT_MAX_NQ * CNT_PAD); if (tr_q == 1) npos = dpos; }
+                }
                 if (cont) {
-                    const uint32_t slot = qbase + npos, so = slot << 4;
+                    const uint32_t slot = (uint32_t)tr_q * p.cap + qbase + npos, so = slot << 4;
                     stq(q.tr[nxt][0], so, make_float4(hit_point.x, hit_point.y, hit_point.z, tr_t));
                     stq(q.tr[nxt][1], so, make_float4(new_d.x, new_d.y, new_d.z, __uint_as_float(tr_pack(tr_hit, rng.draw, is_spec))));
                     stq(q.tr[nxt][2], so, make_float4(thr.x, thr.y, thr.z, __uint_as_float(id)));
                     stq(q.tr[nxt][3], so, make_float4(Lc.x, Lc.y, Lc.z, new_pdf));
                     if (sc.has_vn || sc.tex_i != nullptr) { float2 uv_; uv_.x = tr_u; uv_.y = tr_v; stq(q.tr_uv[nxt], slot << 3, uv_); }
                 }
-                if (__any(tr_defer)) {                        // listed for the next launch's prologue (sub-queue-local position)
-                    const uint32_t lpos = wave_append(tr_defer, &cnt->n_fix_ext[nxt][sl.q * CNT_PAD]);
-                    if (tr_defer) stq(q.fix_ext, (qbase + lpos) << 2, npos);
-                }
             }
             if (cont) { if (!TRACE) st3q(q.Lc[nxt], p.cap, (qbase + npos) << 2, Lc); }
             else if (entry && !(Lc.x == 0.f && Lc.y == 0.f && Lc.z == 0.f)) {
-                // the path ends here (nothing hit, roulette, last bounce): its radiance goes to its slot - added, not stored: a fix-up launch may have put a deferred sample's share there already
+                // the path ends here (nothing hit, roulette, last bounce): its radiance goes to its slot - added, not stored: a fix-up pass may have put a deferred sample's share there already
                 const uint32_t lp_ = id & ((1u << p.pix_bits) - 1u), s_ = id >> p.pix_bits;
                 add_radiance(q.L, p.cap, (s_ * (uint32_t)p.npix + lp_) << 2, Lc, true);
             }
