@@ -538,13 +538,22 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 #ifndef APT_WALK_VOTE
 #define APT_WALK_VOTE 1
 #endif
+#ifndef APT_VOTE_TRI_WEIGHT
+#define APT_VOTE_TRI_WEIGHT 2      // the vote is "primitive test if (lanes waiting for one) x weight >= lanes waiting for a node step"
+#endif
 // after either action: a walking lane with nothing pending and no inner children left takes its next group from the stack, or is finished
 APT_D void walk_settle(const TravStack& ts, int& sp, grp_t& ng, const grp_t& tg, int& state) {
     if (state == 1 && tg.y == 0u && !APT_GROUP_HAS_NODES(ng)) {
         if (sp == 0) state = 2; else ng = tpop(ts, sp);
     }
 }
-#ifdef APT_WALK_WAVES
+// Register budget of the walk kernels: left alone the allocator takes 86 VGPRs for the class-sorting closest-hit walk (five waves per SIMD);
+// asked for seven waves it finds 70 without a spill (eight: 64 and a 20-byte spill).  Measured (product build, one lane, ms per 64 / 32 spp
+// of C4 / C5): extend 18.73 -> 17.79 / 13.35 -> 13.04 at seven, 17.83 / 13.41 at eight, 18.03 / 13.23 at six.
+#ifndef APT_WALK_WAVES
+#define APT_WALK_WAVES 7
+#endif
+#if APT_WALK_WAVES > 0
 #define APT_WALK_ATTR __attribute__((amdgpu_waves_per_eu(APT_WALK_WAVES, APT_WALK_WAVES)))
 #else
 #define APT_WALK_ATTR
@@ -636,7 +645,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
         // or one primitive test for the lanes with some.  Per ray nothing changes - same nodes, same primitives, same order.
         do {
             const bool want_t = state == 1 && tg.y != 0u, want_n = state == 1 && tg.y == 0u;
-            if (__popcll(__ballot(want_t)) >= __popcll(__ballot(want_n))) { if (want_t) tri_one<false>(sc.bvh, tg, r, rec, ws); }
+            if (__popcll(__ballot(want_t)) * APT_VOTE_TRI_WEIGHT >= __popcll(__ballot(want_n))) { if (want_t) tri_one<false>(sc.bvh, tg, r, rec, ws); }
             else if (want_n) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
             walk_settle(ts, sp, ng, tg, state);
         } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
@@ -1321,7 +1330,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
 #if APT_WALK_VOTE
         do {
             const bool want_t = state == 1 && tg.y != 0u, want_n = state == 1 && tg.y == 0u;
-            if (__popcll(__ballot(want_t)) >= __popcll(__ballot(want_n))) {
+            if (__popcll(__ballot(want_t)) * APT_VOTE_TRI_WEIGHT >= __popcll(__ballot(want_n))) {
                 if (want_t && tri_one<true>(sc.bvh, tg, r, rec, ws)) { occluded = true; sp = 0; ng.y = 0u; tg.y = 0u; }      // first occluder ends the walk
             } else if (want_n) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
             walk_settle(ts, sp, ng, tg, state);

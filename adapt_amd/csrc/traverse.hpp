@@ -120,13 +120,16 @@ APT_D grp_t tpop(const TravStack& s, int& sp) {
 #endif
 struct WalkStats { uint32_t nodes, prims; };
 
+// record strides as shift-adds: v_mul_lo_u32 issues at quarter rate and sits at the head of every dependent fetch of the walk
+APT_D uint32_t mul80(uint32_t i) { return (i << 6) + (i << 4); }
+APT_D uint32_t mul48(uint32_t i) { return (i << 5) + (i << 4); }
 APT_D float ubyte_f(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); }       // v_cvt_f32_ubyte<b>
 
 // Fetch node `idx` and test its eight child boxes against the ray segment [0, tmax].
 // Out: hit mask - bits 31..24 the INNER children that are hit, at position 24 + (slot ^ (7 - ray octant)) so that "highest bit
 // first" is front to back; bits 23..0 the primitives of the hit leaf children, by offset from tri_base.
 APT_D uint32_t node8_test(const DevBvh& b, uint32_t idx, const WalkRay& r, float tmax, uint32_t& child_base, uint32_t& tri_base, uint32_t& imask) {
-    const char* base = reinterpret_cast<const char*>(b.nodes) + idx * APT_NODE_BYTES;          // wave-uniform base + 32-bit offset
+    const char* base = reinterpret_cast<const char*>(b.nodes) + ((APT_NODE_BYTES == 80u) ? mul80(idx) : idx * APT_NODE_BYTES);          // wave-uniform base + 32-bit offset
     const uint4 n0 = *reinterpret_cast<const uint4*>(base), n1 = *reinterpret_cast<const uint4*>(base + 16), n2 = *reinterpret_cast<const uint4*>(base + 32),
                 n3 = *reinterpret_cast<const uint4*>(base + 48), n4 = *reinterpret_cast<const uint4*>(base + 64);
     child_base = n1.x; tri_base = n1.y; imask = n0.w >> 24;
@@ -190,7 +193,7 @@ template <bool ANY>
 APT_D bool tri_one(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
     const uint32_t k = 31u - (uint32_t)__clz((int)tg.y);
     tg.y &= ~(1u << k);
-    const char* base = reinterpret_cast<const char*>(b.prims) + (tg.x + k) * 48u;
+    const char* base = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k);
     const float4 p0 = *reinterpret_cast<const float4*>(base), p1 = *reinterpret_cast<const float4*>(base + 16), p2 = *reinterpret_cast<const float4*>(base + 32);
     float u, v;
     const float t = walk_scalar_test(p0, p1, p2, r.o, r.d, u, v);
@@ -206,8 +209,8 @@ APT_D bool tri_two(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, Wa
     const bool two = rest != 0u;
     const uint32_t k1 = two ? 31u - (uint32_t)__clz((int)rest) : k0;
     tg.y = two ? (rest & ~(1u << k1)) : 0u;
-    const char* ba = reinterpret_cast<const char*>(b.prims) + (tg.x + k0) * 48u;
-    const char* bb = reinterpret_cast<const char*>(b.prims) + (tg.x + k1) * 48u;
+    const char* ba = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k0);
+    const char* bb = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k1);
     const float4 a0 = *reinterpret_cast<const float4*>(ba), a1 = *reinterpret_cast<const float4*>(ba + 16), a2 = *reinterpret_cast<const float4*>(ba + 32);
     const float4 b0 = *reinterpret_cast<const float4*>(bb), b1 = *reinterpret_cast<const float4*>(bb + 16), b2 = *reinterpret_cast<const float4*>(bb + 32);
     WALK_COUNT(ws.prims); if (two) WALK_COUNT(ws.prims);
@@ -249,7 +252,7 @@ template <bool ANY>
 APT_D bool tri_one(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
     const uint32_t k = 31u - (uint32_t)__clz((int)tg.y);
     tg.y &= ~(1u << k);
-    const char* base = reinterpret_cast<const char*>(b.prims) + (tg.x + k) * 48u;
+    const char* base = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k);
     const float4 p0 = *reinterpret_cast<const float4*>(base), p1 = *reinterpret_cast<const float4*>(base + 16), p2 = *reinterpret_cast<const float4*>(base + 32);
     float u, v;
     const float t = prim_test(p0, p1, p2, r.o, r.d, u, v);
@@ -270,8 +273,8 @@ APT_D bool tri_two(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, Wa
     const bool two = rest != 0u;
     const uint32_t k1 = two ? 31u - (uint32_t)__clz((int)rest) : k0;
     tg.y = two ? (rest & ~(1u << k1)) : 0u;
-    const char* ba = reinterpret_cast<const char*>(b.prims) + (tg.x + k0) * 48u;
-    const char* bb = reinterpret_cast<const char*>(b.prims) + (tg.x + k1) * 48u;
+    const char* ba = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k0);
+    const char* bb = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k1);
     const float4 a0 = *reinterpret_cast<const float4*>(ba), a1 = *reinterpret_cast<const float4*>(ba + 16), a2 = *reinterpret_cast<const float4*>(ba + 32);
     const float4 b0 = *reinterpret_cast<const float4*>(bb), b1 = *reinterpret_cast<const float4*>(bb + 16), b2 = *reinterpret_cast<const float4*>(bb + 32);
     WALK_COUNT(ws.prims); if (two) WALK_COUNT(ws.prims);

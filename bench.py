@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the bounded oracle sample")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent render lanes (batch pipelines on separate HIP streams); 0 = library default (3)")
     ap.add_argument("--no-exclusive-pass", action="store_true", help="skip the extra untimed one-lane pass that measures every kernel alone")
-    ap.add_argument("--no-profile", action="store_true", help="timed region without the per-launch HIP events (quantifies their overhead)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the repeat of the timed region with per-launch HIP events (the timed region itself never carries them) and the exclusive pass")
     ap.add_argument("--strict-profiles", action="store_true", help="fail if profiles/r0N_<config>_counters.json is missing or was taken on other kernels")
     ap.add_argument("--dump-image", default="", help="rank 0 writes the gathered (W, H, 3) accumulation of the timed region to this .npy file")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for dry runs)")
@@ -210,7 +210,7 @@ def main():
     spp_step = spp * world if args.scaling == "weak" else spp       # weak: per-GPU samples stay at the N = 1 amount
     parsed = load_scene(sdir, sfile)
     rdr = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world,
-                   band_width=BAND_WIDTH, profile=not args.no_profile, spp_per_batch=args.spp_per_batch)
+                   band_width=BAND_WIDTH, profile=False, spp_per_batch=args.spp_per_batch)      # the timed region carries no per-launch events (below)
     info = rdr.info()
     if args.lanes <= 0 and "APT_LANES" not in os.environ and volumetric and bool(((rdr.flat.bxdf_i[:, 2] != 0) & (rdr.flat.bxdf_i[:, 0] < 0)).any()):
         lanes = 4                            # library default for volumetric scenes with null surfaces (api.hip)
@@ -299,13 +299,32 @@ def main():
     props = torch.cuda.get_device_properties(local_rank)
     n_simd = int(props.multi_processor_count) * 4
 
-    timed = region_roofline(st, counters, n_simd, sclk)
-    overlap = round(sum(st["kernel_ms"].values()) / st["render_ms"], 3) if st["render_ms"] > 0 else None
+    # Per-launch HIP events are not free: one record per launch holds the next launch back until the previous one has retired and its
+    # timestamp is written - ~1 % of C2's rate (10 launches per batch), 8-15 % of C4 / C5's (170-700 launches per batch: a kernel per
+    # material class and bounce).  So the TIMED region runs without them (`value` is the rate of the render as a user runs it), and the
+    # same K steps are repeated with the events on (`roofline.timed_region`: per-kernel sums with the lanes overlapping, and what the
+    # events cost: `event_overhead`).
+    timed, overlap, prof = region_roofline(st, counters, n_simd, sclk), None, None
+    if not args.no_profile:
+        rp = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world, band_width=BAND_WIDTH, profile=True,
+                      spp_per_batch=args.spp_per_batch)
+        rp.render(n_spp=1); rp.synchronize()
+        rp.render(n_spp=spp_step); rp.synchronize(); rp.clear()
+        tp = time.perf_counter()
+        for _ in range(args.steps):
+            rp.render(n_spp=spp_step); rp.synchronize()
+        dt_prof = time.perf_counter() - tp
+        stp = rp.stats()
+        rp.close()
+        timed = region_roofline(stp, counters, n_simd, sclk)
+        overlap = round(sum(stp["kernel_ms"].values()) / stp["render_ms"], 3) if stp["render_ms"] > 0 else None
+        prof = {"sum_kernel_ms": round(sum(stp["kernel_ms"].values()), 3), "render_ms": round(stp["render_ms"], 3),
+                "Msamples/s": round(rdr.n_cols * rdr.h * spp_step * args.steps / dt_prof / 1e6, 1), "event_overhead": round(st["render_ms"] and stp["render_ms"] / st["render_ms"] - 1.0, 4)}
     # With more than one render lane, kernels of different batches run side by side on the GPU: a HIP-event bracket in the
     # timed region then measures a kernel that shares the machine (`overlap` = summed kernel time / wall time), which says
     # nothing about the kernel.  The per-kernel rooflines are therefore measured with the same events in an extra, untimed pass of
     # the same workload on ONE lane, where every kernel has the GPU to itself; the timed-region figures stay in `timed_region`.
-    alone, source, one_lane_rate = timed, "timed region (one render lane: kernels do not overlap)", None
+    alone, source, one_lane_rate = timed, "repeat of the timed region with per-launch events (one render lane: kernels do not overlap)", None
     if lanes > 1 and not args.no_exclusive_pass and not args.no_profile:
         os.environ["APT_LANES"] = "1"
         r1 = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world, band_width=BAND_WIDTH, profile=True,
@@ -320,7 +339,7 @@ def main():
         source = f"exclusive pass after the timed region: same workload, {n1} spp, one render lane (kernels of concurrent lanes overlap in the timed region)"
         r1.close()
     elif lanes > 1:
-        source = "timed region with overlapping render lanes (exclusive pass disabled): per-kernel durations include co-scheduled kernels"
+        source = "repeat of the timed region with per-launch events, overlapping render lanes (exclusive pass disabled): per-kernel durations include co-scheduled kernels"
     dom = pick_dominant(alone)
     kb = kernel_bytes(st)
     roofline = {"bound": "hbm", "kernel": f"k_{dom}", "achieved": alone[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alone[dom]["frac"],
@@ -336,7 +355,7 @@ def main():
                 "bytes_per_sample": round(sum(kb.values()) / max(1, st["n_samples"]), 1)}
     if alone is not timed:
         roofline["one_lane_Msamples/s"] = one_lane_rate
-        roofline["timed_region"] = {"per_kernel": timed, "sum_kernel_ms": round(sum(st["kernel_ms"].values()), 3), "render_ms": round(st["render_ms"], 3), "overlap": overlap}
+        roofline["timed_region"] = dict(prof or {}, per_kernel=timed, overlap=overlap, note="the timed region's K steps repeated with per-launch events (the timed region itself carries none)")
 
     out = {
         "metric": "Msamples/s (W*H*spp/s), " + ("volumetric path tracing (homogeneous media)" if volumetric else "unidirectional MIS path tracing"), "value": round(value, 3), "unit": "Msamples/s",
@@ -346,7 +365,7 @@ def main():
         "config": {"workload": label, "scene": f"scenes/{sdir}/{sfile}", "width": W, "height": H, "spp_per_step": spp_step,
                    "max_bounce": bounces, "num_shadow_ray": rdr.num_shadow_ray, "tiling": f"{world} x interleaved {BAND_WIDTH}-column bands",
                    "spp_per_batch": info["spp_per_batch"], "sub_queues": info["n_subqueues"], "shade_variant": info["shade_variant"], "traversal": info["traversal"],
-                   "queue_MiB": round(info["queue_bytes"] / 2 ** 20, 1), "render_lanes": lanes, "seed": 0, "per_launch_events": not args.no_profile},
+                   "queue_MiB": round(info["queue_bytes"] / 2 ** 20, 1), "render_lanes": lanes, "seed": 0, "per_launch_events": False},
         "per_sample": {k: round(st[k] / max(1, st["n_samples"]), 4) for k in ("n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws")},
         "roofline": roofline,
     }
