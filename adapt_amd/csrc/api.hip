@@ -1166,7 +1166,8 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
         { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, p, q, cnt); }
         int cur = 0;
         for (int b = 0; b < p.max_bounce; b++) {
-            if (r->dyn_fetch) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st)); }
+            // (the walk kernels reset each other's work counters - k_shadow_dyn the next bounce's closest-hit counter, k_extend_dyn this bounce's any-hit counter; without light samples the host does)
+            if (r->dyn_fetch && !(p.S > 0)) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st)); }
             { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : (r->trace_mode == 3 ? kExtendFlatHot[r->sorted] : kExtend[r->trace_mode][r->sorted]), dim3(grid_for(total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
             if (r->trace_mode == 3) { LaunchTimer t(r, 1, st, false); hipLaunchKernelGGL(kFixFlat[r->sorted], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
             if (!r->sorted) {
@@ -1183,7 +1184,6 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             }
             if (p.fused) { /* the shade kernel traced the light samples itself */ }
             else if (p.S > 0 && r->dyn_fetch) {
-                unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[1], 0, sizeof(cnt->n_work[1]), st));
                 LaunchTimer t(r, 3, st); hipLaunchKernelGGL(k_shadow_dyn, dim3(grid_for(total * (size_t)p.S, r->grid_shadow, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes_any, st, sc, p, q, cnt, lane_plan);
             } else if (p.S > 0) {
                 p.fix_par = cur;

@@ -156,7 +156,7 @@ struct Counters {
     uint32_t n_cls[8][APT_MAX_NQ * CNT_PAD];
     uint32_t n_fix_ext[2][APT_MAX_NQ * CNT_PAD];  // flat sweep: entries handed to the fix-up launch of the extend stage (by queue parity) ...
     uint32_t n_fix_sh[2][APT_MAX_NQ * CNT_PAD];   // ... and of the shadow stage, by the parity of the bounce that listed them (stages.hpp "fix-up lists")
-    uint32_t n_work[2][APT_MAX_NQ * CNT_PAD];     // BVH walk with dynamic fetch: next unclaimed queue position (0 extend, 1 shadow); zeroed by the host before the launch
+    uint32_t n_work[2][APT_MAX_NQ * CNT_PAD];     // BVH walk with dynamic fetch: next unclaimed queue position (0 extend, 1 shadow); zeroed with the batch's counters, then by the other walk kernel (surface renders with light samples) or by the host before the launch
     uint32_t n_tr[3][8 + 1][APT_MAX_NQ * CNT_PAD];   // rays traced in place: entries of the queues (material classes, then the staging queue) that bounce k of the batch reads, at [k % 3] (bounce k appends to [(k + 1) % 3] and zeroes [(k + 2) % 3], which bounce k - 1 read: no launch in between has to reset a counter)
     uint32_t fix_claim[APT_MAX_NQ * CNT_PAD];     // rays traced in place: which launch of the batch (1 + bounce) has had its fix-up lists claimed by a wave ...
     uint32_t fix_done[APT_MAX_NQ * CNT_PAD];      // ... and served (stages.hpp fix_prologue)
@@ -567,6 +567,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
         cnt->n_shadow[sq * CNT_PAD] = 0; cnt->n_active[cur_q ^ 1][sq * CNT_PAD] = 0;
         for (int w = 0; w < 8; w++) cnt->n_walk[w][sq * CNT_PAD] = 0;
         cnt->stats[sq][ST_EXTEND] += n;
+        cnt->n_work[1][sq * CNT_PAD] = 0;                                          // this bounce's any-hit walk (k_shadow_dyn) starts at the head of its queue
     }
     uint32_t* work = &cnt->n_work[0][sq * CNT_PAD];
     const float* ro = q.ray_o[cur_q]; const float* rd = q.ray_d[cur_q];
@@ -1285,6 +1286,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
     if (blockIdx.x / (uint32_t)p.nq == 0 && threadIdx.x == 0) {
         cnt->stats[sq][ST_SHADOW_TRACED] += n;
         for (int c = 0; c < q.n_classes; c++) cnt->n_cls[c][sq * CNT_PAD] = 0;      // every shade of this bounce is done
+        cnt->n_work[0][sq * CNT_PAD] = 0;                                          // the next bounce's closest-hit walk starts at the head of its queue (a host-side fill per bounce was a launch of its own: 15 us)
     }
     uint32_t* work = &cnt->n_work[1][sq * CNT_PAD];
     const uint32_t qbase = (uint32_t)sq * q.sh_subcap, sc_ = q.sh_cap;
