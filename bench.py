@@ -300,8 +300,8 @@ def main():
     n_simd = int(props.multi_processor_count) * 4
 
     # Per-launch HIP events are not free: one record per launch holds the next launch back until the previous one has retired and its
-    # timestamp is written - ~1 % of C2's rate (10 launches per batch), 8-15 % of C4 / C5's (170-700 launches per batch: a kernel per
-    # material class and bounce).  So the TIMED region runs without them (`value` is the rate of the render as a user runs it), and the
+    # timestamp is written - 0.6 % of C2's rate (10 launches per batch), 1.5-3.6 % of C3 / C4 / C5's (130-200 launches per batch: a kernel
+    # per material class and bounce).  So the TIMED region runs without them (`value` is the rate of the render as a user runs it), and the
     # same K steps are repeated with the events on (`roofline.timed_region`: per-kernel sums with the lanes overlapping, and what the
     # events cost: `event_overhead`).
     timed, overlap, prof = region_roofline(st, counters, n_simd, sclk), None, None
