@@ -781,7 +781,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (p.fused == 2 && cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (rays traced in place address 16-byte slots with 32-bit byte offsets: capacity must stay below 2^28)"); }
     const bool tr_uv = p.fused == 2 && (sc->dev.has_vn || sc->dev.tex_i != nullptr);
     // rays traced in place keep their path records in planes of their own (Queues::tr): the staged pipeline's second ray / state buffers are not carved
-    const size_t tr_q = (p.fused == 2) ? (size_t)(r->sorted ? ncls : 1) + 1 : 0;      // queues per plane: material classes (unsorted: one) + the staging queue
+    const bool stage_top = !(r->sorted && ncls > 1) && APT_TRACE_MULTI == 0;      // one queue: the staging queue lives at the top of the sub-queue's own region (Queues::tr_stage_top)
+    const size_t tr_q = (p.fused == 2) ? (size_t)(r->sorted ? ncls : 1) + (stage_top ? 0 : 1) : 0;      // queues per plane: material classes (unsorted: one) [+ the staging queue]
     if (p.fused == 2 && tr_q * cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (rays traced in place: queues x capacity must stay below 2^28 slots)"); }
     const size_t words = (p.fused == 1 ? 6 * cap : 0) + (p.fused == 2 ? (32 + (tr_uv ? 4 : 0)) * cap * tr_q : 0) - (p.fused == 2 ? (6 + 12) * cap : 0) + (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + (p.fused == 2 ? 0 : cap * 16 * (size_t)ncls) + (walk_lists ? 2 * sh_cap : 0);
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
@@ -801,7 +802,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
             for (int a = 0; a < 4; a++) q.tr[k][a] = (p.fused == 2) ? (float4*)take(4 * cap * tr_q) : nullptr;
             q.tr_uv[k] = tr_uv ? (float2*)take(2 * cap * tr_q) : nullptr;
         }
-        q.tr_ncls = (p.fused == 2) ? (int)tr_q - 1 : 0;
+        q.tr_ncls = (p.fused == 2) ? (int)tr_q - (stage_top ? 0 : 1) : 0; q.tr_stage_top = (p.fused == 2 && stage_top) ? 1 : 0;
         q.fix_ext = (r->trace_mode == 3) ? (uint32_t*)take(cap) : nullptr; q.fix_sh = (r->trace_mode == 3) ? (uint32_t*)take(sh_cap) : nullptr;
         for (int k = 0; k < 2; k++) { q.thr[k] = staged ? take(3 * cap) : nullptr; q.id[k] = staged ? (uint32_t*)take(cap) : nullptr; q.meta[k] = staged ? (uint32_t*)take(cap) : nullptr; q.pdf[k] = staged ? take(cap) : nullptr; }
         q.L = take(4 * cap * l_planes);

@@ -117,7 +117,10 @@ struct Queues {
     // Every plane holds tr_ncls + 1 queues of `cap` slots each: one per material class (class-sorted shading: the shade kernel that traces a
     // continuation ray appends the record to the queue of the HIT primitive's class - sorting costs no pass of its own) and a staging queue
     // (index tr_ncls) for the rays whose hit is left to the reference-order code; slot = queue * cap + sub-queue * subcap + position.
-    float4* tr[2][4]; float2* tr_uv[2]; int tr_ncls;
+    // tr_stage_top (the shipped one-queue case): no memory for the staging queue - its entries grow DOWN from the top of the sub-queue's own
+    // region (slot = sub-queue * subcap + subcap - 1 - position) while the queue grows up from the bottom; the two cannot meet, because what
+    // a bounce appends is at most what it read.
+    float4* tr[2][4]; float2* tr_uv[2]; int tr_ncls, tr_stage_top;
     uint32_t* fix_ext; uint32_t* fix_sh;         // flat sweep: fix-up lists, sub-queue-local entry indices (null elsewhere)
     float* thr[2]; uint32_t* id[2]; uint32_t* meta[2]; float* pdf[2];
     float* sh_o; float* sh_d; float* sh_tmax; float* sh_c; uint32_t* sh_id;
@@ -397,7 +400,7 @@ APT_D void generate_body(const DevScene* sc, const Params& p, const Queues& q, C
             pos = tr_append_pos(app, ocls);
             if (alive) t_samples++;
             if (ocls >= 0) {
-                const uint32_t slot = (uint32_t)ocls * p.cap + (uint32_t)sq * p.subcap + pos, so = slot << 4;
+                const uint32_t slot = (q.tr_stage_top && ocls == q.tr_ncls) ? (uint32_t)sq * p.subcap + p.subcap - 1u - pos : (uint32_t)ocls * p.cap + (uint32_t)sq * p.subcap + pos, so = slot << 4;
                 stq(q.tr[0][0], so, make_float4(cam_o.x, cam_o.y, cam_o.z, hr.t));
                 stq(q.tr[0][1], so, make_float4(dir.x, dir.y, dir.z, __uint_as_float(tr_pack(hr.prim, draws, false))));
                 stq(q.tr[0][2], so, make_float4(1.f, 1.f, 1.f, __uint_as_float(((idx / (uint32_t)p.npix) << p.pix_bits) | (idx % (uint32_t)p.npix))));
@@ -526,6 +529,9 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 // work counter (one atomic per wave), so the walk loops always run with a mostly full wave (Aila & Laine's "persistent threads with
 // dynamic fetch", re-cut for 64-wide waves and an LDS stack).  Per-ray arithmetic and the visiting order inside a ray are those of
 // traverse<false>; only the assignment of rays to lanes changes, and hits are written to the ray's own slot.
+#ifndef APT_DYN_MIN_ACTIVE_SH
+#define APT_DYN_MIN_ACTIVE_SH 32   // the any-hit walk's threshold (its hand-in is one radiance add; measured below)
+#endif
 #ifndef APT_DYN_MIN_ACTIVE
 #define APT_DYN_MIN_ACTIVE 32      // measured 32 / 40 / 52 with the product build's leaf test: C4 extend 21.5 / 22.2 / 26.7 ms per 64 spp, C5 13.5 / 14.05 / 15.8 per 32
 #endif
@@ -763,7 +769,10 @@ APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Co
     const bool need_uv = sc.has_vn || sc.tex_i != nullptr;
     for (uint32_t base = 0; base < n_def; base += 64u) {      // staged rays: closest hit by the reference-order code, then the record joins its class queue (or the path ends)
         const uint32_t li = base + lane_id(); const bool valid = li < n_def;
-        const uint32_t io = ((uint32_t)ncls * p.cap + qbase + (valid ? li : n_def - 1u)) << 4;
+        // (staging at the top of the sub-queue's own region: served from its LOWEST slot upwards - a resolved record is appended at or below the
+        // slot its ray was just read from, never onto a staged ray that is still to be served)
+        const uint32_t lj = valid ? li : n_def - 1u;
+        const uint32_t io = (q.tr_stage_top ? qbase + p.subcap - n_def + lj : (uint32_t)ncls * p.cap + qbase + lj) << 4;
         const float4 ra = ldq(q.tr[cur][0], io), rb = ldq(q.tr[cur][1], io), rc = ldq(q.tr[cur][2], io), rd = ldq(q.tr[cur][3], io);
         const f3 o = mk3(ra.x, ra.y, ra.z), d = mk3(rb.x, rb.y, rb.z);
         HitRec r0, r1; r0.t = r1.t = 1e7f; r0.prim = r1.prim = -1; r0.u = r0.v = r1.u = r1.v = 0.f;
@@ -1204,7 +1213,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                     if (__any(tr_q == 1)) { const uint32_t dpos = wave_append(tr_q == 1, next_counter + APT_MAX_NQ * CNT_PAD); if (tr_q == 1) npos = dpos; }
                 }
                 if (cont) {
-                    const uint32_t slot = (uint32_t)tr_q * p.cap + qbase + npos, so = slot << 4;
+                    const uint32_t slot = (!MULTI && tr_q == 1) ? qbase + p.subcap - 1u - npos : (uint32_t)tr_q * p.cap + qbase + npos, so = slot << 4;      // (one queue: staged rays grow down from the top of the sub-queue's region)
                     stq(q.tr[nxt][0], so, make_float4(hit_point.x, hit_point.y, hit_point.z, tr_t));
                     stq(q.tr[nxt][1], so, make_float4(new_d.x, new_d.y, new_d.z, __uint_as_float(tr_pack(tr_hit, rng.draw, is_spec))));
                     stq(q.tr[nxt][2], so, make_float4(thr.x, thr.y, thr.z, __uint_as_float(id)));
@@ -1328,7 +1337,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
             if (base + (uint32_t)__popcll(m) >= n) exhausted = true;
         }
         if (!__any(state == 1)) break;
-        const uint32_t min_active = exhausted ? 1u : (uint32_t)APT_DYN_MIN_ACTIVE;
+        const uint32_t min_active = exhausted ? 1u : (uint32_t)APT_DYN_MIN_ACTIVE_SH;
 #if APT_WALK_VOTE
         do {
             const bool want_t = state == 1 && tg.y != 0u, want_n = state == 1 && tg.y == 0u;
