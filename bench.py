@@ -266,7 +266,9 @@ def main():
         allr = torch.stack(allr).cpu().numpy()
         dt = float(allr[:, 0].max())                                    # the job is as slow as its slowest rank
         per_rank = {"wall_s": [round(float(x), 5) for x in allr[:, 0]], "render_ms_per_step": [round(float(x), 3) for x in allr[:, 1]],
-                    "gather_ms_per_step": [round(float(x), 3) for x in allr[:, 2]], "samples": [int(x) for x in allr[:, 3]]}
+                    "gather_ms_per_step": [round(float(x), 3) for x in allr[:, 2]], "samples": [int(x) for x in allr[:, 3]],
+                    "collective": {"backend": "RCCL (torch.distributed 'nccl')" if args.backend == "nccl" else args.backend, "world_size": world, "op": "all_gather_into_tensor of the per-rank (n_cols, H, 3) float32 tiles, once per step",
+                                   "tile_bytes_per_rank": int(rdr.n_cols * rdr.h * 12), "queue_MiB_per_rank": round(info["queue_bytes"] / 2 ** 20, 1)}}
 
     total_samples = W * H * spp_step * args.steps
     value = total_samples / dt / 1e6
