@@ -79,15 +79,12 @@ static const int kClassMask[APT_N_CLASS_DEFS] = {
     0x801,      // Blinn-Phong objects without a specular lobe (k_s = 0, finite k_g >= 0: shading.hpp mask bit 11): no double-precision pow
 };
 static const char* kClassName[APT_N_CLASS_DEFS] = {"lambertian", "blinn-phong", "oren-nayar", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans", "microfacet", "blinn-phong(no lobe)"};
-static const shade_fn kClassShade[APT_N_CLASS_DEFS][2] = {
-    {k_shade<0x002, 0x03>, k_shade<0x002, APT_SRC_ALL>}, {k_shade<0x001, 0x03>, k_shade<0x001, APT_SRC_ALL>},
-    {k_shade<0x040, 0x03>, k_shade<0x040, APT_SRC_ALL>}, {k_shade<0x504, 0x03>, k_shade<0x504, APT_SRC_ALL>},
-    {k_shade<0x010, 0x03>, k_shade<0x010, APT_SRC_ALL>}, {k_shade<0x020, 0x03>, k_shade<0x020, APT_SRC_ALL>},
-    {k_shade<0x080, 0x03>, k_shade<0x080, APT_SRC_ALL>}, {k_shade<0x200, 0x03>, k_shade<0x200, APT_SRC_ALL>},
-    {k_shade<0x008, 0x03>, k_shade<0x008, APT_SRC_ALL>}, {k_shade<0x801, 0x03>, k_shade<0x801, APT_SRC_ALL>},
+// [class][emitter set: point + area | all | point + spot (no area light: no emission code, no pdf in the record, both Philox blocks up front)]
+static const shade_fn kClassShade[APT_N_CLASS_DEFS][3] = {
+    {k_shade<0x002, 0x03>, k_shade<0x002, APT_SRC_ALL>, k_shade<0x002, 0x05>}, {k_shade<0x001, 0x03>, k_shade<0x001, APT_SRC_ALL>, k_shade<0x001, 0x05>}, {k_shade<0x040, 0x03>, k_shade<0x040, APT_SRC_ALL>, k_shade<0x040, 0x05>}, {k_shade<0x504, 0x03>, k_shade<0x504, APT_SRC_ALL>, k_shade<0x504, 0x05>}, {k_shade<0x010, 0x03>, k_shade<0x010, APT_SRC_ALL>, k_shade<0x010, 0x05>}, {k_shade<0x020, 0x03>, k_shade<0x020, APT_SRC_ALL>, k_shade<0x020, 0x05>}, {k_shade<0x080, 0x03>, k_shade<0x080, APT_SRC_ALL>, k_shade<0x080, 0x05>}, {k_shade<0x200, 0x03>, k_shade<0x200, APT_SRC_ALL>, k_shade<0x200, 0x05>}, {k_shade<0x008, 0x03>, k_shade<0x008, APT_SRC_ALL>, k_shade<0x008, 0x05>}, {k_shade<0x801, 0x03>, k_shade<0x801, APT_SRC_ALL>, k_shade<0x801, 0x05>},
 };
 // the same class kernels tracing their rays in place (stages.hpp "rays traced in place": product build, flat sweep)
-static const shade_fn kClassShadeTraced[APT_N_CLASS_DEFS][2] = {
+static const shade_fn kClassShadeTraced[APT_N_CLASS_DEFS][2] = {      // (measurement only, see above: [point + area | all])
     {APT_MULTI_FN(k_shade<0x002, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x002, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x001, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x001, APT_SRC_ALL, 0, 3>)},
     {APT_MULTI_FN(k_shade<0x040, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x040, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x504, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x504, APT_SRC_ALL, 0, 3>)},
     {APT_MULTI_FN(k_shade<0x010, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x010, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x020, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x020, APT_SRC_ALL, 0, 3>)},
@@ -765,11 +762,11 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         for (int c = 0; c < sc->n_classes; c++) r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
         if (r->v_ncls > sc->n_classes) r->shade_name += "+miss";
     } else if (r->sorted) {
-        const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : 1;
+        const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : (((sc->src_mask & ~0x05) == 0) ? 2 : 1);
         r->shade_name = "sorted:";
         for (int c = 0; c < ncls; c++) {
             r->class_fn[c] = kClassShade[sc->class_def[c]][smi];
-            r->class_fn_traced[c] = kClassShadeTraced[sc->class_def[c]][smi];
+            r->class_fn_traced[c] = kClassShadeTraced[sc->class_def[c]][smi == 0 ? 0 : 1];
             r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
         }
     }
