@@ -80,8 +80,8 @@ static const int kClassMask[APT_N_CLASS_DEFS] = {
 };
 static const char* kClassName[APT_N_CLASS_DEFS] = {"lambertian", "blinn-phong", "oren-nayar", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans", "microfacet", "blinn-phong(no lobe)"};
 // [class][emitter set: point + area | all | point + spot (no area light: no emission code, no pdf in the record, both Philox blocks up front)]
-static const shade_fn kClassShade[APT_N_CLASS_DEFS][3] = {
-    {k_shade<0x002, 0x03>, k_shade<0x002, APT_SRC_ALL>, k_shade<0x002, 0x05>}, {k_shade<0x001, 0x03>, k_shade<0x001, APT_SRC_ALL>, k_shade<0x001, 0x05>}, {k_shade<0x040, 0x03>, k_shade<0x040, APT_SRC_ALL>, k_shade<0x040, 0x05>}, {k_shade<0x504, 0x03>, k_shade<0x504, APT_SRC_ALL>, k_shade<0x504, 0x05>}, {k_shade<0x010, 0x03>, k_shade<0x010, APT_SRC_ALL>, k_shade<0x010, 0x05>}, {k_shade<0x020, 0x03>, k_shade<0x020, APT_SRC_ALL>, k_shade<0x020, 0x05>}, {k_shade<0x080, 0x03>, k_shade<0x080, APT_SRC_ALL>, k_shade<0x080, 0x05>}, {k_shade<0x200, 0x03>, k_shade<0x200, APT_SRC_ALL>, k_shade<0x200, 0x05>}, {k_shade<0x008, 0x03>, k_shade<0x008, APT_SRC_ALL>, k_shade<0x008, 0x05>}, {k_shade<0x801, 0x03>, k_shade<0x801, APT_SRC_ALL>, k_shade<0x801, 0x05>},
+static const shade_fn kClassShade[APT_N_CLASS_DEFS][3] = {      // (FUSE = 4: the class queues are packed planes, Queues::cq)
+    {k_shade<0x002, 0x03, 0, 4>, k_shade<0x002, APT_SRC_ALL, 0, 4>, k_shade<0x002, 0x05, 0, 4>}, {k_shade<0x001, 0x03, 0, 4>, k_shade<0x001, APT_SRC_ALL, 0, 4>, k_shade<0x001, 0x05, 0, 4>}, {k_shade<0x040, 0x03, 0, 4>, k_shade<0x040, APT_SRC_ALL, 0, 4>, k_shade<0x040, 0x05, 0, 4>}, {k_shade<0x504, 0x03, 0, 4>, k_shade<0x504, APT_SRC_ALL, 0, 4>, k_shade<0x504, 0x05, 0, 4>}, {k_shade<0x010, 0x03, 0, 4>, k_shade<0x010, APT_SRC_ALL, 0, 4>, k_shade<0x010, 0x05, 0, 4>}, {k_shade<0x020, 0x03, 0, 4>, k_shade<0x020, APT_SRC_ALL, 0, 4>, k_shade<0x020, 0x05, 0, 4>}, {k_shade<0x080, 0x03, 0, 4>, k_shade<0x080, APT_SRC_ALL, 0, 4>, k_shade<0x080, 0x05, 0, 4>}, {k_shade<0x200, 0x03, 0, 4>, k_shade<0x200, APT_SRC_ALL, 0, 4>, k_shade<0x200, 0x05, 0, 4>}, {k_shade<0x008, 0x03, 0, 4>, k_shade<0x008, APT_SRC_ALL, 0, 4>, k_shade<0x008, 0x05, 0, 4>}, {k_shade<0x801, 0x03, 0, 4>, k_shade<0x801, APT_SRC_ALL, 0, 4>, k_shade<0x801, 0x05, 0, 4>},
 };
 // the same class kernels tracing their rays in place (stages.hpp "rays traced in place": product build, flat sweep)
 static const shade_fn kClassShadeTraced[APT_N_CLASS_DEFS][2] = {      // (measurement only, see above: [point + area | all])
@@ -107,12 +107,12 @@ typedef void (*occluded_fn)(DevScene, uint32_t, const float*, const float*, cons
 #else
 #define APT_FLAT_FN(...) nullptr          // the flat sweep exists in the fast build only (traverse.hpp)
 #endif
-static const extend_fn kExtend[4][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_extend<1, 0>, k_extend<1, 1>}, {k_extend<2, 0>, k_extend<2, 1>},
-                                        {APT_FLAT_FN(k_extend_flat<0, 0>), APT_FLAT_FN(k_extend_flat<1, 0>)}};   // [mode][sorted] (flat: the self-contained variant, for explicit rays)
+static const extend_fn kExtend[4][3] = {{k_extend<0, 0>, k_extend<0, 1>, k_extend<0, 2>}, {k_extend<1, 0>, k_extend<1, 1>, k_extend<1, 2>}, {k_extend<2, 0>, k_extend<2, 1>, k_extend<2, 2>},
+                                        {APT_FLAT_FN(k_extend_flat<0, 0>), APT_FLAT_FN(k_extend_flat<1, 0>), APT_FLAT_FN(k_extend_flat<2, 0>)}};   // [mode][unsorted | sorted, SoA class queues (volumetric) | sorted, packed class queues] (flat: the self-contained variant, for explicit rays)
 // flat sweep inside a render: the hot variant and its fix-up launch (stages.hpp "fix-up lists"), [sorted]
-static const extend_fn kExtendFlatHot[2] = {APT_FLAT_FN(k_extend_flat<0, 1>), APT_FLAT_FN(k_extend_flat<1, 1>)};
-static const extend_fn kFixFlat[2] = {APT_FLAT_FN(k_fix_flat<0>), APT_FLAT_FN(k_fix_flat<1>)};
-static const extend_fn kExtendDyn[2] = {k_extend_dyn<0>, k_extend_dyn<1>};      // BVH walk with dynamic ray fetch [sorted]
+static const extend_fn kExtendFlatHot[3] = {APT_FLAT_FN(k_extend_flat<0, 1>), APT_FLAT_FN(k_extend_flat<1, 1>), APT_FLAT_FN(k_extend_flat<2, 1>)};
+static const extend_fn kFixFlat[3] = {APT_FLAT_FN(k_fix_flat<0>), APT_FLAT_FN(k_fix_flat<1>), APT_FLAT_FN(k_fix_flat<2>)};
+static const extend_fn kExtendDyn[3] = {k_extend_dyn<0>, k_extend_dyn<1>, k_extend_dyn<2>};      // BVH walk with dynamic ray fetch [sorted]
 static const shadow_fn kShadow[4] = {k_shadow<0>, k_shadow<1>, k_shadow<2>, APT_FLAT_FN(k_shadow_flat<1>)};      // (flat: the hot variant; its list is served by the next kFixFlat launch)
 static const occluded_fn kOccluded[4] = {k_occluded<0>, k_occluded<1>, k_occluded<2>, APT_FLAT_FN(k_occluded_flat)};
 typedef void (*vshade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int);
@@ -778,6 +778,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (p.fused == 2 && cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (rays traced in place address 16-byte slots with 32-bit byte offsets: capacity must stay below 2^28)"); }
     const bool tr_uv = p.fused == 2 && (sc->dev.has_vn || sc->dev.tex_i != nullptr);
     // rays traced in place keep their path records in planes of their own (Queues::tr): the staged pipeline's second ray / state buffers are not carved
+    if (r->sorted && !r->volumetric && (size_t)ncls * cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (packed class queues address 16-byte slots with 32-bit byte offsets: classes x capacity must stay below 2^28)"); }
     const bool stage_top = !(r->sorted && ncls > 1) && APT_TRACE_MULTI == 0;      // one queue: the staging queue lives at the top of the sub-queue's own region (Queues::tr_stage_top)
     const size_t tr_q = (p.fused == 2) ? (size_t)(r->sorted ? ncls : 1) + (stage_top ? 0 : 1) : 0;      // queues per plane: material classes (unsorted: one) [+ the staging queue]
     if (p.fused == 2 && tr_q * cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (rays traced in place: queues x capacity must stay below 2^28 slots)"); }
@@ -810,7 +811,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         q.n_classes = ncls;
         q.miss_class = (r->volumetric && r->v_ncls > sc->n_classes) ? sc->n_classes : -1;
         q.miss_rr_draw = (r->volumetric && ncls > 0 && q.miss_class < 0) ? 1 : 0;
-        for (int c = 0; c < ncls && p.fused != 2; c++) {
+        for (int a = 0; a < 4; a++) q.cq[a] = (ncls > 0 && !r->volumetric && p.fused != 2) ? (float4*)take(4 * cap * (size_t)ncls) : nullptr;
+        for (int c = 0; c < ncls && p.fused != 2 && r->volumetric; c++) {
             Queues::ClassQ& k = q.cls[c];
             k.ray_o = take(3 * cap); k.ray_d = take(3 * cap); k.thr = take(3 * cap); k.id = (uint32_t*)take(cap); k.meta = (uint32_t*)take(cap);
             k.pdf = take(cap); k.t = take(cap); k.prim = (int*)take(cap); k.u = take(cap); k.v = take(cap);
@@ -882,6 +884,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
             if (r->lds_bytes > 64 * 1024) {
                 HIP_TRY(hipFuncSetAttribute((const void*)kExtend[2][0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
                 HIP_TRY(hipFuncSetAttribute((const void*)kExtend[2][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+                HIP_TRY(hipFuncSetAttribute((const void*)kExtend[2][2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
                 HIP_TRY(hipFuncSetAttribute((const void*)kShadow[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
                 HIP_TRY(hipFuncSetAttribute((const void*)kOccluded[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
                 HIP_TRY(hipFuncSetAttribute((const void*)kVShadow[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
@@ -889,6 +892,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         } else if (r->lds_bytes > 64 * 1024) {
             HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kShadow[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kOccluded[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kVShadow[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
@@ -899,6 +903,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (r->dyn_fetch && r->lds_bytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)k_shadow_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
     }
     r->grid_small = cus * (r->volumetric ? 8 : 4);       // streaming stages, persistent grid in 256-thread workgroups per CU.  Measured (tools/grid_sweep.sh, 2 / 3 / 4 / 5 / 8 per CU): C2 3 385 / 3 350 / 3 378 / 3 312 / 3 279 Msamples/s (a shade kernel holds 4 workgroups per CU; a second round of workgroups only adds a tail), C1 / C3 / C4 / C5 within 1 %, V1 823 / 838 / 842 / 840 / 858
@@ -1129,6 +1134,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
     }
     int done = 0, batch = 0;
     hipEvent_t prev_fin = nullptr;
+    const int si = r->sorted ? 2 : 0;            // surface renders keep their class queues as packed planes (Queues::cq; stages.hpp)
     // a call smaller than one full round of lane-batches is split evenly so that every lane has work
     const int batch_cap = (r->cfg.spp_per_batch <= 0 && n_spp < r->n_lanes * r->spp_batch) ? std::max(1, (n_spp + r->n_lanes - 1) / r->n_lanes) : r->spp_batch;
     while (done < n_spp) {
@@ -1166,8 +1172,8 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
         for (int b = 0; b < p.max_bounce; b++) {
             // (the walk kernels reset each other's work counters - k_shadow_dyn the next bounce's closest-hit counter, k_extend_dyn this bounce's any-hit counter; without light samples the host does)
             if (r->dyn_fetch && !(p.S > 0)) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st)); }
-            { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : (r->trace_mode == 3 ? kExtendFlatHot[r->sorted] : kExtend[r->trace_mode][r->sorted]), dim3(grid_for(total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
-            if (r->trace_mode == 3) { LaunchTimer t(r, 1, st, false); hipLaunchKernelGGL(kFixFlat[r->sorted], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
+            { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[si] : (r->trace_mode == 3 ? kExtendFlatHot[si] : kExtend[r->trace_mode][si]), dim3(grid_for(total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
+            if (r->trace_mode == 3) { LaunchTimer t(r, 1, st, false); hipLaunchKernelGGL(kFixFlat[si], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
             if (!r->sorted) {
                 ShadeIn in = {q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.id[cur], q.meta[cur], q.pdf[cur],
                               q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur], q.Lc[cur]};
@@ -1175,7 +1181,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             } else {
                 for (int c = 0; c < q.n_classes; c++) {
                     const Queues::ClassQ& k = q.cls[c];
-                    ShadeIn in = {k.ray_o, k.ray_d, k.thr, k.id, k.meta, k.pdf, k.t, k.prim, k.u, k.v, (const uint32_t*)cnt->n_cls[c]};
+                    ShadeIn in = {k.ray_o, k.ray_d, k.thr, k.id, k.meta, k.pdf, k.t, k.prim, k.u, k.v, (const uint32_t*)cnt->n_cls[c], nullptr, c};      // (the record comes from Queues::cq, class c)
                     LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->class_fn[c], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
                 }
                 if (p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }      // normally k_shadow recycles these
@@ -1190,7 +1196,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             cur ^= 1;
         }
         if (r->trace_mode == 3 && p.S > 0 && p.max_bounce > 0) {     // the last bounce's shadow list (the extend list of this parity is empty)
-            LaunchTimer t(r, 3, st, false); hipLaunchKernelGGL(kFixFlat[r->sorted], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan);
+            LaunchTimer t(r, 3, st, false); hipLaunchKernelGGL(kFixFlat[si], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan);
         }
         }
         // the framebuffer is shared: batch k's samples are added after batch k-1's, whichever lanes they ran on

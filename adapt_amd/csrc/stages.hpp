@@ -133,6 +133,13 @@ struct Queues {
     // launch runs one specialised kernel over coherent waves.  n_classes == 0: unsorted (single-class scenes).
     struct ClassQ { float* ray_o; float* ray_d; float* thr; uint32_t* id; uint32_t* meta; float* pdf; float* t; int* prim; float* u; float* v; };
     ClassQ cls[8];
+    // Surface renders keep the class queues as FOUR 16-byte planes instead (SORTED == 2 in the extend kernels, FUSE == 4 in the class kernels):
+    // A = (ray origin, hit distance), B = (ray direction, hit primitive), C = (throughput, path id), D = (meta, pdf, u, v); every plane holds
+    // n_classes queues of `cap` slots, slot = class * cap + sub-queue * subcap + position.  A record is 4 stores and 4 loads instead of 16
+    // and 16, and - what matters in the BVH walk's hand-in, where a wave's finished rays belong to several classes - the class is part of
+    // the lane's OFFSET: no loop over the classes present, no per-class queue pointers fetched from the argument buffer.  Null: cls[] is used
+    // (the volumetric tracer's event-class queues).
+    float4* cq[4];
     int n_classes;
     int miss_class;                              // volumetric, sorted: class queue that receives the rays that hit nothing (-1: misses are dropped)
     int miss_rr_draw;                            // volumetric, sorted, misses dropped: a dropped miss still counts the roulette draw k_vshade would have made for it (vpt.py:164-172 precedes the hit test), so n_draws stays the reference's
@@ -260,6 +267,15 @@ APT_D TrAppend tr_append_issue(int which, int nq_, uint32_t* counters, uint32_t 
     return a;
 }
 APT_D uint32_t tr_append_pos(const TrAppend& a, int which) { return (uint32_t)__shfl((int)a.raw, which < 0 ? 0 : which) + a.rank; }
+
+// one record of a packed class queue (Queues::cq)
+APT_D void cq_store(const Queues& q, uint32_t slot, f3 o, f3 d, f3 thr, uint32_t id, uint32_t meta, float pdf, float t, int prim, float u, float v) {
+    const uint32_t so = slot << 4;
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(q.cq[0]) + so) = make_float4(o.x, o.y, o.z, t);
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(q.cq[1]) + so) = make_float4(d.x, d.y, d.z, __int_as_float(prim));
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(q.cq[2]) + so) = make_float4(thr.x, thr.y, thr.z, __uint_as_float(id));
+    *reinterpret_cast<float4*>(reinterpret_cast<char*>(q.cq[3]) + so) = make_float4(__uint_as_float(meta), pdf, u, v);
+}
 
 // Queue addressing.  Every queue array is indexed by a 32-bit slot whose BYTE offset also fits 32 bits (the host
 // refuses batches with 12 * capacity >= 4 GiB), and every base pointer is wave-uniform.  Written as
@@ -499,6 +515,8 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
             if ((int)lane_id() < q.n_classes && cnt_vec) tail = atomicAdd(&cnt->n_cls[lane_id()][sl.q * CNT_PAD], cnt_vec);
             const uint32_t cpos = (uint32_t)__shfl((int)tail, cls < 0 ? 0 : cls) + my_rank;
             const uint32_t so = (qbase + cpos) << 2;
+            if (SORTED == 2) { if (cls >= 0) cq_store(q, (uint32_t)cls * p.cap + qbase + cpos, o, d, st_thr, st_id, st_meta, st_pdf, rec.t, rec.prim, rec.u, rec.v); }
+            else
             for (int c = 0; c < q.n_classes; c++) {
                 if (cls == c) {
                     const Queues::ClassQ& k = q.cls[c];
@@ -615,6 +633,8 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
             if ((int)lane_id() < q.n_classes && cnt_vec) tail = atomicAdd(&cnt->n_cls[lane_id()][sq * CNT_PAD], cnt_vec);
             const uint32_t cpos = (uint32_t)__shfl((int)tail, cls < 0 ? 0 : cls) + my_rank;
             const uint32_t so = (qbase + cpos) << 2;
+            if (SORTED == 2) { if (cls >= 0) cq_store(q, (uint32_t)cls * p.cap + qbase + cpos, r.o, r.d, st_thr, st_id, st_meta, st_pdf, rec.t, rec.prim, rec.u, rec.v); }
+            else
             for (int c = 0; c < q.n_classes; c++) {
                 if (cls == c) {
                     const Queues::ClassQ& k = q.cls[c];
@@ -818,12 +838,14 @@ APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Co
 #endif
 template <int BM, int SM, int TEX = 0, int FUSE = 0>
 __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_LAMBERT_WAVES : APT_SHADE_WAVES))) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
+    constexpr bool CQ = FUSE == 4;                             // input: a packed class queue (Queues::cq); output: the staged pipeline's (as FUSE == 0)
+    constexpr int FZ = CQ ? 0 : FUSE;
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
-    uint32_t n = (FUSE >= 2) ? 0u : in.counts[sl.q * CNT_PAD];
+    uint32_t n = (FZ >= 2) ? 0u : in.counts[sl.q * CNT_PAD];
     const uint32_t qbase = (uint32_t)sl.q * p.subcap, sh_qbase = (uint32_t)sl.q * q.sh_subcap;
-    uint32_t* next_counter = (FUSE >= 2) ? &cnt->n_tr[(bounce + 1) % 3][0][sl.q * CNT_PAD] : &cnt->n_active[nxt][sl.q * CNT_PAD];      // (FUSE == 2: the first queue's tail)
-    if (FUSE >= 2 && sl.first == 0 && threadIdx.x == 0) {      // (read by the previous bounce, appended to by the next one)
+    uint32_t* next_counter = (FZ >= 2) ? &cnt->n_tr[(bounce + 1) % 3][0][sl.q * CNT_PAD] : &cnt->n_active[nxt][sl.q * CNT_PAD];      // (FZ == 2: the first queue's tail)
+    if (FZ >= 2 && sl.first == 0 && threadIdx.x == 0) {      // (read by the previous bounce, appended to by the next one)
         cnt->n_tr[(bounce + 2) % 3][in.cls][sl.q * CNT_PAD] = 0;
         if (in.cls == 0) cnt->n_tr[(bounce + 2) % 3][q.tr_ncls][sl.q * CNT_PAD] = 0;
     }
@@ -846,11 +868,13 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
     // trips.  So the next row's record is requested at the top of this row - after this row's shading record, so that waiting for that
     // one (vmcnt counts in order) does not wait for the prefetch - and lands while this row is shaded.
     constexpr bool PF = ((APT_SHADE_PREFETCH != 0) && BM == 0x002 && SM == 0x1 && TEX == 0) || (APT_SHADE_PREFETCH == 2 && TEX == 0);
-    constexpr bool TRACE = FUSE >= 2;                         // the continuation ray is traced in place too ("rays traced in place" above)
-    constexpr bool MULTI = FUSE == 3;                         // ... FUSE = 2: one queue (unsorted), one light sample per vertex - the kernel of C1 / C2, which carries nothing else; FUSE = 3: queues by material class, any number of light samples
+    constexpr bool TRACE = FZ >= 2;                         // the continuation ray is traced in place too ("rays traced in place" above)
+    constexpr bool MULTI = FZ == 3;                         // ... FZ = 2: one queue (unsorted), one light sample per vertex - the kernel of C1 / C2, which carries nothing else; FZ = 3: queues by material class, any number of light samples
     static_assert(APT_FLAT_MAX_PRIMS < (int)TR_NO_PRIM, "the packed record keeps the hit primitive in 8 bits");
-    const uint32_t in_base = TRACE ? (uint32_t)in.cls * p.cap + qbase : qbase;      // first slot of the queue this workgroup reads
-    const float4* trA = TRACE ? q.tr[cur][0] : nullptr; const float4* trB = TRACE ? q.tr[cur][1] : nullptr; const float4* trC = TRACE ? q.tr[cur][2] : nullptr; const float4* trD = TRACE ? q.tr[cur][3] : nullptr;
+    constexpr bool PK = TRACE || CQ;                           // the input record is four 16-byte planes
+    const uint32_t in_base = PK ? (uint32_t)in.cls * p.cap + qbase : qbase;      // first slot of the queue this workgroup reads
+    const float4* trA = TRACE ? q.tr[cur][0] : (CQ ? q.cq[0] : nullptr); const float4* trB = TRACE ? q.tr[cur][1] : (CQ ? q.cq[1] : nullptr);
+    const float4* trC = TRACE ? q.tr[cur][2] : (CQ ? q.cq[2] : nullptr); const float4* trD = TRACE ? q.tr[cur][3] : (CQ ? q.cq[3] : nullptr);
     int pf_prim = -1; float pf_t = 0.f; f3 pf_o = splat3(0.f), pf_d = splat3(0.f), pf_thr = splat3(0.f); uint32_t pf_id = 0, pf_meta = 0;      // (TRACE: pf_prim holds the packed word pm)
     auto prefetch = [&](uint32_t b) {            // straight-line loads (lanes past the end re-read the last entry: never used), so that no wait lands at the end of a branch
         const uint32_t ps = min(b + threadIdx.x, n - 1u);
@@ -878,7 +902,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
     if (PF && n > 0) prefetch(sl.first);
     auto prefetch_prim = [&](uint32_t b) {
         const uint32_t ps = in_base + min(b + threadIdx.x, n - 1u);
-        pf_prim = TRACE ? ldq(reinterpret_cast<const int*>(trB), (ps << 4) + 12u) : ldq(in.prim, ps << 2);
+        pf_prim = PK ? ldq(reinterpret_cast<const int*>(trB), (ps << 4) + 12u) : ldq(in.prim, ps << 2);
     };
     if (PFP && n > 0) prefetch_prim(sl.first);
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
@@ -908,7 +932,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         }
         f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), thr = splat3(0.f), hit_point = splat3(0.f);
         uint32_t id = 0, draw0 = 0, l_off = 0;                 // l_off: byte offset of this path's radiance slot
-        // FUSE: the radiance the path has gathered so far (camera rays carry none: nothing is read at bounce 0) and, for entries that end
+        // FZ: the radiance the path has gathered so far (camera rays carry none: nothing is read at bounce 0) and, for entries that end
         // here without being shaded (nothing hit, roulette), the path id that names the slot it goes to
         f3 Lc = splat3(0.f);
         const bool entry = alive;
@@ -917,8 +941,8 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
             if (alive && bounce > 0) { const float4 dd = ldq(trD, idx << 4); Lc = mk3(dd.x, dd.y, dd.z); if (SM & 2) ray_pdf = dd.w; }
             if (alive && bounce > 0) id = PF ? cu_id : __float_as_uint(ldq(reinterpret_cast<const float*>(trC), (idx << 4) + 12u));
         } else {
-        if (FUSE && alive && bounce > 0) Lc = ld3q(in.Lc, p.cap, idx << 2);
-        if (FUSE && alive && bounce > 0) id = PF ? cu_id : ldq(in.id, idx << 2);
+        if (FZ && alive && bounce > 0) Lc = ld3q(in.Lc, p.cap, idx << 2);
+        if (FZ && alive && bounce > 0) id = PF ? cu_id : ldq(in.id, idx << 2);
         }
         bool was_spec = false;
         Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
@@ -928,7 +952,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
         if (alive) {
             const uint32_t io = idx << 2;
-            int prim = (PF || PFP) ? cu_prim : (TRACE ? tr_prim(__float_as_uint(ldq(reinterpret_cast<const float*>(trB), (idx << 4) + 12u))) : ldq(in.prim, io));
+            int prim = (PF || PFP) ? cu_prim : (TRACE ? tr_prim(__float_as_uint(ldq(reinterpret_cast<const float*>(trB), (idx << 4) + 12u))) : (CQ ? ldq(reinterpret_cast<const int*>(trB), (idx << 4) + 12u) : ldq(in.prim, io)));
             if (prim < 0) alive = false;                         // nothing hit: path ends (vanilla_renderer.py:49)
             else {
                 uint32_t meta; float tr_t_in = cu_t; float2 tr_uv_in; tr_uv_in.x = tr_uv_in.y = 0.f;
@@ -937,6 +961,10 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                     const float4 a = ldq(trA, idx << 4), b_ = ldq(trB, idx << 4), c = ldq(trC, idx << 4);
                     o = mk3(a.x, a.y, a.z); tr_t_in = a.w; d = mk3(b_.x, b_.y, b_.z); thr = mk3(c.x, c.y, c.z); id = __float_as_uint(c.w);
                     meta = tr_meta(__float_as_uint(b_.w), (uint32_t)bounce);
+                } else if (CQ) {
+                    const float4 a = ldq(trA, idx << 4), b_ = ldq(trB, idx << 4), c = ldq(trC, idx << 4), dd = ldq(trD, idx << 4);
+                    o = mk3(a.x, a.y, a.z); tr_t_in = a.w; d = mk3(b_.x, b_.y, b_.z); thr = mk3(c.x, c.y, c.z); id = __float_as_uint(c.w);
+                    meta = __float_as_uint(dd.x); if (SM & 2) ray_pdf = dd.y; tr_uv_in.x = dd.z; tr_uv_in.y = dd.w;
                 } else {
                     o = ld3q(in.ray_o, p.cap, io);
                     d = ld3q(in.ray_d, p.cap, io);
@@ -944,7 +972,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                     id = ldq(in.id, io);
                     meta = ldq(in.meta, io);
                 }
-                if ((SM & 2) && !TRACE) ray_pdf = ldq(in.pdf, io);          // (its only reader is the emission MIS weight: scenes without area lights never look at it)
+                if ((SM & 2) && !PK) ray_pdf = ldq(in.pdf, io);          // (its only reader is the emission MIS weight: scenes without area lights never look at it)
                 was_spec = (meta >> 24) & 1u;
                 f3 rec_kd;
                 const bool need_uv = sc.has_vn || (TEX && sc.tex_i != nullptr);      // otherwise nobody reads the barycentrics (and the flat extend kernel does not write them)
@@ -957,14 +985,14 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                         it.n_s = (ld3(vn) * (1.f - bu - bv) + ld3(vn + 3) * bu) + ld3(vn + 6) * bv;
                     }
                 }
-                else if (TRACE && PFP) build_hit_rec(sc, cu_ra, cu_rb, prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
-                else if (TRACE) build_hit(sc, prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
+                else if (PK && PFP) build_hit_rec(sc, cu_ra, cu_rb, prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
+                else if (PK) build_hit(sc, prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
                 else if (PFP) build_hit_rec(sc, cu_ra, cu_rb, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
                 else build_hit(sc, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
                 if (BM == 0x002) bx.k_d = rec_kd;               // Lambertian-only scenes: type 1, not delta, not a BSDF (the defaults above), colour from the record
                 else bx = sc.bxdf[it.obj_id];
                 if (TEX && sc.tex_i != nullptr) {                // the scene declares image textures (TEX kernels only, see below)
-                    const float bu = TRACE ? tr_uv_in.x : ldq(in.u, io), bv = TRACE ? tr_uv_in.y : ldq(in.v, io);
+                    const float bu = PK ? tr_uv_in.x : ldq(in.u, io), bv = PK ? tr_uv_in.y : ldq(in.v, io);
                     f3 tx;
                     if (bounce == 0) {                           // PathTracer.process_ns, applied to the camera ray's hit only (vanilla_renderer.py:42)
                         if (get_uv_item(sc, 1, it.obj_id, prim, bu, bv, tx)) { m33 R; rotation_between(mk3(0.f, 1.f, 0.f), it.n_g, R); it.n_s = mul(R, tx); }
@@ -1013,10 +1041,10 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
         if (sc.n_sources == 1) src_only = ld_src_uniform(sc.src);
         // light samples by vertex: ONE queue-tail atomic per tile row for all S samples of every vertex
         uint32_t vbase = 0;
-        if (!FUSE && p.nee_vm) vbase = wave_append(alive, shadow_counter);
+        if (!FZ && p.nee_vm) vbase = wave_append(alive, shadow_counter);
         bool f_want = false; f3 f_dir = mk3(0.f, 0.f, 1.f), f_c = splat3(0.f); float f_tmax = 0.f;
         const bool alive_nee = alive;
-        f3 f_sum = splat3(0.f); bool f_any = false;            // FUSE: the vertex's unoccluded light samples, summed in sample order (as the by-vertex shadow kernel sums them), added to the path's radiance once
+        f3 f_sum = splat3(0.f); bool f_any = false;            // FZ: the vertex's unoccluded light samples, summed in sample order (as the by-vertex shadow kernel sums them), added to the path's radiance once
 #if APT_FAST
         auto trace_light = [&](bool want, f3 dir, f3 c, float tmax) {
             // a light sample swept in place; a ray that needs the reference-order sweep leaves as a shadow-queue entry for the next launch's prologue
@@ -1080,7 +1108,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                         // Upstream the MIS weight multiplies the light sample even when the shadow ray is
                         // occluded (0 * NaN), so a NaN weight poisons the whole pixel-sample, which is then
                         // zeroed at the end (vanilla_renderer.py:87-95,119).  Reproduce that without tracing.
-                        if (FUSE) Lc = splat3(mis_w); else stL(q.L, p.cap, l_off, splat3(mis_w));
+                        if (FZ) Lc = splat3(mis_w); else stL(q.L, p.cap, l_off, splat3(mis_w));
                         poisoned = true;
                     } else {
                         f3 c = (direct_spec * shadow_int) * mis_w;
@@ -1092,7 +1120,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
             }
             SH_TICK(2);
             t_shadow += wave_count(sampled); t_poison += wave_count(poisoned);
-            if (!FUSE && p.nee_vm) {
+            if (!FZ && p.nee_vm) {
                 const uint32_t so = (sh_qbase + (uint32_t)s * p.subcap + vbase) << 2, sc_ = q.sh_cap;        // plane s of the sub-queue's region: consecutive lanes, consecutive entries
                 if (want) {
                     st3q(q.sh_o, sc_, so, hit_point);
@@ -1101,7 +1129,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                     st3q(q.sh_c, sc_, so, contrib);
                 } else if (alive) stq(q.sh_tmax, so, -1.0f);                   // the vertex has no sample s worth tracing
                 if (alive && s == 0) stq(q.sh_id, so, l_off);                   // one radiance slot per vertex, kept with its first entry
-            } else if (FUSE) {
+            } else if (FZ) {
                 // traced at the end of the row, when little else is live: one sample per vertex waits in registers, several are parked in LDS
                 // ([sample][component][thread]: conflict-free; a sample not worth tracing is marked by a negative distance)
                 if (!MULTI || p.S == 1) { f_want = want; f_dir = light_dir; f_c = contrib; f_tmax = emitter_d; }
@@ -1140,7 +1168,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                 f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_s);
                 if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
                     f3 add = (emit_int * emission_weight) * thr;
-                    if (FUSE) Lc = Lc + add;
+                    if (FZ) Lc = Lc + add;
                     else add_radiance(q.L, p.cap, l_off, add, true);      // (nothing else touches the path's slot while its shade kernel runs)
                 }
             }
@@ -1196,7 +1224,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
             if (SM & 2) stq(q.pdf[nxt], so, new_pdf);
         }
 #if APT_FAST
-        if (FUSE) {
+        if (FZ) {
             for (int s = 0; s < (MULTI ? p.S : 1); s++) {       // the row's light samples
                 if (MULTI && p.S > 1) {
                     const lds_f* park = (const lds_f*)reinterpret_cast<const float*>(s_dyn) + ((uint32_t)s * 7u * BLOCK + threadIdx.x);
@@ -1231,7 +1259,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
 #endif
         SH_TICK(5);
     }
-    if (FUSE) { flush_uniform(t_traced, &cnt->stats[sl.q][ST_SHADOW_TRACED]); flush_uniform(t_lit, &cnt->stats[sl.q][ST_LIT]); }
+    if (FZ) { flush_uniform(t_traced, &cnt->stats[sl.q][ST_SHADOW_TRACED]); flush_uniform(t_lit, &cnt->stats[sl.q][ST_LIT]); }
     if (TRACE) flush_uniform(t_extend, &cnt->stats[sl.q][ST_EXTEND]);
 #ifdef APT_SHADE_PROF
     sprof[6] = __builtin_readcyclecounter() - life0_;
@@ -1450,6 +1478,10 @@ APT_D void extend_flat_body(const DevScene& sc, const Params& p, const Queues& q
             if ((int)lane_id() < q.n_classes && cnt_vec) tail = atomicAdd(&cnt->n_cls[lane_id()][sl.q * CNT_PAD], cnt_vec);
             const uint32_t so0 = (qbase + (uint32_t)__shfl((int)tail, cls0 < 0 ? 0 : cls0) + rank0) << 2;
             const uint32_t so1 = (qbase + (uint32_t)__shfl((int)tail, cls1 < 0 ? 0 : cls1) + rank1) << 2;
+            if (SORTED == 2) {
+                if (cls0 >= 0) cq_store(q, (uint32_t)cls0 * p.cap + (so0 >> 2), o0, d0, mk3(tx.x, ty.x, tz.x), pid.x, pmeta.x, ppdf.x, r0.t, r0.prim, r0.u, r0.v);
+                if (cls1 >= 0) cq_store(q, (uint32_t)cls1 * p.cap + (so1 >> 2), o1, d1, mk3(tx.y, ty.y, tz.y), pid.y, pmeta.y, ppdf.y, r1.t, r1.prim, r1.u, r1.v);
+            } else
             for (int c = 0; c < q.n_classes; c++) {
                 const Queues::ClassQ& k = q.cls[c];
                 if (cls0 == c) {
