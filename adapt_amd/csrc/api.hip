@@ -854,7 +854,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         pl.ovf = nullptr; pl.ovf_stride = 0; pl.lds_nodes = 0; pl.lds_prims = 0;
         const size_t stack_b = (size_t)pl.stack_depth * BLOCK * 8;
         r->plan = pl;
-        r->lds_bytes = stack_b;
+        r->lds_bytes = stack_b + (size_t)6 * BLOCK * 4;      // (+ k_extend_dyn's parked path state: six floats per thread)
         if (r->lds_bytes > 160 * 1024) { return fail(APT_E_INVALID, "apt_renderer_create: BVH too deep for the LDS traversal stack"); }
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->lds_bytes));
         r->grid_trace = cus * per_cu;

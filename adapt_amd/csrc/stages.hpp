@@ -594,6 +594,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
         cnt->n_work[1][sq * CNT_PAD] = 0;                                          // this bounce's any-hit walk (k_shadow_dyn) starts at the head of its queue
     }
     uint32_t* work = &cnt->n_work[0][sq * CNT_PAD];
+    lds_f* park = (lds_f*)(reinterpret_cast<float*>(s_dyn) + (size_t)plan.stack_depth * BLOCK * 2) + threadIdx.x;      // six floats per thread behind the stack ([component][thread]): the ray's throughput, id, meta, pdf while it walks
     const float* ro = q.ray_o[cur_q]; const float* rd = q.ray_d[cur_q];
     const uint32_t qbase = (uint32_t)sq * p.subcap;
     // per-lane ray state
@@ -616,8 +617,10 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
             if (fin) { stq(q.hit_t, io, rec.t); stq(q.hit_prim, io, rec.prim); stq(q.hit_u, io, rec.u); stq(q.hit_v, io, rec.v); }
         } else if (__any(fin)) {
             // (as in k_extend: the rest of the record is requested first, the queue tails of all classes move with ONE atomic instruction)
+            // (the rest of the path's record was fetched WITH the ray - six coalesced loads at the claim - and has waited in LDS behind the stack:
+            // fetched here, by the finished lanes' scattered queue positions, it was six of the ~42 scattered accesses a ray makes)
             f3 st_thr = splat3(0.f); uint32_t st_id = 0, st_meta = 0; float st_pdf = 0.f;
-            if (fin) { st_thr = ld3q(q.thr[cur_q], p.cap, io); st_id = ldq(q.id[cur_q], io); st_meta = ldq(q.meta[cur_q], io); st_pdf = ldq(q.pdf[cur_q], io); }
+            if (fin) { st_thr = mk3(park[0], park[BLOCK], park[2 * BLOCK]); st_id = __float_as_uint(park[3 * BLOCK]); st_meta = __float_as_uint(park[4 * BLOCK]); st_pdf = park[5 * BLOCK]; }
 #if APT_FAST_LEAVES
             const int cls = !fin ? -1 : ((rec.prim >= 0) ? fin_cls : q.miss_class);
 #else
@@ -659,6 +662,11 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
             if (need && pos < n) {
                 io = (qbase + pos) << 2;
                 r = make_walk_ray(ld3q(ro, p.cap, io), ld3q(rd, p.cap, io));
+                if (SORTED) {
+                    const f3 t_ = ld3q(q.thr[cur_q], p.cap, io);
+                    park[0] = t_.x; park[BLOCK] = t_.y; park[2 * BLOCK] = t_.z;
+                    park[3 * BLOCK] = __uint_as_float(ldq(q.id[cur_q], io)); park[4 * BLOCK] = __uint_as_float(ldq(q.meta[cur_q], io)); park[5 * BLOCK] = ldq(q.pdf[cur_q], io);
+                }
                 rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
                 sp = 0; ng = APT_ROOT_GROUP; state = 1;
             }
@@ -1326,6 +1334,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
         cnt->n_work[0][sq * CNT_PAD] = 0;                                          // the next bounce's closest-hit walk starts at the head of its queue (a host-side fill per bounce was a launch of its own: 15 us)
     }
     uint32_t* work = &cnt->n_work[1][sq * CNT_PAD];
+    lds_f* park = (lds_f*)(reinterpret_cast<float*>(s_dyn) + (size_t)plan.stack_depth * BLOCK * 2) + threadIdx.x;      // four floats per thread behind the stack: the light sample's contribution and radiance slot while its ray walks
     const uint32_t qbase = (uint32_t)sq * q.sh_subcap, sc_ = q.sh_cap;
     int state = 0;                              // 0 no ray, 1 walking, 2 finished
     bool occluded = false;
@@ -1339,11 +1348,11 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
     uint32_t t_lit = 0;
     for (;;) {
         if (state == 2) {
-            f3 c = ld3q(q.sh_c, sc_, io);
+            f3 c = mk3(park[0], park[BLOCK], park[2 * BLOCK]);      // (contribution and slot were fetched with the ray - coalesced - and have waited in LDS: k_extend_dyn)
             const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));       // see k_shadow
             if (occluded && weird) c = c * 0.f;
             if (!occluded || weird) {
-                add_radiance(q.L, p.cap, ldq(q.sh_id, io), c, APT_EXCLUSIVE_L(p));
+                add_radiance(q.L, p.cap, __float_as_uint(park[3 * BLOCK]), c, APT_EXCLUSIVE_L(p));
             }
             if (!occluded) t_lit++;
             state = 0;
@@ -1359,6 +1368,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
                 io = (qbase + pos) << 2;
                 r = make_walk_ray(ld3q(q.sh_o, sc_, io), ld3q(q.sh_d, sc_, io));
                 const float dist = ldq(q.sh_tmax, io);
+                { const f3 c_ = ld3q(q.sh_c, sc_, io); park[0] = c_.x; park[BLOCK] = c_.y; park[2 * BLOCK] = c_.z; park[3 * BLOCK] = __uint_as_float(ldq(q.sh_id, io)); }
                 rec.t = (dist > 0.0f) ? dist - 1e-4f : 1e7f;
                 occluded = false; sp = 0; ng = APT_ROOT_GROUP; state = 1;
             }
