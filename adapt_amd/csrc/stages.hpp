@@ -305,6 +305,29 @@ APT_D DevSrc ld_src_uniform(const DevSrc* p) {
     return s;
 }
 
+// An emitter record picked per lane (scenes with several lights): the 64-byte record as FOUR 16-byte loads.  Left to the compiler the struct
+// copy dissolves into one 4-byte load per field at its use site - up to nine scattered loads per light sample, most of the scattered
+// accesses a vertex of the mesh scenes makes (C4: 18 of 25 with two light samples) - and the vector-memory pipe pays per lane address.
+#ifndef APT_SRC_VEC
+#define APT_SRC_VEC 1
+#endif
+APT_D DevSrc ld_src_lane(const DevSrc* p) {
+#if APT_SRC_VEC
+    static_assert(sizeof(DevSrc) == 64, "DevSrc is read as four float4");
+    const float4* q4 = reinterpret_cast<const float4*>(p);
+    float4 a = q4[0], b = q4[1], c = q4[2], d = q4[3];
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));      // (keeps the four loads whole)
+    asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w), "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
+    DevSrc s;
+    s.type = __float_as_int(a.x); s.bool_bits = __float_as_int(a.y); s.obj_ref_id = __float_as_int(a.z); s.prim_first = __float_as_int(a.w);
+    s.intensity = mk3(b.x, b.y, b.z); s.dir = mk3(b.w, c.x, c.y); s.pos = mk3(c.z, c.w, d.x);
+    s.inv_area = d.y; s.r = d.z; s.prim_count = __float_as_int(d.w);
+    return s;
+#else
+    return *p;
+#endif
+}
+
 // local pixel -> (global column, row)
 APT_D void local_to_global(const Params& p, uint32_t lp, int& i, int& j) {
     int lc = (int)(lp / (uint32_t)p.H);
@@ -1098,7 +1121,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                 }
                 if (!valid) break_flag = true;
                 else {
-                    const DevSrc src = (ns == 1) ? src_only : sc.src[sidx];
+                    const DevSrc src = (ns == 1) ? src_only : ld_src_lane(sc.src + sidx);
                     f3 shadow_int; float direct_pdf;
                     f3 emit_pos = emitter_sample_hit<SM>(src, geom, hit_point, rng, shadow_int, direct_pdf);
                     f3 to_emitter = emit_pos - hit_point;
