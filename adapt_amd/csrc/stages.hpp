@@ -328,6 +328,27 @@ APT_D DevSrc ld_src_lane(const DevSrc* p) {
 #endif
 }
 
+// ... and an object's surface-model record (80 bytes) as five
+#ifndef APT_BXDF_VEC
+#define APT_BXDF_VEC 1
+#endif
+APT_D DevBxdf ld_bxdf_lane(const DevBxdf* p) {
+#if APT_BXDF_VEC
+    static_assert(sizeof(DevBxdf) == 80, "DevBxdf is read as five float4");
+    const float4* q4 = reinterpret_cast<const float4*>(p);
+    float4 a = q4[0], b = q4[1], c = q4[2], d = q4[3], e = q4[4];
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+    asm volatile("" : "+v"(c.x), "+v"(c.y), "+v"(c.z), "+v"(c.w), "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w), "+v"(e.x));
+    DevBxdf x;
+    x.type = __float_as_int(a.x); x.is_delta = __float_as_int(a.y); x.is_bsdf = __float_as_int(a.z); x._pad = 0;
+    x.k_d = mk3(b.x, b.y, b.z); x.k_s = mk3(b.w, c.x, c.y); x.k_g = mk3(c.z, c.w, d.x); x.mean = mk3(d.y, d.z, d.w);
+    x.ior = e.x; x._pad2[0] = x._pad2[1] = x._pad2[2] = 0.f;
+    return x;
+#else
+    return *p;
+#endif
+}
+
 // local pixel -> (global column, row)
 APT_D void local_to_global(const Params& p, uint32_t lp, int& i, int& j) {
     int lc = (int)(lp / (uint32_t)p.H);
@@ -1021,7 +1042,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                 else if (PFP) build_hit_rec(sc, cu_ra, cu_rb, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
                 else build_hit(sc, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
                 if (BM == 0x002) bx.k_d = rec_kd;               // Lambertian-only scenes: type 1, not delta, not a BSDF (the defaults above), colour from the record
-                else bx = sc.bxdf[it.obj_id];
+                else bx = ld_bxdf_lane(sc.bxdf + it.obj_id);
                 if (TEX && sc.tex_i != nullptr) {                // the scene declares image textures (TEX kernels only, see below)
                     const float bu = PK ? tr_uv_in.x : ldq(in.u, io), bv = PK ? tr_uv_in.y : ldq(in.v, io);
                     f3 tx;
