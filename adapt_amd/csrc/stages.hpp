@@ -1142,7 +1142,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
                 }
                 if (!valid) break_flag = true;
                 else {
-                    const DevSrc src = (ns == 1) ? src_only : ld_src_lane(sc.src + sidx);
+                    const DevSrc src = (ns == 1) ? src_only : (CQ ? ld_src_lane(sc.src + sidx) : sc.src[sidx]);      // (whole-record loads in the class kernels only: in C2's traced kernel their sixteen registers cost the fourth wave, 127 -> 132 VGPRs)
                     f3 shadow_int; float direct_pdf;
                     f3 emit_pos = emitter_sample_hit<SM>(src, geom, hit_point, rng, shadow_int, direct_pdf);
                     f3 to_emitter = emit_pos - hit_point;
