@@ -1,0 +1,45 @@
+"""Occupancy guard for the hot kernels.  A kernel's register allocation decides how many waves a SIMD holds (512 VGPRs per lane: <= 128 ->
+four waves, <= 72 -> seven), and it is the maximum over every path the compiler sees, including ones a config never takes: an innocent
+change elsewhere in stages.hpp can cost C2's shade kernel its fourth wave (-10 %: it happened, profiles/NOTES.md).  This test compiles the
+hot instantiations for gfx950 with -Rpass-analysis=kernel-resource-usage (hipcc cross-compiles without a GPU; ~10 s) and holds each to
+the budget it ships with."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# (explicit instantiation, mangled-name prefix, VGPR budget, why)
+KERNELS = [
+    ("k_shade<0x002, 0x01, 0, 2>(DevScene, Params, Queues, Counters*, ShadeIn, int, int)", "_Z7k_shadeILi2ELi1ELi0ELi2EE", 128, "C1 / C2: rays traced in place, four waves per SIMD"),
+    ("k_shade<0x002, 0x05, 0, 4>(DevScene, Params, Queues, Counters*, ShadeIn, int, int)", "_Z7k_shadeILi2ELi5ELi0ELi4EE", 128, "C4's Lambertian class (spot lights)"),
+    ("k_shade<0x801, 0x03, 0, 4>(DevScene, Params, Queues, Counters*, ShadeIn, int, int)", "_Z7k_shadeILi2049ELi3ELi0ELi4EE", 128, "C3's wall class (Blinn-Phong without a lobe)"),
+    ("k_extend_dyn<2>(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan)", "_Z12k_extend_dynILi2EE", 72, "C4 / C5: closest-hit walk, seven waves per SIMD"),
+    ("k_extend_flat<2, 1>(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan)", "_Z13k_extend_flatILi2ELi1EE", 96, "C3: hot flat sweep, five waves per SIMD"),
+]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_hot_kernels_keep_their_register_budget(tmp_path):
+    src = tmp_path / "probe.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n#include <algorithm>\n#include <cmath>\n#include <cstdio>\n#include <cstdlib>\n#include <cstring>\n"
+                   f'#include "{ROOT}/include/adapt_mi.h"\n#include "{ROOT}/adapt_amd/csrc/bvh_build.hpp"\n#include "{ROOT}/adapt_amd/csrc/stages.hpp"\n'
+                   + "".join(f"template __global__ void {inst};\n" for inst, *_ in KERNELS))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-ffp-contract=off",
+           "-DAPT_FAST=1", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", str(src), "-o", str(tmp_path / "probe.o")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    usage = {}
+    for blk in out.stderr.split("Function Name: ")[1:]:
+        name = blk.split("\n")[0].split(" [")[0].strip()
+        v = re.search(r"VGPRs: (\d+)", blk); s = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", blk)
+        usage[name] = (int(v.group(1)), int(s.group(1)) if s else 0)
+    for inst, prefix, budget, why in KERNELS:
+        hit = [(n, u) for n, u in usage.items() if n.startswith(prefix)]
+        assert len(hit) == 1, (prefix, sorted(usage))
+        vgprs, scratch = hit[0][1]
+        assert vgprs <= budget and scratch == 0, f"{inst}: {vgprs} VGPRs, {scratch} B scratch; budget {budget} ({why})"
