@@ -527,7 +527,18 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
 #define UP(buf, vec) do { hipError_t e_ = upload(s->buf, vec); if (e_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload " #buf ": ") + hipGetErrorString(e_)); } } while (0)
     std::vector<int> slot_info((size_t)N);                // leaf slot -> primitive | material class << 28 (traverse.hpp walk_info)
     {
-        for (int slot = 0; slot < N; slot++) { const int k = s->wide.prim_order[(size_t)slot]; slot_info[(size_t)slot] = k | (pcls_host[(size_t)k] << 28); }
+        // Three class bits (28..30), so that the word stays non-negative: k_extend_dyn reads a negative word as "nothing hit".  A scene
+        // with more classes than class queues (all nine surface models + the lobe-free walls) renders unsorted through the all-models
+        // kernel, nobody reads the class then, and none is packed (a compact id of 8 would have set the sign bit: every closest hit on
+        // the ninth class lost).
+        if (N >= (1 << 28)) { delete s; return fail(APT_E_INVALID, "apt_scene_create: more than 2^28 primitives"); }
+        const bool pack_cls = s->n_classes <= APT_MAX_CLASSES;
+        for (int slot = 0; slot < N; slot++) {
+            const int k = s->wide.prim_order[(size_t)slot];
+            const uint32_t c = pack_cls ? (uint32_t)pcls_host[(size_t)k] : 0u;
+            if (c >= (uint32_t)APT_MAX_CLASSES) { delete s; return fail(APT_E_INVALID, "apt_scene_create: material class id does not fit the leaf-slot word"); }
+            slot_info[(size_t)slot] = (int)((uint32_t)k | (c << 28));
+        }
     }
     UP(nodes, s->wide.nodes); UP(prims, recs); UP(slot_prim, slot_info); UP(normals, nrm); UP(vnormals, vn); UP(precom, prec); UP(prim_obj, prim_obj);
     UP(obj_info, oi); UP(emitter_id, ei); UP(bxdf, bx); UP(src, sr); UP(sweep_recs, sw); UP(sweep_tab, sw_tab); UP(obj_aabb, aabb);

@@ -828,11 +828,18 @@ APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Co
     const uint32_t epoch = (uint32_t)bounce + 1u;
     const int ncls = q.tr_ncls;
     uint32_t* n_def_p = &cnt->n_tr[bounce % 3][ncls][sq * CNT_PAD]; uint32_t* n_sh_p = &cnt->n_fix_sh[cur ^ 1][sq * CNT_PAD];
-    const uint32_t n_def = *n_def_p, n_sh = min(*n_sh_p, q.sh_subcap);
-    if ((n_def | n_sh) == 0u) return;
-    uint32_t old = 0;
-    if (lane_id() == 0) old = atomicMax(&cnt->fix_claim[sq * CNT_PAD], epoch);
-    old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);
+    // Memory order.  The list lengths are read first (acquire: the claim word below is read AFTER them), then the claim word.  A wave that
+    // finds this bounce claimed - by a running or a finished server - waits for "done" with an acquire load whatever lengths it saw, so
+    // that everything the server appended or added (queue records, counters, radiance slots) happens-before this wave's reads; the
+    // server resets the light-sample list BEFORE it publishes "done", and only after its claim, so lengths of zero seen together with an
+    // unclaimed bounce are the lists' true lengths.
+    const uint32_t n_def = __hip_atomic_load(n_def_p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), n_sh = min(__hip_atomic_load(n_sh_p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), q.sh_subcap);
+    uint32_t old = __hip_atomic_load(&cnt->fix_claim[sq * CNT_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old < epoch) {
+        if ((n_def | n_sh) == 0u) return;                     // nothing listed, nobody serving
+        if (lane_id() == 0) old = atomicMax(&cnt->fix_claim[sq * CNT_PAD], epoch);
+        old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);
+    }
     if (old >= epoch) {                                       // somebody else serves (or has served) the lists of this bounce
         while (__hip_atomic_load(&cnt->fix_done[sq * CNT_PAD], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(16);
         return;
@@ -881,11 +888,9 @@ APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Co
         t_lit += (valid && !occ) ? 1u : 0u;
     }
     flush_stat(t_lit, &cnt->stats[sq][ST_LIT]);
+    if (lane_id() == 0) __hip_atomic_store(n_sh_p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // consumed - before "done" is published (the bounce after this one appends to this list again; the staging queue's counter rotates with the others)
     __threadfence();
-    if (lane_id() == 0) {
-        __hip_atomic_store(&cnt->fix_done[sq * CNT_PAD], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        *n_sh_p = 0u;                                         // consumed (the bounce after this one appends to this list again; the staging queue's counter rotates with the others)
-    }
+    if (lane_id() == 0) __hip_atomic_store(&cnt->fix_done[sq * CNT_PAD], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif
 template <int BM, int SM, int TEX = 0, int FUSE = 0>

@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 # edges), 1.032 with 16, 1.016 with 4; the per-rank rate itself does not depend on the band width.
 BAND_WIDTH = 4
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-ROUND = 4                       # profiles/r0<ROUND>_<config>_counters.json: PMC figures of THIS round's kernels
+ROUND = 5                       # profiles/r0<ROUND>_<config>_counters.json: PMC figures of THIS round's kernels
 STAGES = ("extend", "shade", "shadow")
 
 CONFIGS = {
@@ -146,6 +146,18 @@ def pick_dominant(per):
     return STAGES[0]
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command line under torch.distributed.run."""
+    import socket
+    import subprocess
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL's device-buffer exchange between the ranks needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,14 +182,18 @@ def main():
         args.dump_image = os.path.abspath(args.dump_image)
     os.chdir(ROOT)                  # texture / .vol paths inside scene files are relative to the repository root (rocprofv3 runs from /tmp)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: no launcher has set the rendezvous variables, so this process becomes the launcher - it
+        # re-executes itself under torch.distributed.run (one process per GPU, 127.0.0.1 rendezvous on a free port) and hands back
+        # the ranks' exit code; rank 0 of that run prints the JSON line on this process's stdout
+        sys.exit(self_launch(args.gpus))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
-        args.gpus = world
+        args.gpus = world               # the launcher's world is authoritative (torch.distributed.run --nproc-per-node)
     if not torch.cuda.is_available():
         sys.exit("bench.py: no HIP device visible; the render path has no CPU fallback")
     if args.single_device:
@@ -260,14 +276,19 @@ def main():
     per_rank = None
     if dist is not None:
         dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"
-        mine = torch.tensor([dt_local, st["render_ms"] / max(1, args.steps), float(np.mean(gather_ms)) if gather_ms else 0.0, float(st["n_samples"])], dtype=torch.float64, device=dev)
+        mine = torch.tensor([dt_local, st["render_ms"] / max(1, args.steps), float(np.mean(gather_ms)) if gather_ms else 0.0, float(st["n_samples"]), float(local_rank)], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         allr = torch.stack(allr).cpu().numpy()
         dt = float(allr[:, 0].max())                                    # the job is as slow as its slowest rank
         per_rank = {"wall_s": [round(float(x), 5) for x in allr[:, 0]], "render_ms_per_step": [round(float(x), 3) for x in allr[:, 1]],
                     "gather_ms_per_step": [round(float(x), 3) for x in allr[:, 2]], "samples": [int(x) for x in allr[:, 3]],
-                    "collective": {"backend": "RCCL (torch.distributed 'nccl')" if args.backend == "nccl" else args.backend, "world_size": world, "op": "all_gather_into_tensor of the per-rank (n_cols, H, 3) float32 tiles, once per step",
+                    "collective": {"backend": "RCCL (torch.distributed 'nccl')" if args.backend == "nccl" else args.backend, "world_size": world,
+                                   # what the process group itself reports (did the collective see N ranks, and which library carried it)
+                                   "process_group": {"backend": str(dist.get_backend()), "world_size": int(dist.get_world_size()),
+                                                     "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None,
+                                                     "devices": sorted(set(int(x) for x in allr[:, 4]))},
+                                   "op": "all_gather_into_tensor of the per-rank (n_cols, H, 3) float32 tiles, once per step",
                                    "tile_bytes_per_rank": int(rdr.n_cols * rdr.h * 12), "queue_MiB_per_rank": round(info["queue_bytes"] / 2 ** 20, 1)}}
 
     total_samples = W * H * spp_step * args.steps
@@ -344,7 +365,20 @@ def main():
         source = "repeat of the timed region with per-launch events, overlapping render lanes (exclusive pass disabled): per-kernel durations include co-scheduled kernels"
     dom = pick_dominant(alone)
     kb = kernel_bytes(st)
-    roofline = {"bound": "hbm", "kernel": f"k_{dom}", "achieved": alone[dom]["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alone[dom]["frac"],
+    # What binds the dominant kernel.  `frac_credited` prices its ALGORITHMIC bytes (SURVEY 8(d)'s per-unit figure - for a kernel that
+    # absorbed other stages, theirs too) against the HBM peak; `frac_hbm_moved` prices the bytes the PMC counters saw cross the HBM side.
+    # A kernel that moves fewer bytes than it is credited with (traffic / algorithmic < 1: the fused C1 / C2 kernel never writes its
+    # rays, hits or light samples) is not waiting for HBM, and the headline fields then describe the resource it does wait for: VALU
+    # issue (wave-instructions per second against n_simd x sclk / 4), with both HBM fractions kept beside it.
+    d_ = alone[dom]
+    moved = (d_["traffic"] / (d_["avg_launch_ms"] * 1e-3) / 1e9) if d_.get("traffic") and d_["avg_launch_ms"] > 0 else None
+    hbm = {"achieved_credited_GB/s": d_["GB/s"], "frac_credited": d_["frac"], "achieved_moved_GB/s": round(moved, 1) if moved is not None else None,
+           "frac_hbm_moved": round(moved / HBM_PEAK_GBS, 5) if moved is not None else None, "peak_GB/s": HBM_PEAK_GBS,
+           "traffic_over_algorithmic": d_.get("traffic_over_algorithmic")}
+    valu_bound = "valu" in d_ and d_.get("traffic_over_algorithmic") is not None and d_["traffic_over_algorithmic"] < 1.0
+    head = ({"bound": "valu", "achieved": d_["valu"]["Ginst/s"], "peak": d_["valu"]["peak_Ginst/s"], "unit": "Gwave-inst/s", "frac": d_["valu"]["busy_frac"]} if valu_bound
+            else {"bound": "hbm", "achieved": d_["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d_["frac"]})
+    roofline = {**head, "kernel": f"k_{dom}", "hbm": hbm, "frac_credited": hbm["frac_credited"], "frac_hbm_moved": hbm["frac_hbm_moved"],
                 "traffic": alone[dom].get("traffic"), "bytes_per_launch": alone[dom]["bytes_per_launch"], "avg_launch_ms": alone[dom]["avg_launch_ms"],
                 "launches": alone[dom]["launches"], "measured_in": source, "render_lanes": lanes,
                 "dominant_rule": "largest summed time among extend / shade / shadow in the exclusive pass; within 15 % the order extend > shade > shadow decides",

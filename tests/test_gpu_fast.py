@@ -719,3 +719,75 @@ def test_two_gpu_rccl_bench_equals_the_single_gpu_image(tmp_path):
         assert line["n_gpus"] == n and line["value"] > 0
         imgs[n] = np.load(img)
     assert np.array_equal(imgs[1], imgs[2])
+
+
+def test_plain_bench_gpus_2_launches_itself(tmp_path):
+    """`python bench.py --gpus 2 ...` started WITHOUT torch.distributed.run (as the driver starts N = 1): bench.py becomes its own launcher,
+    two ranks render on cuda:0 (--single-device) and gather over gloo; the line says n_gpus == 2, the process group reports a world of two,
+    and the gathered image is the one-rank image bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    imgs = {}
+    for n in (1, 2):
+        img = str(tmp_path / f"self{n}.npy")
+        cmd = [sys.executable, "bench.py", "--gpus", str(n), "--config", "c1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-exclusive-pass",
+               "--scaling", "strong", "--spp", "6", "--dump-image", img] + (["--single-device", "--backend", "gloo"] if n > 1 else [])
+        res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-2000:]
+        line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == n and line["value"] > 0
+        if n > 1:
+            pg = line["per_rank"]["collective"]["process_group"]
+            assert pg["world_size"] == 2 and pg["backend"] == "gloo" and len(line["per_rank"]["samples"]) == 2
+        imgs[n] = np.load(img)
+    assert np.array_equal(imgs[1], imgs[2])
+
+
+def test_nine_material_classes_on_the_tree_lose_no_hits(monkeypatch):
+    """with all nine surface-model classes in one scene (the microfacet switch on) there are more classes than class
+    queues, the scene renders unsorted through the all-models kernel - and the leaf-slot word of the product build's tree must not carry
+    a class id at all: id 8 in bits 28.. set the sign bit, which the walk's hand-in reads as "nothing hit", so every closest hit on the
+    ninth class's object was lost.  Nine small bunnies, one per class, in the Cornell room; product build against the exact build."""
+    import adapt_amd.materials as mats
+    from adapt_amd import synth
+    from adapt_amd.renderer import Renderer
+    monkeypatch.setattr(mats, "ENABLE_MICROFACET", True)
+    b = synth._Builder()
+    white = synth._brdf("lambertian", "#BDBDBD")
+    synth._room(b, white, synth._brdf("lambertian", "#DD2525"), synth._brdf("lambertian", "#25DD25"))
+    m = synth._mat
+    nine = [synth._brdf("lambertian", "#FFFFFF"), synth._brdf("phong", "#BCBCBC", "8.0", "#303030"), synth._brdf("specular", "#DEDEDE"),
+            synth._brdf("mod-phong", "#BCBCBC", "10.0", "#424242"),
+            m('<brdf type="fresnel-blend" id="fb"><rgb name="k_d" value="#CACACA"/><rgb name="k_s" value="#333333"/><rgb name="k_g" r="10" g="1000"/></brdf>'),
+            m('<brdf type="oren-nayar" id="on"><rgb name="k_d" value="#C8B496"/><rgb name="sigma" value="20.0"/></brdf>'),
+            m('<brdf type="thin-coat" id="tc"><rgb name="k_d" value="#9696C8"/><rgb name="k_s" value="0.9"/><rgb name="sigma" r="20" g="20" b="1.5"/></brdf>'),
+            m('<bsdf type="lambertian" id="lt"><rgb name="k_d" value="#E0E0E0"/><medium type="transparent"><float name="ior" value="1.4"/></medium></bsdf>'),
+            m('<brdf type="microfacet" id="mf"><rgb name="k_d" value="#E0C8A0"/><rgb name="roughness" value="0.2"/><rgb name="ref_ior" r="1.0" g="1.5" b="0.0"/></brdf>')]
+    bunny = synth._bunny(1)
+    for k, mat in enumerate(nine):
+        b.mesh(synth._place(bunny, 0.3, (0.95 + 1.8 * (k % 3), 0.0, 0.9 + 1.75 * (k // 3))), mat)
+    point = synth.SOURCE_MAP["point"](synth.xet.fromstring('<emitter type="point" id="p"><rgb name="emission" value="30.0, 30.0, 30.0"/><point name="center" x="2.78" y="5.0" z="2.8"/></emitter>'))
+    tup = b.finish([point], synth._sensor(96, 72, 6, 1))
+    f = Renderer(*tup, width=96, height=72)
+    e = Renderer(*tup, width=96, height=72, exact=True)
+    try:
+        assert f.info()["traversal"] == "bvh" == e.info()["traversal"] and f.info()["arithmetic"] == "fast"
+        assert "all models" in f.info()["shade_variant"], f.info()["shade_variant"]            # nine classes: unsorted
+        o, d, _ = _rays(60000, 23)
+        prim, t, _ = f.intersect(o, d)
+        prim_o, t_o, _ = e.intersect(o, d)
+        assert (prim == prim_o).mean() >= 0.999 and np.array_equal(prim >= 0, prim_o >= 0)
+        first = f.flat.obj_info[:, 0]
+        obj = np.searchsorted(first, np.maximum(prim, 0), side="right") - 1
+        for k in range(5, 14):                                                                # every bunny is hit by some of the rays
+            assert ((obj == k) & (prim >= 0)).sum() > 50, k
+        f.render(n_spp=4); e.render(n_spp=4)
+        sf, se = f.stats(), e.stats()
+        for key in ("n_extend", "n_shade", "n_shadow", "n_draws"):
+            assert abs(sf[key] - se[key]) <= max(2e-3 * se[key], 50), (key, sf[key], se[key])
+    finally:
+        f.close(); e.close()

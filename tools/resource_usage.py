@@ -10,7 +10,7 @@ for blk in txt.split("Function Name: ")[1:]:
         m = re.search(k + r": (\d+)", blk); return int(m.group(1)) if m else -1
     rows.append((name, g("VGPRs"), g("AGPRs"), g("SGPRs"), g("ScratchSize \[bytes/lane\]"), g("Occupancy \[waves/SIMD\]"), g("LDS Size \[bytes/block\]")))
 try:
-    dem = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.split("\n")
+    dem = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.split("\n")
 except Exception:
     dem = [r[0] for r in rows]
 for r, d in zip(rows, dem):

@@ -45,6 +45,19 @@ def first_db(sub):
     return sqlite3.connect(fs[0]) if fs else None
 
 
+# Register columns: rocprofv3's arch_vgpr_count reads HALF of a wave64 kernel's allocation on gfx950 (64 for the 128-VGPR shade kernel), so
+# the table carries what the code object itself records - .vgpr_count + .agpr_count in granules of 8 (tools/kernel_meta.py) - and the waves
+# per SIMD that follow from it (512 registers per lane); `arch(rocprof)` is kept next to it so that the two can be told apart.
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_meta import kernel_meta  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+META = {}
+for lib in (os.environ.get("ADAPT_MI_LIB"), os.path.join(ROOT, "adapt_amd", "libadapt_mi.so")):
+    if lib and os.path.exists(lib):
+        META = kernel_meta(lib)
+        break
+
 db = first_db("stats")
 print("== kernel time (rocprofv3 --kernel-trace --stats), all dispatches of the run")
 if db:
@@ -53,9 +66,11 @@ if db:
          "from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.kernel_name order by 3 desc")
     rows = list(db.execute(q))
     tot = sum(r[2] for r in rows) or 1
-    print(f"{'kernel':40s} {'calls':>6s} {'total_us':>11s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s} {'vgpr':>5s} {'sgpr':>5s} {'lds_B':>7s}")
+    print(f"{'kernel':40s} {'calls':>6s} {'total_us':>11s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s} {'pct':>6s} {'vgpr_alloc':>10s} {'waves/SIMD':>10s} {'arch(rocprof)':>13s} {'sgpr':>5s} {'lds_B':>7s}")
     for r in rows:
-        print(f"{short(r[0]):40s} {r[1]:6d} {r[2] / 1e3:11.1f} {r[3] / 1e3:9.2f} {r[4] / 1e3:9.2f} {r[5] / 1e3:9.2f} {100 * r[2] / tot:6.2f} {r[6]:5d} {r[7]:5d} {r[8]:7d}")
+        m = META.get(r[0].replace(".kd", ""))
+        alloc, waves = (f"{m['alloc']:d}", f"{m['waves_per_simd']:d}") if m else ("?", "?")
+        print(f"{short(r[0]):40s} {r[1]:6d} {r[2] / 1e3:11.1f} {r[3] / 1e3:9.2f} {r[4] / 1e3:9.2f} {r[5] / 1e3:9.2f} {100 * r[2] / tot:6.2f} {alloc:>10s} {waves:>10s} {r[6]:13d} {r[7]:5d} {r[8]:7d}")
 
 print("\n== PMC passes (summed over the run's dispatches, per kernel)")
 acc = defaultdict(lambda: defaultdict(float))
