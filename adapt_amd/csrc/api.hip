@@ -83,6 +83,15 @@ static const char* kClassName[APT_N_CLASS_DEFS] = {"lambertian", "blinn-phong", 
 static const shade_fn kClassShade[APT_N_CLASS_DEFS][3] = {      // (FUSE = 4: the class queues are packed planes, Queues::cq)
     {k_shade<0x002, 0x03, 0, 4>, k_shade<0x002, APT_SRC_ALL, 0, 4>, k_shade<0x002, 0x05, 0, 4>}, {k_shade<0x001, 0x03, 0, 4>, k_shade<0x001, APT_SRC_ALL, 0, 4>, k_shade<0x001, 0x05, 0, 4>}, {k_shade<0x040, 0x03, 0, 4>, k_shade<0x040, APT_SRC_ALL, 0, 4>, k_shade<0x040, 0x05, 0, 4>}, {k_shade<0x504, 0x03, 0, 4>, k_shade<0x504, APT_SRC_ALL, 0, 4>, k_shade<0x504, 0x05, 0, 4>}, {k_shade<0x010, 0x03, 0, 4>, k_shade<0x010, APT_SRC_ALL, 0, 4>, k_shade<0x010, 0x05, 0, 4>}, {k_shade<0x020, 0x03, 0, 4>, k_shade<0x020, APT_SRC_ALL, 0, 4>, k_shade<0x020, 0x05, 0, 4>}, {k_shade<0x080, 0x03, 0, 4>, k_shade<0x080, APT_SRC_ALL, 0, 4>, k_shade<0x080, 0x05, 0, 4>}, {k_shade<0x200, 0x03, 0, 4>, k_shade<0x200, APT_SRC_ALL, 0, 4>, k_shade<0x200, 0x05, 0, 4>}, {k_shade<0x008, 0x03, 0, 4>, k_shade<0x008, APT_SRC_ALL, 0, 4>, k_shade<0x008, 0x05, 0, 4>}, {k_shade<0x801, 0x03, 0, 4>, k_shade<0x801, APT_SRC_ALL, 0, 4>, k_shade<0x801, 0x05, 0, 4>},
 };
+// Class kernels in groups (stages.hpp k_shade_group): one launch per GROUP and bounce instead of one per class.  Groups follow the register
+// footprints - a kernel allocates for its largest member: 0 = up to 128 VGPRs (four waves per SIMD), 1 = up to 168 (three), 2 = beyond (two).
+typedef void (*group_fn)(DevScene, Params, Queues, Counters*, GroupIn, int, int);
+#define APT_N_GROUPS 3
+static const int kClassGroup[APT_N_CLASS_DEFS] = {0, 1, 1, 0, 2, 2, 1, 0, 1, 0};      // class definition -> group
+static const int kClassSlot[APT_N_CLASS_DEFS] = {0, 0, 1, 1, 0, 1, 2, 2, 3, 3};       // ... and its member slot there (the B0..B3 order below)
+#define APT_GROUP_ROW(SM) {k_shade_group<SM, 4, 0x002, 0x504, 0x200, 0x801>, k_shade_group<SM, 3, 0x001, 0x040, 0x080, 0x008>, k_shade_group<SM, 1, 0x010, 0x020, 0, 0>}
+// (group 0 is held to four waves per SIMD: its members allocate 120-126 VGPRs alone, 129 together - the allocator then parks one 8-byte constant in scratch)
+static const group_fn kGroupShade[3][APT_N_GROUPS] = {APT_GROUP_ROW(0x03), APT_GROUP_ROW(APT_SRC_ALL), APT_GROUP_ROW(0x05)};      // [emitter set, as kClassShade][group]
 // the same class kernels tracing their rays in place (stages.hpp "rays traced in place": product build, flat sweep)
 static const shade_fn kClassShadeTraced[APT_N_CLASS_DEFS][2] = {      // (measurement only, see above: [point + area | all])
     {APT_MULTI_FN(k_shade<0x002, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x002, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x001, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x001, APT_SRC_ALL, 0, 3>)},
@@ -139,7 +148,7 @@ static const VShadeVariant kVShadeVolVariants[] = {       // scenes with a grid 
     {APT_BX_ALL, APT_SRC_ALL, k_vshade<APT_BX_ALL, APT_SRC_ALL, 1>, "volumetric + grid volume: all models"},
 };
 typedef void (*vshadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan, int);
-static const vshadow_fn kVShadow[4] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>, APT_FLAT_FN(k_vshadow<3>)};     // volumetric: transmittance walk (one closest-hit query per pass)
+static const vshadow_fn kVShadow[5] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>, APT_FLAT_FN(k_vshadow<3>), APT_FLAT_FN(k_vshadow_flat)};     // volumetric: transmittance walk (one closest-hit query per pass; [4]: the flat sweep, two samples per lane, every segment in one launch)
 #define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
 
 // ============================================================== host side
@@ -209,6 +218,9 @@ struct apt_renderer {
     vshade_fn vclass_fn[APT_N_CLASS_DEFS + 1] = {};     // sorted volumetric shading: kernel per class queue (the miss class last)
     int v_ncls = 0;               // class queues in use (surface classes + the miss class when misses matter)
     shade_fn class_fn[APT_N_CLASS_DEFS] = {};
+    int shade_groups = 1;                                 // class kernels launched in groups (APT_SHADE_GROUPS=0: one launch per class, for A/B)
+    group_fn group_fn_[APT_N_GROUPS] = {};                // ... the group kernels for this scene's emitter set
+    int group_cls[APT_N_GROUPS][4] = {};                  // ... compact class id of each member slot (-1: the scene has no such class)
     shade_fn class_fn_traced[APT_N_CLASS_DEFS] = {};      // ... tracing their rays in place (Params::fused == 2)
     std::string shade_name;
     LdsPlan plan{};
@@ -707,7 +719,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     p.keep_order = c.volumetric ? 1 : 0; p.volumetric_flat = c.volumetric ? 1 : 0; p.fix_par = 0;
     p.nee_vm = (!c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
     if (const char* f = getenv("APT_NEE_VM")) p.nee_vm = (atoi(f) != 0 && !c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
-    p.l_planes = (!c.volumetric && !p.nee_vm && S >= 2 && S <= 4) ? S : 1;        // stages.hpp APT_EXCLUSIVE_L: one radiance plane per light sample of a vertex
+    p.l_planes = (!p.nee_vm && S >= 2 && S <= 4) ? S : 1;        // stages.hpp APT_EXCLUSIVE_L: one radiance plane per light sample of a vertex
     p.fused = 0;
     p.pix_bits = 0; while ((1u << p.pix_bits) < (uint32_t)r->npix) p.pix_bits++;
     if (((uint64_t)B << p.pix_bits) > (1ull << 32)) { return fail(APT_E_INVALID, "apt_renderer_create: spp_per_batch x pixels does not fit the 32-bit path id"); }
@@ -775,8 +787,12 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     } else if (r->sorted) {
         const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : (((sc->src_mask & ~0x05) == 0) ? 2 : 1);
         r->shade_name = "sorted:";
+        for (int g = 0; g < APT_N_GROUPS; g++) { r->group_fn_[g] = kGroupShade[smi][g]; for (int k = 0; k < 4; k++) r->group_cls[g][k] = -1; }
+        if (const char* f = getenv("APT_SHADE_GROUPS")) r->shade_groups = atoi(f) != 0 ? 1 : 0;
+        if (r->shade_groups) r->shade_name = "sorted, launched in register-footprint groups:";
         for (int c = 0; c < ncls; c++) {
             r->class_fn[c] = kClassShade[sc->class_def[c]][smi];
+            r->group_cls[kClassGroup[sc->class_def[c]]][kClassSlot[sc->class_def[c]]] = c;
             r->class_fn_traced[c] = kClassShadeTraced[sc->class_def[c]][smi == 0 ? 0 : 1];
             r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
         }
@@ -924,8 +940,11 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (const char* g = getenv("APT_GRID_SHADOW")) r->grid_shadow = cus * std::max(1, atoi(g));
     r->grid_vshadow = r->grid_trace; r->vshadow_nt = r->trace_nt; r->vshadow_lds = r->lds_bytes;
     r->vshadow_mode = r->trace_mode;
-    if (r->trace_mode == 3) {                            // measured: V2 530 -> 500, V3 543 -> 499 Msamples/s with the walk on the flat sweep's one-ray adapter
+    if (r->trace_mode == 3) {                            // measured: V2 530 -> 500, V3 543 -> 499 Msamples/s with the walk on the flat sweep's one-ray adapter (k_vshadow<3>: half of every packed instruction idle)
         r->vshadow_mode = (tile_ok && sc->max_obj_prims >= APT_SWEEP_LIST_MIN) ? 2 : 1;
+        // ... so the flat walk is a kernel of its own: two samples per lane, all segments of a sample in one launch (volumetric.hpp k_vshadow_flat); APT_VSHADOW_FLAT=0: the tiled / wave sweep, for A/B
+        const char* vf = getenv("APT_VSHADOW_FLAT");
+        if (!(vf && atoi(vf) == 0)) r->vshadow_mode = 4;
         if (r->vshadow_mode == 1) { int occ = 0; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kVShadow[1], BLOCK, 0) != hipSuccess || occ < 1) occ = 4; r->grid_vshadow = cus * std::min(occ, 8) * 2; r->vshadow_lds = 0; }
     }
     if (r->vshadow_mode == 2) {
@@ -933,6 +952,9 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         r->vshadow_lds = APT_TILE_LDS_BYTES(APT_VSHADOW_NT, sc->n_objects);
         r->grid_vshadow = cus * std::max(1, std::min((int)((160 * 1024) / r->vshadow_lds), (APT_VSHADOW_WAVES * 4) / (APT_VSHADOW_NT / 64)));
         if (r->vshadow_lds > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kVShadow[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->vshadow_lds));
+    }
+    if (r->vshadow_mode == 4) {                          // (the flat trace kernels' grid and tile: r->grid_trace was sized for trace_mode 3 above)
+        r->vshadow_nt = BLOCK; r->vshadow_lds = 0; r->grid_vshadow = r->grid_trace;
     }
     if (const char* g = getenv("APT_GRID_VSHADOW")) r->grid_vshadow = cus * std::max(1, atoi(g));
     r->grid_vshadow = ((r->grid_vshadow + nq - 1) / nq) * nq;
@@ -1076,9 +1098,10 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
                 }
                 if (is.p.S > 0) {
                     const int n_pass = r->scene->has_null_surface ? 7 : 1;       // track_ray walks at most seven segments (vpt.py:113)
+                    const int items = r->vshadow_mode == 4 ? 2 * r->vshadow_nt : r->vshadow_nt;        // queue entries per workgroup tile
                     for (int pass = 0; pass < n_pass; pass++) {
                         LaunchTimer t(r, 3, st);
-                        hipLaunchKernelGGL(kVShadow[r->vshadow_mode], dim3(grid_for(is.total * (size_t)is.p.S, r->grid_vshadow, nq, r->vshadow_nt)), dim3(r->vshadow_nt), r->vshadow_lds, st, sc, is.p, q, cnt, lane_plan, pass);
+                        hipLaunchKernelGGL(kVShadow[r->vshadow_mode], dim3(grid_for(is.total * (size_t)is.p.S, r->grid_vshadow, nq, items)), dim3(r->vshadow_nt), r->vshadow_lds, st, sc, is.p, q, cnt, lane_plan, pass);
                     }
                 }
                 is.cur ^= 1;
@@ -1190,6 +1213,14 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
                               q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur], q.Lc[cur]};
                 LaunchTimer t(r, 2, st); hipLaunchKernelGGL(p.fused ? r->shade->fused : r->shade->fn, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
             } else {
+                if (r->shade_groups) {
+                    for (int g = 0; g < APT_N_GROUPS; g++) {       // one launch per register-footprint group: its workgroups walk the member classes' queues one after the other
+                        GroupIn gi; bool any = false;
+                        for (int k = 0; k < 4; k++) { const int c = r->group_cls[g][k]; gi.cls[k] = c; gi.counts[k] = c >= 0 ? (const uint32_t*)cnt->n_cls[c] : nullptr; any = any || c >= 0; }
+                        if (!any) continue;
+                        LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->group_fn_[g], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, gi, cur, b);
+                    }
+                } else
                 for (int c = 0; c < q.n_classes; c++) {
                     const Queues::ClassQ& k = q.cls[c];
                     ShadeIn in = {k.ray_o, k.ray_d, k.thr, k.id, k.meta, k.pdf, k.t, k.prim, k.u, k.v, (const uint32_t*)cnt->n_cls[c], nullptr, c};      // (the record comes from Queues::cq, class c)
@@ -1309,6 +1340,16 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
             (long long)sum(8), (long long)sum(9), (long long)sum(10), (long long)sum(11), (long long)sum(12), (long long)sum(13), (long long)sum(14), (long long)sum(15), (long long)r->launches[2], r->kernel_ms[2]);
 #endif
 #ifdef APT_WALK_STATS
+    {
+        unsigned long long wd[2][8], w2[2][8];
+        (void)hipMemcpy(wd, (const char*)r->counters.p + offsetof(Counters, wdbg), sizeof(wd), hipMemcpyDeviceToHost);
+        for (auto& ln : r->extra) { (void)hipMemcpy(w2, (const char*)ln.counters.p + offsetof(Counters, wdbg), sizeof(w2), hipMemcpyDeviceToHost); for (int a = 0; a < 2; a++) for (int k = 0; k < 8; k++) wd[a][k] += w2[a][k]; }
+        for (int a = 0; a < 2; a++) {
+            const double it = (double)(wd[a][0] + wd[a][2]);
+            fprintf(stderr, "[walk sched] %s: node iterations %llu at %.1f lanes, primitive iterations %llu at %.1f lanes, %.1f lanes hold a ray per iteration; %llu refills claiming %.1f rays each\n", a ? "any-hit" : "closest-hit",
+                    wd[a][0], (double)wd[a][1] / std::max(1.0, (double)wd[a][0]), wd[a][2], (double)wd[a][3] / std::max(1.0, (double)wd[a][2]), (double)wd[a][4] / std::max(1.0, it), wd[a][5], (double)wd[a][6] / std::max(1.0, (double)wd[a][5]));
+        }
+    }
     fprintf(stderr, "[walk stats] closest-hit rays %lld: %.2f node steps, %.2f primitive tests per ray | shadow rays %lld: %.2f node steps, %.2f primitive tests per ray\n",
             (long long)out->n_extend, (double)sum(10) / (double)std::max<int64_t>(1, out->n_extend), (double)sum(11) / (double)std::max<int64_t>(1, out->n_extend),
             (long long)out->n_shadow_traced, (double)sum(12) / (double)std::max<int64_t>(1, out->n_shadow_traced), (double)sum(13) / (double)std::max<int64_t>(1, out->n_shadow_traced));

@@ -174,6 +174,9 @@ struct Counters {
 #ifdef APT_SHADE_PROF
     unsigned long long dbg[2 * 16384];           // per-wave (start, end) of the last k_shade launch, 100 MHz ticks
 #endif
+#ifdef APT_WALK_STATS
+    unsigned long long wdbg[2][8];               // walk scheduling, [closest-hit | any-hit]: node iterations, lanes in them, primitive iterations, lanes in them, lanes holding a ray (summed over iterations), refills, lanes claimed, -
+#endif
 };
 
 // meta word: draw index [0,16) | bounce [16,24) | is_specular bit 24
@@ -609,6 +612,9 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 #ifndef APT_VOTE_TRI_WEIGHT
 #define APT_VOTE_TRI_WEIGHT 2      // the vote is "primitive test if (lanes waiting for one) x weight >= lanes waiting for a node step"
 #endif
+#ifndef APT_VOTE_TRI_WEIGHT_SH
+#define APT_VOTE_TRI_WEIGHT_SH APT_VOTE_TRI_WEIGHT      // the any-hit walk's weight (a primitive test that finds an occluder ends the lane's walk)
+#endif
 // after either action: a walking lane with nothing pending and no inner children left takes its next group from the stack, or is finished
 APT_D void walk_settle(const TravStack& ts, int& sp, grp_t& ng, const grp_t& tg, int& state) {
     if (state == 1 && tg.y == 0u && !APT_GROUP_HAS_NODES(ng)) {
@@ -650,6 +656,9 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
     int sp = 0;
     grp_t ng = mk_grp(0u, 0u), tg = mk_grp(0u, 0u);       // node group / triangle group of the ray being walked (traverse.hpp)
     bool exhausted = false;                     // wave-uniform: the work counter has run past the queue
+#ifdef APT_WALK_STATS
+    uint32_t wd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (;;) {
         // ---- hand in finished rays (all lanes take part: the class appends are ballot-compacted)
         const bool fin = state == 2;
@@ -715,6 +724,9 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
                 sp = 0; ng = APT_ROOT_GROUP; state = 1;
             }
             if (base + (uint32_t)__popcll(m) >= n) exhausted = true;
+#ifdef APT_WALK_STATS
+            wd[5]++; wd[6] += (uint32_t)__popcll(__ballot(need && pos < n));
+#endif
         }
         if (!__any(state == 1)) break;
         // ---- walk: the while-while loop of traverse<false>, left as soon as too few lanes still hold a ray
@@ -724,6 +736,9 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
         // or one primitive test for the lanes with some.  Per ray nothing changes - same nodes, same primitives, same order.
         do {
             const bool want_t = state == 1 && tg.y != 0u, want_n = state == 1 && tg.y == 0u;
+#ifdef APT_WALK_STATS
+            { const uint32_t a_ = (uint32_t)__popcll(__ballot(want_t)), b_ = (uint32_t)__popcll(__ballot(want_n)); wd[4] += a_ + b_; if (a_ * APT_VOTE_TRI_WEIGHT >= b_) { wd[2]++; wd[3] += a_; } else { wd[0]++; wd[1] += b_; } }
+#endif
             if (__popcll(__ballot(want_t)) * APT_VOTE_TRI_WEIGHT >= __popcll(__ballot(want_n))) { if (want_t) tri_one<false>(sc.bvh, tg, r, rec, ws); }
             else if (want_n) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
             walk_settle(ts, sp, ng, tg, state);
@@ -740,6 +755,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
     }
 #ifdef APT_WALK_STATS
     flush_stat(ws.nodes, &cnt->stats[sq][10]); flush_stat(ws.prims, &cnt->stats[sq][11]);
+    if (lane_id() == 0) for (int k = 0; k < 7; k++) atomicAdd(&cnt->wdbg[0][k], (unsigned long long)wd[k]);
 #endif
 }
 
@@ -894,7 +910,7 @@ APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Co
 }
 #endif
 template <int BM, int SM, int TEX = 0, int FUSE = 0>
-__global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_LAMBERT_WAVES : APT_SHADE_WAVES))) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
+APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, const ShadeIn& in, int cur, int bounce) {
     constexpr bool CQ = FUSE == 4;                             // input: a packed class queue (Queues::cq); output: the staged pipeline's (as FUSE == 0)
     constexpr int FZ = CQ ? 0 : FUSE;
     const int nxt = cur ^ 1;
@@ -1329,6 +1345,30 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
     if (lane_id() == 0 && s_draws[threadIdx.x >> 6]) atomicAdd(&cnt->stats[sl.q][ST_DRAWS], (unsigned long long)s_draws[threadIdx.x >> 6]);
     flush_uniform(t_poison, &cnt->stats[sl.q][ST_POISON]);
 }
+template <int BM, int SM, int TEX = 0, int FUSE = 0>
+__global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_LAMBERT_WAVES : APT_SHADE_WAVES))) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
+    shade_body<BM, SM, TEX, FUSE>(sc, p, q, cnt, in, cur, bounce);
+}
+
+// ---- class kernels in groups: ONE launch shades several material classes.
+// A class-sorted bounce was one launch per class (C5: 8 x 16 per batch), and a launch costs its lane 15-30 us however short its queue -
+// the pipeline drains, the next grid is dispatched, 1024 workgroups read their queue lengths: most of C5's shade time, a tenth of C3's.
+// The classes of a bounce are independent, so a group kernel walks the class queues of its members one after the other - every workgroup
+// its sub-queue of class A, then of class B, ... with no barrier in between: a workgroup that runs out of A entries starts on B while
+// others still shade A - and the launch boundary between them is gone.  A kernel's register allocation is the maximum over its members',
+// so the groups follow the footprints (api.hip kClassGroup): <= 128 VGPRs / four waves per SIMD (Lambertian, delta, lobe-free Blinn-Phong,
+// Lambertian transmission), <= 168 / three (Blinn-Phong, Oren-Nayar, thin coat, microfacet), beyond / two (modified Phong, Fresnel blend).
+// Members absent from the scene are skipped by a wave-uniform test (GroupIn::cls < 0).  Per vertex nothing changes: same class code, same
+// queues, same order inside a queue - images and statistics are those of the one-launch-per-class schedule bit for bit (GPU test).
+struct GroupIn { const uint32_t* counts[4]; int cls[4]; };     // per member: the class queue's per-sub-queue entry counts, its compact class id (-1: not in this scene)
+template <int SM, int WAVES, int B0, int B1, int B2, int B3>
+__global__ void __launch_bounds__(BLOCK, WAVES) k_shade_group(DevScene sc, Params p, Queues q, Counters* cnt, GroupIn g, int cur, int bounce) {
+    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    if constexpr (B0 != 0) if (g.cls[0] >= 0) { in.counts = g.counts[0]; in.cls = g.cls[0]; shade_body<B0, SM, 0, 4>(sc, p, q, cnt, in, cur, bounce); }
+    if constexpr (B1 != 0) if (g.cls[1] >= 0) { in.counts = g.counts[1]; in.cls = g.cls[1]; shade_body<B1, SM, 0, 4>(sc, p, q, cnt, in, cur, bounce); }
+    if constexpr (B2 != 0) if (g.cls[2] >= 0) { in.counts = g.counts[2]; in.cls = g.cls[2]; shade_body<B2, SM, 0, 4>(sc, p, q, cnt, in, cur, bounce); }
+    if constexpr (B3 != 0) if (g.cls[3] >= 0) { in.counts = g.counts[3]; in.cls = g.cls[3]; shade_body<B3, SM, 0, 4>(sc, p, q, cnt, in, cur, bounce); }
+}
 
 // ------------------------------------------------------------------- shadow
 template <int MODE>
@@ -1395,6 +1435,9 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
     grp_t ng = mk_grp(0u, 0u), tg = mk_grp(0u, 0u);
     bool exhausted = false;
     uint32_t t_lit = 0;
+#ifdef APT_WALK_STATS
+    uint32_t wd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (;;) {
         if (state == 2) {
             f3 c = mk3(park[0], park[BLOCK], park[2 * BLOCK]);      // (contribution and slot were fetched with the ray - coalesced - and have waited in LDS: k_extend_dyn)
@@ -1422,13 +1465,19 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
                 occluded = false; sp = 0; ng = APT_ROOT_GROUP; state = 1;
             }
             if (base + (uint32_t)__popcll(m) >= n) exhausted = true;
+#ifdef APT_WALK_STATS
+            wd[5]++; wd[6] += (uint32_t)__popcll(__ballot(need && pos < n));
+#endif
         }
         if (!__any(state == 1)) break;
         const uint32_t min_active = exhausted ? 1u : (uint32_t)APT_DYN_MIN_ACTIVE_SH;
 #if APT_WALK_VOTE
         do {
             const bool want_t = state == 1 && tg.y != 0u, want_n = state == 1 && tg.y == 0u;
-            if (__popcll(__ballot(want_t)) * APT_VOTE_TRI_WEIGHT >= __popcll(__ballot(want_n))) {
+#ifdef APT_WALK_STATS
+            { const uint32_t a_ = (uint32_t)__popcll(__ballot(want_t)), b_ = (uint32_t)__popcll(__ballot(want_n)); wd[4] += a_ + b_; if (a_ * APT_VOTE_TRI_WEIGHT_SH >= b_) { wd[2]++; wd[3] += a_; } else { wd[0]++; wd[1] += b_; } }
+#endif
+            if (__popcll(__ballot(want_t)) * APT_VOTE_TRI_WEIGHT_SH >= __popcll(__ballot(want_n))) {
                 if (want_t && tri_one<true>(sc.bvh, tg, r, rec, ws)) { occluded = true; sp = 0; ng.y = 0u; tg.y = 0u; }      // first occluder ends the walk
             } else if (want_n) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
             walk_settle(ts, sp, ng, tg, state);
@@ -1446,6 +1495,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
     flush_stat(t_lit, &cnt->stats[sq][ST_LIT]);
 #ifdef APT_WALK_STATS
     flush_stat(ws.nodes, &cnt->stats[sq][12]); flush_stat(ws.prims, &cnt->stats[sq][13]);
+    if (lane_id() == 0) for (int k = 0; k < 7; k++) atomicAdd(&cnt->wdbg[1][k], (unsigned long long)wd[k]);
 #endif
 }
 

@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(BLOCK, (((BM == 0x402 || BM == 0x00a || BM == 
                 st3q(q.sh_d, sc_, so, light_dir);
                 stq(q.sh_tmax, so, emitter_d);
                 st3q(q.sh_c, sc_, so, contrib);
-                stq(q.sh_id, so, l_off);
+                stq(q.sh_id, so, l_off | ((p.l_planes > 1) ? (uint32_t)s : 0u));      // (the sample's radiance plane rides in the slot word's low bits, as in k_shade)
             }
         }
 
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(VSHADOW_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAV
             }
             if (arrived || blocked) {
                 if (!(c.x == 0.f && c.y == 0.f && c.z == 0.f)) {
-                    add_radiance(q.L, p.cap, ldq(q.sh_id, io), c, false);
+                    add_radiance(q.L, p.cap, ldq(q.sh_id, io), c, APT_EXCLUSIVE_L(p));      // (one radiance plane per light sample of a vertex, or one sample: no two entries of a launch share a slot)
                 }
                 if (arrived) t_lit++;
             }
@@ -486,6 +486,93 @@ __global__ void __launch_bounds__(VSHADOW_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAV
     flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);
     flush_stat(t_track, &cnt->stats[sl.q][ST_TRACK]);
 }
+
+#if APT_FAST
+// track_ray on the flat sweep (product build, scenes of up to APT_FLAT_MAX_PRIMS primitives): TWO light samples per lane - the two halves of
+// every packed instruction of the sweep (traverse.hpp flat_closest2).  k_vshadow<tile> tests a lane's one ray with the reference's
+// arithmetic through workgroup lists in LDS; this kernel keeps its pass structure (pass 0 reads the queue, pass p the slot list of the
+// samples that crossed a null surface in pass p - 1: a sweep is wave-uniform over the records, so the survivors have to be packed densely
+// again or later segments cost what the first one did - measured with all segments in one launch: V1 walk 38.5 -> 33.0 ms only) and
+// replaces the intersector.  Per sample the arithmetic after the hit is k_vshadow's; the hit itself is the flat sweep's (t
+// within 1e-5 relative, same primitive unless tied; coplanar near-ties and zero-component directions settled by the reference-order code
+// inside flat_closest2).
+__global__ void __launch_bounds__(BLOCK) k_vshadow_flat(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan, int pass) {
+    const SubLoop sl = sub_loop(p.nq, FLAT_NT);
+    const uint32_t n = min(pass == 0 ? cnt->n_shadow[sl.q * CNT_PAD] : cnt->n_walk[pass][sl.q * CNT_PAD], q.sh_subcap);
+    if (pass == 0 && sl.first == 0 && threadIdx.x == 0) {
+        cnt->stats[sl.q][ST_SHADOW_TRACED] += n;
+        for (int c = 0; c < q.n_classes; c++) cnt->n_cls[c][sl.q * CNT_PAD] = 0;      // every shade of this iteration is done
+    }
+    const uint32_t qbase = (uint32_t)sl.q * q.sh_subcap, sc_ = q.sh_cap;
+    const uint32_t* list_in = q.sh_walk[pass & 1];
+    uint32_t* list_out = q.sh_walk[(pass + 1) & 1];
+    uint32_t* next_counter = &cnt->n_walk[pass + 1][sl.q * CNT_PAD];
+    const f3 world_ue = sc.med[sc.n_objects].u_e;
+    const bool world_scat = sc.med[sc.n_objects].type >= 0;
+    const bool excl = APT_EXCLUSIVE_L(p);
+    uint32_t t_lit = 0, t_track = 0;
+    // one segment of one sample, given its closest hit (k_vshadow's per-sample block); returns true when the sample has to walk on
+    auto segment = [&](bool valid, f3& o, const f3& d, float& depth, f3& c, const HitRec& rec, uint32_t io) -> bool {
+        if (!valid) return false;
+        t_track++;
+        int obj = -1; bool in_free = true, blocked = false, arrived = false, walk_on = false; float seg = depth;
+        if (rec.prim < 0) { if (!world_scat) arrived = true; }             // nothing in the way and nothing to attenuate: done
+        else {
+            obj = sc.prim_obj[rec.prim];
+            if (vpt_non_null(sc, obj)) blocked = true;
+            else {
+                Hit it; build_hit(sc, rec.prim, rec.t, rec.u, rec.v, o, d, it);
+                in_free = dot(it.n_g, d) < 0.f;
+                seg = rec.t;
+            }
+        }
+        if (blocked) c = c * 0.f;                                           // NaN for a non-finite c, exactly as upstream's 0 * x
+        else if (!arrived) {
+            // get_transmittance, vpt.py:52-62
+            if (in_free && world_scat) c = c * exp_neg(world_ue, seg);
+            else if (!in_free && vpt_is_scattering(sc, obj)) c = c * exp_neg(sc.med[obj].u_e, seg);
+            o = o + d * seg;
+            depth -= seg;
+            if (depth <= 5e-5f || pass >= 6) arrived = true;                // at the light, or the seventh segment (vpt.py:113)
+            else walk_on = true;
+        }
+        if (arrived || blocked) {
+            if (!(c.x == 0.f && c.y == 0.f && c.z == 0.f)) add_radiance(q.L, p.cap, ldq(q.sh_id, io), c, excl);
+            if (arrived) t_lit++;
+        }
+        return walk_on;
+    };
+    for (uint32_t base = sl.first; base < n; base += sl.stride) {
+        const uint32_t pos = base + 2u * threadIdx.x;
+        const bool v0 = pos < n, v1 = pos + 1u < n;
+        uint32_t i0 = qbase + (v0 ? pos : n - 1u), i1 = qbase + (v1 ? pos + 1u : n - 1u);
+        if (pass > 0) { i0 = ldq(list_in, i0 << 2); i1 = ldq(list_in, i1 << 2); }      // slots of samples that are still walking
+        const uint32_t io0 = i0 << 2, io1 = i1 << 2;
+        f3 o0 = ld3q(q.sh_o, sc_, io0), o1 = ld3q(q.sh_o, sc_, io1);
+        const f3 d0 = ld3q(q.sh_d, sc_, io0), d1 = ld3q(q.sh_d, sc_, io1);
+        float depth0 = ldq(q.sh_tmax, io0), depth1 = ldq(q.sh_tmax, io1);
+        f3 c0 = ld3q(q.sh_c, sc_, io0), c1 = ld3q(q.sh_c, sc_, io1);
+        HitRec r0, r1; int k0, k1;
+        r0.t = (depth0 > 0.0f) ? depth0 - 1e-4f : 1e7f; r0.prim = -1; r0.u = r0.v = 0.f;
+        r1.t = (depth1 > 0.0f) ? depth1 - 1e-4f : 1e7f; r1.prim = -1; r1.u = r1.v = 0.f;
+        flat_closest2(sc.flat, sc.sweep, sc.prim_class, o0, d0, o1, d1, r0, r1, k0, k1);
+        const bool on0 = segment(v0, o0, d0, depth0, c0, r0, io0);
+        const bool on1 = segment(v1, o1, d1, depth1, c1, r1, io1);
+        if (list_out != nullptr) {
+            // both entries of the lane with ONE tail atomic per wave: the wave's first entries, then its second ones
+            const unsigned long long m0 = __ballot(on0), m1 = __ballot(on1);
+            uint32_t tail = 0;
+            if (lane_id() == 0 && (m0 | m1)) tail = atomicAdd(next_counter, (uint32_t)(__popcll(m0) + __popcll(m1)));
+            tail = (uint32_t)__builtin_amdgcn_readlane((int)tail, 0);
+            const uint32_t w0 = tail + rank_in(m0), w1 = tail + (uint32_t)__popcll(m0) + rank_in(m1);
+            if (on0 && w0 < q.sh_subcap) { st3q(q.sh_o, sc_, io0, o0); stq(q.sh_tmax, io0, depth0); st3q(q.sh_c, sc_, io0, c0); stq(list_out, (qbase + w0) << 2, i0); }
+            if (on1 && w1 < q.sh_subcap) { st3q(q.sh_o, sc_, io1, o1); stq(q.sh_tmax, io1, depth1); st3q(q.sh_c, sc_, io1, c1); stq(list_out, (qbase + w1) << 2, i1); }
+        }
+    }
+    flush_stat(t_lit, &cnt->stats[sl.q][ST_LIT]);
+    flush_stat(t_track, &cnt->stats[sl.q][ST_TRACK]);
+}
+#endif
 
 // ------------------------------------------------------- unit entry kernel
 // Medium functions on explicit inputs (parity probe): one medium row and 7 input floats per test, 8 output floats; RNG = Philox

@@ -109,6 +109,16 @@ def image_metrics(a, b):
     return {"relMSE": float(rel), "max_abs": float(np.abs(a - b).max()), "frac_within": float(within)}
 
 
+def record_metric(name, values):
+    """Measured parity figures of a GPU test, one JSON line each, into the file APT_TEST_METRICS_LOG names (unset: nothing is written).
+    The tolerances in the tests are these measurements with a stated margin; the log of record is profiles/r0N_parity_metrics.log."""
+    path = os.environ.get("APT_TEST_METRICS_LOG")
+    if path:
+        import json
+        with open(path, "a") as f:
+            f.write(json.dumps({"test": name, **{k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in values.items()}}) + "\n")
+
+
 # ---- the reference's own bundled scenes, as arrays (tests/golden/refscene_*.npz; the XML files stay in /root/reference)
 VPT_SCENE_TAGS = sorted(f[len("vptscene_"):-4] for f in os.listdir(GOLDEN) if f.startswith("vptscene_") and f.endswith(".npz"))
 REF_SCENE_TAGS = sorted(f[len("refscene_"):-4] for f in os.listdir(GOLDEN) if f.startswith("refscene_") and f.endswith(".npz"))

@@ -19,7 +19,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import SCENES, golden, image_metrics
+from conftest import SCENES, golden, image_metrics, record_metric
 from adapt_amd.scene_pack import make_config
 
 pytestmark = pytest.mark.gpu
@@ -180,6 +180,30 @@ def test_full_size_parity_c2_c3_product_build(tag, spp, renderer, parsed, oracle
         assert abs(st[k] - ost[k]) <= 5e-4 * ost[k], (k, st[k], ost[k])
     # non-finite pixels (upstream lets +inf through, vanilla_renderer.py:119): the oracle's, or zero-pdf knife-edges and nothing else
     if not np.array_equal(np.isfinite(acc), np.isfinite(ref)):
+        ok, findings = oracle_scene(tag).explain_non_finite(rc, acc, ref, spp)
+        assert ok, findings
+
+
+def test_c2_full_frame_every_pixel_128_spp_product_build(renderer, parsed, oracle_scene):
+    """BASELINE configs[1] at its full film size and bounce count, 128 of its 1024 spp, product build against the oracle on the same Philox
+    stream, EVERY pixel (~5 s of the box's host threads: un-gated, unlike the 1024-spp comparison above).  SURVEY 8(d) asks for 99 % of the
+    pixels within 1e-3 (1 + x) and relMSE 1e-4; the run of record at 1024 spp measured 99.96 % and 5.3e-8, and the bounds here are
+    that measurement with a margin of two."""
+    from oracle import binding as ob
+    tag, spp = "cbox", 128
+    r = renderer(tag)
+    assert (r.w, r.h) == (512, 512) and r.info()["arithmetic"] == "fast" and r.info()["traversal"] == "flat"
+    r.render(n_spp=spp)
+    acc, st = r.color.to_numpy(), r.stats()
+    rc = make_config(parsed(tag)[3])
+    ref, cnt, ost = oracle_scene(tag).render(rc, spp, threads=ob.num_threads())
+    fin = np.isfinite(acc).all(axis=2) & np.isfinite(ref).all(axis=2)
+    m = image_metrics(np.where(fin[..., None], acc, 0) / spp, np.where(fin[..., None], ref, 0) / spp)
+    record_metric("c2 full frame 128 spp product build", dict(m, n_shade=st["n_shade"], n_shade_oracle=ost["n_shade"], non_finite=int((~fin).sum())))
+    assert m["frac_within"] >= 0.998 and m["relMSE"] <= 2e-6, m
+    for k in ("n_shade", "n_shadow", "n_draws"):
+        assert abs(st[k] - ost[k]) <= 2e-5 * ost[k], (k, st[k], ost[k])
+    if not np.array_equal(np.isfinite(acc), np.isfinite(ref)):                   # zero-pdf knife-edges and nothing else (DESIGN section 5)
         ok, findings = oracle_scene(tag).explain_non_finite(rc, acc, ref, spp)
         assert ok, findings
 
@@ -396,18 +420,22 @@ def test_rays_with_a_zero_direction_component_get_the_reference_answer(renderer,
 
 
 # tag, width, height, spp, overrides, min fraction of pixels within 1e-3 (1 + |x|), max relMSE.
-# C1 (the config the tolerance is stated on) and the other diffuse Cornell renders hold the per-pixel criterion; scenes with glass,
-# mirrors or glossy lobes are chaotic in the hit point and are held to relMSE (measured on MI355X: 2e-5 .. 1.7e-3 at these sizes).
+# C1 (the config the tolerance is stated on) and the other diffuse Cornell renders hold SURVEY 8(d)'s per-pixel criterion with room to spare;
+# scenes with glass, mirrors or glossy lobes are chaotic in the hit point (an ulp in a hit is amplified by every bounce and re-draws the
+# path).  Every bound is the value MEASURED on MI355X (round 5, profiles/r05_parity_metrics.log; the GPU path is bit-reproducible, so
+# the measurement is a property of the build) with a margin of two on the failing fraction and on relMSE:
+#   measured: cbox 256 99.945 % / 2.9e-7, cbox 96 99.946 % / 5.2e-7, balls_mono 99.71 % / 3.8e-7, glass_box 96.8 % / 2.6e-5, features_a
+#   91.2 % / 7.3e-5, features_b 93.2 % / 3.7e-4, features_c 92.2 % / 8.7e-5, textured 98.0 % / 1.4e-4, microfacet 99.67 % / 5.5e-6
 IMAGE_CASES = [
-    ("cbox", 256, 256, 64, {"max_bounce": 4}, 0.99, 1e-4),
-    ("cbox", 96, 96, 64, {}, 0.99, 1e-4),
-    ("balls_mono", 96, 96, 64, {}, 0.95, 1e-4),
-    ("glass_box", 96, 96, 64, {}, 0.94, 2e-4),
-    ("features_a", 96, 96, 64, {}, 0.85, 1e-3),
-    ("features_b", 96, 96, 64, {}, 0.85, 2e-3),
-    ("features_c", 96, 96, 64, {}, 0.85, 5e-3),
-    ("textured", 64, 48, 16, {}, 0.93, 2e-3),           # (its normal-mapped wall sends out rays that are not of unit length: traverse.hpp flat_needs_cull)
-    ("microfacet", 64, 48, 16, {}, 0.95, 1e-3),
+    ("cbox", 256, 256, 64, {"max_bounce": 4}, 0.9989, 6e-7),
+    ("cbox", 96, 96, 64, {}, 0.9989, 1.1e-6),
+    ("balls_mono", 96, 96, 64, {}, 0.994, 8e-7),
+    ("glass_box", 96, 96, 64, {}, 0.936, 5.5e-5),
+    ("features_a", 96, 96, 64, {}, 0.824, 1.5e-4),
+    ("features_b", 96, 96, 64, {}, 0.863, 7.5e-4),
+    ("features_c", 96, 96, 64, {}, 0.843, 1.8e-4),
+    ("textured", 64, 48, 16, {}, 0.96, 3e-4),           # (its normal-mapped wall sends out rays that are not of unit length: traverse.hpp flat_needs_cull)
+    ("microfacet", 64, 48, 16, {}, 0.993, 1.2e-5),
 ]
 
 
@@ -421,6 +449,7 @@ def test_image_matches_oracle_same_stream(tag, w, h, spp, ov, min_within, max_re
     from oracle import binding as ob
     ref, cnt, ost = oracle_scene(tag).render(rc, spp, threads=ob.num_threads())
     m = image_metrics(acc / spp, ref / spp)
+    record_metric(f"image_case {tag} {w}x{h}x{spp} {ov}", m)
     assert m["frac_within"] >= min_within and m["relMSE"] <= max_rel, m
     assert st["n_samples"] == ost["n_samples"] == w * h * spp
     for k in ("n_shade", "n_shadow", "n_draws"):                              # no systematic deviation: coplanar faces, NaN slabs and the like are reproduced
@@ -607,13 +636,13 @@ def test_full_size_c4_crop_product_build_vs_brute_force_oracle():
     """BASELINE configs[3] at full geometry on the build bench.py measures (its BVH walk may differ from the exact build's inside SURVEY
     8(d)'s intersector tolerance: this is the test that holds it to the oracle, not a tie to the exact build on a toy scene)."""
     from gpu_cases import c4_crop_vs_brute_force_oracle
-    assert c4_crop_vs_brute_force_oracle(within=0.985, rel=3e-4)["arithmetic"] == "fast"
+    assert c4_crop_vs_brute_force_oracle(within=0.999, rel=1e-8)["arithmetic"] == "fast"          # (measured: 100 %, 3.9e-12)
 
 
 @pytest.mark.parametrize("cx,cy", [(640, 360), (330, 250), (930, 200)])
 def test_full_size_c5_crop_product_build_vs_brute_force_oracle(cx, cy):
     from gpu_cases import c5_crop_vs_brute_force_oracle
-    assert c5_crop_vs_brute_force_oracle(cx, cy, within=0.985, rel=3e-4)["arithmetic"] == "fast"
+    assert c5_crop_vs_brute_force_oracle(cx, cy, within=0.999, rel=3e-6)["arithmetic"] == "fast"          # (measured, worst of the three windows: 99.967 %, 1.2e-6)
 
 
 @pytest.mark.parametrize("tag,mode", [("cbox", "tile"), ("balls_mono", "sweep"), ("features_b", "tile"), ("glass_box", "sweep"), ("features_a", "sweep")])
@@ -791,3 +820,55 @@ def test_nine_material_classes_on_the_tree_lose_no_hits(monkeypatch):
             assert abs(sf[key] - se[key]) <= max(2e-3 * se[key], 50), (key, sf[key], se[key])
     finally:
         f.close(); e.close()
+
+
+@pytest.mark.parametrize("which,exact", [("balls_mono", False), ("features_b", False), ("bunny_field1", False), ("balls_mono", True)])
+def test_group_launches_render_the_per_class_schedule_bit_for_bit(which, exact, parsed, monkeypatch):
+    """Class kernels launched in register-footprint groups (stages.hpp k_shade_group: one launch per group and bounce, its workgroups walk
+    the member classes' queues one after the other) against one launch per class (APT_SHADE_GROUPS=0): the same class code over the same
+    queues in the same order inside a queue - the image and every path statistic are equal to the last bit."""
+    from adapt_amd.renderer import Renderer
+    from adapt_amd.synth import bunny_field
+    tup = bunny_field(levels=1) if which == "bunny_field1" else parsed(which)
+    out = {}
+    for groups in ("1", "0"):
+        monkeypatch.setenv("APT_SHADE_GROUPS", groups)
+        r = Renderer(*tup, width=96, height=64, exact=exact)
+        try:
+            assert ("groups" in r.info()["shade_variant"]) == (groups == "1"), r.info()["shade_variant"]
+            r.render(n_spp=6)
+            out[groups] = (r.color.to_numpy().copy(), r.stats())
+        finally:
+            r.close()
+    assert np.array_equal(out["1"][0], out["0"][0], equal_nan=True)
+    for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"):
+        assert out["1"][1][k] == out["0"][1][k], (k, out["1"][1][k], out["0"][1][k])
+    assert out["1"][1]["launches"]["shade"] < out["0"][1]["launches"]["shade"]
+
+
+@pytest.mark.parametrize("tag", ["vpt_cbox", "media_a"])
+def test_flat_transmittance_walk_against_the_tiled_walk(tag, monkeypatch):
+    """k_vshadow_flat (two light samples per lane on the flat sweep) against the walk it replaces in
+    the product build (APT_VSHADOW_FLAT=0: k_vshadow<tile / sweep>, the reference's arithmetic) on the same stream:
+    the same samples are followed (n_shadow_traced equal), segments walked and samples that arrive agree to 1e-3 (a hit within an ulp of
+    the light or of a null surface may fall on the other side), the images to the product build's per-pixel tolerance."""
+    from conftest import scene_from_golden
+    from adapt_amd.renderer import VolumeRenderer
+    tup, g = scene_from_golden(tag, "vptscene")
+    w, h = int(g["width"]), int(g["height"])
+    out = {}
+    for flat in ("1", "0"):
+        monkeypatch.setenv("APT_VSHADOW_FLAT", flat)
+        r = VolumeRenderer(*tup, width=w, height=h)
+        try:
+            assert r.info()["arithmetic"] == "fast"
+            r.render(n_spp=24)
+            out[flat] = (r.color.to_numpy() / 24, r.stats())
+        finally:
+            r.close()
+    a, b = out["1"], out["0"]
+    assert a[1]["n_shadow_traced"] == b[1]["n_shadow_traced"] and a[1]["n_shade"] == b[1]["n_shade"] and a[1]["n_draws"] == b[1]["n_draws"]
+    for k in ("n_track", "n_lit"):
+        assert abs(a[1][k] - b[1][k]) <= max(1e-3 * b[1][k], 20), (k, a[1][k], b[1][k])
+    m = image_metrics(a[0], b[0])
+    assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-4, m
