@@ -909,21 +909,46 @@ APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Co
     if (lane_id() == 0) __hip_atomic_store(&cnt->fix_done[sq * CNT_PAD], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif
+// The shade kernels' scalar operands.  Scene, parameters and queues arrive by value in the kernel-argument segment - ~1.8 KB, of which a
+// tile row touches ~165 dwords - and left alone the compiler loads every field it needs ONCE, in front of the row loop, where 102 scalar
+// registers cannot hold them: the rest lives in lanes of two spill VGPRs and comes back through v_readlane at every use (242 of the 2 200
+// VALU instructions of C2's row loop - on the unit this kernel is bound by).  So the arguments are read THROUGH THE SEGMENT POINTER, and
+// the pointer is made opaque at the head of every phase of a row (an empty asm: APT_ARGS_PHASE): a field's load can then not be hoisted
+// above the phase that uses it, it becomes an s_load (scalar memory, not a VALU issue slot; the segment stays in the scalar cache) next
+// to its use, and its register is free again after the phase.
+#ifndef APT_ARGS_RELOAD
+#define APT_ARGS_RELOAD 1
+#endif
+struct ShadeArgs3 { DevScene sc; Params p; Queues q; };          // the leading arguments of every shade kernel, laid out as the segment lays them out
+typedef const __attribute__((address_space(4))) ShadeArgs3* args3_ptr;
+APT_D args3_ptr kernel_args3() { return (args3_ptr)__builtin_amdgcn_kernarg_segment_ptr(); }
+APT_D const ShadeArgs3* args_fresh(args3_ptr a) {
+#if APT_ARGS_RELOAD
+    asm volatile("" : "+s"(a));
+#endif
+    return (const ShadeArgs3*)a;
+}
+#if APT_ARGS_RELOAD
+#define APT_ARGS_PHASE() (A_ = args_fresh(A0))
+#else
+#define APT_ARGS_PHASE() ((void)0)
+#endif
 template <int BM, int SM, int TEX = 0, int FUSE = 0>
-APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, const ShadeIn& in, int cur, int bounce) {
+APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, int bounce) {
+    const ShadeArgs3* A_ = args_fresh(A0);                      // scene, parameters, queues: read through the kernel-argument segment, re-fetched per phase (APT_ARGS_PHASE)
     constexpr bool CQ = FUSE == 4;                             // input: a packed class queue (Queues::cq); output: the staged pipeline's (as FUSE == 0)
     constexpr int FZ = CQ ? 0 : FUSE;
     const int nxt = cur ^ 1;
-    const SubLoop sl = sub_loop(p.nq);
+    const SubLoop sl = sub_loop((A_->p).nq);
     uint32_t n = (FZ >= 2) ? 0u : in.counts[sl.q * CNT_PAD];
-    const uint32_t qbase = (uint32_t)sl.q * p.subcap, sh_qbase = (uint32_t)sl.q * q.sh_subcap;
+    const uint32_t qbase = (uint32_t)sl.q * (A_->p).subcap, sh_qbase = (uint32_t)sl.q * (A_->q).sh_subcap;
     uint32_t* next_counter = (FZ >= 2) ? &cnt->n_tr[(bounce + 1) % 3][0][sl.q * CNT_PAD] : &cnt->n_active[nxt][sl.q * CNT_PAD];      // (FZ == 2: the first queue's tail)
     if (FZ >= 2 && sl.first == 0 && threadIdx.x == 0) {      // (read by the previous bounce, appended to by the next one)
         cnt->n_tr[(bounce + 2) % 3][in.cls][sl.q * CNT_PAD] = 0;
-        if (in.cls == 0) cnt->n_tr[(bounce + 2) % 3][q.tr_ncls][sl.q * CNT_PAD] = 0;
+        if (in.cls == 0) cnt->n_tr[(bounce + 2) % 3][(A_->q).tr_ncls][sl.q * CNT_PAD] = 0;
     }
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
-    const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
+    const EmitterGeom geom = {(A_->sc).precom, (A_->sc).normals, (A_->sc).obj_info};
     uint32_t t_shade = 0, t_shadow = 0, t_poison = 0, t_traced = 0, t_lit = 0;        // wave-uniform tallies (SGPRs)
     __shared__ uint32_t s_draws[BLOCK / 64];                  // RNG draws of this wave: a per-lane tally would hold a VGPR for the whole kernel
     if (lane_id() == 0) s_draws[threadIdx.x >> 6] = 0;
@@ -945,9 +970,9 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
     constexpr bool MULTI = FZ == 3;                         // ... FZ = 2: one queue (unsorted), one light sample per vertex - the kernel of C1 / C2, which carries nothing else; FZ = 3: queues by material class, any number of light samples
     static_assert(APT_FLAT_MAX_PRIMS < (int)TR_NO_PRIM, "the packed record keeps the hit primitive in 8 bits");
     constexpr bool PK = TRACE || CQ;                           // the input record is four 16-byte planes
-    const uint32_t in_base = PK ? (uint32_t)in.cls * p.cap + qbase : qbase;      // first slot of the queue this workgroup reads
-    const float4* trA = TRACE ? q.tr[cur][0] : (CQ ? q.cq[0] : nullptr); const float4* trB = TRACE ? q.tr[cur][1] : (CQ ? q.cq[1] : nullptr);
-    const float4* trC = TRACE ? q.tr[cur][2] : (CQ ? q.cq[2] : nullptr); const float4* trD = TRACE ? q.tr[cur][3] : (CQ ? q.cq[3] : nullptr);
+    const uint32_t in_base = PK ? (uint32_t)in.cls * (A_->p).cap + qbase : qbase;      // first slot of the queue this workgroup reads
+    const float4* trA = TRACE ? (A_->q).tr[cur][0] : (CQ ? (A_->q).cq[0] : nullptr); const float4* trB = TRACE ? (A_->q).tr[cur][1] : (CQ ? (A_->q).cq[1] : nullptr);
+    const float4* trC = TRACE ? (A_->q).tr[cur][2] : (CQ ? (A_->q).cq[2] : nullptr); const float4* trD = TRACE ? (A_->q).tr[cur][3] : (CQ ? (A_->q).cq[3] : nullptr);
     int pf_prim = -1; float pf_t = 0.f; f3 pf_o = splat3(0.f), pf_d = splat3(0.f), pf_thr = splat3(0.f); uint32_t pf_id = 0, pf_meta = 0;      // (TRACE: pf_prim holds the packed word pm)
     auto prefetch = [&](uint32_t b) {            // straight-line loads (lanes past the end re-read the last entry: never used), so that no wait lands at the end of a branch
         const uint32_t ps = min(b + threadIdx.x, n - 1u);
@@ -959,7 +984,7 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
         }
         const uint32_t pio = (qbase + ps) << 2;
         pf_prim = ldq(in.prim, pio); pf_t = ldq(in.t, pio);
-        pf_o = ld3q(in.ray_o, p.cap, pio); pf_d = ld3q(in.ray_d, p.cap, pio); pf_thr = ld3q(in.thr, p.cap, pio);
+        pf_o = ld3q(in.ray_o, (A_->p).cap, pio); pf_d = ld3q(in.ray_d, (A_->p).cap, pio); pf_thr = ld3q(in.thr, (A_->p).cap, pio);
         pf_id = ldq(in.id, pio); pf_meta = ldq(in.meta, pio);
     };
     // the kernels without registers for that (material classes: 124-128 VGPRs) prefetch only the hit primitive - one register - so that a
@@ -968,7 +993,7 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
     uint32_t t_extend = 0;
 #if APT_FAST
     if (TRACE) {
-        fix_prologue(sc, p, q, cnt, cur, sl.q, bounce);       // before the queue's length is read: the prologue may append to it
+        fix_prologue((A_->sc), (A_->p), (A_->q), cnt, cur, sl.q, bounce);       // before the queue's length is read: the prologue may append to it
         n = __hip_atomic_load(&cnt->n_tr[bounce % 3][in.cls][sl.q * CNT_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
@@ -983,6 +1008,7 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
         unsigned long long stick_ = __builtin_readcyclecounter();
         sprof[7] += 1;
 #endif
+        APT_ARGS_PHASE();
         const uint32_t pos = base + threadIdx.x;
         const uint32_t idx = in_base + pos;
         bool alive = pos < n;
@@ -991,14 +1017,14 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
         float4 cu_ra = make_float4(0.f, 0.f, 0.f, 0.f), cu_rb = cu_ra; uint32_t cu_key = 0;
         if (PFP) {
             const int rp = max(cu_prim, 0);
-            cu_ra = sc.prim_shade[2 * rp]; cu_rb = sc.prim_shade[2 * rp + 1];
+            cu_ra = (A_->sc).prim_shade[2 * rp]; cu_rb = (A_->sc).prim_shade[2 * rp + 1];
             prefetch_prim(base + sl.stride);
         }
         if (PF) {
             const int rp = max(cu_prim, 0);
-            cu_ra = sc.prim_shade[2 * rp]; cu_rb = sc.prim_shade[2 * rp + 1];
-            cu_key = cu_id & ((1u << p.pix_bits) - 1u);
-            if (p.world != 1) cu_key = ldq(p.pix_key, cu_key << 2);     // (multi-GPU: the pixel's global key; requested here for the same reason)
+            cu_ra = (A_->sc).prim_shade[2 * rp]; cu_rb = (A_->sc).prim_shade[2 * rp + 1];
+            cu_key = cu_id & ((1u << (A_->p).pix_bits) - 1u);
+            if ((A_->p).world != 1) cu_key = ldq((A_->p).pix_key, cu_key << 2);     // (multi-GPU: the pixel's global key; requested here for the same reason)
             __builtin_amdgcn_sched_barrier(0);                 // the record first, then the prefetch: the wait for the record must not include the prefetch
             prefetch(base + sl.stride);
             __builtin_amdgcn_sched_barrier(0);
@@ -1014,7 +1040,7 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
             if (alive && bounce > 0) { const float4 dd = ldq(trD, idx << 4); Lc = mk3(dd.x, dd.y, dd.z); if (SM & 2) ray_pdf = dd.w; }
             if (alive && bounce > 0) id = PF ? cu_id : __float_as_uint(ldq(reinterpret_cast<const float*>(trC), (idx << 4) + 12u));
         } else {
-        if (FZ && alive && bounce > 0) Lc = ld3q(in.Lc, p.cap, idx << 2);
+        if (FZ && alive && bounce > 0) Lc = ld3q(in.Lc, (A_->p).cap, idx << 2);
         if (FZ && alive && bounce > 0) id = PF ? cu_id : ldq(in.id, idx << 2);
         }
         bool was_spec = false;
@@ -1039,58 +1065,58 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
                     o = mk3(a.x, a.y, a.z); tr_t_in = a.w; d = mk3(b_.x, b_.y, b_.z); thr = mk3(c.x, c.y, c.z); id = __float_as_uint(c.w);
                     meta = __float_as_uint(dd.x); if (SM & 2) ray_pdf = dd.y; tr_uv_in.x = dd.z; tr_uv_in.y = dd.w;
                 } else {
-                    o = ld3q(in.ray_o, p.cap, io);
-                    d = ld3q(in.ray_d, p.cap, io);
-                    thr = ld3q(in.thr, p.cap, io);
+                    o = ld3q(in.ray_o, (A_->p).cap, io);
+                    d = ld3q(in.ray_d, (A_->p).cap, io);
+                    thr = ld3q(in.thr, (A_->p).cap, io);
                     id = ldq(in.id, io);
                     meta = ldq(in.meta, io);
                 }
                 if ((SM & 2) && !PK) ray_pdf = ldq(in.pdf, io);          // (its only reader is the emission MIS weight: scenes without area lights never look at it)
                 was_spec = (meta >> 24) & 1u;
                 f3 rec_kd;
-                const bool need_uv = sc.has_vn || (TEX && sc.tex_i != nullptr);      // otherwise nobody reads the barycentrics (and the flat extend kernel does not write them)
-                if (TRACE && need_uv && !PF) tr_uv_in = ldq(q.tr_uv[cur], idx << 3);
+                const bool need_uv = (A_->sc).has_vn || (TEX && (A_->sc).tex_i != nullptr);      // otherwise nobody reads the barycentrics (and the flat extend kernel does not write them)
+                if (TRACE && need_uv && !PF) tr_uv_in = ldq((A_->q).tr_uv[cur], idx << 3);
                 if (PF) {
-                    build_hit_rec(sc, cu_ra, cu_rb, prim, cu_t, 0.f, 0.f, o, d, it, hit_light, rec_kd, false);
-                    if (sc.has_vn && __float_as_int(cu_ra.w) >= 0) {       // vertex normals: the barycentrics are fetched (and waited for) inside this branch only
-                        if (TRACE) tr_uv_in = ldq(q.tr_uv[cur], idx << 3);
-                        const float* vn = sc.vnormals + 9 * prim; const float bu = TRACE ? tr_uv_in.x : ldq(in.u, io), bv = TRACE ? tr_uv_in.y : ldq(in.v, io);
+                    build_hit_rec((A_->sc), cu_ra, cu_rb, prim, cu_t, 0.f, 0.f, o, d, it, hit_light, rec_kd, false);
+                    if ((A_->sc).has_vn && __float_as_int(cu_ra.w) >= 0) {       // vertex normals: the barycentrics are fetched (and waited for) inside this branch only
+                        if (TRACE) tr_uv_in = ldq((A_->q).tr_uv[cur], idx << 3);
+                        const float* vn = (A_->sc).vnormals + 9 * prim; const float bu = TRACE ? tr_uv_in.x : ldq(in.u, io), bv = TRACE ? tr_uv_in.y : ldq(in.v, io);
                         it.n_s = (ld3(vn) * (1.f - bu - bv) + ld3(vn + 3) * bu) + ld3(vn + 6) * bv;
                     }
                 }
-                else if (PK && PFP) build_hit_rec(sc, cu_ra, cu_rb, prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
-                else if (PK) build_hit(sc, prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
-                else if (PFP) build_hit_rec(sc, cu_ra, cu_rb, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
-                else build_hit(sc, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
+                else if (PK && PFP) build_hit_rec((A_->sc), cu_ra, cu_rb, prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
+                else if (PK) build_hit((A_->sc), prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
+                else if (PFP) build_hit_rec((A_->sc), cu_ra, cu_rb, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
+                else build_hit((A_->sc), prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
                 if (BM == 0x002) bx.k_d = rec_kd;               // Lambertian-only scenes: type 1, not delta, not a BSDF (the defaults above), colour from the record
-                else bx = ld_bxdf_lane(sc.bxdf + it.obj_id);
-                if (TEX && sc.tex_i != nullptr) {                // the scene declares image textures (TEX kernels only, see below)
+                else bx = ld_bxdf_lane((A_->sc).bxdf + it.obj_id);
+                if (TEX && (A_->sc).tex_i != nullptr) {                // the scene declares image textures (TEX kernels only, see below)
                     const float bu = PK ? tr_uv_in.x : ldq(in.u, io), bv = PK ? tr_uv_in.y : ldq(in.v, io);
                     f3 tx;
                     if (bounce == 0) {                           // PathTracer.process_ns, applied to the camera ray's hit only (vanilla_renderer.py:42)
-                        if (get_uv_item(sc, 1, it.obj_id, prim, bu, bv, tx)) { m33 R; rotation_between(mk3(0.f, 1.f, 0.f), it.n_g, R); it.n_s = mul(R, tx); }
-                        if (get_uv_item(sc, 2, it.obj_id, prim, bu, bv, tx)) it.n_s = delocalize(it.n_s, tx);
+                        if (get_uv_item((A_->sc), 1, it.obj_id, prim, bu, bv, tx)) { m33 R; rotation_between(mk3(0.f, 1.f, 0.f), it.n_g, R); it.n_s = mul(R, tx); }
+                        if (get_uv_item((A_->sc), 2, it.obj_id, prim, bu, bv, tx)) it.n_s = delocalize(it.n_s, tx);
                     }
                     // it.tex (vanilla_renderer.py:66): every surface model reads its diffuse colour as select(tex invalid, k_d, tex)
                     // and nothing else reads k_d on the device, so a valid lookup simply replaces this path's copy of k_d
-                    if (get_uv_item(sc, 0, it.obj_id, prim, bu, bv, tx)) bx.k_d = tx;
+                    if (get_uv_item((A_->sc), 0, it.obj_id, prim, bu, bv, tx)) bx.k_d = tx;
                 }
                 SH_TICK(0);
-                const uint32_t lp = id & ((1u << p.pix_bits) - 1u), s = id >> p.pix_bits;
-                l_off = (s * (uint32_t)p.npix + lp) << 2;
+                const uint32_t lp = id & ((1u << (A_->p).pix_bits) - 1u), s = id >> (A_->p).pix_bits;
+                l_off = (s * (uint32_t)(A_->p).npix + lp) << 2;
                 draw0 = meta & 0xffffu;
-                rng_init(rng, PF ? cu_key : ((p.world == 1) ? lp : ldq(p.pix_key, lp << 2)), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
+                rng_init(rng, PF ? cu_key : (((A_->p).world == 1) ? lp : ldq((A_->p).pix_key, lp << 2)), (A_->p).seed, (uint32_t)((A_->p).cnt_base + (int)s + 1), draw0);
                 // tail of the previous iteration: emission MIS weight for this hit (vanilla_renderer.py:111-117)
-                if (bounce > 0 && p.use_mis) {
+                if (bounce > 0 && (A_->p).use_mis) {
                     float e_pdf = 0.0f;
-                    if (hit_light >= 0 && bx.is_delta == 0 && !was_spec) e_pdf = emitter_solid_angle_pdf(sc.src[hit_light], it, d);
+                    if (hit_light >= 0 && bx.is_delta == 0 && !was_spec) e_pdf = emitter_solid_angle_pdf((A_->sc).src[hit_light], it, d);
                     emission_weight = balance(ray_pdf, e_pdf);
                 }
                 if (!(SM & 2)) rng_open(rng);                   // no area lights: a shade with one light sample draws at most five numbers (rng.hpp)
                 // Russian roulette / cut-off (vanilla_renderer.py:50-57)
-                if (p.use_rr) {
+                if ((A_->p).use_rr) {
                     float mx = max3(thr);
-                    if (mx < p.rr_threshold && bounce >= p.rr_bounce_th) {
+                    if (mx < (A_->p).rr_threshold && bounce >= (A_->p).rr_bounce_th) {
                         if (rng_float(rng) > mx) alive = false;
                         else thr = thr * (1.f / (mx + 1e-7f));
                     }
@@ -1103,32 +1129,33 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
         }
         // prefetching kernel: both queue-tail atomics of the row are sent early and awaited once, at the end of the row, so that the only
         // full wait of a row comes after all of its arithmetic - by then the next row's record has long arrived
-        const bool cont_early = alive && (bounce + 1) < p.max_bounce;
+        const bool cont_early = alive && (bounce + 1) < (A_->p).max_bounce;
         Append next_app; next_app.m = 0ull; next_app.raw = 0u;
         if (PF && !TRACE) next_app = append_issue(cont_early, next_counter);
         SH_TICK(1);
 
+        APT_ARGS_PHASE();
         // ---- next-event estimation: one shadow-queue entry per useful light sample
         bool break_flag = false;
         DevSrc src_only;                                      // the scene's only light, read once through the scalar path
-        if (sc.n_sources == 1) src_only = ld_src_uniform(sc.src);
+        if ((A_->sc).n_sources == 1) src_only = ld_src_uniform((A_->sc).src);
         // light samples by vertex: ONE queue-tail atomic per tile row for all S samples of every vertex
         uint32_t vbase = 0;
-        if (!FZ && p.nee_vm) vbase = wave_append(alive, shadow_counter);
+        if (!FZ && (A_->p).nee_vm) vbase = wave_append(alive, shadow_counter);
         bool f_want = false; f3 f_dir = mk3(0.f, 0.f, 1.f), f_c = splat3(0.f); float f_tmax = 0.f;
         const bool alive_nee = alive;
         f3 f_sum = splat3(0.f); bool f_any = false;            // FZ: the vertex's unoccluded light samples, summed in sample order (as the by-vertex shadow kernel sums them), added to the path's radiance once
 #if APT_FAST
         auto trace_light = [&](bool want, f3 dir, f3 c, float tmax) {
             // a light sample swept in place; a ray that needs the reference-order sweep leaves as a shadow-queue entry for the next launch's prologue
-            const bool defer = want && flat_needs_cull(sc.flat, dir);
+            const bool defer = want && flat_needs_cull((A_->sc).flat, dir);
             bool occ = false;
-            if (__any(want && !defer)) occ = flat_any1(sc.flat, hit_point, dir, (tmax > 0.0f) ? tmax - 1e-4f : 1e7f);
+            if (__any(want && !defer)) occ = flat_any1((A_->sc).flat, hit_point, dir, (tmax > 0.0f) ? tmax - 1e-4f : 1e7f);
             if (__any(defer)) {
                 const uint32_t spos = wave_append(defer, &cnt->n_fix_sh[cur][sl.q * CNT_PAD]);
-                if (defer && spos < q.sh_subcap) {
-                    const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
-                    st3q(q.sh_o, sc_, so, hit_point); st3q(q.sh_d, sc_, so, dir); stq(q.sh_tmax, so, tmax); st3q(q.sh_c, sc_, so, c); stq(q.sh_id, so, l_off);
+                if (defer && spos < (A_->q).sh_subcap) {
+                    const uint32_t so = (sh_qbase + spos) << 2, sc_ = (A_->q).sh_cap;
+                    st3q((A_->q).sh_o, sc_, so, hit_point); st3q((A_->q).sh_d, sc_, so, dir); stq((A_->q).sh_tmax, so, tmax); st3q((A_->q).sh_c, sc_, so, c); stq((A_->q).sh_id, so, l_off);
                 }
             }
             const bool traced = want && !defer;
@@ -1141,16 +1168,16 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
         };
 #endif
         bool late_want = false; f3 late_dir = splat3(0.f), late_c = splat3(0.f); float late_tmax = 0.f; Append late_app; late_app.m = 0ull; late_app.raw = 0u;
-        for (int s = 0; s < p.S; s++) {
+        for (int s = 0; s < (A_->p).S; s++) {
             bool want = false, sampled = false, poisoned = false;
             f3 light_dir = splat3(0.f), contrib = splat3(0.f);
             float emitter_d = 0.f;
             if (alive && !break_flag) {
                 // sample_light (path_tracer.py:537-554): one int is always drawn
-                const int ns = sc.n_sources;                    // wave-uniform: one light needs no modulo
+                const int ns = (A_->sc).n_sources;                    // wave-uniform: one light needs no modulo
                 int sidx = rng_int(rng);
                 sidx = (ns == 1) ? 0 : pymod(sidx, ns);
-                float emitter_pdf = p.inv_ns;
+                float emitter_pdf = (A_->p).inv_ns;
                 bool valid = true;
                 if (hit_light >= 0) {
                     if (ns <= 1) valid = false;
@@ -1158,77 +1185,78 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
                         sidx = rng_int(rng);
                         sidx = (ns == 2) ? 0 : pymod(sidx, ns - 1);
                         if (sidx >= hit_light) sidx += 1;
-                        emitter_pdf = p.inv_ns1;
+                        emitter_pdf = (A_->p).inv_ns1;
                     }
                 }
                 if (!valid) break_flag = true;
                 else {
-                    const DevSrc src = (ns == 1) ? src_only : (CQ ? ld_src_lane(sc.src + sidx) : sc.src[sidx]);      // (whole-record loads in the class kernels only: in C2's traced kernel their sixteen registers cost the fourth wave, 127 -> 132 VGPRs)
+                    const DevSrc src = (ns == 1) ? src_only : (CQ ? ld_src_lane((A_->sc).src + sidx) : (A_->sc).src[sidx]);      // (whole-record loads in the class kernels only: in C2's traced kernel their sixteen registers cost the fourth wave, 127 -> 132 VGPRs)
                     f3 shadow_int; float direct_pdf;
                     f3 emit_pos = emitter_sample_hit<SM>(src, geom, hit_point, rng, shadow_int, direct_pdf);
                     f3 to_emitter = emit_pos - hit_point;
                     emitter_d = norm(to_emitter);
                     light_dir = to_emitter / emitter_d;
                     sampled = true;
-                    f3 direct_spec = surface_eval<BM>(bx, it, d, light_dir, sc.world_ior, p.two_sides);
+                    f3 direct_spec = surface_eval<BM>(bx, it, d, light_dir, (A_->sc).world_ior, (A_->p).two_sides);
                     float mis_w = 1.0f;
-                    if (p.use_mis && !(src.bool_bits & 0x01)) {
+                    if ((A_->p).use_mis && !(src.bool_bits & 0x01)) {
                         float light_pdf = emitter_pdf * direct_pdf;
-                        float bsdf_pdf_v = surface_pdf<BM>(bx, it, light_dir, d, sc.world_ior, p.two_sides);
+                        float bsdf_pdf_v = surface_pdf<BM>(bx, it, light_dir, d, (A_->sc).world_ior, (A_->p).two_sides);
                         mis_w = balance(light_pdf, bsdf_pdf_v);
                     }
                     if (isnan(mis_w)) {
                         // Upstream the MIS weight multiplies the light sample even when the shadow ray is
                         // occluded (0 * NaN), so a NaN weight poisons the whole pixel-sample, which is then
                         // zeroed at the end (vanilla_renderer.py:87-95,119).  Reproduce that without tracing.
-                        if (FZ) Lc = splat3(mis_w); else stL(q.L, p.cap, l_off, splat3(mis_w));
+                        if (FZ) Lc = splat3(mis_w); else stL((A_->q).L, (A_->p).cap, l_off, splat3(mis_w));
                         poisoned = true;
                     } else {
                         f3 c = (direct_spec * shadow_int) * mis_w;
                         if (ns != 1) c = c / emitter_pdf;               // one light: the pdf is exactly 1 and x / 1 == x (wave-uniform branch)
-                        contrib = (c * p.inv_S) * thr;
+                        contrib = (c * (A_->p).inv_S) * thr;
                         want = !(contrib.x == 0.f && contrib.y == 0.f && contrib.z == 0.f);
                     }
                 }
             }
             SH_TICK(2);
             t_shadow += wave_count(sampled); t_poison += wave_count(poisoned);
-            if (!FZ && p.nee_vm) {
-                const uint32_t so = (sh_qbase + (uint32_t)s * p.subcap + vbase) << 2, sc_ = q.sh_cap;        // plane s of the sub-queue's region: consecutive lanes, consecutive entries
+            if (!FZ && (A_->p).nee_vm) {
+                const uint32_t so = (sh_qbase + (uint32_t)s * (A_->p).subcap + vbase) << 2, sc_ = (A_->q).sh_cap;        // plane s of the sub-queue's region: consecutive lanes, consecutive entries
                 if (want) {
-                    st3q(q.sh_o, sc_, so, hit_point);
-                    st3q(q.sh_d, sc_, so, light_dir);
-                    stq(q.sh_tmax, so, emitter_d);
-                    st3q(q.sh_c, sc_, so, contrib);
-                } else if (alive) stq(q.sh_tmax, so, -1.0f);                   // the vertex has no sample s worth tracing
-                if (alive && s == 0) stq(q.sh_id, so, l_off);                   // one radiance slot per vertex, kept with its first entry
+                    st3q((A_->q).sh_o, sc_, so, hit_point);
+                    st3q((A_->q).sh_d, sc_, so, light_dir);
+                    stq((A_->q).sh_tmax, so, emitter_d);
+                    st3q((A_->q).sh_c, sc_, so, contrib);
+                } else if (alive) stq((A_->q).sh_tmax, so, -1.0f);                   // the vertex has no sample s worth tracing
+                if (alive && s == 0) stq((A_->q).sh_id, so, l_off);                   // one radiance slot per vertex, kept with its first entry
             } else if (FZ) {
                 // traced at the end of the row, when little else is live: one sample per vertex waits in registers, several are parked in LDS
                 // ([sample][component][thread]: conflict-free; a sample not worth tracing is marked by a negative distance)
-                if (!MULTI || p.S == 1) { f_want = want; f_dir = light_dir; f_c = contrib; f_tmax = emitter_d; }
+                if (!MULTI || (A_->p).S == 1) { f_want = want; f_dir = light_dir; f_c = contrib; f_tmax = emitter_d; }
                 else {
                     lds_f* park = (lds_f*)reinterpret_cast<float*>(s_dyn) + ((uint32_t)s * 7u * BLOCK + threadIdx.x);
                     park[0] = light_dir.x; park[BLOCK] = light_dir.y; park[2 * BLOCK] = light_dir.z;
                     park[3 * BLOCK] = contrib.x; park[4 * BLOCK] = contrib.y; park[5 * BLOCK] = contrib.z;
                     park[6 * BLOCK] = want ? emitter_d : -1.0f;
                 }
-            } else if (PF && APT_SHADE_LATE_SHADOW && s == p.S - 1) {
+            } else if (PF && APT_SHADE_LATE_SHADOW && s == (A_->p).S - 1) {
                 late_app = append_issue(want, shadow_counter);
                 late_want = want; late_dir = light_dir; late_c = contrib; late_tmax = emitter_d;
             } else {
                 uint32_t spos = wave_append(want, shadow_counter);
-                if (want && spos < q.sh_subcap) {
-                    const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
-                    st3q(q.sh_o, sc_, so, hit_point);
-                    st3q(q.sh_d, sc_, so, light_dir);
-                    stq(q.sh_tmax, so, emitter_d);
-                    st3q(q.sh_c, sc_, so, contrib);
-                    stq(q.sh_id, so, l_off | ((p.l_planes > 1) ? (uint32_t)s : 0u));
+                if (want && spos < (A_->q).sh_subcap) {
+                    const uint32_t so = (sh_qbase + spos) << 2, sc_ = (A_->q).sh_cap;
+                    st3q((A_->q).sh_o, sc_, so, hit_point);
+                    st3q((A_->q).sh_d, sc_, so, light_dir);
+                    stq((A_->q).sh_tmax, so, emitter_d);
+                    st3q((A_->q).sh_c, sc_, so, contrib);
+                    stq((A_->q).sh_id, so, l_off | (((A_->p).l_planes > 1) ? (uint32_t)s : 0u));
                 }
             }
         }
 
         SH_TICK(3);
+        APT_ARGS_PHASE();
         // ---- emission of the surface we are on, then sample the continuation
         bool cont = false;
         f3 new_d = mk3(0.f, 1.f, 0.f);
@@ -1238,11 +1266,11 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
             // emission of the surface we are on (vanilla_renderer.py:99-104).  It has to stay AFTER the light sampling: with
             // two-sided BRDFs the evaluation above flips it.n_s in place, upstream as here, and eval_le sees the flipped normal.
             if ((SM & 2) && hit_light >= 0) {
-                f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_s);
+                f3 emit_int = emitter_eval_le((A_->sc).src[hit_light], hit_point - o, it.n_s);
                 if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
                     f3 add = (emit_int * emission_weight) * thr;
                     if (FZ) Lc = Lc + add;
-                    else add_radiance(q.L, p.cap, l_off, add, true);      // (nothing else touches the path's slot while its shade kernel runs)
+                    else add_radiance((A_->q).L, (A_->p).cap, l_off, add, true);      // (nothing else touches the path's slot while its shade kernel runs)
                 }
             }
             f3 spec;
@@ -1251,23 +1279,24 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
             // un-normalised interpolated vertex normal, i.e. of the barycentrics, which the product build's intersectors return to 1e-6 and not
             // to the bit: DESIGN.md section 5 "non-finite pixels".  Re-sampling such a vertex here with the reference's own triangle test was
             // measured: it costs the Lambertian kernel its fourth wave per SIMD, 122 -> 130 / 158 VGPRs inline / as a loop.)
-            new_d = surface_sample<BM>(bx, it, d, sc.world_ior, p.two_sides, rng, spec, new_pdf, is_spec);
+            new_d = surface_sample<BM>(bx, it, d, (A_->sc).world_ior, (A_->p).two_sides, rng, spec, new_pdf, is_spec);
             thr = thr * (spec / new_pdf);
-            cont = (bounce + 1) < p.max_bounce;
+            cont = (bounce + 1) < (A_->p).max_bounce;
         }
         if (rng.draw != draw0) atomicAdd(&s_draws[threadIdx.x >> 6], rng.draw - draw0);      // also paths that died in the roulette
         SH_TICK(4);
-        if (PF && APT_SHADE_LATE_SHADOW && !p.nee_vm && p.S > 0) {
+        if (PF && APT_SHADE_LATE_SHADOW && !(A_->p).nee_vm && (A_->p).S > 0) {
             const uint32_t spos = append_pos(late_app);
-            if (late_want && spos < q.sh_subcap) {
-                const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
-                st3q(q.sh_o, sc_, so, hit_point);
-                st3q(q.sh_d, sc_, so, late_dir);
-                stq(q.sh_tmax, so, late_tmax);
-                st3q(q.sh_c, sc_, so, late_c);
-                stq(q.sh_id, so, l_off | ((p.l_planes > 1) ? (uint32_t)(p.S - 1) : 0u));
+            if (late_want && spos < (A_->q).sh_subcap) {
+                const uint32_t so = (sh_qbase + spos) << 2, sc_ = (A_->q).sh_cap;
+                st3q((A_->q).sh_o, sc_, so, hit_point);
+                st3q((A_->q).sh_d, sc_, so, late_dir);
+                stq((A_->q).sh_tmax, so, late_tmax);
+                st3q((A_->q).sh_c, sc_, so, late_c);
+                stq((A_->q).sh_id, so, l_off | (((A_->p).l_planes > 1) ? (uint32_t)((A_->p).S - 1) : 0u));
             }
         }
+        APT_ARGS_PHASE();
 #if APT_FAST
         // rays traced in place: the continuation ray meets the scene's records here.  Only rays that hit something (or whose answer is left
         // to the reference-order code: listed, with a provisional record) enter the next queue; the tail atomic is on its way while the light
@@ -1276,30 +1305,31 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
         TrAppend tr_app; tr_app.raw = 0u; tr_app.rank = 0u;
         if (TRACE) {
             int tr_idx = -1, tr_run = -1, hit_cls = 0;
-            if (__any(cont)) tr_idx = flat_closest1(sc.flat, hit_point, new_d, 1e7f, tr_t, tr_run);
-            const bool tr_defer = cont && (tr_run >= 0 || flat_needs_cull(sc.flat, new_d));
+            if (__any(cont)) tr_idx = flat_closest1((A_->sc).flat, hit_point, new_d, 1e7f, tr_t, tr_run);
+            const bool tr_defer = cont && (tr_run >= 0 || flat_needs_cull((A_->sc).flat, new_d));
             t_extend += wave_count(cont);
             cont = cont && (tr_idx >= 0 || tr_defer);
-            if (cont && !tr_defer) { HitRec hr; flat_resolve(sc.flat, tr_idx, tr_t, hit_point, new_d, hr, hit_cls); tr_hit = hr.prim; tr_u = hr.u; tr_v = hr.v; }
-            tr_q = !cont ? -1 : (tr_defer ? q.tr_ncls : (q.tr_ncls > 1 ? hit_cls : 0));
-            if (MULTI) tr_app = tr_append_issue(tr_q, q.tr_ncls + 1, next_counter, APT_MAX_NQ * CNT_PAD);
+            if (cont && !tr_defer) { HitRec hr; flat_resolve((A_->sc).flat, tr_idx, tr_t, hit_point, new_d, hr, hit_cls); tr_hit = hr.prim; tr_u = hr.u; tr_v = hr.v; }
+            tr_q = !cont ? -1 : (tr_defer ? (A_->q).tr_ncls : ((A_->q).tr_ncls > 1 ? hit_cls : 0));
+            if (MULTI) tr_app = tr_append_issue(tr_q, (A_->q).tr_ncls + 1, next_counter, APT_MAX_NQ * CNT_PAD);
             else { const Append a_ = append_issue(tr_q == 0, next_counter); tr_app.raw = a_.raw; tr_app.rank = rank_in(a_.m); }      // (one queue; a staged ray - rare - moves the staging queue's tail by itself, below)
         }
 #endif
         uint32_t npos = (PF && !TRACE) ? append_pos(next_app) : (TRACE ? 0u : wave_append(cont, next_counter));
         if (cont && !TRACE) {
             const uint32_t so = (qbase + npos) << 2;
-            st3q(q.ray_o[nxt], p.cap, so, hit_point);
-            st3q(q.ray_d[nxt], p.cap, so, new_d);
-            st3q(q.thr[nxt], p.cap, so, thr);
-            stq(q.id[nxt], so, id);
-            stq(q.meta[nxt], so, pack_meta(rng.draw, (uint32_t)(bounce + 1), is_spec));
-            if (SM & 2) stq(q.pdf[nxt], so, new_pdf);
+            st3q((A_->q).ray_o[nxt], (A_->p).cap, so, hit_point);
+            st3q((A_->q).ray_d[nxt], (A_->p).cap, so, new_d);
+            st3q((A_->q).thr[nxt], (A_->p).cap, so, thr);
+            stq((A_->q).id[nxt], so, id);
+            stq((A_->q).meta[nxt], so, pack_meta(rng.draw, (uint32_t)(bounce + 1), is_spec));
+            if (SM & 2) stq((A_->q).pdf[nxt], so, new_pdf);
         }
+        APT_ARGS_PHASE();
 #if APT_FAST
         if (FZ) {
-            for (int s = 0; s < (MULTI ? p.S : 1); s++) {       // the row's light samples
-                if (MULTI && p.S > 1) {
+            for (int s = 0; s < (MULTI ? (A_->p).S : 1); s++) {       // the row's light samples
+                if (MULTI && (A_->p).S > 1) {
                     const lds_f* park = (const lds_f*)reinterpret_cast<const float*>(s_dyn) + ((uint32_t)s * 7u * BLOCK + threadIdx.x);
                     f_dir = mk3(park[0], park[BLOCK], park[2 * BLOCK]); f_c = mk3(park[3 * BLOCK], park[4 * BLOCK], park[5 * BLOCK]);
                     f_tmax = park[6 * BLOCK]; f_want = alive_nee && !(f_tmax < 0.0f);
@@ -1314,19 +1344,19 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
                     if (__any(tr_q == 1)) { const uint32_t dpos = wave_append(tr_q == 1, next_counter + APT_MAX_NQ * CNT_PAD); if (tr_q == 1) npos = dpos; }
                 }
                 if (cont) {
-                    const uint32_t slot = (!MULTI && tr_q == 1) ? qbase + p.subcap - 1u - npos : (uint32_t)tr_q * p.cap + qbase + npos, so = slot << 4;      // (one queue: staged rays grow down from the top of the sub-queue's region)
-                    stq(q.tr[nxt][0], so, make_float4(hit_point.x, hit_point.y, hit_point.z, tr_t));
-                    stq(q.tr[nxt][1], so, make_float4(new_d.x, new_d.y, new_d.z, __uint_as_float(tr_pack(tr_hit, rng.draw, is_spec))));
-                    stq(q.tr[nxt][2], so, make_float4(thr.x, thr.y, thr.z, __uint_as_float(id)));
-                    stq(q.tr[nxt][3], so, make_float4(Lc.x, Lc.y, Lc.z, new_pdf));
-                    if (sc.has_vn || sc.tex_i != nullptr) { float2 uv_; uv_.x = tr_u; uv_.y = tr_v; stq(q.tr_uv[nxt], slot << 3, uv_); }
+                    const uint32_t slot = (!MULTI && tr_q == 1) ? qbase + (A_->p).subcap - 1u - npos : (uint32_t)tr_q * (A_->p).cap + qbase + npos, so = slot << 4;      // (one queue: staged rays grow down from the top of the sub-queue's region)
+                    stq((A_->q).tr[nxt][0], so, make_float4(hit_point.x, hit_point.y, hit_point.z, tr_t));
+                    stq((A_->q).tr[nxt][1], so, make_float4(new_d.x, new_d.y, new_d.z, __uint_as_float(tr_pack(tr_hit, rng.draw, is_spec))));
+                    stq((A_->q).tr[nxt][2], so, make_float4(thr.x, thr.y, thr.z, __uint_as_float(id)));
+                    stq((A_->q).tr[nxt][3], so, make_float4(Lc.x, Lc.y, Lc.z, new_pdf));
+                    if ((A_->sc).has_vn || (A_->sc).tex_i != nullptr) { float2 uv_; uv_.x = tr_u; uv_.y = tr_v; stq((A_->q).tr_uv[nxt], slot << 3, uv_); }
                 }
             }
-            if (cont) { if (!TRACE) st3q(q.Lc[nxt], p.cap, (qbase + npos) << 2, Lc); }
+            if (cont) { if (!TRACE) st3q((A_->q).Lc[nxt], (A_->p).cap, (qbase + npos) << 2, Lc); }
             else if (entry && !(Lc.x == 0.f && Lc.y == 0.f && Lc.z == 0.f)) {
                 // the path ends here (nothing hit, roulette, last bounce): its radiance goes to its slot - added, not stored: a fix-up pass may have put a deferred sample's share there already
-                const uint32_t lp_ = id & ((1u << p.pix_bits) - 1u), s_ = id >> p.pix_bits;
-                add_radiance(q.L, p.cap, (s_ * (uint32_t)p.npix + lp_) << 2, Lc, true);
+                const uint32_t lp_ = id & ((1u << (A_->p).pix_bits) - 1u), s_ = id >> (A_->p).pix_bits;
+                add_radiance((A_->q).L, (A_->p).cap, (s_ * (uint32_t)(A_->p).npix + lp_) << 2, Lc, true);
             }
         }
 #endif
@@ -1347,7 +1377,7 @@ APT_D void shade_body(const DevScene& sc, const Params& p, const Queues& q, Coun
 }
 template <int BM, int SM, int TEX = 0, int FUSE = 0>
 __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_LAMBERT_WAVES : APT_SHADE_WAVES))) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
-    shade_body<BM, SM, TEX, FUSE>(sc, p, q, cnt, in, cur, bounce);
+    shade_body<BM, SM, TEX, FUSE>(kernel_args3(), cnt, in, cur, bounce);
 }
 
 // ---- class kernels in groups: ONE launch shades several material classes.
@@ -1364,10 +1394,10 @@ struct GroupIn { const uint32_t* counts[4]; int cls[4]; };     // per member: th
 template <int SM, int WAVES, int B0, int B1, int B2, int B3>
 __global__ void __launch_bounds__(BLOCK, WAVES) k_shade_group(DevScene sc, Params p, Queues q, Counters* cnt, GroupIn g, int cur, int bounce) {
     ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    if constexpr (B0 != 0) if (g.cls[0] >= 0) { in.counts = g.counts[0]; in.cls = g.cls[0]; shade_body<B0, SM, 0, 4>(sc, p, q, cnt, in, cur, bounce); }
-    if constexpr (B1 != 0) if (g.cls[1] >= 0) { in.counts = g.counts[1]; in.cls = g.cls[1]; shade_body<B1, SM, 0, 4>(sc, p, q, cnt, in, cur, bounce); }
-    if constexpr (B2 != 0) if (g.cls[2] >= 0) { in.counts = g.counts[2]; in.cls = g.cls[2]; shade_body<B2, SM, 0, 4>(sc, p, q, cnt, in, cur, bounce); }
-    if constexpr (B3 != 0) if (g.cls[3] >= 0) { in.counts = g.counts[3]; in.cls = g.cls[3]; shade_body<B3, SM, 0, 4>(sc, p, q, cnt, in, cur, bounce); }
+    if constexpr (B0 != 0) if (g.cls[0] >= 0) { in.counts = g.counts[0]; in.cls = g.cls[0]; shade_body<B0, SM, 0, 4>(kernel_args3(), cnt, in, cur, bounce); }
+    if constexpr (B1 != 0) if (g.cls[1] >= 0) { in.counts = g.counts[1]; in.cls = g.cls[1]; shade_body<B1, SM, 0, 4>(kernel_args3(), cnt, in, cur, bounce); }
+    if constexpr (B2 != 0) if (g.cls[2] >= 0) { in.counts = g.counts[2]; in.cls = g.cls[2]; shade_body<B2, SM, 0, 4>(kernel_args3(), cnt, in, cur, bounce); }
+    if constexpr (B3 != 0) if (g.cls[3] >= 0) { in.counts = g.counts[3]; in.cls = g.cls[3]; shade_body<B3, SM, 0, 4>(kernel_args3(), cnt, in, cur, bounce); }
 }
 
 // ------------------------------------------------------------------- shadow
