@@ -147,6 +147,19 @@ static const VShadeVariant kVShadeVolVariants[] = {       // scenes with a grid 
     {0x402, 0x03, k_vshade<0x402, 0x03, 1>, "volumetric + grid volume: lambertian+null/point+area"},
     {APT_BX_ALL, APT_SRC_ALL, k_vshade<APT_BX_ALL, APT_SRC_ALL, 1>, "volumetric + grid volume: all models"},
 };
+// Volumetric shading sorted by EVENT (volumetric.hpp k_vevent / k_vshade_ev): rows = the surface classes (kClassMask order; the volumetric
+// tracer does not split Blinn-Phong by lobe), then the all-models surface kernel (textured scenes, or more classes than queues: ONE surface
+// queue), then the medium kernel; [emitter set: point + area | all][without / with a grid volume]
+typedef void (*vevent_fn)(DevScene, Params, Queues, Counters*, int, int);
+typedef void (*vev_shade_fn)(DevScene, Params, Queues, Counters*, int, int);
+static const vevent_fn kVEvent[2] = {k_vevent<0>, k_vevent<1>};
+#define APT_VEV_ROW(BM, MI) {{k_vshade_ev<BM, 0x03, 0, MI>, k_vshade_ev<BM, 0x03, 1, MI>}, {k_vshade_ev<BM, APT_SRC_ALL, 0, MI>, k_vshade_ev<BM, APT_SRC_ALL, 1, MI>}}
+#define APT_VEV_ALL (APT_N_CLASS_DEFS)
+#define APT_VEV_MEDIUM (APT_N_CLASS_DEFS + 1)
+static const vev_shade_fn kVEventShade[APT_N_CLASS_DEFS + 2][2][2] = {
+    APT_VEV_ROW(0x002, 0), APT_VEV_ROW(0x001, 0), APT_VEV_ROW(0x040, 0), APT_VEV_ROW(0x504, 0), APT_VEV_ROW(0x010, 0), APT_VEV_ROW(0x020, 0), APT_VEV_ROW(0x080, 0),
+    APT_VEV_ROW(0x200, 0), APT_VEV_ROW(0x008, 0), APT_VEV_ROW(0x001, 0), APT_VEV_ROW(APT_BX_ALL, 0), APT_VEV_ROW(0x000, 1),
+};
 typedef void (*vshadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan, int);
 static const vshadow_fn kVShadow[5] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>, APT_FLAT_FN(k_vshadow<3>), APT_FLAT_FN(k_vshadow_flat)};     // volumetric: transmittance walk (one closest-hit query per pass; [4]: the flat sweep, two samples per lane, every segment in one launch)
 #define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
@@ -183,6 +196,8 @@ struct apt_scene {
     bool gpu_built = false;              // the binary tree came from the device builder (bvh_gpu.hip)
     bool world_scattering = false;       // the world medium scatters (rays that hit nothing still take part, vpt.py:176-181)
     bool has_null_surface = false;       // some object carries a null BSDF (rays pass, vpt.py:189-191)
+    std::vector<int> obj_class;          // per object: compact material class
+    std::vector<uint8_t> obj_null;       // per object: null BSDF (never shaded)
     bool phong_no_lobe = true;           // every Blinn-Phong material has k_s = 0 and finite k_g >= 0
     float box_min[3] = {1e3f, 1e3f, 1e3f}, box_max[3] = {-1e3f, -1e3f, -1e3f};    // union of the object boxes (path_tracer.py:130-134)
     int n_classes = 0;                   // material classes present (compact ids 0..n_classes-1)
@@ -217,6 +232,10 @@ struct apt_renderer {
     const VShadeVariant* vshade = nullptr;
     vshade_fn vclass_fn[APT_N_CLASS_DEFS + 1] = {};     // sorted volumetric shading: kernel per class queue (the miss class last)
     int v_ncls = 0;               // class queues in use (surface classes + the miss class when misses matter)
+    int vevent = 0;               // volumetric shading sorted by event: k_vevent decides what every path does, one kernel per event queue (v_ncls of them: surface classes, the medium last)
+    int vev_single = 0;           // ... with ONE surface queue served by the all-models kernel (textured scenes, more classes than queues)
+    vev_shade_fn vev_fn[APT_MAX_CLASSES] = {};
+    bool vev_live[APT_MAX_CLASSES] = {};      // an event queue that can receive entries at all (a class of null surfaces only is never shaded)
     shade_fn class_fn[APT_N_CLASS_DEFS] = {};
     int shade_groups = 1;                                 // class kernels launched in groups (APT_SHADE_GROUPS=0: one launch per class, for A/B)
     group_fn group_fn_[APT_N_GROUPS] = {};                // ... the group kernels for this scene's emitter set
@@ -481,6 +500,9 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
             }
             if (s->n_classes <= APT_MAX_CLASSES) break;
         }
+        s->obj_class = obj_cls;
+        s->obj_null.resize((size_t)O);
+        for (int o = 0; o < O; o++) s->obj_null[(size_t)o] = (bx[(size_t)o].is_bsdf && bx[(size_t)o].type < 0) ? 1 : 0;
         std::vector<int> pcls((size_t)N);
         for (int k = 0; k < N; k++) pcls[(size_t)k] = obj_cls[(size_t)prim_obj[(size_t)k]];
         pcls_host = pcls;
@@ -766,6 +788,24 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         const bool keep_miss = sc->world_scattering || sc->has_volume;
         int vs = (!textured && r->vshade->bm == APT_BX_ALL && sc->n_classes >= 2 && sc->n_classes + (keep_miss ? 1 : 0) <= APT_MAX_CLASSES) ? 1 : 0;
         if (const char* force = getenv("APT_SORTED")) vs = (atoi(force) != 0 && !textured && sc->n_classes + (keep_miss ? 1 : 0) <= APT_MAX_CLASSES) ? 1 : 0;
+        // shading sorted by EVENT (the shipped pipeline; APT_VEVENT=0: the one-kernel iteration above, unsorted or sorted by surface class)
+        r->vevent = 1;
+        if (const char* f = getenv("APT_VEVENT")) r->vevent = atoi(f) != 0 ? 1 : 0;
+        if (r->vevent) {
+            vs = 0; r->sorted = 0;
+            r->vev_single = (textured || sc->n_classes + 1 > APT_MAX_CLASSES) ? 1 : 0;
+            const int n_surf = r->vev_single ? 1 : sc->n_classes;
+            r->v_ncls = n_surf + 1;
+            const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : 1, vi = sc->has_volume ? 1 : 0;
+            for (int c = 0; c < n_surf; c++) {
+                r->vev_fn[c] = kVEventShade[r->vev_single ? APT_VEV_ALL : sc->class_def[c]][smi][vi];
+                r->vev_live[c] = false;
+            }
+            for (size_t o = 0; o < sc->obj_class.size(); o++)           // which surface queues can receive a hit at all
+                if (!sc->obj_null[o]) r->vev_live[r->vev_single ? 0 : sc->obj_class[o]] = true;
+            r->vev_fn[n_surf] = kVEventShade[APT_VEV_MEDIUM][smi][vi];
+            r->vev_live[n_surf] = true;
+        }
         if (vs) {
             r->sorted = 1;
             r->v_ncls = sc->n_classes + (keep_miss ? 1 : 0);
@@ -780,7 +820,11 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     r->shade_name = r->volumetric ? r->vshade->name : r->shade->name;
     if (p.fused == 2) r->shade_name += " [rays traced in place]";
     else if (p.fused == 1) r->shade_name += " [light samples traced in place]";
-    if (r->sorted && r->volumetric) {
+    if (r->vevent) {
+        r->shade_name = std::string(sc->has_volume ? "volumetric + grid volume, sorted by event: medium | " : "volumetric, sorted by event: medium | ");
+        if (r->vev_single) r->shade_name += "all surface models";
+        else for (int c = 0; c < sc->n_classes; c++) r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
+    } else if (r->sorted && r->volumetric) {
         r->shade_name = std::string(sc->has_volume ? "volumetric + grid volume, sorted:" : "volumetric, sorted:");
         for (int c = 0; c < sc->n_classes; c++) r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
         if (r->v_ncls > sc->n_classes) r->shade_name += "+miss";
@@ -805,7 +849,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (p.fused == 2 && cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (rays traced in place address 16-byte slots with 32-bit byte offsets: capacity must stay below 2^28)"); }
     const bool tr_uv = p.fused == 2 && (sc->dev.has_vn || sc->dev.tex_i != nullptr);
     // rays traced in place keep their path records in planes of their own (Queues::tr): the staged pipeline's second ray / state buffers are not carved
-    if (r->sorted && !r->volumetric && (size_t)ncls * cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (packed class queues address 16-byte slots with 32-bit byte offsets: classes x capacity must stay below 2^28)"); }
+    if (((r->sorted && !r->volumetric) || r->vevent) && (size_t)ncls * cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (packed class queues address 16-byte slots with 32-bit byte offsets: classes x capacity must stay below 2^28)"); }
     const bool stage_top = !(r->sorted && ncls > 1) && APT_TRACE_MULTI == 0;      // one queue: the staging queue lives at the top of the sub-queue's own region (Queues::tr_stage_top)
     const size_t tr_q = (p.fused == 2) ? (size_t)(r->sorted ? ncls : 1) + (stage_top ? 0 : 1) : 0;      // queues per plane: material classes (unsorted: one) [+ the staging queue]
     if (p.fused == 2 && tr_q * cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (rays traced in place: queues x capacity must stay below 2^28 slots)"); }
@@ -836,10 +880,10 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
         q.sh_walk[0] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr; q.sh_walk[1] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr;
         q.n_classes = ncls;
-        q.miss_class = (r->volumetric && r->v_ncls > sc->n_classes) ? sc->n_classes : -1;
-        q.miss_rr_draw = (r->volumetric && ncls > 0 && q.miss_class < 0) ? 1 : 0;
-        for (int a = 0; a < 4; a++) q.cq[a] = (ncls > 0 && !r->volumetric && p.fused != 2) ? (float4*)take(4 * cap * (size_t)ncls) : nullptr;
-        for (int c = 0; c < ncls && p.fused != 2 && r->volumetric; c++) {
+        q.miss_class = (r->volumetric && !r->vevent && r->v_ncls > sc->n_classes) ? sc->n_classes : -1;
+        q.miss_rr_draw = (r->volumetric && !r->vevent && ncls > 0 && q.miss_class < 0) ? 1 : 0;
+        for (int a = 0; a < 4; a++) q.cq[a] = (ncls > 0 && (!r->volumetric || r->vevent) && p.fused != 2) ? (float4*)take(4 * cap * (size_t)ncls) : nullptr;      // (event queues of the volumetric tracer: the same packed planes)
+        for (int c = 0; c < ncls && p.fused != 2 && r->volumetric && !r->vevent; c++) {
             Queues::ClassQ& k = q.cls[c];
             k.ray_o = take(3 * cap); k.ray_d = take(3 * cap); k.thr = take(3 * cap); k.id = (uint32_t*)take(cap); k.meta = (uint32_t*)take(cap);
             k.pdf = take(cap); k.t = take(cap); k.prim = (int*)take(cap); k.u = take(cap); k.v = take(cap);
@@ -1084,7 +1128,15 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
                 if (r->dyn_fetch) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st)); }
                 { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : (r->trace_mode == 3 ? kExtendFlatHot[r->sorted] : kExtend[r->trace_mode][r->sorted]), dim3(grid_for(is.total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
                 if (r->trace_mode == 3) { LaunchTimer t(r, 1, st, false); hipLaunchKernelGGL(kFixFlat[r->sorted], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
-                if (!r->sorted) {
+                if (r->vevent) {
+                    // what every path does this iteration (roulette, hit or world box, free path), then one kernel per event queue
+                    { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(kVEvent[r->scene->has_volume ? 1 : 0], dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, is.cur, r->vev_single); }
+                    for (int c = 0; c < r->v_ncls; c++) {
+                        if (!r->vev_live[c]) continue;
+                        LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vev_fn[c], dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, c, is.cur);
+                    }
+                    if (is.p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }     // normally k_vshadow's first pass recycles these
+                } else if (!r->sorted) {
                     ShadeIn in = {q.ray_o[is.cur], q.ray_d[is.cur], q.thr[is.cur], q.id[is.cur], q.meta[is.cur], q.pdf[is.cur],
                                   q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[is.cur]};
                     LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vshade->fn, dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, in, is.cur);

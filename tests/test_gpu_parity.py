@@ -844,7 +844,7 @@ def test_full_size_properties_volumetric_fog_box():
     from adapt_amd.renderer import Renderer, VolumeRenderer
     tup = scene_parsing(os.path.join(ROOT, "scenes", "vpt"), "cbox_fog.xml")
     r = VolumeRenderer(*tup)
-    assert (r.w, r.h, r.max_bounce, r.num_shadow_ray) == (512, 512, 16, 1) and r.info()["shade_variant"].startswith("volumetric: lambertian+null")
+    assert (r.w, r.h, r.max_bounce, r.num_shadow_ray) == (512, 512, 16, 1) and r.info()["shade_variant"].startswith("volumetric, sorted by event: medium | lambertian")
     r.render(n_spp=24)
     st, img = r.stats(), r.color.to_numpy()
     n = 512 * 512 * 24
