@@ -43,25 +43,14 @@ typedef void (*shade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int, int)
 #else
 #define APT_FUSED_FN(...) nullptr         // light samples traced by the shade kernel: a product-build path (it rides on the flat sweep's records)
 #endif
-// Rays traced in place by the class-sorted kernels and with several light samples per vertex (k_shade FUSE = 3) - measured on C3 and NOT
-// shipped (profiles/NOTES.md: the class kernels go from 124-128 to 147-168 VGPRs, four waves per SIMD to three, and take 108 ms per 256 spp
-// where extend + shade + shadow of the staged pipeline take 87: 970 -> 901 Msamples/s).  -DAPT_TRACE_MULTI=1 instantiates them (APT_FUSED=2 then selects them).
-#ifndef APT_TRACE_MULTI
-#define APT_TRACE_MULTI 0
-#endif
-#if APT_FAST && APT_TRACE_MULTI
-#define APT_MULTI_FN(...) __VA_ARGS__
-#else
-#define APT_MULTI_FN(...) nullptr
-#endif
-struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_fn fused, traced, traced_multi; };      // fused: the variant that traces its own light samples (stages.hpp k_shade FUSE = 1); traced: ... and its continuation ray (FUSE = 2: one light sample per vertex; traced_multi, FUSE = 3: any number)
+struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_fn fused, traced; };      // fused: the variant that traces its own light samples (stages.hpp k_shade FUSE = 1); traced: ... and its continuation ray (FUSE = 2: one light sample per vertex)
 static const ShadeVariant kShadeVariants[] = {
-    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade<0x002, 0x01, 0, 1>), APT_FUSED_FN(k_shade<0x002, 0x01, 0, 2>), APT_MULTI_FN(k_shade<0x002, 0x01, 0, 3>)},
-    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade<0x003, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x003, 0x03, 0, 2>), APT_MULTI_FN(k_shade<0x003, 0x03, 0, 3>)},
-    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade<0x107, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x107, 0x03, 0, 2>), APT_MULTI_FN(k_shade<0x107, 0x03, 0, 3>)},
-    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 2>), APT_MULTI_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 3>)},
+    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade<0x002, 0x01, 0, 1>), APT_FUSED_FN(k_shade<0x002, 0x01, 0, 2>)},
+    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade<0x003, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x003, 0x03, 0, 2>)},
+    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade<0x107, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x107, 0x03, 0, 2>)},
+    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 2>)},
 };
-static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 2>), APT_MULTI_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 3>)};
+static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 2>)};
 // Material classes for sorted shading: (class mask) x (emitter mask: point+area | all)
 // A kernel's register allocation is the maximum over the models it contains, so the classes are as fine as the models'
 // footprints differ: Lambertian alone runs at 4 waves per SIMD, together with Blinn-Phong (three double pows) at 2-3.
@@ -92,14 +81,6 @@ static const int kClassSlot[APT_N_CLASS_DEFS] = {0, 0, 1, 1, 0, 1, 2, 2, 3, 3}; 
 #define APT_GROUP_ROW(SM) {k_shade_group<SM, 4, 0x002, 0x504, 0x200, 0x801>, k_shade_group<SM, 3, 0x001, 0x040, 0x080, 0x008>, k_shade_group<SM, 1, 0x010, 0x020, 0, 0>}
 // (group 0 is held to four waves per SIMD: its members allocate 120-126 VGPRs alone, 129 together - the allocator then parks one 8-byte constant in scratch)
 static const group_fn kGroupShade[3][APT_N_GROUPS] = {APT_GROUP_ROW(0x03), APT_GROUP_ROW(APT_SRC_ALL), APT_GROUP_ROW(0x05)};      // [emitter set, as kClassShade][group]
-// the same class kernels tracing their rays in place (stages.hpp "rays traced in place": product build, flat sweep)
-static const shade_fn kClassShadeTraced[APT_N_CLASS_DEFS][2] = {      // (measurement only, see above: [point + area | all])
-    {APT_MULTI_FN(k_shade<0x002, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x002, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x001, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x001, APT_SRC_ALL, 0, 3>)},
-    {APT_MULTI_FN(k_shade<0x040, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x040, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x504, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x504, APT_SRC_ALL, 0, 3>)},
-    {APT_MULTI_FN(k_shade<0x010, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x010, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x020, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x020, APT_SRC_ALL, 0, 3>)},
-    {APT_MULTI_FN(k_shade<0x080, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x080, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x200, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x200, APT_SRC_ALL, 0, 3>)},
-    {APT_MULTI_FN(k_shade<0x008, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x008, APT_SRC_ALL, 0, 3>)}, {APT_MULTI_FN(k_shade<0x801, 0x03, 0, 3>), APT_MULTI_FN(k_shade<0x801, APT_SRC_ALL, 0, 3>)},
-};
 #define APT_CLASS_PHONG 1
 #define APT_CLASS_PHONG_NO_LOBE 9
 static int class_of(int is_bsdf, int type, bool no_lobe) {
@@ -116,37 +97,14 @@ typedef void (*occluded_fn)(DevScene, uint32_t, const float*, const float*, cons
 #else
 #define APT_FLAT_FN(...) nullptr          // the flat sweep exists in the fast build only (traverse.hpp)
 #endif
-static const extend_fn kExtend[4][3] = {{k_extend<0, 0>, k_extend<0, 1>, k_extend<0, 2>}, {k_extend<1, 0>, k_extend<1, 1>, k_extend<1, 2>}, {k_extend<2, 0>, k_extend<2, 1>, k_extend<2, 2>},
-                                        {APT_FLAT_FN(k_extend_flat<0, 0>), APT_FLAT_FN(k_extend_flat<1, 0>), APT_FLAT_FN(k_extend_flat<2, 0>)}};   // [mode][unsorted | sorted, SoA class queues (volumetric) | sorted, packed class queues] (flat: the self-contained variant, for explicit rays)
+static const extend_fn kExtend[4][2] = {{k_extend<0, 0>, k_extend<0, 1>}, {k_extend<1, 0>, k_extend<1, 1>}, {k_extend<2, 0>, k_extend<2, 1>},
+                                        {APT_FLAT_FN(k_extend_flat<0, 0>), APT_FLAT_FN(k_extend_flat<1, 0>)}};   // [mode][unsorted | sorted into the packed class queues] (flat: the self-contained variant, for explicit rays)
 // flat sweep inside a render: the hot variant and its fix-up launch (stages.hpp "fix-up lists"), [sorted]
-static const extend_fn kExtendFlatHot[3] = {APT_FLAT_FN(k_extend_flat<0, 1>), APT_FLAT_FN(k_extend_flat<1, 1>), APT_FLAT_FN(k_extend_flat<2, 1>)};
-static const extend_fn kFixFlat[3] = {APT_FLAT_FN(k_fix_flat<0>), APT_FLAT_FN(k_fix_flat<1>), APT_FLAT_FN(k_fix_flat<2>)};
-static const extend_fn kExtendDyn[3] = {k_extend_dyn<0>, k_extend_dyn<1>, k_extend_dyn<2>};      // BVH walk with dynamic ray fetch [sorted]
+static const extend_fn kExtendFlatHot[2] = {APT_FLAT_FN(k_extend_flat<0, 1>), APT_FLAT_FN(k_extend_flat<1, 1>)};
+static const extend_fn kFixFlat[2] = {APT_FLAT_FN(k_fix_flat<0>), APT_FLAT_FN(k_fix_flat<1>)};
+static const extend_fn kExtendDyn[2] = {k_extend_dyn<0>, k_extend_dyn<1>};      // BVH walk with dynamic ray fetch [sorted]
 static const shadow_fn kShadow[4] = {k_shadow<0>, k_shadow<1>, k_shadow<2>, APT_FLAT_FN(k_shadow_flat<1>)};      // (flat: the hot variant; its list is served by the next kFixFlat launch)
 static const occluded_fn kOccluded[4] = {k_occluded<0>, k_occluded<1>, k_occluded<2>, APT_FLAT_FN(k_occluded_flat)};
-typedef void (*vshade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int);
-struct VShadeVariant { int bm, sm; vshade_fn fn; const char* name; };
-static const VShadeVariant kVShadeVariants[] = {          // first match wins; 0x400 = "other BSDF" = the null surface
-    {0x402, 0x03, k_vshade<0x402, 0x03>, "volumetric: lambertian+null/point+area"},
-    {0x503, 0x07, k_vshade<0x503, 0x07>, "volumetric: phong+lambertian+glass+null/point+area+spot"},
-    {APT_BX_ALL, APT_SRC_ALL, k_vshade<APT_BX_ALL, APT_SRC_ALL>, "volumetric: all models"},
-};
-// sorted volumetric shading: one kernel per surface class (kClassMask order) plus the class of rays that hit nothing (index
-// APT_N_CLASS_DEFS: media only), without / with a grid volume.  Every class kernel carries the medium code; what it sheds is the
-// other surface models, i.e. most of the all-models kernel's 256 VGPRs + AGPR spills.
-static const vshade_fn kVClassShade[APT_N_CLASS_DEFS + 1][2] = {
-    {k_vshade<0x002, APT_SRC_ALL>, k_vshade<0x002, APT_SRC_ALL, 1>}, {k_vshade<0x001, APT_SRC_ALL>, k_vshade<0x001, APT_SRC_ALL, 1>},
-    {k_vshade<0x040, APT_SRC_ALL>, k_vshade<0x040, APT_SRC_ALL, 1>}, {k_vshade<0x504, APT_SRC_ALL>, k_vshade<0x504, APT_SRC_ALL, 1>},
-    {k_vshade<0x010, APT_SRC_ALL>, k_vshade<0x010, APT_SRC_ALL, 1>}, {k_vshade<0x020, APT_SRC_ALL>, k_vshade<0x020, APT_SRC_ALL, 1>},
-    {k_vshade<0x080, APT_SRC_ALL>, k_vshade<0x080, APT_SRC_ALL, 1>}, {k_vshade<0x200, APT_SRC_ALL>, k_vshade<0x200, APT_SRC_ALL, 1>},
-    {k_vshade<0x008, APT_SRC_ALL>, k_vshade<0x008, APT_SRC_ALL, 1>},
-    {k_vshade<0x001, APT_SRC_ALL>, k_vshade<0x001, APT_SRC_ALL, 1>},        // (the volumetric tracer does not split Blinn-Phong by lobe)
-    {k_vshade<0x000, APT_SRC_ALL>, k_vshade<0x000, APT_SRC_ALL, 1>},
-};
-static const VShadeVariant kVShadeVolVariants[] = {       // scenes with a grid volume
-    {0x402, 0x03, k_vshade<0x402, 0x03, 1>, "volumetric + grid volume: lambertian+null/point+area"},
-    {APT_BX_ALL, APT_SRC_ALL, k_vshade<APT_BX_ALL, APT_SRC_ALL, 1>, "volumetric + grid volume: all models"},
-};
 // Volumetric shading sorted by EVENT (volumetric.hpp k_vevent / k_vshade_ev): rows = the surface classes (kClassMask order; the volumetric
 // tracer does not split Blinn-Phong by lobe), then the all-models surface kernel (textured scenes, or more classes than queues: ONE surface
 // queue), then the medium kernel; [emitter set: point + area | all][without / with a grid volume]
@@ -161,7 +119,7 @@ static const vev_shade_fn kVEventShade[APT_N_CLASS_DEFS + 2][2][2] = {
     APT_VEV_ROW(0x200, 0), APT_VEV_ROW(0x008, 0), APT_VEV_ROW(0x001, 0), APT_VEV_ROW(APT_BX_ALL, 0), APT_VEV_ROW(0x000, 1),
 };
 typedef void (*vshadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan, int);
-static const vshadow_fn kVShadow[5] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>, APT_FLAT_FN(k_vshadow<3>), APT_FLAT_FN(k_vshadow_flat)};     // volumetric: transmittance walk (one closest-hit query per pass; [4]: the flat sweep, two samples per lane, every segment in one launch)
+static const vshadow_fn kVShadow[5] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>, nullptr, APT_FLAT_FN(k_vshadow_flat)};     // volumetric: transmittance walk (one closest-hit query per pass; [4]: the flat sweep, two samples per lane, every segment in one launch)
 #define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
 
 // ============================================================== host side
@@ -229,8 +187,6 @@ struct apt_renderer {
     int volumetric = 0;           // 1 = VolumeRenderer.render semantics (volumetric.hpp)
     int dyn_fetch = 0;            // BVH mode: closest-hit walk with dynamic ray fetch (k_extend_dyn)
     int ovf_levels = 0;           // traversal-stack levels beyond the LDS part
-    const VShadeVariant* vshade = nullptr;
-    vshade_fn vclass_fn[APT_N_CLASS_DEFS + 1] = {};     // sorted volumetric shading: kernel per class queue (the miss class last)
     int v_ncls = 0;               // class queues in use (surface classes + the miss class when misses matter)
     int vevent = 0;               // volumetric shading sorted by event: k_vevent decides what every path does, one kernel per event queue (v_ncls of them: surface classes, the medium last)
     int vev_single = 0;           // ... with ONE surface queue served by the all-models kernel (textured scenes, more classes than queues)
@@ -240,7 +196,6 @@ struct apt_renderer {
     int shade_groups = 1;                                 // class kernels launched in groups (APT_SHADE_GROUPS=0: one launch per class, for A/B)
     group_fn group_fn_[APT_N_GROUPS] = {};                // ... the group kernels for this scene's emitter set
     int group_cls[APT_N_GROUPS][4] = {};                  // ... compact class id of each member slot (-1: the scene has no such class)
-    shade_fn class_fn_traced[APT_N_CLASS_DEFS] = {};      // ... tracing their rays in place (Params::fused == 2)
     std::string shade_name;
     LdsPlan plan{};
     size_t lds_bytes = 0, lds_bytes_any = 0;     // dynamic LDS of the closest-hit / any-hit trace kernels
@@ -738,7 +693,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     }
     // flat sweep with several light samples per vertex: the samples are queued by vertex and the shadow kernel adds a vertex's samples with
     // one read-modify-write (stages.hpp k_shadow_flat); otherwise 2-4 samples per vertex add into one radiance plane each
-    p.keep_order = c.volumetric ? 1 : 0; p.volumetric_flat = c.volumetric ? 1 : 0; p.fix_par = 0;
+    p.volumetric_flat = c.volumetric ? 1 : 0; p.fix_par = 0;
     p.nee_vm = (!c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
     if (const char* f = getenv("APT_NEE_VM")) p.nee_vm = (atoi(f) != 0 && !c.volumetric && r->trace_mode == 3 && S > 1) ? 1 : 0;
     p.l_planes = (!p.nee_vm && S >= 2 && S <= 4) ? S : 1;        // stages.hpp APT_EXCLUSIVE_L: one radiance plane per light sample of a vertex
@@ -766,9 +721,6 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     {
         const bool can1 = r->trace_mode == 3 && !r->sorted && !c.volumetric && S == 1 && r->shade->fused != nullptr;
         bool can2 = can1 && r->shade->traced != nullptr;
-#if APT_TRACE_MULTI      // (measurement only: class-sorted queues and several light samples per vertex - those wait in LDS for the end of the tile row, 28 bytes each per thread)
-        can2 = r->trace_mode == 3 && !c.volumetric && r->shade->traced_multi != nullptr && S <= 8;
-#endif
         p.fused = can2 ? 2 : (can1 ? 1 : 0);
         if (const char* f = getenv("APT_FUSED")) { const int want = atoi(f); p.fused = (want >= 2 && can2) ? 2 : ((want >= 1 && can1) ? 1 : 0); }
         if (p.fused == 2) { p.nee_vm = 0; p.l_planes = 1; }      // no shadow queue: a vertex's light samples are summed in registers
@@ -777,57 +729,32 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         if (c.max_bounce > 255) { return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer keeps the bounce count in 8 bits (max_bounce <= 255)"); }
         if (!sc->has_aabb) { return fail(APT_E_INVALID, "apt_renderer_create: the volumetric tracer needs the object boxes (world bound)"); }
         r->sorted = 0;
-        if (sc->has_volume) {
-            for (const VShadeVariant& v : kVShadeVolVariants)
-                if ((sc->bx_mask & ~v.bm) == 0 && (sc->src_mask & ~v.sm) == 0 && !(textured && v.bm != APT_BX_ALL)) { r->vshade = &v; break; }
-        } else
-        for (const VShadeVariant& v : kVShadeVariants)
-            if ((sc->bx_mask & ~v.bm) == 0 && (sc->src_mask & ~v.sm) == 0 && !(textured && v.bm != APT_BX_ALL)) { r->vshade = &v; break; }
-        if (!r->vshade) { return fail(APT_E_INVALID, "apt_renderer_create: scene uses a material or emitter type the volumetric kernels do not know"); }
-        // event-class sorting pays when the all-models kernel would be needed for a scene of several material classes
-        const bool keep_miss = sc->world_scattering || sc->has_volume;
-        int vs = (!textured && r->vshade->bm == APT_BX_ALL && sc->n_classes >= 2 && sc->n_classes + (keep_miss ? 1 : 0) <= APT_MAX_CLASSES) ? 1 : 0;
-        if (const char* force = getenv("APT_SORTED")) vs = (atoi(force) != 0 && !textured && sc->n_classes + (keep_miss ? 1 : 0) <= APT_MAX_CLASSES) ? 1 : 0;
-        // shading sorted by EVENT (the shipped pipeline; APT_VEVENT=0: the one-kernel iteration above, unsorted or sorted by surface class)
+        // shading sorted by EVENT (volumetric.hpp): k_vevent, then one kernel per event queue - the surface classes, the medium last
         r->vevent = 1;
-        if (const char* f = getenv("APT_VEVENT")) r->vevent = atoi(f) != 0 ? 1 : 0;
-        if (r->vevent) {
-            vs = 0; r->sorted = 0;
-            r->vev_single = (textured || sc->n_classes + 1 > APT_MAX_CLASSES) ? 1 : 0;
-            const int n_surf = r->vev_single ? 1 : sc->n_classes;
-            r->v_ncls = n_surf + 1;
-            const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : 1, vi = sc->has_volume ? 1 : 0;
-            for (int c = 0; c < n_surf; c++) {
-                r->vev_fn[c] = kVEventShade[r->vev_single ? APT_VEV_ALL : sc->class_def[c]][smi][vi];
-                r->vev_live[c] = false;
-            }
-            for (size_t o = 0; o < sc->obj_class.size(); o++)           // which surface queues can receive a hit at all
-                if (!sc->obj_null[o]) r->vev_live[r->vev_single ? 0 : sc->obj_class[o]] = true;
-            r->vev_fn[n_surf] = kVEventShade[APT_VEV_MEDIUM][smi][vi];
-            r->vev_live[n_surf] = true;
+        r->vev_single = (textured || sc->n_classes + 1 > APT_MAX_CLASSES) ? 1 : 0;
+        const int n_surf = r->vev_single ? 1 : sc->n_classes;
+        r->v_ncls = n_surf + 1;
+        const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : 1, vi = sc->has_volume ? 1 : 0;
+        for (int c = 0; c < n_surf; c++) {
+            r->vev_fn[c] = kVEventShade[r->vev_single ? APT_VEV_ALL : sc->class_def[c]][smi][vi];
+            r->vev_live[c] = false;
         }
-        if (vs) {
-            r->sorted = 1;
-            r->v_ncls = sc->n_classes + (keep_miss ? 1 : 0);
-            for (int c = 0; c < sc->n_classes; c++) r->vclass_fn[c] = kVClassShade[sc->class_def[c]][sc->has_volume ? 1 : 0];
-            if (keep_miss) r->vclass_fn[sc->n_classes] = kVClassShade[APT_N_CLASS_DEFS][sc->has_volume ? 1 : 0];      // the last row: rays that hit nothing
-        }
+        for (size_t o = 0; o < sc->obj_class.size(); o++)           // which surface queues can receive a hit at all
+            if (!sc->obj_null[o]) r->vev_live[r->vev_single ? 0 : sc->obj_class[o]] = true;
+        r->vev_fn[n_surf] = kVEventShade[APT_VEV_MEDIUM][smi][vi];
+        r->vev_live[n_surf] = true;
         for (int a = 0; a < 3; a++) {                         // path_tracer.py:136-138
             p.w_min[a] = std::min(c.cam_t[a], sc->box_min[a]) - 0.1f; p.w_max[a] = std::max(c.cam_t[a], sc->box_max[a]) + 0.1f;
         }
     }
     const int ncls = r->volumetric ? r->v_ncls : (r->sorted ? sc->n_classes : 0);
-    r->shade_name = r->volumetric ? r->vshade->name : r->shade->name;
+    r->shade_name = r->shade->name;
     if (p.fused == 2) r->shade_name += " [rays traced in place]";
     else if (p.fused == 1) r->shade_name += " [light samples traced in place]";
     if (r->vevent) {
         r->shade_name = std::string(sc->has_volume ? "volumetric + grid volume, sorted by event: medium | " : "volumetric, sorted by event: medium | ");
         if (r->vev_single) r->shade_name += "all surface models";
         else for (int c = 0; c < sc->n_classes; c++) r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
-    } else if (r->sorted && r->volumetric) {
-        r->shade_name = std::string(sc->has_volume ? "volumetric + grid volume, sorted:" : "volumetric, sorted:");
-        for (int c = 0; c < sc->n_classes; c++) r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
-        if (r->v_ncls > sc->n_classes) r->shade_name += "+miss";
     } else if (r->sorted) {
         const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : (((sc->src_mask & ~0x05) == 0) ? 2 : 1);
         r->shade_name = "sorted:";
@@ -837,7 +764,6 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         for (int c = 0; c < ncls; c++) {
             r->class_fn[c] = kClassShade[sc->class_def[c]][smi];
             r->group_cls[kClassGroup[sc->class_def[c]]][kClassSlot[sc->class_def[c]]] = c;
-            r->class_fn_traced[c] = kClassShadeTraced[sc->class_def[c]][smi == 0 ? 0 : 1];
             r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
         }
     }
@@ -850,8 +776,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     const bool tr_uv = p.fused == 2 && (sc->dev.has_vn || sc->dev.tex_i != nullptr);
     // rays traced in place keep their path records in planes of their own (Queues::tr): the staged pipeline's second ray / state buffers are not carved
     if (((r->sorted && !r->volumetric) || r->vevent) && (size_t)ncls * cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (packed class queues address 16-byte slots with 32-bit byte offsets: classes x capacity must stay below 2^28)"); }
-    const bool stage_top = !(r->sorted && ncls > 1) && APT_TRACE_MULTI == 0;      // one queue: the staging queue lives at the top of the sub-queue's own region (Queues::tr_stage_top)
-    const size_t tr_q = (p.fused == 2) ? (size_t)(r->sorted ? ncls : 1) + (stage_top ? 0 : 1) : 0;      // queues per plane: material classes (unsorted: one) [+ the staging queue]
+    const bool stage_top = true;      // the staging queue lives at the top of the sub-queue's own region (Queues::tr_stage_top)
+    const size_t tr_q = (p.fused == 2) ? 1 : 0;      // queues per plane (rays traced in place: unsorted renders, one queue)
     if (p.fused == 2 && tr_q * cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (rays traced in place: queues x capacity must stay below 2^28 slots)"); }
     const size_t words = (p.fused == 1 ? 6 * cap : 0) + (p.fused == 2 ? (32 + (tr_uv ? 4 : 0)) * cap * tr_q : 0) - (p.fused == 2 ? (6 + 12) * cap : 0) + (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + (p.fused == 2 ? 0 : cap * 16 * (size_t)ncls) + (walk_lists ? 2 * sh_cap : 0);
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
@@ -880,14 +806,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
         q.sh_walk[0] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr; q.sh_walk[1] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr;
         q.n_classes = ncls;
-        q.miss_class = (r->volumetric && !r->vevent && r->v_ncls > sc->n_classes) ? sc->n_classes : -1;
-        q.miss_rr_draw = (r->volumetric && !r->vevent && ncls > 0 && q.miss_class < 0) ? 1 : 0;
-        for (int a = 0; a < 4; a++) q.cq[a] = (ncls > 0 && (!r->volumetric || r->vevent) && p.fused != 2) ? (float4*)take(4 * cap * (size_t)ncls) : nullptr;      // (event queues of the volumetric tracer: the same packed planes)
-        for (int c = 0; c < ncls && p.fused != 2 && r->volumetric && !r->vevent; c++) {
-            Queues::ClassQ& k = q.cls[c];
-            k.ray_o = take(3 * cap); k.ray_d = take(3 * cap); k.thr = take(3 * cap); k.id = (uint32_t*)take(cap); k.meta = (uint32_t*)take(cap);
-            k.pdf = take(cap); k.t = take(cap); k.prim = (int*)take(cap); k.u = take(cap); k.v = take(cap);
-        }
+        for (int a = 0; a < 4; a++) q.cq[a] = (ncls > 0 && p.fused != 2) ? (float4*)take(4 * cap * (size_t)ncls) : nullptr;      // class queues / the volumetric tracer's event queues: packed planes
         return hipSuccess;
     };
     hipError_t e = carve(r->pool, r->q);
@@ -955,7 +874,6 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
             if (r->lds_bytes > 64 * 1024) {
                 HIP_TRY(hipFuncSetAttribute((const void*)kExtend[2][0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
                 HIP_TRY(hipFuncSetAttribute((const void*)kExtend[2][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
-                HIP_TRY(hipFuncSetAttribute((const void*)kExtend[2][2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
                 HIP_TRY(hipFuncSetAttribute((const void*)kShadow[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
                 HIP_TRY(hipFuncSetAttribute((const void*)kOccluded[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
                 HIP_TRY(hipFuncSetAttribute((const void*)kVShadow[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
@@ -963,7 +881,6 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         } else if (r->lds_bytes > 64 * 1024) {
             HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
-            HIP_TRY(hipFuncSetAttribute((const void*)kExtend[0][2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kShadow[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kOccluded[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
             HIP_TRY(hipFuncSetAttribute((const void*)kVShadow[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
@@ -974,7 +891,6 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (r->dyn_fetch && r->lds_bytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[0], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[2], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)k_shadow_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
     }
     r->grid_small = cus * (r->volumetric ? 8 : 4);       // streaming stages, persistent grid in 256-thread workgroups per CU.  Measured (tools/grid_sweep.sh, 2 / 3 / 4 / 5 / 8 per CU): C2 3 385 / 3 350 / 3 378 / 3 312 / 3 279 Msamples/s (a shade kernel holds 4 workgroups per CU; a second round of workgroups only adds a tail), C1 / C3 / C4 / C5 within 1 %, V1 823 / 838 / 842 / 840 / 858
@@ -1128,23 +1044,12 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
                 if (r->dyn_fetch) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_work[0], 0, sizeof(cnt->n_work[0]), st)); }
                 { LaunchTimer t(r, 1, st); hipLaunchKernelGGL(r->dyn_fetch ? kExtendDyn[r->sorted] : (r->trace_mode == 3 ? kExtendFlatHot[r->sorted] : kExtend[r->trace_mode][r->sorted]), dim3(grid_for(is.total, r->grid_trace, nq, r->trace_items)), dim3(r->trace_nt), r->lds_bytes, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
                 if (r->trace_mode == 3) { LaunchTimer t(r, 1, st, false); hipLaunchKernelGGL(kFixFlat[r->sorted], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, is.p, q, cnt, is.cur, (const uint32_t*)cnt->n_active[is.cur], lane_plan); }
-                if (r->vevent) {
+                {
                     // what every path does this iteration (roulette, hit or world box, free path), then one kernel per event queue
                     { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(kVEvent[r->scene->has_volume ? 1 : 0], dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, is.cur, r->vev_single); }
                     for (int c = 0; c < r->v_ncls; c++) {
                         if (!r->vev_live[c]) continue;
                         LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vev_fn[c], dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, c, is.cur);
-                    }
-                    if (is.p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }     // normally k_vshadow's first pass recycles these
-                } else if (!r->sorted) {
-                    ShadeIn in = {q.ray_o[is.cur], q.ray_d[is.cur], q.thr[is.cur], q.id[is.cur], q.meta[is.cur], q.pdf[is.cur],
-                                  q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[is.cur]};
-                    LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vshade->fn, dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, in, is.cur);
-                } else {
-                    for (int c = 0; c < q.n_classes; c++) {
-                        const Queues::ClassQ& k = q.cls[c];
-                        ShadeIn in = {k.ray_o, k.ray_d, k.thr, k.id, k.meta, k.pdf, k.t, k.prim, k.u, k.v, (const uint32_t*)cnt->n_cls[c]};
-                        LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vclass_fn[c], dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, in, is.cur);
                     }
                     if (is.p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }     // normally k_vshadow's first pass recycles these
                 }
@@ -1220,7 +1125,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
     }
     int done = 0, batch = 0;
     hipEvent_t prev_fin = nullptr;
-    const int si = r->sorted ? 2 : 0;            // surface renders keep their class queues as packed planes (Queues::cq; stages.hpp)
+    const int si = r->sorted ? 1 : 0;            // (sorted: extend appends every hit path's record to the packed queue of its material class, Queues::cq)
     // a call smaller than one full round of lane-batches is split evenly so that every lane has work
     const int batch_cap = (r->cfg.spp_per_batch <= 0 && n_spp < r->n_lanes * r->spp_batch) ? std::max(1, (n_spp + r->n_lanes - 1) / r->n_lanes) : r->spp_batch;
     while (done < n_spp) {
@@ -1242,10 +1147,9 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate_trace, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, sc, p, q, cnt); }
             int cur = 0;
             for (int b = 0; b < p.max_bounce; b++) {
-                for (int c = 0; c < q.tr_ncls; c++) {       // (the records are Queues::tr[cur]: one queue per material class, or one for the scene)
-                    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c};
-                    const size_t park = (p.S > 1) ? (size_t)p.S * 7 * BLOCK * sizeof(float) : 0;      // k_shade: light samples parked in LDS
-                    LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->sorted ? r->class_fn_traced[c] : (p.S == 1 ? r->shade->traced : r->shade->traced_multi), dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), park, st, sc, p, q, cnt, in, cur, b);
+                {                                           // (the records are Queues::tr[cur]: one queue for the scene)
+                    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                    LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->shade->traced, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
                 }
                 cur ^= 1;
             }
@@ -1274,8 +1178,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
                     }
                 } else
                 for (int c = 0; c < q.n_classes; c++) {
-                    const Queues::ClassQ& k = q.cls[c];
-                    ShadeIn in = {k.ray_o, k.ray_d, k.thr, k.id, k.meta, k.pdf, k.t, k.prim, k.u, k.v, (const uint32_t*)cnt->n_cls[c], nullptr, c};      // (the record comes from Queues::cq, class c)
+                    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (const uint32_t*)cnt->n_cls[c], nullptr, c};      // (the record comes from Queues::cq, class c)
                     LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->class_fn[c], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
                 }
                 if (p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }      // normally k_shadow recycles these

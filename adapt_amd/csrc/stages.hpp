@@ -95,7 +95,6 @@ struct Params {
     uint32_t pix_bits;
     const uint32_t* pix_key;  // local pixel -> global pixel index x * H + y = the RNG key (host-built; band mapping folded in)
     float inv_ns, inv_ns1;    // 1 / n_sources, 1 / (n_sources - 1): sample_light's pdfs (path_tracer.py:537-554)
-    int keep_order;           // 1: the flat extend kernel's class appends keep the queue's entry order (volumetric renders: the transmittance walk's wave-wide culls want neighbouring rays in a wave)
     int fix_par;              // flat sweep: queue parity of the current bounce (which shadow fix-up list the hot shadow kernel appends to); set per launch
     int volumetric_flat;      // 1: volumetric render (the flat shadow kernels never run: the fix-up launch has no shadow list)
     int nee_vm;               // 1: light samples are queued BY VERTEX (one slot per vertex and sub-queue, sample s in plane s of the sub-queue's region, unwanted samples marked tmax < 0), so that the flat shadow kernel adds a vertex's samples with ONE read-modify-write and the shade kernel moves the queue tail once per tile row (flat sweep, S > 1)
@@ -128,21 +127,15 @@ struct Queues {
     float* L;                                    // 3 components, indexed by path id
     float* Lc[2];                                // fused shading: the path's radiance so far, a queue component like thr (3 components; null elsewhere)
     uint32_t sh_cap, sh_subcap;
-    // Material-sorted shading (scenes with >= 2 material classes): extend drops misses and appends each hit
-    // path's full record (ray + state + hit, 64 B) to the dense queue of its material class, so every shade
-    // launch runs one specialised kernel over coherent waves.  n_classes == 0: unsorted (single-class scenes).
-    struct ClassQ { float* ray_o; float* ray_d; float* thr; uint32_t* id; uint32_t* meta; float* pdf; float* t; int* prim; float* u; float* v; };
-    ClassQ cls[8];
-    // Surface renders keep the class queues as FOUR 16-byte planes instead (SORTED == 2 in the extend kernels, FUSE == 4 in the class kernels):
-    // A = (ray origin, hit distance), B = (ray direction, hit primitive), C = (throughput, path id), D = (meta, pdf, u, v); every plane holds
-    // n_classes queues of `cap` slots, slot = class * cap + sub-queue * subcap + position.  A record is 4 stores and 4 loads instead of 16
-    // and 16, and - what matters in the BVH walk's hand-in, where a wave's finished rays belong to several classes - the class is part of
-    // the lane's OFFSET: no loop over the classes present, no per-class queue pointers fetched from the argument buffer.  Null: cls[] is used
-    // (the volumetric tracer's event-class queues).
+    // Material-sorted shading (scenes with >= 2 material classes): extend drops misses and appends each hit path's full record (ray + state
+    // + hit, 64 B) to the dense queue of its material class, so every shade launch runs one specialised kernel over coherent waves; the
+    // volumetric tracer's EVENT queues (volumetric.hpp k_vevent) are the same thing.  n_classes == 0: unsorted (single-class scenes).
+    // The queues are FOUR 16-byte planes: A = (ray origin, hit distance), B = (ray direction, hit primitive), C = (throughput, path id),
+    // D = (meta, pdf, u, v); every plane holds n_classes queues of `cap` slots, slot = class * cap + sub-queue * subcap + position.  A
+    // record is 4 stores and 4 loads, and - what matters in the BVH walk's hand-in, where a wave's finished rays belong to several classes -
+    // the class is part of the lane's OFFSET: no loop over the classes present, no per-class queue pointers.
     float4* cq[4];
     int n_classes;
-    int miss_class;                              // volumetric, sorted: class queue that receives the rays that hit nothing (-1: misses are dropped)
-    int miss_rr_draw;                            // volumetric, sorted, misses dropped: a dropped miss still counts the roulette draw k_vshade would have made for it (vpt.py:164-172 precedes the hit test), so n_draws stays the reference's
 };
 #define APT_MAX_CLASSES 8
 // what one shade launch reads: either ray queue `cur` + the hit arrays (unsorted) or one class queue (sorted)
@@ -499,15 +492,6 @@ __global__ void __launch_bounds__(BLOCK) k_generate_trace(DevScene sc, Params p,
 // next-ray queue of this bounce (it was the current queue of the previous bounce) and the
 // shadow queue.  `n_src` = per-sub-queue counts (normally cnt->n_active[cur]).
 // MODE 0: BVH traversal (LDS-staged nodes + per-lane LDS stack); MODE 1: wave-uniform sweep (small scenes)
-// Volumetric tracer, sorted shading, scenes where a ray that hits nothing has nothing left to do: such rays are dropped by the extend
-// stage instead of travelling to a shade kernel.  Upstream's loop plays Russian roulette BEFORE it looks at the hit (vpt.py:164-172),
-// so a dropped ray may owe one random number; count it, so that the draw statistic equals the reference's loop draw for draw.
-APT_D void count_dropped_miss(const Params& p, const Queues& q, Counters* cnt, int cur, uint32_t io, int sq) {
-    if (!p.use_rr) return;
-    const f3 thr = ld3q(q.thr[cur], p.cap, io);
-    const uint32_t bounce = (ldq(q.meta[cur], io) >> 23) & 0xffu;
-    if (max3(thr) < p.rr_threshold && (int)bounce >= p.rr_bounce_th) atomicAdd(&cnt->stats[sq][ST_DRAWS], 1ull);
-}
 template <int MODE, int SORTED>
 __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 1)) k_extend(DevScene sc, Params p, Queues q, Counters* cnt, int cur, const uint32_t* n_src, LdsPlan plan) {
     __shared__ float s_sweep[MODE == 1 ? APT_SWEEP_LDS_FLOATS(BLOCK) : 1];
@@ -551,7 +535,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
             // its appends instead of one per class present; the record stores then run class by class with scalar queue pointers.
             // the rest of the path's record travels with the hit: requested before the class lookup and the tail atomic, so that all three round trips overlap
             const f3 st_thr = ld3q(q.thr[cur], p.cap, io); const uint32_t st_id = ldq(q.id[cur], io), st_meta = ldq(q.meta[cur], io); const float st_pdf = ldq(q.pdf[cur], io);
-            const int cls = !valid ? -1 : ((rec.prim >= 0) ? sc.prim_class[rec.prim] : q.miss_class);
+            const int cls = (valid && rec.prim >= 0) ? sc.prim_class[rec.prim] : -1;
             uint32_t my_rank = 0, cnt_vec = 0;
             for (int c = 0; c < q.n_classes; c++) {
                 const unsigned long long m = __ballot(cls == c);
@@ -561,20 +545,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
             uint32_t tail = 0;
             if ((int)lane_id() < q.n_classes && cnt_vec) tail = atomicAdd(&cnt->n_cls[lane_id()][sl.q * CNT_PAD], cnt_vec);
             const uint32_t cpos = (uint32_t)__shfl((int)tail, cls < 0 ? 0 : cls) + my_rank;
-            const uint32_t so = (qbase + cpos) << 2;
-            if (SORTED == 2) { if (cls >= 0) cq_store(q, (uint32_t)cls * p.cap + qbase + cpos, o, d, st_thr, st_id, st_meta, st_pdf, rec.t, rec.prim, rec.u, rec.v); }
-            else
-            for (int c = 0; c < q.n_classes; c++) {
-                if (cls == c) {
-                    const Queues::ClassQ& k = q.cls[c];
-                    st3q(k.ray_o, p.cap, so, o);
-                    st3q(k.ray_d, p.cap, so, d);
-                    st3q(k.thr, p.cap, so, st_thr);
-                    stq(k.id, so, st_id); stq(k.meta, so, st_meta); stq(k.pdf, so, st_pdf);
-                    stq(k.t, so, rec.t); stq(k.prim, so, rec.prim); stq(k.u, so, rec.u); stq(k.v, so, rec.v);
-                }
-            }
-            if (q.miss_rr_draw && valid && rec.prim < 0) count_dropped_miss(p, q, cnt, cur, io, sl.q);
+            if (cls >= 0) cq_store(q, (uint32_t)cls * p.cap + qbase + cpos, o, d, st_thr, st_id, st_meta, st_pdf, rec.t, rec.prim, rec.u, rec.v);
         }
 #ifdef APT_TILE_PROF
         if (MODE == 2) { unsigned long long t2_ = __builtin_readcyclecounter(); tile_prof[5] += tile_t1 - tile_t0; tile_prof[6] += t2_ - tile_t1; tile_prof[7] += 1; }
@@ -602,13 +573,10 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 #endif
 // Wave-level scheduling of the walk.  The while-while loop (a node step for every walking lane, then primitive tests until the slowest
 // lane has none left) kept half of the issue slots idle: most node steps leave a lane nothing to test, a few leave it a handful, and
-// the wave pays for the longest list (measured, C4: lane utilisation 0.58, of which the primitive loop ran at ~0.25).  With APT_WALK_VOTE
+// the wave pays for the longest list (measured, C4: lane utilisation 0.58, of which the primitive loop ran at ~0.25).  Now
 // an iteration performs ONE kind of action, the one more lanes are waiting for - a node step (lanes whose pending primitive group is
 // empty) or one primitive test (lanes with pending primitives) - and the others sit that iteration out; lanes gather on whichever side
 // is the minority until it becomes the majority.
-#ifndef APT_WALK_VOTE
-#define APT_WALK_VOTE 1
-#endif
 #ifndef APT_VOTE_TRI_WEIGHT
 #define APT_VOTE_TRI_WEIGHT 2      // the vote is "primitive test if (lanes waiting for one) x weight >= lanes waiting for a node step"
 #endif
@@ -675,9 +643,9 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
             f3 st_thr = splat3(0.f); uint32_t st_id = 0, st_meta = 0; float st_pdf = 0.f;
             if (fin) { st_thr = mk3(park[0], park[BLOCK], park[2 * BLOCK]); st_id = __float_as_uint(park[3 * BLOCK]); st_meta = __float_as_uint(park[4 * BLOCK]); st_pdf = park[5 * BLOCK]; }
 #if APT_FAST_LEAVES
-            const int cls = !fin ? -1 : ((rec.prim >= 0) ? fin_cls : q.miss_class);
+            const int cls = (fin && rec.prim >= 0) ? fin_cls : -1;
 #else
-            const int cls = !fin ? -1 : ((rec.prim >= 0) ? sc.prim_class[rec.prim] : q.miss_class);
+            const int cls = (fin && rec.prim >= 0) ? sc.prim_class[rec.prim] : -1;
 #endif
             uint32_t my_rank = 0, cnt_vec = 0;
             for (int c = 0; c < q.n_classes; c++) {
@@ -688,20 +656,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
             uint32_t tail = 0;
             if ((int)lane_id() < q.n_classes && cnt_vec) tail = atomicAdd(&cnt->n_cls[lane_id()][sq * CNT_PAD], cnt_vec);
             const uint32_t cpos = (uint32_t)__shfl((int)tail, cls < 0 ? 0 : cls) + my_rank;
-            const uint32_t so = (qbase + cpos) << 2;
-            if (SORTED == 2) { if (cls >= 0) cq_store(q, (uint32_t)cls * p.cap + qbase + cpos, r.o, r.d, st_thr, st_id, st_meta, st_pdf, rec.t, rec.prim, rec.u, rec.v); }
-            else
-            for (int c = 0; c < q.n_classes; c++) {
-                if (cls == c) {
-                    const Queues::ClassQ& k = q.cls[c];
-                    st3q(k.ray_o, p.cap, so, r.o);
-                    st3q(k.ray_d, p.cap, so, r.d);
-                    st3q(k.thr, p.cap, so, st_thr);
-                    stq(k.id, so, st_id); stq(k.meta, so, st_meta); stq(k.pdf, so, st_pdf);
-                    stq(k.t, so, rec.t); stq(k.prim, so, rec.prim); stq(k.u, so, rec.u); stq(k.v, so, rec.v);
-                }
-            }
-            if (q.miss_rr_draw && fin && rec.prim < 0) count_dropped_miss(p, q, cnt, cur_q, io, sq);
+            if (cls >= 0) cq_store(q, (uint32_t)cls * p.cap + qbase + cpos, r.o, r.d, st_thr, st_id, st_meta, st_pdf, rec.t, rec.prim, rec.u, rec.v);
         }
         if (fin) state = 0;
         // ---- claim fresh rays for the idle lanes
@@ -731,7 +686,6 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
         if (!__any(state == 1)) break;
         // ---- walk: the while-while loop of traverse<false>, left as soon as too few lanes still hold a ray
         const uint32_t min_active = exhausted ? 1u : (uint32_t)APT_DYN_MIN_ACTIVE;
-#if APT_WALK_VOTE
         // One action per iteration for the whole wave, chosen by vote (see walk_settle): a node step for the lanes without pending primitives,
         // or one primitive test for the lanes with some.  Per ray nothing changes - same nodes, same primitives, same order.
         do {
@@ -743,15 +697,6 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
             else if (want_n) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
             walk_settle(ts, sp, ng, tg, state);
         } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
-#else
-        do {
-            if (state == 1) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
-            tri_group<false>(sc.bvh, tg, r, rec, ws);
-            if (state == 1 && !APT_GROUP_HAS_NODES(ng)) {
-                if (sp == 0) state = 2; else ng = tpop(ts, sp);
-            }
-        } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
-#endif
     }
 #ifdef APT_WALK_STATS
     flush_stat(ws.nodes, &cnt->stats[sq][10]); flush_stat(ws.prims, &cnt->stats[sq][11]);
@@ -967,7 +912,6 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
     // one (vmcnt counts in order) does not wait for the prefetch - and lands while this row is shaded.
     constexpr bool PF = ((APT_SHADE_PREFETCH != 0) && BM == 0x002 && SM == 0x1 && TEX == 0) || (APT_SHADE_PREFETCH == 2 && TEX == 0);
     constexpr bool TRACE = FZ >= 2;                         // the continuation ray is traced in place too ("rays traced in place" above)
-    constexpr bool MULTI = FZ == 3;                         // ... FZ = 2: one queue (unsorted), one light sample per vertex - the kernel of C1 / C2, which carries nothing else; FZ = 3: queues by material class, any number of light samples
     static_assert(APT_FLAT_MAX_PRIMS < (int)TR_NO_PRIM, "the packed record keeps the hit primitive in 8 bits");
     constexpr bool PK = TRACE || CQ;                           // the input record is four 16-byte planes
     const uint32_t in_base = PK ? (uint32_t)in.cls * (A_->p).cap + qbase : qbase;      // first slot of the queue this workgroup reads
@@ -1143,7 +1087,6 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
         uint32_t vbase = 0;
         if (!FZ && (A_->p).nee_vm) vbase = wave_append(alive, shadow_counter);
         bool f_want = false; f3 f_dir = mk3(0.f, 0.f, 1.f), f_c = splat3(0.f); float f_tmax = 0.f;
-        const bool alive_nee = alive;
         f3 f_sum = splat3(0.f); bool f_any = false;            // FZ: the vertex's unoccluded light samples, summed in sample order (as the by-vertex shadow kernel sums them), added to the path's radiance once
 #if APT_FAST
         auto trace_light = [&](bool want, f3 dir, f3 c, float tmax) {
@@ -1230,15 +1173,8 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
                 } else if (alive) stq((A_->q).sh_tmax, so, -1.0f);                   // the vertex has no sample s worth tracing
                 if (alive && s == 0) stq((A_->q).sh_id, so, l_off);                   // one radiance slot per vertex, kept with its first entry
             } else if (FZ) {
-                // traced at the end of the row, when little else is live: one sample per vertex waits in registers, several are parked in LDS
-                // ([sample][component][thread]: conflict-free; a sample not worth tracing is marked by a negative distance)
-                if (!MULTI || (A_->p).S == 1) { f_want = want; f_dir = light_dir; f_c = contrib; f_tmax = emitter_d; }
-                else {
-                    lds_f* park = (lds_f*)reinterpret_cast<float*>(s_dyn) + ((uint32_t)s * 7u * BLOCK + threadIdx.x);
-                    park[0] = light_dir.x; park[BLOCK] = light_dir.y; park[2 * BLOCK] = light_dir.z;
-                    park[3 * BLOCK] = contrib.x; park[4 * BLOCK] = contrib.y; park[5 * BLOCK] = contrib.z;
-                    park[6 * BLOCK] = want ? emitter_d : -1.0f;
-                }
+                // traced at the end of the row, when little else is live: the vertex's one light sample waits in registers
+                f_want = want; f_dir = light_dir; f_c = contrib; f_tmax = emitter_d;
             } else if (PF && APT_SHADE_LATE_SHADOW && s == (A_->p).S - 1) {
                 late_app = append_issue(want, shadow_counter);
                 late_want = want; late_dir = light_dir; late_c = contrib; late_tmax = emitter_d;
@@ -1310,9 +1246,8 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
             t_extend += wave_count(cont);
             cont = cont && (tr_idx >= 0 || tr_defer);
             if (cont && !tr_defer) { HitRec hr; flat_resolve((A_->sc).flat, tr_idx, tr_t, hit_point, new_d, hr, hit_cls); tr_hit = hr.prim; tr_u = hr.u; tr_v = hr.v; }
-            tr_q = !cont ? -1 : (tr_defer ? (A_->q).tr_ncls : ((A_->q).tr_ncls > 1 ? hit_cls : 0));
-            if (MULTI) tr_app = tr_append_issue(tr_q, (A_->q).tr_ncls + 1, next_counter, APT_MAX_NQ * CNT_PAD);
-            else { const Append a_ = append_issue(tr_q == 0, next_counter); tr_app.raw = a_.raw; tr_app.rank = rank_in(a_.m); }      // (one queue; a staged ray - rare - moves the staging queue's tail by itself, below)
+            tr_q = !cont ? -1 : (tr_defer ? 1 : 0);            // (the queue, or the staging area at the top of its sub-queue's region)
+            { const Append a_ = append_issue(tr_q == 0, next_counter); tr_app.raw = a_.raw; tr_app.rank = rank_in(a_.m); }      // (one queue; a staged ray - rare - moves the staging queue's tail by itself, below)
         }
 #endif
         uint32_t npos = (PF && !TRACE) ? append_pos(next_app) : (TRACE ? 0u : wave_append(cont, next_counter));
@@ -1328,23 +1263,13 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
         APT_ARGS_PHASE();
 #if APT_FAST
         if (FZ) {
-            for (int s = 0; s < (MULTI ? (A_->p).S : 1); s++) {       // the row's light samples
-                if (MULTI && (A_->p).S > 1) {
-                    const lds_f* park = (const lds_f*)reinterpret_cast<const float*>(s_dyn) + ((uint32_t)s * 7u * BLOCK + threadIdx.x);
-                    f_dir = mk3(park[0], park[BLOCK], park[2 * BLOCK]); f_c = mk3(park[3 * BLOCK], park[4 * BLOCK], park[5 * BLOCK]);
-                    f_tmax = park[6 * BLOCK]; f_want = alive_nee && !(f_tmax < 0.0f);
-                }
-                trace_light(f_want, f_dir, f_c, f_tmax);
-            }
+            trace_light(f_want, f_dir, f_c, f_tmax);               // the row's light samples
             if (f_any) Lc = Lc + f_sum;
             if (TRACE) {
-                if (MULTI) npos = tr_append_pos(tr_app, tr_q);
-                else {
-                    npos = (uint32_t)__builtin_amdgcn_readlane((int)tr_app.raw, 0) + tr_app.rank;
-                    if (__any(tr_q == 1)) { const uint32_t dpos = wave_append(tr_q == 1, next_counter + APT_MAX_NQ * CNT_PAD); if (tr_q == 1) npos = dpos; }
-                }
+                npos = (uint32_t)__builtin_amdgcn_readlane((int)tr_app.raw, 0) + tr_app.rank;
+                if (__any(tr_q == 1)) { const uint32_t dpos = wave_append(tr_q == 1, next_counter + APT_MAX_NQ * CNT_PAD); if (tr_q == 1) npos = dpos; }
                 if (cont) {
-                    const uint32_t slot = (!MULTI && tr_q == 1) ? qbase + (A_->p).subcap - 1u - npos : (uint32_t)tr_q * (A_->p).cap + qbase + npos, so = slot << 4;      // (one queue: staged rays grow down from the top of the sub-queue's region)
+                    const uint32_t slot = (tr_q == 1) ? qbase + (A_->p).subcap - 1u - npos : (uint32_t)tr_q * (A_->p).cap + qbase + npos, so = slot << 4;      // (one queue: staged rays grow down from the top of the sub-queue's region)
                     stq((A_->q).tr[nxt][0], so, make_float4(hit_point.x, hit_point.y, hit_point.z, tr_t));
                     stq((A_->q).tr[nxt][1], so, make_float4(new_d.x, new_d.y, new_d.z, __uint_as_float(tr_pack(tr_hit, rng.draw, is_spec))));
                     stq((A_->q).tr[nxt][2], so, make_float4(thr.x, thr.y, thr.z, __uint_as_float(id)));
@@ -1501,7 +1426,6 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
         }
         if (!__any(state == 1)) break;
         const uint32_t min_active = exhausted ? 1u : (uint32_t)APT_DYN_MIN_ACTIVE_SH;
-#if APT_WALK_VOTE
         do {
             const bool want_t = state == 1 && tg.y != 0u, want_n = state == 1 && tg.y == 0u;
 #ifdef APT_WALK_STATS
@@ -1512,15 +1436,6 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
             } else if (want_n) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
             walk_settle(ts, sp, ng, tg, state);
         } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
-#else
-        do {
-            if (state == 1) group_step(sc.bvh, ts, sp, ng, tg, r, rec.t, ws);
-            if (tri_group<true>(sc.bvh, tg, r, rec, ws)) { occluded = true; sp = 0; ng.y = 0u; tg.y = 0u; }      // first occluder ends the walk
-            if (state == 1 && !APT_GROUP_HAS_NODES(ng)) {
-                if (sp == 0) state = 2; else ng = tpop(ts, sp);
-            }
-        } while ((uint32_t)__popcll(__ballot(state == 1)) >= min_active);
-#endif
     }
     flush_stat(t_lit, &cnt->stats[sq][ST_LIT]);
 #ifdef APT_WALK_STATS
@@ -1601,43 +1516,23 @@ APT_D void extend_flat_body(const DevScene& sc, const Params& p, const Queues& q
             v2u pid = ld2q<v2u>(q.id[cur], io), pmeta = ld2q<v2u>(q.meta[cur], io); v2f ppdf = ld2q<v2f>(q.pdf[cur], io);
             if (VAR == 2 && odd) { tx = mk2(tx.y, tx.x); ty = mk2(ty.y, ty.x); tz = mk2(tz.y, tz.x); ppdf = mk2(ppdf.y, ppdf.x); v2u t_; t_.x = pid.y; t_.y = pid.x; pid = t_; t_.x = pmeta.y; t_.y = pmeta.x; pmeta = t_; }
             // (a deferred entry joins its class queue in the fix-up launch)
-            const int cls0 = (!v0 || sp0) ? -1 : ((r0.prim >= 0) ? c0 : q.miss_class), cls1 = (!v1 || sp1) ? -1 : ((r1.prim >= 0) ? c1 : q.miss_class);
+            const int cls0 = (v0 && !sp0 && r0.prim >= 0) ? c0 : -1, cls1 = (v1 && !sp1 && r1.prim >= 0) ? c1 : -1;
             uint32_t rank0 = 0, rank1 = 0, cnt_vec = 0;
             for (int c = 0; c < q.n_classes; c++) {
                 const unsigned long long m0 = __ballot(cls0 == c), m1 = __ballot(cls1 == c);
-                // queue order = entry order (a lane's two entries stay neighbours): the stages downstream are the more coherent for it - the
-                // volumetric transmittance walk's wave-wide culls lost 16 % when a class queue held the wave's first entries, then its second ones
-                // (surface renders keep "first entries, then second entries": each record store then writes consecutive words - C3's extend 7.2 against 8.4 ms per 128 spp - and nothing downstream cares)
-                const uint32_t n0 = (uint32_t)__popcll(m0), below = rank_in(m0) + rank_in(m1);
-                if (cls0 == c) rank0 = p.keep_order ? below : rank_in(m0);
-                if (cls1 == c) rank1 = p.keep_order ? below + ((cls0 == c) ? 1u : 0u) : n0 + rank_in(m1);
+                // queue order: the wave's first entries, then its second ones - each record store then writes consecutive slots (C3's extend 7.2
+                // against 8.4 ms per 128 spp with a lane's two entries kept neighbours) and nothing downstream cares
+                const uint32_t n0 = (uint32_t)__popcll(m0);
+                if (cls0 == c) rank0 = rank_in(m0);
+                if (cls1 == c) rank1 = n0 + rank_in(m1);
                 if ((int)lane_id() == c) cnt_vec = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
             }
             uint32_t tail = 0;
             if ((int)lane_id() < q.n_classes && cnt_vec) tail = atomicAdd(&cnt->n_cls[lane_id()][sl.q * CNT_PAD], cnt_vec);
             const uint32_t so0 = (qbase + (uint32_t)__shfl((int)tail, cls0 < 0 ? 0 : cls0) + rank0) << 2;
             const uint32_t so1 = (qbase + (uint32_t)__shfl((int)tail, cls1 < 0 ? 0 : cls1) + rank1) << 2;
-            if (SORTED == 2) {
-                if (cls0 >= 0) cq_store(q, (uint32_t)cls0 * p.cap + (so0 >> 2), o0, d0, mk3(tx.x, ty.x, tz.x), pid.x, pmeta.x, ppdf.x, r0.t, r0.prim, r0.u, r0.v);
-                if (cls1 >= 0) cq_store(q, (uint32_t)cls1 * p.cap + (so1 >> 2), o1, d1, mk3(tx.y, ty.y, tz.y), pid.y, pmeta.y, ppdf.y, r1.t, r1.prim, r1.u, r1.v);
-            } else
-            for (int c = 0; c < q.n_classes; c++) {
-                const Queues::ClassQ& k = q.cls[c];
-                if (cls0 == c) {
-                    st3q(k.ray_o, p.cap, so0, o0); st3q(k.ray_d, p.cap, so0, d0); st3q(k.thr, p.cap, so0, mk3(tx.x, ty.x, tz.x));
-                    stq(k.id, so0, pid.x); stq(k.meta, so0, pmeta.x); stq(k.pdf, so0, ppdf.x);
-                    stq(k.t, so0, r0.t); stq(k.prim, so0, r0.prim); stq(k.u, so0, r0.u); stq(k.v, so0, r0.v);
-                }
-                if (cls1 == c) {
-                    st3q(k.ray_o, p.cap, so1, o1); st3q(k.ray_d, p.cap, so1, d1); st3q(k.thr, p.cap, so1, mk3(tx.y, ty.y, tz.y));
-                    stq(k.id, so1, pid.y); stq(k.meta, so1, pmeta.y); stq(k.pdf, so1, ppdf.y);
-                    stq(k.t, so1, r1.t); stq(k.prim, so1, r1.prim); stq(k.u, so1, r1.u); stq(k.v, so1, r1.v);
-                }
-            }
-            if (q.miss_rr_draw) {
-                if (v0 && !sp0 && r0.prim < 0) count_dropped_miss(p, q, cnt, cur, io0, sl.q);
-                if (v1 && !sp1 && r1.prim < 0) count_dropped_miss(p, q, cnt, cur, io + 4u, sl.q);
-            }
+            if (cls0 >= 0) cq_store(q, (uint32_t)cls0 * p.cap + (so0 >> 2), o0, d0, mk3(tx.x, ty.x, tz.x), pid.x, pmeta.x, ppdf.x, r0.t, r0.prim, r0.u, r0.v);
+            if (cls1 >= 0) cq_store(q, (uint32_t)cls1 * p.cap + (so1 >> 2), o1, d1, mk3(tx.y, ty.y, tz.y), pid.y, pmeta.y, ppdf.y, r1.t, r1.prim, r1.u, r1.v);
         }
     }
 }

@@ -29,9 +29,6 @@ struct DevBvh {
 //                                  sphere   q0=(centre, r)                  q2=(-, prim_id, 1, -)
 // primitive record, product build: triangle q0=(p0, U.x)  q1=(U.yz, V.xy)   q2=(V.z, T.xyz)      rows U, V, T of [e1 e2 n]^-1 (flat_build.cpp planar_rows)
 //                                  sphere   q0=(centre, NaN) q1=(r, -, -, -)
-#ifndef APT_FLAT_UNFUSED_HEIGHT
-#define APT_FLAT_UNFUSED_HEIGHT 0
-#endif
 #ifndef APT_FAST_LEAVES
 #define APT_FAST_LEAVES APT_FAST     // product build: precomputed-transform leaf records (0: the exact build's records and test in the product build, measurement only)
 #endif
@@ -747,17 +744,7 @@ APT_D void planar_solve(cf_ptr r, const FlatRays& q, v2f& t, v2f& u, v2f& v) {
     const v2f ux = sp2(r[3]), uy = sp2(r[4]), uz = sp2(r[5]);
     const v2f vx = sp2(r[6]), vy = sp2(r[7]), vz = sp2(r[8]);
     const v2f tx = sp2(r[9]), ty = sp2(r[10]), tz = sp2(r[11]);
-#if APT_FLAT_UNFUSED_HEIGHT
-    // The height of the ray's origin over the plane is a small difference of large products - for a ray that starts ON the plane, pure
-    // rounding noise - and t = height / cosine exceeds the 1e-4 threshold for grazing rays only when that noise is large enough: the share of
-    // rays that "re-hit" the surface they start on scales with the noise.  Upstream's adjugate solve rounds every product and every sum
-    // (tracer_base.py:206-207); a fused chain rounds a third as often, carries less noise and produced fewer such re-hits: -2.3e-4 shaded
-    // vertices on scenes/test/textured.xml (normal-mapped directions graze their own wall), the same sign under every seed.  With the height
-    // rounded like upstream's - product, product, sum, product, sum - the noise has upstream's distribution.
-    const v2f t_o = (tx * sx + ty * sy) + tz * sz;
-#else
     const v2f t_o = fma2(tx, sx, fma2(ty, sy, tz * sz));
-#endif
     const v2f t_d = fma2(tx, q.dx, fma2(ty, q.dy, tz * q.dz));
     v2f inv; inv.x = __builtin_amdgcn_rcpf(t_d.x); inv.y = __builtin_amdgcn_rcpf(t_d.y);
     t = -t_o * inv;
@@ -987,11 +974,7 @@ APT_D bool flat_any1(const FlatScene& fl, f3 o, f3 d, float lim) {
         const v2f ux = ld2c(r + 6), uy = ld2c(r + 8), uz = ld2c(r + 10);
         const v2f vx = ld2c(r + 12), vy = ld2c(r + 14), vz = ld2c(r + 16);
         const v2f tx = ld2c(r + 18), ty = ld2c(r + 20), tz = ld2c(r + 22);
-#if APT_FLAT_UNFUSED_HEIGHT
-        const v2f t_o = (tx * sx + ty * sy) + tz * sz;
-#else
         const v2f t_o = fma2(tx, sx, fma2(ty, sy, tz * sz));
-#endif
         const v2f t_d = fma2(tx, dx, fma2(ty, dy, tz * dz));
         v2f inv; inv.x = __builtin_amdgcn_rcpf(t_d.x); inv.y = __builtin_amdgcn_rcpf(t_d.y);
         t = -t_o * inv;
@@ -1043,11 +1026,7 @@ APT_D int flat_closest1(const FlatScene& fl, f3 o, f3 d, float lim, float& t_out
         const v2f ux = ld2c(r + 6), uy = ld2c(r + 8), uz = ld2c(r + 10);
         const v2f vx = ld2c(r + 12), vy = ld2c(r + 14), vz = ld2c(r + 16);
         const v2f tx = ld2c(r + 18), ty = ld2c(r + 20), tz = ld2c(r + 22);
-#if APT_FLAT_UNFUSED_HEIGHT
-        const v2f t_o = (tx * sx + ty * sy) + tz * sz;
-#else
         const v2f t_o = fma2(tx, sx, fma2(ty, sy, tz * sz));
-#endif
         const v2f t_d = fma2(tx, dx, fma2(ty, dy, tz * dz));
         v2f inv; inv.x = __builtin_amdgcn_rcpf(t_d.x); inv.y = __builtin_amdgcn_rcpf(t_d.y);
         t = -t_o * inv;
@@ -1126,13 +1105,5 @@ APT_D int flat_closest1(const FlatScene& fl, f3 o, f3 d, float lim, float& t_out
     } else b.runner = -1;
     t_out = b.t; runner = b.runner;
     return b.idx;
-}
-// one-ray adapters (volumetric transmittance walk, which keeps its one-entry-per-lane loop): the ray rides in both halves
-template <bool ANY>
-APT_D bool flat_sweep(const FlatScene& fl, const SweepScene& sw, f3 o, f3 d, HitRec& rec) {
-    if (ANY) { bool a, b; flat_any2(fl, sw, o, d, o, d, rec.t, rec.t, a, b); return a; }
-    HitRec other = rec; int c0, c1;
-    flat_closest2(fl, sw, sw.prim_obj, o, d, o, d, rec, other, c0, c1);     // (class output unused here: any int table serves the fallback lookup)
-    return false;
 }
 #endif

@@ -1,17 +1,14 @@
 // Volumetric path tracer stages (homogeneous participating media and grid volumes).
 //
 // Replaces VolumeRenderer.render of the reference (renderer/vpt.py:145-258) on the same wavefront skeleton as the surface path
-// tracer: k_generate and k_extend are shared; k_vshade is the loop body between two closest-hit queries (Russian roulette, free
-// path sampling, null-surface pass-through, light sampling, emission, phase-function / surface scattering) and k_vshadow is
+// tracer: k_generate and k_extend are shared; k_vevent + k_vshade_ev are the loop body between two closest-hit queries (Russian roulette,
+// free path sampling, null-surface pass-through | light sampling, emission, phase-function / surface scattering) and k_vshadow is
 // track_ray (vpt.py:99-138): the transmittance walk of a light sample through null surfaces and media, up to seven closest-hit
 // queries per sample.  Media: the world's and those attached to BSDF objects (bxdf/medium.py:71-125), phase functions H-G,
 // multi-H-G and Rayleigh (bxdf/phase.py, sampler/phase_sampling.py), and one RGB grid volume (bxdf/volume.py: delta tracking for
 // free paths, ratio tracking for light samples).
 #pragma once
 #include "stages.hpp"
-#ifndef APT_VSHADE_LEAN_WAVES
-#define APT_VSHADE_LEAN_WAVES 3
-#endif
 #ifndef APT_VSHADOW_WAVES
 #define APT_VSHADOW_WAVES 5
 #endif
@@ -179,237 +176,15 @@ APT_D f3 vol_transmittance(const DevVolume& vo, f3 ray_o, f3 ray_d, f3 thp, floa
     return (vo.type == 2) ? channel_vec(ch, Tr / pdf) : splat3(Tr);
 }
 
-// ------------------------------------------------------------------- vshade
-// One iteration of the while-loop of vpt.py:161-253 for every path of ray queue `cur` (unsorted) or of one event-class queue
-// (sorted: k_extend appended every ray to the queue of the surface class it hit, or to the miss class), given its closest hit.  The bounce
-// counter lives in the path's meta word (a null-surface pass-through re-queues the path without counting a bounce) and the
-// float slot that carries ray_pdf in the surface tracer carries emission_weight here (vpt.py:247-253 computes it at the END of
-// an iteration, from the interaction being left).
-// BM / SM: material and emitter masks as in k_shade (code for absent models is compiled out); the all-models variant also carries
-// the image-texture lookup.
-// VOL: the scene holds a grid volume (delta tracking in the free-path step, ratio tracking inside the light sampling).
-template <int BM, int SM, int VOL = 0>
-__global__ void __launch_bounds__(BLOCK, (((BM == 0x402 || BM == 0x00a || BM == 0x000 || BM == 0x504 || BM == 0x200) && !VOL) ? APT_VSHADE_LEAN_WAVES : 1)) k_vshade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur) {
-    constexpr bool TEX = (BM == APT_BX_ALL);
-    const int nxt = cur ^ 1;
-    const SubLoop sl = sub_loop(p.nq);
-    const uint32_t n = in.counts[sl.q * CNT_PAD];
-    const uint32_t qbase = (uint32_t)sl.q * p.subcap, sh_qbase = (uint32_t)sl.q * q.sh_subcap;
-    uint32_t* next_counter = &cnt->n_active[nxt][sl.q * CNT_PAD];
-    uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
-    const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
-    const DevMedium* world = sc.med + sc.n_objects;           // wave-uniform address: scalar loads
-    const bool world_scat = world->type >= 0;
-    uint32_t t_shade = 0, t_shadow = 0, t_poison = 0;
-    __shared__ uint32_t s_draws[BLOCK / 64];
-    if (lane_id() == 0) s_draws[threadIdx.x >> 6] = 0;
-    for (uint32_t base = sl.first; base < n; base += sl.stride) {
-        const uint32_t pos = base + threadIdx.x;
-        const uint32_t idx = qbase + pos;
-        bool alive = pos < n, shade = false, cont = false, is_mi = false, vol_event = false, in_free = true;
-        f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), thr = splat3(0.f), hit_point = splat3(0.f);
-        uint32_t id = 0, draw0 = 0, l_off = 0, bounce = 0;
-        float emission_weight = 1.f;
-        Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
-        Hit it; it.obj_id = -1; it.prim_id = -1; it.n_s = it.n_g = mk3(1.f, 0.f, 0.f); it.min_depth = 0.f;
-        int hit_light = -1, rec_light = -1;
-        DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
-        const DevMedium* med = world;                         // the medium of a medium interaction (a pointer, not a 17-register copy)
-        if (alive) {
-            const uint32_t io = idx << 2;
-            o = ld3q(in.ray_o, p.cap, io);
-            d = ld3q(in.ray_d, p.cap, io);
-            thr = ld3q(in.thr, p.cap, io);
-            id = ldq(in.id, io);
-            const uint32_t meta = ldq(in.meta, io);
-            emission_weight = ldq(in.pdf, io);
-            bounce = (meta >> 23) & 0xffu; draw0 = meta & 0x7fffffu;           // volumetric meta word: draw index [0,23) | bounce [23,31)
-            const uint32_t lp = id & ((1u << p.pix_bits) - 1u), s = id >> p.pix_bits;
-            l_off = (s * (uint32_t)p.npix + lp) << 2;
-            rng_init(rng, (p.world == 1) ? lp : ldq(p.pix_key, lp << 2), p.seed, (uint32_t)(p.cnt_base + (int)s + 1), draw0);
-            // Step 1: Russian roulette / cut-off BEFORE the intersection is looked at (vpt.py:164-172)
-            if (p.use_rr) {
-                const float mx = max3(thr);
-                if (mx < p.rr_threshold && (int)bounce >= p.rr_bounce_th) {
-                    if (rng_float(rng) > mx) alive = false;
-                    else thr = thr * (1.f / (mx + 1e-7f));
-                }
-            } else if (max3(thr) < 1e-5f) alive = false;
-            if (alive) {
-                // Step 2: the hit, or the far side of the world box when the world itself scatters (vpt.py:173-181)
-                const int prim = ldq(in.prim, io);
-                if (prim < 0) {
-                    if (!world_scat && !VOL) alive = false;
-                    else { it.min_depth = world_bound_time(p, o, d); in_free = true; }
-                } else {
-                    f3 rec_kd;
-                    build_hit(sc, prim, ldq(in.t, io), ldq(in.u, io), ldq(in.v, io), o, d, it, rec_light, rec_kd);
-                    in_free = dot(it.n_g, d) < 0.f;
-                    bx = sc.bxdf[it.obj_id];
-                }
-            }
-            if (alive) {
-                // Step 3: free-path sampling in the medium the segment crosses (vpt.py:72-97,184)
-                f3 beta = splat3(1.f);
-                const bool world_valid = in_free && world_scat;
-                const float depth0 = it.min_depth;
-                if (world_valid || vpt_is_scattering(sc, it.obj_id)) {
-                    float mfp = it.min_depth;
-                    if (world_valid) { med = world; is_mi = medium_sample_mfp(*med, it.min_depth, rng, mfp, beta); }
-                    else if (!in_free) { med = sc.med + it.obj_id; is_mi = medium_sample_mfp(*med, it.min_depth, rng, mfp, beta); }
-                    it.min_depth = mfp;
-                }
-                if (VOL) {                                                  // a grid-volume event overrides the homogeneous one (vpt.py:91-96)
-                    f3 vb; const float vt = vol_sample_mfp(sc.vol, o, d, thr, depth0, rng, vb);
-                    if (vt > 0.f) {
-                        is_mi = true; vol_event = true; it.min_depth = vt; beta = vb;
-                        med = in_free ? world : sc.med + it.obj_id;         // what eval() looks at for such an event (path_tracer.py:466-470)
-                    }
-                }
-                if (it.obj_id < 0 && !is_mi) alive = false;                 // left the world box
-                else {
-                    hit_point = d * it.min_depth + o;
-                    thr = thr * beta;
-                    if (!is_mi && !vpt_non_null(sc, it.obj_id)) cont = true;    // null surface: walk on, no bounce counted (vpt.py:189-191)
-                    else {
-                        shade = true;
-                        if (!is_mi) {
-                            hit_light = rec_light;
-                            f3 tx;
-                            if (TEX && sc.tex_i != nullptr && get_uv_item(sc, 0, it.obj_id, it.prim_id, ldq(in.u, io), ldq(in.v, io), tx)) bx.k_d = tx;   // vpt.py:199
-                        }
-                    }
-                }
-            }
-        }
-        t_shade += wave_count(shade);
-
-        // ---- Step 4: light sampling; the transmittance along the sample is k_vshadow's job
-        bool break_flag = false;
-        DevSrc src_only;
-        if (sc.n_sources == 1) src_only = ld_src_uniform(sc.src);
-        for (int s = 0; s < p.S; s++) {
-            bool want = false, sampled = false, poisoned = false;
-            f3 light_dir = splat3(0.f), contrib = splat3(0.f);
-            float emitter_d = 0.f;
-            if (shade && !break_flag) {
-                const int ns = sc.n_sources;
-                int sidx = rng_int(rng);
-                sidx = (ns == 1) ? 0 : pymod(sidx, ns);
-                float emitter_pdf = p.inv_ns;
-                bool valid = true;
-                if (hit_light >= 0) {
-                    if (ns <= 1) valid = false;
-                    else {
-                        sidx = rng_int(rng);
-                        sidx = (ns == 2) ? 0 : pymod(sidx, ns - 1);
-                        if (sidx >= hit_light) sidx += 1;
-                        emitter_pdf = p.inv_ns1;
-                    }
-                }
-                if (!valid) break_flag = true;
-                else {
-                    const DevSrc src = (ns == 1) ? src_only : sc.src[sidx];
-                    f3 shadow_int; float direct_pdf;
-                    const f3 emit_pos = emitter_sample_hit<SM>(src, geom, hit_point, rng, shadow_int, direct_pdf);
-                    const f3 to_emitter = emit_pos - hit_point;
-                    emitter_d = norm(to_emitter);
-                    light_dir = to_emitter / emitter_d;
-                    sampled = true;
-                    if (VOL) shadow_int = shadow_int * vol_transmittance(sc.vol, hit_point, light_dir, thr, emitter_d, rng);    // track_ray's first step (vpt.py:107-108): draws from the path's stream, here and now
-                    f3 direct_spec;
-                    if (is_mi) direct_spec = splat3(phase_eval_p(*med, d, light_dir));
-                    else direct_spec = surface_eval<BM>(bx, it, d, light_dir, sc.world_ior, p.two_sides);
-                    float mis_w = 1.0f;
-                    if (p.use_mis && !(src.bool_bits & 0x01)) {
-                        const float light_pdf = emitter_pdf * direct_pdf;
-                        const float bsdf_pdf_v = is_mi ? direct_spec.x : surface_pdf<BM>(bx, it, light_dir, d, sc.world_ior, p.two_sides);
-                        mis_w = balance(light_pdf, bsdf_pdf_v);
-                    }
-                    if (isnan(mis_w)) { stL(q.L, p.cap, l_off, splat3(mis_w)); poisoned = true; }     // as in k_shade: the sample is zeroed at the end
-                    else {
-                        f3 c = (direct_spec * shadow_int) * mis_w;
-                        if (ns != 1) c = c / emitter_pdf;
-                        contrib = (c * p.inv_S) * thr;
-                        want = !(contrib.x == 0.f && contrib.y == 0.f && contrib.z == 0.f);
-                    }
-                }
-            }
-            t_shadow += wave_count(sampled); t_poison += wave_count(poisoned);
-            const uint32_t spos = wave_append(want, shadow_counter);
-            if (want && spos < q.sh_subcap) {
-                const uint32_t so = (sh_qbase + spos) << 2, sc_ = q.sh_cap;
-                st3q(q.sh_o, sc_, so, hit_point);
-                st3q(q.sh_d, sc_, so, light_dir);
-                stq(q.sh_tmax, so, emitter_d);
-                st3q(q.sh_c, sc_, so, contrib);
-                stq(q.sh_id, so, l_off | ((p.l_planes > 1) ? (uint32_t)s : 0u));      // (the sample's radiance plane rides in the slot word's low bits, as in k_shade)
-            }
-        }
-
-        // ---- Steps 5-6: emission of the surface we are on, the next direction, the emission weight of the NEXT hit
-        f3 new_d = d;
-        bool is_spec = false;
-        if (shade) {
-            if ((SM & 2) && hit_light >= 0) {
-                const f3 emit_int = emitter_eval_le(sc.src[hit_light], hit_point - o, it.n_g);      // geometric normal here (vpt.py:233)
-                if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
-                    const f3 add = (emit_int * emission_weight) * thr;
-                    add_radiance(q.L, p.cap, l_off, add, true);
-                }
-            }
-            float ray_pdf = 1.f;
-            if (is_mi) {                                                        // Medium.sample_new_rays, medium.py:112-121
-                if (VOL && vol_event) {                                         // GridVolume.sample_new_rays: its own phase function
-                    const f3 local = phase_sample_p(sc.vol.ph, d, rng, ray_pdf);
-                    new_d = delocalize(d, local);
-                } else if (med->type >= 0) {
-                    const f3 local = phase_sample_p(*med, d, rng, ray_pdf);
-                    new_d = delocalize(d, local);
-                }
-                cont = true;                                                    // a medium event never ends the path by itself
-            } else {
-                f3 spec;
-                new_d = surface_sample<BM>(bx, it, d, sc.world_ior, p.two_sides, rng, spec, ray_pdf, is_spec);
-                cont = !(max3(spec) == 0.f || ray_pdf == 0.f);                  // vpt.py:240-241
-                if (cont) thr = thr * (spec / ray_pdf);
-            }
-            bounce += 1;
-            if ((int)bounce >= p.max_bounce) cont = false;
-            if (cont && it.obj_id >= 0) {                                       // vpt.py:247-253, with THIS interaction
-                hit_light = rec_light;
-                if (p.use_mis) {
-                    float e_pdf = 0.0f;
-                    if (hit_light >= 0 && bx.is_delta == 0 && !is_spec) e_pdf = emitter_solid_angle_pdf(sc.src[hit_light], it, new_d);
-                    emission_weight = balance(ray_pdf, e_pdf);
-                }
-            }
-        }
-        if (rng.draw != draw0) atomicAdd(&s_draws[threadIdx.x >> 6], rng.draw - draw0);
-        const uint32_t npos = wave_append(cont, next_counter);
-        if (cont) {
-            const uint32_t so = (qbase + npos) << 2;
-            st3q(q.ray_o[nxt], p.cap, so, hit_point);
-            st3q(q.ray_d[nxt], p.cap, so, new_d);
-            st3q(q.thr[nxt], p.cap, so, thr);
-            stq(q.id[nxt], so, id);
-            stq(q.meta[nxt], so, (rng.draw & 0x7fffffu) | (bounce << 23));      // tracking loops draw thousands of numbers per path: 16 bits would wrap
-            if (rng.draw > 0x7fffffu) atomicAdd(&cnt->stats[sl.q][ST_OVERFLOW], 1ull);     // a path that outgrows even 23 bits would silently re-use random numbers: reported by apt_synchronize / apt_get_stats
-            stq(q.pdf[nxt], so, emission_weight);
-        }
-    }
-    flush_uniform(t_shade, &cnt->stats[sl.q][ST_SHADE]);
-    flush_uniform(t_shadow, &cnt->stats[sl.q][ST_SHADOW]);
-    if (lane_id() == 0 && s_draws[threadIdx.x >> 6]) atomicAdd(&cnt->stats[sl.q][ST_DRAWS], (unsigned long long)s_draws[threadIdx.x >> 6]);
-    flush_uniform(t_poison, &cnt->stats[sl.q][ST_POISON]);
-}
-
 // ------------------------------------------------------------------- events
-// The same iteration in two stages, sorted by EVENT in between (the shipped volumetric pipeline; k_vshade above is the one-kernel form, kept
-// for A/B: APT_VEVENT=0).  One kernel for the whole loop body carries the roulette, the free-path sampling, the null-surface pass-through,
-// the light sampling with phase function AND every surface model of its class, and two ways to scatter: 170-240 VGPRs (two waves per
-// SIMD), and a wave's lanes take different branches - a medium event next to a surface hit next to a ray that only crosses the fog cube's
-// skin.  What a path does in an iteration is decided by steps 1-3 alone, before anything is shaded:
+// One iteration of the while-loop of vpt.py:161-253 in two stages, sorted by EVENT in between.  (Rounds 1-4 ran the whole loop body as ONE
+// kernel, k_vshade: roulette, free-path sampling, null-surface pass-through, light sampling with the phase function AND every surface model
+// of its class, two ways to scatter - 170-240 VGPRs, two waves per SIMD, and a wave's lanes in different branches: a medium event next to a
+// surface hit next to a ray that only crosses the fog cube's skin.  Measured against it, round 5: V1 1 051 -> 1 241, V2 665 -> 995, V3 638 ->
+// 990 Msamples/s; the one-kernel form is gone.)  The bounce counter lives in the path's meta word (a null-surface pass-through re-queues the
+// path without counting a bounce) and the float slot that carries ray_pdf in the surface tracer carries emission_weight here (vpt.py:247-253
+// computes it at the END of an iteration, from the interaction being left).  What a path does in an iteration is decided by steps 1-3
+// alone, before anything is shaded:
 //   k_vevent      steps 1-3 for every ray of the queue, given its closest hit (unsorted extend): Russian roulette, the hit or the world
 //                 box, free-path sampling (+ delta tracking through a grid volume).  A path that ends is dropped; a path that crosses a
 //                 null surface is re-queued at once (no bounce counted); every other path is an EVENT - a medium interaction, or a hit on a
@@ -418,7 +193,9 @@ __global__ void __launch_bounds__(BLOCK, (((BM == 0x402 || BM == 0x00a || BM == 
 //                 u, v).  No surface model, no emitter, no phase function in it.
 //   k_vshade_ev   steps 4-6 for one event queue: <MI = 1> the medium kernel (phase function, no surface model), <MI = 0, class mask> one
 //                 surface class (no phase function, no free-path code): light sampling, emission, scattering, the next hit's emission weight.
-// Per path nothing changes: the draws are taken in the reference's order (the draw index travels in the record), the arithmetic is k_vshade's.
+// The draws are taken in the reference's order (the draw index travels in the record).  BM / SM: material and emitter masks as in k_shade (code
+// for absent models is compiled out; the all-models kernel also carries the image-texture lookup); VOL: the scene holds a grid volume (delta
+// tracking in the free-path step, ratio tracking inside the light sampling).
 // meta word of an event record: draw index [0,23) | bounce [23,31) | bit 31: the interaction is a grid-volume collision
 // A medium event in front of a SPHERE keeps the sphere's own hit distance in the record's u slot (build_hit needs it for the normal
 // upstream computed before the free path overwrote min_depth, and a sphere has no barycentrics).
@@ -726,9 +503,6 @@ __global__ void __launch_bounds__(VSHADOW_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAV
         HitRec rec; rec.t = (depth > 0.0f) ? depth - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
         if (MODE == 0) traverse<false>(sc.bvh, make_stack(plan), o, d, rec);
         else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
-#if APT_FAST
-        else if (MODE == 3) flat_sweep<false>(sc.flat, sc.sweep, o, d, rec);
-#endif
         else sweep_tile<false, APT_VSHADOW_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
         bool arrived = false, walk_on = false;
         f3 c = splat3(0.f);

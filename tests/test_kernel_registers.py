@@ -18,8 +18,10 @@ KERNELS = [
     ("k_shade<0x002, 0x01, 0, 2>(DevScene, Params, Queues, Counters*, ShadeIn, int, int)", "_Z7k_shadeILi2ELi1ELi0ELi2EE", 128, "C1 / C2: rays traced in place, four waves per SIMD"),
     ("k_shade<0x002, 0x05, 0, 4>(DevScene, Params, Queues, Counters*, ShadeIn, int, int)", "_Z7k_shadeILi2ELi5ELi0ELi4EE", 128, "C4's Lambertian class (spot lights)"),
     ("k_shade<0x801, 0x03, 0, 4>(DevScene, Params, Queues, Counters*, ShadeIn, int, int)", "_Z7k_shadeILi2049ELi3ELi0ELi4EE", 128, "C3's wall class (Blinn-Phong without a lobe)"),
-    ("k_extend_dyn<2>(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan)", "_Z12k_extend_dynILi2EE", 72, "C4 / C5: closest-hit walk, seven waves per SIMD"),
-    ("k_extend_flat<2, 1>(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan)", "_Z13k_extend_flatILi2ELi1EE", 96, "C3: hot flat sweep, five waves per SIMD"),
+    ("k_extend_dyn<1>(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan)", "_Z12k_extend_dynILi1EE", 72, "C4 / C5: closest-hit walk, seven waves per SIMD"),
+    ("k_shade_group<0x03, 4, 0x002, 0x504, 0x200, 0x801>(DevScene, Params, Queues, Counters*, GroupIn, int, int)", "_Z13k_shade_groupILi3ELi4ELi2ELi1284ELi512ELi2049EE", 128, "C3 / C5: the four-wave group of class kernels"),
+    ("k_vshade_ev<0x002, 0x03, 0, 0>(DevScene, Params, Queues, Counters*, int, int)", "_Z11k_vshade_evILi2ELi3ELi0ELi0EE", 128, "V1 / V2: the Lambertian surface events of the volumetric tracer"),
+    ("k_extend_flat<1, 1>(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan)", "_Z13k_extend_flatILi1ELi1EE", 96, "C3: hot flat sweep, five waves per SIMD"),
 ]
 
 
@@ -27,7 +29,7 @@ KERNELS = [
 def test_hot_kernels_keep_their_register_budget(tmp_path):
     src = tmp_path / "probe.hip"
     src.write_text("#include <hip/hip_runtime.h>\n#include <algorithm>\n#include <cmath>\n#include <cstdio>\n#include <cstdlib>\n#include <cstring>\n"
-                   f'#include "{ROOT}/include/adapt_mi.h"\n#include "{ROOT}/adapt_amd/csrc/bvh_build.hpp"\n#include "{ROOT}/adapt_amd/csrc/stages.hpp"\n'
+                   f'#include "{ROOT}/include/adapt_mi.h"\n#include "{ROOT}/adapt_amd/csrc/bvh_build.hpp"\n#include "{ROOT}/adapt_amd/csrc/stages.hpp"\n#include "{ROOT}/adapt_amd/csrc/volumetric.hpp"\n'
                    + "".join(f"template __global__ void {inst};\n" for inst, *_ in KERNELS))
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-ffp-contract=off",
            "-DAPT_FAST=1", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", str(src), "-o", str(tmp_path / "probe.o")]
