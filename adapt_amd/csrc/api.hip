@@ -1054,7 +1054,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
                     if (is.p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }     // normally k_vshadow's first pass recycles these
                 }
                 if (is.p.S > 0) {
-                    const int n_pass = r->scene->has_null_surface ? 7 : 1;       // track_ray walks at most seven segments (vpt.py:113)
+                    const int n_pass = r->scene->has_null_surface ? (r->vshadow_mode == 4 ? APT_VSHADOW_FLAT_PASSES : 7) : 1;       // track_ray walks at most seven segments (vpt.py:113); the flat walk's last launch walks the later segments itself
                     const int items = r->vshadow_mode == 4 ? 2 * r->vshadow_nt : r->vshadow_nt;        // queue entries per workgroup tile
                     for (int pass = 0; pass < n_pass; pass++) {
                         LaunchTimer t(r, 3, st);

@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(BLOCK) k_vevent(DevScene sc, Params p, Queues 
                     else { it.min_depth = world_bound_time(p, o, d); in_free = true; }
                 } else {
                     hu = ldq(q.hit_u, io); hv = ldq(q.hit_v, io);
-                    build_hit(sc, prim, ldq(q.hit_t, io), hu, hv, o, d, it);
+                    { int l_; f3 kd_; build_hit_rec(sc, sc.prim_shade[2 * prim], sc.prim_shade[2 * prim + 1], prim, ldq(q.hit_t, io), hu, hv, o, d, it, l_, kd_, false); }      // (object, geometric normal, distance: the shading normal is the event kernel's business)
                     in_free = dot(it.n_g, d) < 0.f;
                     t_surface = it.min_depth;
                 }
@@ -549,6 +549,9 @@ __global__ void __launch_bounds__(VSHADOW_NT(MODE), (MODE == 2 ? APT_VSHADOW_WAV
     flush_stat(t_track, &cnt->stats[sl.q][ST_TRACK]);
 }
 
+#ifndef APT_VSHADOW_FLAT_PASSES
+#define APT_VSHADOW_FLAT_PASSES 3      // launches per iteration in scenes with null surfaces: segment 0, segment 1, the rest
+#endif
 #if APT_FAST
 // track_ray on the flat sweep (product build, scenes of up to APT_FLAT_MAX_PRIMS primitives): TWO light samples per lane - the two halves of
 // every packed instruction of the sweep (traverse.hpp flat_closest2).  k_vshadow<tile> tests a lane's one ray with the reference's
@@ -574,7 +577,7 @@ __global__ void __launch_bounds__(BLOCK) k_vshadow_flat(DevScene sc, Params p, Q
     const bool excl = APT_EXCLUSIVE_L(p);
     uint32_t t_lit = 0, t_track = 0;
     // one segment of one sample, given its closest hit (k_vshadow's per-sample block); returns true when the sample has to walk on
-    auto segment = [&](bool valid, f3& o, const f3& d, float& depth, f3& c, const HitRec& rec, uint32_t io) -> bool {
+    auto segment = [&](bool valid, f3& o, const f3& d, float& depth, f3& c, const HitRec& rec, uint32_t io, int seg_no) -> bool {
         if (!valid) return false;
         t_track++;
         int obj = -1; bool in_free = true, blocked = false, arrived = false, walk_on = false; float seg = depth;
@@ -595,7 +598,7 @@ __global__ void __launch_bounds__(BLOCK) k_vshadow_flat(DevScene sc, Params p, Q
             else if (!in_free && vpt_is_scattering(sc, obj)) c = c * exp_neg(sc.med[obj].u_e, seg);
             o = o + d * seg;
             depth -= seg;
-            if (depth <= 5e-5f || pass >= 6) arrived = true;                // at the light, or the seventh segment (vpt.py:113)
+            if (depth <= 5e-5f || seg_no >= 6) arrived = true;              // at the light, or the seventh segment (vpt.py:113)
             else walk_on = true;
         }
         if (arrived || blocked) {
@@ -614,13 +617,19 @@ __global__ void __launch_bounds__(BLOCK) k_vshadow_flat(DevScene sc, Params p, Q
         const f3 d0 = ld3q(q.sh_d, sc_, io0), d1 = ld3q(q.sh_d, sc_, io1);
         float depth0 = ldq(q.sh_tmax, io0), depth1 = ldq(q.sh_tmax, io1);
         f3 c0 = ld3q(q.sh_c, sc_, io0), c1 = ld3q(q.sh_c, sc_, io1);
-        HitRec r0, r1; int k0, k1;
-        r0.t = (depth0 > 0.0f) ? depth0 - 1e-4f : 1e7f; r0.prim = -1; r0.u = r0.v = 0.f;
-        r1.t = (depth1 > 0.0f) ? depth1 - 1e-4f : 1e7f; r1.prim = -1; r1.u = r1.v = 0.f;
-        flat_closest2(sc.flat, sc.sweep, sc.prim_class, o0, d0, o1, d1, r0, r1, k0, k1);
-        const bool on0 = segment(v0, o0, d0, depth0, c0, r0, io0);
-        const bool on1 = segment(v1, o1, d1, depth1, c1, r1, io1);
-        if (list_out != nullptr) {
+        bool on0 = v0, on1 = v1;
+        for (int seg = pass; ; seg++) {
+            HitRec r0, r1; int k0, k1;
+            r0.t = !on0 ? -1.0f : ((depth0 > 0.0f) ? depth0 - 1e-4f : 1e7f); r0.prim = -1; r0.u = r0.v = 0.f;      // (a finished sample searches below a negative limit: nothing is accepted)
+            r1.t = !on1 ? -1.0f : ((depth1 > 0.0f) ? depth1 - 1e-4f : 1e7f); r1.prim = -1; r1.u = r1.v = 0.f;
+            flat_closest2(sc.flat, sc.sweep, sc.prim_class, o0, d0, o1, d1, r0, r1, k0, k1);
+            on0 = segment(on0, o0, d0, depth0, c0, r0, io0, seg);
+            on1 = segment(on1, o1, d1, depth1, c1, r1, io1, seg);
+            // the last launch of an iteration (pass APT_VSHADOW_FLAT_PASSES - 1) walks what is left of its samples' segments itself: by then a
+            // handful of samples are still going (V1: a tenth after two segments), and four more launches over near-empty lists cost more than a thin wave
+            if (pass < APT_VSHADOW_FLAT_PASSES - 1 || seg >= 6 || !__any(on0 || on1)) break;
+        }
+        if (list_out != nullptr && pass < APT_VSHADOW_FLAT_PASSES - 1) {
             // both entries of the lane with ONE tail atomic per wave: the wave's first entries, then its second ones
             const unsigned long long m0 = __ballot(on0), m1 = __ballot(on1);
             uint32_t tail = 0;

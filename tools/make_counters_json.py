@@ -29,7 +29,7 @@ unit_name = {"extend": "queued ray", "shade": "queue entry", "shadow": "traced s
 
 
 def stage(name):
-    for key, pre in (("extend", ("k_extend",)), ("shadow", ("k_shadow", "k_vshadow")), ("shade", ("k_shade", "k_vshade"))):
+    for key, pre in (("extend", ("k_extend",)), ("shadow", ("k_shadow", "k_vshadow")), ("shade", ("k_shade", "k_vshade", "k_vevent"))):
         if any(p in name for p in pre):
             return key
     return None

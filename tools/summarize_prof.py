@@ -12,32 +12,24 @@ from collections import defaultdict
 out = sys.argv[1]
 
 
+_DEM = {}
+
+
 def short(name):
-    if "k_extend_dyn" in name:
-        return "k_extend_dyn<bvh, dynamic fetch" + (", sorted>" if "ILi1E" in name else ">")
-    if "k_shadow_dyn" in name:
-        return "k_shadow_dyn<bvh, dynamic fetch>"
-    if "k_extend_flat" in name:
-        return "k_extend_flat<flat sweep, 2 rays / lane" + (", sorted>" if "ILi1E" in name else ">")
-    if "k_shadow_flat" in name:
-        return "k_shadow_flat<flat sweep, 2 rays / lane>"
-    for k in ("k_generate", "k_extend", "k_vshade", "k_vshadow", "k_shade", "k_shadow", "k_finalize", "k_divide"):
-        if k in name:
-            tag = k
-            if k == "k_vshade":
-                import re
-                m = re.search(r"k_vshadeILi(\d+)ELi(\d+)E", name)
-                if m:
-                    tag += f"<bx=0x{int(m.group(1)):x},src=0x{int(m.group(2)):x}>"
-            if k in ("k_extend", "k_shadow", "k_vshadow"):
-                tag += "<sweep>" if "ILi1E" in name else ("<tile>" if "ILi2E" in name else "<bvh>")
-            if k == "k_shade":
-                import re
-                m = re.search(r"k_shadeILi(\d+)ELi(\d+)E", name)
-                if m:
-                    tag += f"<bx=0x{int(m.group(1)):x},src=0x{int(m.group(2)):x}>"
-            return tag
-    return name.split("(")[0][:48]
+    """Demangled kernel name without its argument list (template arguments say which variant ran: k_shade<material mask, emitter mask,
+    textures, FUSE>, k_shade_group<emitter mask, waves, member masks...>, k_vshade_ev<material mask, emitter mask, grid volume, medium>,
+    k_extend / k_shadow / k_vshadow<traversal mode: 0 tree, 1 sweep, 2 tile>, k_extend_dyn / k_extend_flat<sorted, ...>)."""
+    if name not in _DEM:
+        import re
+        import subprocess
+        try:
+            d = subprocess.run(["c++filt", name.replace(".kd", "")], capture_output=True, text=True).stdout.strip()
+        except Exception:
+            d = name
+        d = re.sub(r"^void ", "", d)
+        d = d.split("(")[0] if d.startswith("k_") else d.split("(")[0][:48]
+        _DEM[name] = d
+    return _DEM[name]
 
 
 def first_db(sub):
