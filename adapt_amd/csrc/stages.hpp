@@ -906,7 +906,7 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
 #define SH_TICK(k) do { } while (0)
 #endif
     // Software prefetch (the Lambertian / point-light kernel, which has the registers for it: C1 / C2).  A kernel that only streams
-    // k_shade's queues (13 SoA reads, 22 SoA writes per entry, same grid) moves 5.1 TB/s (tools/probes/stream_probe.hip), k_shade ~3:
+    // k_shade's queues (13 SoA reads, 22 SoA writes per entry, same grid) moves 5.1 TB/s (tools/history/probes/stream_probe.hip), k_shade ~3:
     // with 4 waves per SIMD each wave's loads are in flight only between its tile rows, and every row starts with two dependent round
     // trips.  So the next row's record is requested at the top of this row - after this row's shading record, so that waiting for that
     // one (vmcnt counts in order) does not wait for the prefetch - and lands while this row is shaded.
