@@ -43,14 +43,14 @@ typedef void (*shade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int, int)
 #else
 #define APT_FUSED_FN(...) nullptr         // light samples traced by the shade kernel: a product-build path (it rides on the flat sweep's records)
 #endif
-struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_fn fused, traced; };      // fused: the variant that traces its own light samples (stages.hpp k_shade FUSE = 1); traced: ... and its continuation ray (FUSE = 2: one light sample per vertex)
+struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_fn traced; };      // traced: the variant that traces its light sample and its continuation ray itself (stages.hpp k_shade FUSE = 2: flat sweep, one light sample per vertex)
 static const ShadeVariant kShadeVariants[] = {
-    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade<0x002, 0x01, 0, 1>), APT_FUSED_FN(k_shade<0x002, 0x01, 0, 2>)},
-    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade<0x003, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x003, 0x03, 0, 2>)},
-    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade<0x107, 0x03, 0, 1>), APT_FUSED_FN(k_shade<0x107, 0x03, 0, 2>)},
-    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 2>)},
+    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade<0x002, 0x01, 0, 2>)},
+    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade<0x003, 0x03, 0, 2>)},
+    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade<0x107, 0x03, 0, 2>)},
+    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 2>)},
 };
-static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 1>), APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 2>)};
+static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 2>)};
 // Material classes for sorted shading: (class mask) x (emitter mask: point+area | all)
 // A kernel's register allocation is the maximum over the models it contains, so the classes are as fine as the models'
 // footprints differ: Lambertian alone runs at 4 waves per SIMD, together with Blinn-Phong (three double pows) at 2-3.
@@ -719,10 +719,10 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     // ... and, by default, its continuation ray too (FUSE = 2, "rays traced in place": no extend launch, no fix-up launch per bounce); APT_FUSED=0|1|2
     // - unsorted or sorted by material class, any number of light samples per vertex
     {
-        const bool can1 = r->trace_mode == 3 && !r->sorted && !c.volumetric && S == 1 && r->shade->fused != nullptr;
+        const bool can1 = r->trace_mode == 3 && !r->sorted && !c.volumetric && S == 1;
         bool can2 = can1 && r->shade->traced != nullptr;
-        p.fused = can2 ? 2 : (can1 ? 1 : 0);
-        if (const char* f = getenv("APT_FUSED")) { const int want = atoi(f); p.fused = (want >= 2 && can2) ? 2 : ((want >= 1 && can1) ? 1 : 0); }
+        p.fused = can2 ? 2 : 0;
+        if (const char* f = getenv("APT_FUSED")) { const int want = atoi(f); p.fused = (want >= 2 && can2) ? 2 : 0; }
         if (p.fused == 2) { p.nee_vm = 0; p.l_planes = 1; }      // no shadow queue: a vertex's light samples are summed in registers
     }
     if (r->volumetric) {
@@ -750,7 +750,6 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     const int ncls = r->volumetric ? r->v_ncls : (r->sorted ? sc->n_classes : 0);
     r->shade_name = r->shade->name;
     if (p.fused == 2) r->shade_name += " [rays traced in place]";
-    else if (p.fused == 1) r->shade_name += " [light samples traced in place]";
     if (r->vevent) {
         r->shade_name = std::string(sc->has_volume ? "volumetric + grid volume, sorted by event: medium | " : "volumetric, sorted by event: medium | ");
         if (r->vev_single) r->shade_name += "all surface models";
@@ -779,7 +778,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     const bool stage_top = true;      // the staging queue lives at the top of the sub-queue's own region (Queues::tr_stage_top)
     const size_t tr_q = (p.fused == 2) ? 1 : 0;      // queues per plane (rays traced in place: unsorted renders, one queue)
     if (p.fused == 2 && tr_q * cap >= ((size_t)1 << 28)) { return fail(APT_E_INVALID, "apt_renderer_create: batch too large (rays traced in place: queues x capacity must stay below 2^28 slots)"); }
-    const size_t words = (p.fused == 1 ? 6 * cap : 0) + (p.fused == 2 ? (32 + (tr_uv ? 4 : 0)) * cap * tr_q : 0) - (p.fused == 2 ? (6 + 12) * cap : 0) + (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + (p.fused == 2 ? 0 : cap * 16 * (size_t)ncls) + (walk_lists ? 2 * sh_cap : 0);
+    const size_t words = (p.fused == 2 ? (32 + (tr_uv ? 4 : 0)) * cap * tr_q : 0) - (p.fused == 2 ? (6 + 12) * cap : 0) + (r->trace_mode == 3 ? cap + sh_cap : 0) + cap * (6 * 2 + 4 + (3 + 1 + 1 + 1) * 2 + 4 * l_planes) + sh_cap * (3 + 3 + 1 + 3 + 1) + (p.fused == 2 ? 0 : cap * 16 * (size_t)ncls) + (walk_lists ? 2 * sh_cap : 0);
     auto carve = [&](DevBuf& pool, Queues& q) -> hipError_t {
         hipError_t e_ = pool.alloc(words * 4);
         if (e_ != hipSuccess) return e_;
@@ -801,7 +800,6 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         q.fix_ext = (r->trace_mode == 3) ? (uint32_t*)take(cap) : nullptr; q.fix_sh = (r->trace_mode == 3) ? (uint32_t*)take(sh_cap) : nullptr;
         for (int k = 0; k < 2; k++) { q.thr[k] = staged ? take(3 * cap) : nullptr; q.id[k] = staged ? (uint32_t*)take(cap) : nullptr; q.meta[k] = staged ? (uint32_t*)take(cap) : nullptr; q.pdf[k] = staged ? take(cap) : nullptr; }
         q.L = take(4 * cap * l_planes);
-        for (int k = 0; k < 2; k++) q.Lc[k] = (p.fused == 1) ? take(3 * cap) : nullptr;
         q.sh_o = take(3 * sh_cap); q.sh_d = take(3 * sh_cap); q.sh_tmax = take(sh_cap); q.sh_c = take(3 * sh_cap); q.sh_id = (uint32_t*)take(sh_cap);
         q.sh_cap = (uint32_t)sh_cap; q.sh_subcap = (uint32_t)sh_subcap;
         q.sh_walk[0] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr; q.sh_walk[1] = walk_lists ? (uint32_t*)take(sh_cap) : nullptr;
@@ -1148,7 +1146,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             int cur = 0;
             for (int b = 0; b < p.max_bounce; b++) {
                 {                                           // (the records are Queues::tr[cur]: one queue for the scene)
-                    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
                     LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->shade->traced, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
                 }
                 cur ^= 1;
@@ -1166,8 +1164,8 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             if (r->trace_mode == 3) { LaunchTimer t(r, 1, st, false); hipLaunchKernelGGL(kFixFlat[si], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
             if (!r->sorted) {
                 ShadeIn in = {q.ray_o[cur], q.ray_d[cur], q.thr[cur], q.id[cur], q.meta[cur], q.pdf[cur],
-                              q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur], q.Lc[cur]};
-                LaunchTimer t(r, 2, st); hipLaunchKernelGGL(p.fused ? r->shade->fused : r->shade->fn, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
+                              q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur]};
+                LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->shade->fn, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
             } else {
                 if (r->shade_groups) {
                     for (int g = 0; g < APT_N_GROUPS; g++) {       // one launch per register-footprint group: its workgroups walk the member classes' queues one after the other
@@ -1178,7 +1176,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
                     }
                 } else
                 for (int c = 0; c < q.n_classes; c++) {
-                    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (const uint32_t*)cnt->n_cls[c], nullptr, c};      // (the record comes from Queues::cq, class c)
+                    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (const uint32_t*)cnt->n_cls[c], c};      // (the record comes from Queues::cq, class c)
                     LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->class_fn[c], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
                 }
                 if (p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }      // normally k_shadow recycles these
@@ -1270,7 +1268,7 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
     out->n_samples = sum(ST_SAMPLES); out->n_extend = sum(ST_EXTEND); out->n_shade = sum(ST_SHADE);
     out->n_shadow = sum(ST_SHADOW); out->n_shadow_traced = sum(ST_SHADOW_TRACED); out->n_lit = sum(ST_LIT);
     out->n_draws = sum(ST_DRAWS); out->n_poisoned = sum(ST_POISON); out->n_track = sum(ST_TRACK);
-#if defined(APT_SHADE_PROF) || defined(APT_TILE_PROF) || defined(APT_WALK_STATS)
+#if defined(APT_SHADE_PROF) || defined(APT_TILE_PROF) || defined(APT_WALK_STATS) || defined(APT_NEAR_STATS)
     const int64_t n_overflow = 0;                // profiling builds keep their counters in stats[8..15], which overlaps ST_OVERFLOW
 #else
     const int64_t n_overflow = sum(ST_OVERFLOW);
@@ -1293,6 +1291,9 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
     }
     fprintf(stderr, "[shade prof] wave-cycles: load+hit %lld | mis/rr %lld | nee %lld | shadow append %lld | bsdf sample %lld | wave lifetime (100MHz ticks) %lld | wave lifetime (cycles) %lld | iterations %lld ; launches %lld kernel_ms %.3f\n",
             (long long)sum(8), (long long)sum(9), (long long)sum(10), (long long)sum(11), (long long)sum(12), (long long)sum(13), (long long)sum(14), (long long)sum(15), (long long)r->launches[2], r->kernel_ms[2]);
+#endif
+#ifdef APT_NEAR_STATS
+    fprintf(stderr, "[near stats] shaded vertices %lld, of which within 2e-3 of the vertex before them %lld\n", (long long)out->n_shade, (long long)sum(14));
 #endif
 #ifdef APT_WALK_STATS
     {

@@ -125,7 +125,6 @@ struct Queues {
     float* sh_o; float* sh_d; float* sh_tmax; float* sh_c; uint32_t* sh_id;
     uint32_t* sh_walk[2];                        // volumetric, scenes with null surfaces: slot lists of the samples that walk on (ping-pong)
     float* L;                                    // 3 components, indexed by path id
-    float* Lc[2];                                // fused shading: the path's radiance so far, a queue component like thr (3 components; null elsewhere)
     uint32_t sh_cap, sh_subcap;
     // Material-sorted shading (scenes with >= 2 material classes): extend drops misses and appends each hit path's full record (ray + state
     // + hit, 64 B) to the dense queue of its material class, so every shade launch runs one specialised kernel over coherent waves; the
@@ -143,7 +142,6 @@ struct ShadeIn {
     const float* ray_o; const float* ray_d; const float* thr; const uint32_t* id; const uint32_t* meta; const float* pdf;
     const float* t; const int* prim; const float* u; const float* v;
     const uint32_t* counts;                      // per-sub-queue entry counts (stride CNT_PAD)
-    const float* Lc;                             // fused shading: carried radiance of the entries (null elsewhere)
     int cls;                                     // rays traced in place: which of Queues::tr's queues this launch reads
 };
 
@@ -895,6 +893,9 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
     const EmitterGeom geom = {(A_->sc).precom, (A_->sc).normals, (A_->sc).obj_info};
     uint32_t t_shade = 0, t_shadow = 0, t_poison = 0, t_traced = 0, t_lit = 0;        // wave-uniform tallies (SGPRs)
+#ifdef APT_NEAR_STATS
+    uint32_t t_near = 0;
+#endif
     __shared__ uint32_t s_draws[BLOCK / 64];                  // RNG draws of this wave: a per-lane tally would hold a VGPR for the whole kernel
     if (lane_id() == 0) s_draws[threadIdx.x >> 6] = 0;
 #ifdef APT_SHADE_PROF
@@ -984,8 +985,6 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
             if (alive && bounce > 0) { const float4 dd = ldq(trD, idx << 4); Lc = mk3(dd.x, dd.y, dd.z); if (SM & 2) ray_pdf = dd.w; }
             if (alive && bounce > 0) id = PF ? cu_id : __float_as_uint(ldq(reinterpret_cast<const float*>(trC), (idx << 4) + 12u));
         } else {
-        if (FZ && alive && bounce > 0) Lc = ld3q(in.Lc, (A_->p).cap, idx << 2);
-        if (FZ && alive && bounce > 0) id = PF ? cu_id : ldq(in.id, idx << 2);
         }
         bool was_spec = false;
         Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
@@ -1068,6 +1067,9 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
             }
         }
         t_shade += wave_count(alive);
+#ifdef APT_NEAR_STATS      // diagnostic build (tools/gpu_bias_probe.py --near): shaded vertices that sit within 2e-3 of the vertex before them - rays that re-hit the surface they left
+        t_near += wave_count(alive && bounce > 0 && it.min_depth < 2e-3f);
+#endif
         if (alive) {
             hit_point = d * it.min_depth + o;
         }
@@ -1277,8 +1279,7 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
                     if ((A_->sc).has_vn || (A_->sc).tex_i != nullptr) { float2 uv_; uv_.x = tr_u; uv_.y = tr_v; stq((A_->q).tr_uv[nxt], slot << 3, uv_); }
                 }
             }
-            if (cont) { if (!TRACE) st3q((A_->q).Lc[nxt], (A_->p).cap, (qbase + npos) << 2, Lc); }
-            else if (entry && !(Lc.x == 0.f && Lc.y == 0.f && Lc.z == 0.f)) {
+            if (!cont && entry && !(Lc.x == 0.f && Lc.y == 0.f && Lc.z == 0.f)) {
                 // the path ends here (nothing hit, roulette, last bounce): its radiance goes to its slot - added, not stored: a fix-up pass may have put a deferred sample's share there already
                 const uint32_t lp_ = id & ((1u << (A_->p).pix_bits) - 1u), s_ = id >> (A_->p).pix_bits;
                 add_radiance((A_->q).L, (A_->p).cap, (s_ * (uint32_t)(A_->p).npix + lp_) << 2, Lc, true);
@@ -1299,6 +1300,9 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
     flush_uniform(t_shadow, &cnt->stats[sl.q][ST_SHADOW]);
     if (lane_id() == 0 && s_draws[threadIdx.x >> 6]) atomicAdd(&cnt->stats[sl.q][ST_DRAWS], (unsigned long long)s_draws[threadIdx.x >> 6]);
     flush_uniform(t_poison, &cnt->stats[sl.q][ST_POISON]);
+#ifdef APT_NEAR_STATS
+    flush_uniform(t_near, &cnt->stats[sl.q][14]);
+#endif
 }
 template <int BM, int SM, int TEX = 0, int FUSE = 0>
 __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_LAMBERT_WAVES : APT_SHADE_WAVES))) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
@@ -1318,7 +1322,7 @@ __global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_L
 struct GroupIn { const uint32_t* counts[4]; int cls[4]; };     // per member: the class queue's per-sub-queue entry counts, its compact class id (-1: not in this scene)
 template <int SM, int WAVES, int B0, int B1, int B2, int B3>
 __global__ void __launch_bounds__(BLOCK, WAVES) k_shade_group(DevScene sc, Params p, Queues q, Counters* cnt, GroupIn g, int cur, int bounce) {
-    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if constexpr (B0 != 0) if (g.cls[0] >= 0) { in.counts = g.counts[0]; in.cls = g.cls[0]; shade_body<B0, SM, 0, 4>(kernel_args3(), cnt, in, cur, bounce); }
     if constexpr (B1 != 0) if (g.cls[1] >= 0) { in.counts = g.counts[1]; in.cls = g.cls[1]; shade_body<B1, SM, 0, 4>(kernel_args3(), cnt, in, cur, bounce); }
     if constexpr (B2 != 0) if (g.cls[2] >= 0) { in.counts = g.counts[2]; in.cls = g.cls[2]; shade_body<B2, SM, 0, 4>(kernel_args3(), cnt, in, cur, bounce); }
