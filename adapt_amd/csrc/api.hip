@@ -510,8 +510,8 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         if (e.type == 1) { e.prim_first = d->obj_info[3 * e.obj_ref_id]; e.prim_count = d->obj_info[3 * e.obj_ref_id + 2] ? -1 : d->obj_info[3 * e.obj_ref_id + 1]; }
     }
     std::vector<float> nrm(d->normals, d->normals + (size_t)N * 3);
-    std::vector<float> vn((size_t)N * 9, 0.f);
-    if (d->v_normals) vn.assign(d->v_normals, d->v_normals + (size_t)N * 9);
+    std::vector<float> vn((size_t)N * 12, 0.f);           // three 16-byte records per primitive (DevScene::vnormals)
+    if (d->v_normals) for (size_t k = 0; k < (size_t)N * 3; k++) for (int a = 0; a < 3; a++) vn[4 * k + a] = d->v_normals[3 * k + a];
     std::vector<int> oi(d->obj_info, d->obj_info + (size_t)O * 3), ei(d->emitter_id, d->emitter_id + (size_t)O);
 #define UP(buf, vec) do { hipError_t e_ = upload(s->buf, vec); if (e_ != hipSuccess) { delete s; return fail(APT_E_HIP, std::string("upload " #buf ": ") + hipGetErrorString(e_)); } } while (0)
     std::vector<int> slot_info((size_t)N);                // leaf slot -> primitive | material class << 28 (traverse.hpp walk_info)
@@ -535,7 +535,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     ds.bvh.nodes = s->nodes.as<uint4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.slot_prim = s->slot_prim.as<int>(); ds.bvh.n_nodes = s->wide.n_nodes(); ds.bvh.n_prims = N;
     ds.sweep.stream = s->sweep_recs.as<float>(); ds.sweep.obj_tab = s->sweep_tab.as<int>(); ds.sweep.prim_obj = s->prim_obj.as<int>(); ds.sweep.n_objects = O;
     s->has_aabb = d->obj_aabb != nullptr;
-    ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float>(); ds.precom = s->precom.as<float>();
+    ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float4>(); ds.precom = s->precom.as<float>();
     ds.flat.precom = ds.precom;
     ds.prim_obj = s->prim_obj.as<int>(); ds.prim_class = s->prim_class.as<int>(); ds.obj_info = s->obj_info.as<int>(); ds.emitter_id = s->emitter_id.as<int>();
     ds.bxdf = s->bxdf.as<DevBxdf>(); ds.src = s->src.as<DevSrc>();

@@ -51,7 +51,7 @@ struct DevScene {
     SweepScene sweep;         // small scenes: uniform brute-force sweep instead of the BVH
     FlatScene flat;           // small scenes, fast build: precomputed-transform records, two per packed instruction (traverse.hpp "Flat sweep")
     const float* normals;     // n_prims*3
-    const float* vnormals;    // n_prims*9
+    const float4* vnormals;   // n_prims*3: the three vertex normals as 16-byte records (three loads per vertex; as nine packed floats they were nine 4-byte gathers, and the vector-memory pipe pays per lane address)
     const float* precom;      // n_prims*9  (v1-v0, v2-v0, v0) | sphere (centre, rrr, centre)
     const int* prim_obj;      // n_prims
     const int* prim_class;    // n_prims: material class of the owning object (sorted shading), see APT_CLASS_* in api.hip
@@ -748,9 +748,9 @@ APT_D void build_hit_rec(const DevScene& sc, float4 ra, float4 rb, int prim, flo
     } else {
         it.n_g = mk3(ra.x, ra.y, ra.z);
         if (with_vn && sc.has_vn) {
-            const float* vn = sc.vnormals + 9 * prim;
+            const float4 v0 = sc.vnormals[3 * prim], v1 = sc.vnormals[3 * prim + 1], v2 = sc.vnormals[3 * prim + 2];
             // interpolated vertex normal, NOT re-normalised (tracer_base.py:228-230)
-            it.n_s = (ld3(vn) * (1.f - u - v) + ld3(vn + 3) * u) + ld3(vn + 6) * v;
+            it.n_s = (mk3(v0.x, v0.y, v0.z) * (1.f - u - v) + mk3(v1.x, v1.y, v1.z) * u) + mk3(v2.x, v2.y, v2.z) * v;
         } else it.n_s = it.n_g;
     }
 }
@@ -1023,8 +1023,9 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
                     build_hit_rec((A_->sc), cu_ra, cu_rb, prim, cu_t, 0.f, 0.f, o, d, it, hit_light, rec_kd, false);
                     if ((A_->sc).has_vn && __float_as_int(cu_ra.w) >= 0) {       // vertex normals: the barycentrics are fetched (and waited for) inside this branch only
                         if (TRACE) tr_uv_in = ldq((A_->q).tr_uv[cur], idx << 3);
-                        const float* vn = (A_->sc).vnormals + 9 * prim; const float bu = TRACE ? tr_uv_in.x : ldq(in.u, io), bv = TRACE ? tr_uv_in.y : ldq(in.v, io);
-                        it.n_s = (ld3(vn) * (1.f - bu - bv) + ld3(vn + 3) * bu) + ld3(vn + 6) * bv;
+                        const float4* vn = (A_->sc).vnormals + 3 * prim; const float bu = TRACE ? tr_uv_in.x : ldq(in.u, io), bv = TRACE ? tr_uv_in.y : ldq(in.v, io);
+                        const float4 v0 = vn[0], v1 = vn[1], v2 = vn[2];
+                        it.n_s = (mk3(v0.x, v0.y, v0.z) * (1.f - bu - bv) + mk3(v1.x, v1.y, v1.z) * bu) + mk3(v2.x, v2.y, v2.z) * bv;
                     }
                 }
                 else if (PK && PFP) build_hit_rec((A_->sc), cu_ra, cu_rb, prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
