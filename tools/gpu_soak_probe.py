@@ -17,15 +17,18 @@ scenes = [("cbox", "c2_cbox.xml", Renderer), ("csphere", "c3_balls_mono.xml", Re
           ("test", "media_a.xml", VolumeRenderer), ("test", "volgrid_b.xml", VolumeRenderer), ("test", "textured.xml", Renderer)]
 parsed = [(scene_parsing(os.path.join(ROOT, "scenes", d), f), cls) for d, f, cls in scenes]
 t0 = time.time()
-for it in range(8):
+ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 16           # (round 4 ran 8: a leak shows as drift that keeps growing with the cycles, one-off runtime pools as a step that stays)
+for it in range(ROUNDS):
     for tup, cls in parsed:
         for mode in ("", "bvh"):
             if mode: os.environ["APT_TRAVERSAL"] = mode
             else: os.environ.pop("APT_TRAVERSAL", None)
             r = cls(*tup, width=96, height=64)
             r.render(n_spp=3); r.pixels.to_numpy(); r.stats(); r.close()
+    if (it + 1) % 4 == 0:
+        print("  after %3d create / render / destroy cycles: free memory drift %.3f GiB" % ((it + 1) * len(parsed) * 2, base - free_gb()), flush=True)
 os.environ.pop("APT_TRAVERSAL", None)
-print("create/destroy x", 8 * len(parsed) * 2, "in %.1fs; free memory drift %.3f GiB" % (time.time() - t0, base - free_gb()), flush=True)
+print("create/destroy x", ROUNDS * len(parsed) * 2, "in %.1fs; free memory drift %.3f GiB" % (time.time() - t0, base - free_gb()), flush=True)
 r = Renderer(*parsed[0][0])
 t0 = time.time()
 for k in range(12):
