@@ -142,7 +142,7 @@ struct apt_scene {
     DevScene dev{};
     apt::BvhData bvh;                    // binary SAH tree (leaves of <= 3 primitives): the intermediate of the build
     apt::WideBvhData wide;               // 8-wide quantised tree: what the kernels walk
-    DevBuf nodes, prims, slot_prim, normals, vnormals, precom, emit_tri, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
+    DevBuf nodes, prims, slot_prim, normals, vnormals, precom, prim_obj, prim_class, obj_info, emitter_id, bxdf, src, sweep_recs, sweep_tab, obj_aabb;
     DevBuf flat_pairs;                   // the flat records two by two (traverse.hpp FlatScene::pairs)
     DevBuf flat_recs, flat_tab;          // flat sweep (fast build, small scenes): records and the per-record table (traverse.hpp FlatScene)
     bool has_flat = false;
@@ -529,16 +529,13 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
             slot_info[(size_t)slot] = (int)((uint32_t)k | (c << 28));
         }
     }
-    std::vector<float> etri((size_t)N * 12, 0.f);         // (DevScene::emit_tri)
-    for (size_t k = 0; k < (size_t)N; k++) for (int row = 0; row < 3; row++) { for (int a = 0; a < 3; a++) etri[12 * k + 4 * row + a] = prec[9 * k + 3 * row + a]; etri[12 * k + 4 * row + 3] = nrm[3 * k + row]; }
-    UP(emit_tri, etri);
     UP(nodes, s->wide.nodes); UP(prims, recs); UP(slot_prim, slot_info); UP(normals, nrm); UP(vnormals, vn); UP(precom, prec); UP(prim_obj, prim_obj);
     UP(obj_info, oi); UP(emitter_id, ei); UP(bxdf, bx); UP(src, sr); UP(sweep_recs, sw); UP(sweep_tab, sw_tab); UP(obj_aabb, aabb);
     DevScene& ds = s->dev;
     ds.bvh.nodes = s->nodes.as<uint4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.slot_prim = s->slot_prim.as<int>(); ds.bvh.n_nodes = s->wide.n_nodes(); ds.bvh.n_prims = N;
     ds.sweep.stream = s->sweep_recs.as<float>(); ds.sweep.obj_tab = s->sweep_tab.as<int>(); ds.sweep.prim_obj = s->prim_obj.as<int>(); ds.sweep.n_objects = O;
     s->has_aabb = d->obj_aabb != nullptr;
-    ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float4>(); ds.precom = s->precom.as<float>(); ds.emit_tri = s->emit_tri.as<float4>();
+    ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float4>(); ds.precom = s->precom.as<float>();
     ds.flat.precom = ds.precom;
     ds.prim_obj = s->prim_obj.as<int>(); ds.prim_class = s->prim_class.as<int>(); ds.obj_info = s->obj_info.as<int>(); ds.emitter_id = s->emitter_id.as<int>();
     ds.bxdf = s->bxdf.as<DevBxdf>(); ds.src = s->src.as<DevSrc>();

@@ -651,9 +651,8 @@ APT_D float surface_pdf(const DevBxdf& b, Hit& it, f3 outdir, f3 incid, float wo
 
 // ------------------------------------------------------------------ emitters
 struct EmitterGeom {        // what sample_hit needs from the attached object
-    // n_prims*3 records of 16 bytes: (v1 - v0, n.x), (v2 - v0, n.y), (v0, n.z) | sphere (centre, -), (r r r, -), (centre, -): a light sample reads its
-    // triangle with three loads (as nine + three packed floats it was twelve 4-byte gathers per sample - four samples per vertex on C3)
-    const float4* tri;
+    const float* precom;    // n_prims*9: (v1-v0, v2-v0, v0) | sphere (centre, rrr, centre)
+    const float* normals;   // n_prims*3
     const int* obj_info;    // n_objects*3
 };
 APT_D f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
@@ -672,9 +671,9 @@ APT_D f3 emitter_sample_hit(const DevSrc& s, const EmitterGeom& g, f3 hit_pos, P
         pdf = s.inv_area;
         f3 normal;
         if (s.prim_count < 0) {
-            const float4 c0 = g.tri[3 * s.prim_first], c1 = g.tri[3 * s.prim_first + 1];
-            f3 center = mk3(c0.x, c0.y, c0.z);
-            float radius = c1.x;
+            const float* pc = g.precom + 9 * s.prim_first;
+            f3 center = ld3(pc);
+            float radius = pc[3];
             f3 to_hit = normalize(hit_pos - center);
             float p;
             f3 local = sample_uniform_sphere(r, p);
@@ -683,9 +682,9 @@ APT_D f3 emitter_sample_hit(const DevSrc& s, const EmitterGeom& g, f3 hit_pos, P
             pdf = p / (radius * radius);
         } else {
             int tri = pymod(rng_int(r), s.prim_count) + s.prim_first;
-            const float4 t0 = g.tri[3 * tri], t1 = g.tri[3 * tri + 1], t2 = g.tri[3 * tri + 2];
-            normal = mk3(t0.w, t1.w, t2.w);
-            pos = sample_on_triangle(r, mk3(t0.x, t0.y, t0.z), mk3(t1.x, t1.y, t1.z)) + mk3(t2.x, t2.y, t2.z);
+            normal = ld3(g.normals + 3 * tri);
+            const float* pc = g.precom + 9 * tri;
+            pos = sample_on_triangle(r, ld3(pc), ld3(pc + 3)) + ld3(pc + 6);
         }
         f3 diff = hit_pos - pos;
         float dl = dot(normalize(diff), normal);

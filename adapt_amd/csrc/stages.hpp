@@ -53,7 +53,6 @@ struct DevScene {
     const float* normals;     // n_prims*3
     const float4* vnormals;   // n_prims*3: the three vertex normals as 16-byte records (three loads per vertex; as nine packed floats they were nine 4-byte gathers, and the vector-memory pipe pays per lane address)
     const float* precom;      // n_prims*9  (v1-v0, v2-v0, v0) | sphere (centre, rrr, centre)
-    const float4* emit_tri;   // n_prims*3: precom and the geometric normal as three 16-byte records (shading.hpp EmitterGeom: what a light sample reads)
     const int* prim_obj;      // n_prims
     const int* prim_class;    // n_prims: material class of the owning object (sorted shading), see APT_CLASS_* in api.hip
     const int* obj_info;      // n_objects*3
@@ -896,7 +895,7 @@ APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, i
         if (in.cls == 0) cnt->n_tr[(bounce + 2) % 3][(A_->q).tr_ncls][sl.q * CNT_PAD] = 0;
     }
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
-    const EmitterGeom geom = {(A_->sc).emit_tri, (A_->sc).obj_info};
+    const EmitterGeom geom = {(A_->sc).precom, (A_->sc).normals, (A_->sc).obj_info};
     uint32_t t_shade = 0, t_shadow = 0, t_poison = 0, t_traced = 0, t_lit = 0;        // wave-uniform tallies (SGPRs)
 #ifdef APT_NEAR_STATS
     uint32_t t_near = 0;
@@ -1789,7 +1788,7 @@ __global__ void k_emitter_probe(DevScene sc, int n, const float* in, uint32_t se
     if (k >= n) return;
     const float* x = in + 11 * k;
     const DevSrc s = sc.src[(int)x[0]];
-    const EmitterGeom geom = {sc.emit_tri, sc.obj_info};
+    const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
     Philox r; rng_init(r, (uint32_t)k, seed, 1u, 0u);
     f3 inten; float pdf;
     f3 pos = emitter_sample_hit<APT_SRC_ALL>(s, geom, ld3(x + 1), r, inten, pdf);

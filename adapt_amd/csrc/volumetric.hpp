@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(BLOCK) k_vshade_ev(DevScene sc, Params p, Queu
     const uint32_t qbase = (uint32_t)sl.q * p.subcap, sh_qbase = (uint32_t)sl.q * q.sh_subcap, in_base = (uint32_t)cls * p.cap + qbase;
     uint32_t* next_counter = &cnt->n_active[nxt][sl.q * CNT_PAD];
     uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
-    const EmitterGeom geom = {sc.emit_tri, sc.obj_info};
+    const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
     const DevMedium* world = sc.med + sc.n_objects;
     uint32_t t_shade = 0, t_shadow = 0, t_poison = 0;
     __shared__ uint32_t s_draws[BLOCK / 64];
