@@ -68,10 +68,6 @@ static const int kClassMask[APT_N_CLASS_DEFS] = {
     0x801,      // Blinn-Phong objects without a specular lobe (k_s = 0, finite k_g >= 0: shading.hpp mask bit 11): no double-precision pow
 };
 static const char* kClassName[APT_N_CLASS_DEFS] = {"lambertian", "blinn-phong", "oren-nayar", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans", "microfacet", "blinn-phong(no lobe)"};
-// [class][emitter set: point + area | all | point + spot (no area light: no emission code, no pdf in the record, both Philox blocks up front)]
-static const shade_fn kClassShade[APT_N_CLASS_DEFS][3] = {      // (FUSE = 4: the class queues are packed planes, Queues::cq)
-    {k_shade<0x002, 0x03, 0, 4>, k_shade<0x002, APT_SRC_ALL, 0, 4>, k_shade<0x002, 0x05, 0, 4>}, {k_shade<0x001, 0x03, 0, 4>, k_shade<0x001, APT_SRC_ALL, 0, 4>, k_shade<0x001, 0x05, 0, 4>}, {k_shade<0x040, 0x03, 0, 4>, k_shade<0x040, APT_SRC_ALL, 0, 4>, k_shade<0x040, 0x05, 0, 4>}, {k_shade<0x504, 0x03, 0, 4>, k_shade<0x504, APT_SRC_ALL, 0, 4>, k_shade<0x504, 0x05, 0, 4>}, {k_shade<0x010, 0x03, 0, 4>, k_shade<0x010, APT_SRC_ALL, 0, 4>, k_shade<0x010, 0x05, 0, 4>}, {k_shade<0x020, 0x03, 0, 4>, k_shade<0x020, APT_SRC_ALL, 0, 4>, k_shade<0x020, 0x05, 0, 4>}, {k_shade<0x080, 0x03, 0, 4>, k_shade<0x080, APT_SRC_ALL, 0, 4>, k_shade<0x080, 0x05, 0, 4>}, {k_shade<0x200, 0x03, 0, 4>, k_shade<0x200, APT_SRC_ALL, 0, 4>, k_shade<0x200, 0x05, 0, 4>}, {k_shade<0x008, 0x03, 0, 4>, k_shade<0x008, APT_SRC_ALL, 0, 4>, k_shade<0x008, 0x05, 0, 4>}, {k_shade<0x801, 0x03, 0, 4>, k_shade<0x801, APT_SRC_ALL, 0, 4>, k_shade<0x801, 0x05, 0, 4>},
-};
 // Class kernels in groups (stages.hpp k_shade_group): one launch per GROUP and bounce instead of one per class.  Groups follow the register
 // footprints - a kernel allocates for its largest member: 0 = up to 128 VGPRs (four waves per SIMD), 1 = up to 168 (three), 2 = beyond (two).
 typedef void (*group_fn)(DevScene, Params, Queues, Counters*, GroupIn, int, int);
@@ -80,7 +76,7 @@ static const int kClassGroup[APT_N_CLASS_DEFS] = {0, 1, 1, 0, 2, 2, 1, 0, 1, 0};
 static const int kClassSlot[APT_N_CLASS_DEFS] = {0, 0, 1, 1, 0, 1, 2, 2, 3, 3};       // ... and its member slot there (the B0..B3 order below)
 #define APT_GROUP_ROW(SM) {k_shade_group<SM, 4, 0x002, 0x504, 0x200, 0x801>, k_shade_group<SM, 3, 0x001, 0x040, 0x080, 0x008>, k_shade_group<SM, 1, 0x010, 0x020, 0, 0>}
 // (group 0 is held to four waves per SIMD: its members allocate 120-126 VGPRs alone, 129 together - the allocator then parks one 8-byte constant in scratch)
-static const group_fn kGroupShade[3][APT_N_GROUPS] = {APT_GROUP_ROW(0x03), APT_GROUP_ROW(APT_SRC_ALL), APT_GROUP_ROW(0x05)};      // [emitter set, as kClassShade][group]
+static const group_fn kGroupShade[3][APT_N_GROUPS] = {APT_GROUP_ROW(0x03), APT_GROUP_ROW(APT_SRC_ALL), APT_GROUP_ROW(0x05)};      // [emitter set: point + area | all | point + spot (no area light: no emission code, no pdf in the record, both Philox blocks up front)][group]
 #define APT_CLASS_PHONG 1
 #define APT_CLASS_PHONG_NO_LOBE 9
 static int class_of(int is_bsdf, int type, bool no_lobe) {
@@ -192,8 +188,6 @@ struct apt_renderer {
     int vev_single = 0;           // ... with ONE surface queue served by the all-models kernel (textured scenes, more classes than queues)
     vev_shade_fn vev_fn[APT_MAX_CLASSES] = {};
     bool vev_live[APT_MAX_CLASSES] = {};      // an event queue that can receive entries at all (a class of null surfaces only is never shaded)
-    shade_fn class_fn[APT_N_CLASS_DEFS] = {};
-    int shade_groups = 1;                                 // class kernels launched in groups (APT_SHADE_GROUPS=0: one launch per class, for A/B)
     group_fn group_fn_[APT_N_GROUPS] = {};                // ... the group kernels for this scene's emitter set
     int group_cls[APT_N_GROUPS][4] = {};                  // ... compact class id of each member slot (-1: the scene has no such class)
     std::string shade_name;
@@ -758,10 +752,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : (((sc->src_mask & ~0x05) == 0) ? 2 : 1);
         r->shade_name = "sorted:";
         for (int g = 0; g < APT_N_GROUPS; g++) { r->group_fn_[g] = kGroupShade[smi][g]; for (int k = 0; k < 4; k++) r->group_cls[g][k] = -1; }
-        if (const char* f = getenv("APT_SHADE_GROUPS")) r->shade_groups = atoi(f) != 0 ? 1 : 0;
-        if (r->shade_groups) r->shade_name = "sorted, launched in register-footprint groups:";
+        r->shade_name = "sorted, launched in register-footprint groups:";
         for (int c = 0; c < ncls; c++) {
-            r->class_fn[c] = kClassShade[sc->class_def[c]][smi];
             r->group_cls[kClassGroup[sc->class_def[c]]][kClassSlot[sc->class_def[c]]] = c;
             r->shade_name += std::string(c ? "+" : "") + kClassName[sc->class_def[c]];
         }
@@ -1167,17 +1159,11 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
                               q.hit_t, q.hit_prim, q.hit_u, q.hit_v, (const uint32_t*)cnt->n_active[cur]};
                 LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->shade->fn, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
             } else {
-                if (r->shade_groups) {
-                    for (int g = 0; g < APT_N_GROUPS; g++) {       // one launch per register-footprint group: its workgroups walk the member classes' queues one after the other
-                        GroupIn gi; bool any = false;
-                        for (int k = 0; k < 4; k++) { const int c = r->group_cls[g][k]; gi.cls[k] = c; gi.counts[k] = c >= 0 ? (const uint32_t*)cnt->n_cls[c] : nullptr; any = any || c >= 0; }
-                        if (!any) continue;
-                        LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->group_fn_[g], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, gi, cur, b);
-                    }
-                } else
-                for (int c = 0; c < q.n_classes; c++) {
-                    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (const uint32_t*)cnt->n_cls[c], c};      // (the record comes from Queues::cq, class c)
-                    LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->class_fn[c], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
+                for (int g = 0; g < APT_N_GROUPS; g++) {       // one launch per register-footprint group: its workgroups walk the member classes' queues one after the other
+                    GroupIn gi; bool any = false;
+                    for (int k = 0; k < 4; k++) { const int c = r->group_cls[g][k]; gi.cls[k] = c; gi.counts[k] = c >= 0 ? (const uint32_t*)cnt->n_cls[c] : nullptr; any = any || c >= 0; }
+                    if (!any) continue;
+                    LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->group_fn_[g], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, gi, cur, b);
                 }
                 if (p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }      // normally k_shadow recycles these
             }

@@ -855,30 +855,6 @@ def test_nine_material_classes_on_the_tree_lose_no_hits(monkeypatch):
         f.close(); e.close()
 
 
-@pytest.mark.parametrize("which,exact", [("balls_mono", False), ("features_b", False), ("bunny_field1", False), ("balls_mono", True)])
-def test_group_launches_render_the_per_class_schedule_bit_for_bit(which, exact, parsed, monkeypatch):
-    """Class kernels launched in register-footprint groups (stages.hpp k_shade_group: one launch per group and bounce, its workgroups walk
-    the member classes' queues one after the other) against one launch per class (APT_SHADE_GROUPS=0): the same class code over the same
-    queues in the same order inside a queue - the image and every path statistic are equal to the last bit."""
-    from adapt_amd.renderer import Renderer
-    from adapt_amd.synth import bunny_field
-    tup = bunny_field(levels=1) if which == "bunny_field1" else parsed(which)
-    out = {}
-    for groups in ("1", "0"):
-        monkeypatch.setenv("APT_SHADE_GROUPS", groups)
-        r = Renderer(*tup, width=96, height=64, exact=exact)
-        try:
-            assert ("groups" in r.info()["shade_variant"]) == (groups == "1"), r.info()["shade_variant"]
-            r.render(n_spp=6)
-            out[groups] = (r.color.to_numpy().copy(), r.stats())
-        finally:
-            r.close()
-    assert np.array_equal(out["1"][0], out["0"][0], equal_nan=True)
-    for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"):
-        assert out["1"][1][k] == out["0"][1][k], (k, out["1"][1][k], out["0"][1][k])
-    assert out["1"][1]["launches"]["shade"] < out["0"][1]["launches"]["shade"]
-
-
 @pytest.mark.parametrize("tag", ["vpt_cbox", "media_a"])
 def test_flat_transmittance_walk_against_the_tiled_walk(tag, monkeypatch):
     """k_vshadow_flat (two light samples per lane on the flat sweep) against the walk it replaces in

@@ -16,8 +16,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # (explicit instantiation, mangled-name prefix, VGPR budget, why)
 KERNELS = [
     ("k_shade<0x002, 0x01, 0, 2>(DevScene, Params, Queues, Counters*, ShadeIn, int, int)", "_Z7k_shadeILi2ELi1ELi0ELi2EE", 128, "C1 / C2: rays traced in place, four waves per SIMD"),
-    ("k_shade<0x002, 0x05, 0, 4>(DevScene, Params, Queues, Counters*, ShadeIn, int, int)", "_Z7k_shadeILi2ELi5ELi0ELi4EE", 128, "C4's Lambertian class (spot lights)"),
-    ("k_shade<0x801, 0x03, 0, 4>(DevScene, Params, Queues, Counters*, ShadeIn, int, int)", "_Z7k_shadeILi2049ELi3ELi0ELi4EE", 128, "C3's wall class (Blinn-Phong without a lobe)"),
+    ("k_shade_group<0x05, 4, 0x002, 0x504, 0x200, 0x801>(DevScene, Params, Queues, Counters*, GroupIn, int, int)", "_Z13k_shade_groupILi5ELi4ELi2ELi1284ELi512ELi2049EE", 128, "C4: the four-wave group of class kernels, spot lights"),
     ("k_extend_dyn<1>(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan)", "_Z12k_extend_dynILi1EE", 72, "C4 / C5: closest-hit walk, seven waves per SIMD"),
     ("k_shade_group<0x03, 4, 0x002, 0x504, 0x200, 0x801>(DevScene, Params, Queues, Counters*, GroupIn, int, int)", "_Z13k_shade_groupILi3ELi4ELi2ELi1284ELi512ELi2049EE", 128, "C3 / C5: the four-wave group of class kernels"),
     ("k_vshade_ev<0x002, 0x03, 0, 0>(DevScene, Params, Queues, Counters*, int, int)", "_Z11k_vshade_evILi2ELi3ELi0ELi0EE", 128, "V1 / V2: the Lambertian surface events of the volumetric tracer"),
