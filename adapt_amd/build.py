@@ -17,12 +17,18 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libadapt_mi.so")                 # default build: fast arithmetic (APT_FAST=1)
 LIB_EXACT = os.path.join(HERE, "libadapt_mi_exact.so")     # bit-parity build: the reference's float32 arithmetic, operation for operation
 SOURCES = ["api.hip", "bvh_gpu.hip", "bvh_build.cpp", "bvh_linear.cpp", "bvh_wide.cpp", "flat_build.cpp"]
-HEADERS = ["vec.hpp", "rng.hpp", "shading.hpp", "traverse.hpp", "stages.hpp", "bvh_build.hpp", os.path.join("..", "..", "include", "adapt_mi.h"), "volumetric.hpp"]
+HEADERS = ["vec.hpp", "rng.hpp", "shading.hpp", "traverse.hpp", "stages.hpp", "shade_stage.hpp", "unit_kernels.hpp", "bvh_build.hpp", os.path.join("..", "..", "include", "adapt_mi.h"), "volumetric.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-fast-math",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          # every queue/list append here is already aggregated per wave by hand (ballot + one atomic from lane 0);
          # LLVM's atomic optimizer would wrap that in a second aggregation and serialise independent atomics
-         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
+         "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+         # the SLP vectoriser pairs independent float operations into v_pk_* instructions - same arithmetic, element for element - and its
+         # 64-bit register pairs cost every shading kernel 12-20 VGPRs (the four-wave class group 127 + spills -> 115, the walk 72 -> 64,
+         # the all-models kernel one wave -> two) for issue slots these kernels are not short of; without it, same box, old -> new
+         # Msamples/s: C2 4163 -> 4267, C3 1095 -> 1142, V1 1214 -> 1277, V3 965 -> 1057, nothing slower (profiles/NOTES.md, round 5).
+         # The flat sweep's two-rays-per-lane packed FMAs are written as vector types by hand and stay.
+         "-fno-slp-vectorize"]
 # Two builds of the same sources (DESIGN.md "float parity policy"), both with -ffp-contract=off, IEEE division / sqrt and transcendentals
 # evaluated in double and rounded once - the shading arithmetic written in csrc/ is the arithmetic executed in BOTH (measured: FMA
 # contraction in the shading code buys nothing - k_shade is bound by its dependent loads and Philox - but turns exact zeros such as

@@ -4,7 +4,7 @@
 // Taichi side (field allocation + upload: tracer_base.py:76-134, path_tracer.py:245-274; one
 // kernel launch per spp: render.py:118-122; readback: utils/watermark.py:23) happens here:
 // scene upload, BVH build, queue allocation in HBM, the per-batch stage schedule on a private
-// HIP stream, statistics and HIP-event timing.  Stage kernels live in stages.hpp.
+// HIP stream, statistics and HIP-event timing.  Stage kernels live in stages.hpp, shade_stage.hpp and volumetric.hpp.
 #include <hip/hip_runtime.h>
 #include <chrono>
 
@@ -19,7 +19,8 @@
 
 #include "../../include/adapt_mi.h"
 #include "bvh_build.hpp"
-#include "stages.hpp"
+#include "shade_stage.hpp"
+#include "unit_kernels.hpp"
 #include "volumetric.hpp"
 
 #define APT_EXPORT extern "C" __attribute__((visibility("default")))
@@ -41,16 +42,17 @@ typedef void (*shade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int, int)
 #if APT_FAST
 #define APT_FUSED_FN(...) __VA_ARGS__
 #else
-#define APT_FUSED_FN(...) nullptr         // light samples traced by the shade kernel: a product-build path (it rides on the flat sweep's records)
+#define APT_FUSED_FN(...) nullptr         // rays traced by the shade kernel: a product-build path (it rides on the flat sweep's records)
 #endif
-struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_fn traced; };      // traced: the variant that traces its light sample and its continuation ray itself (stages.hpp k_shade FUSE = 2: flat sweep, one light sample per vertex)
+typedef void (*shade_traced_fn)(DevScene, Params, Queues, Counters*, int, int);
+struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_traced_fn traced; };      // traced: the kernel that traces its light sample and its continuation ray itself (shade_stage.hpp k_shade_traced: flat sweep, one light sample per vertex)
 static const ShadeVariant kShadeVariants[] = {
-    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade<0x002, 0x01, 0, 2>)},
-    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade<0x003, 0x03, 0, 2>)},
-    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade<0x107, 0x03, 0, 2>)},
-    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 0, 2>)},
+    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade_traced<0x002, 0x01>)},
+    {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade_traced<0x003, 0x03>)},
+    {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade_traced<0x107, 0x03>)},
+    {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade_traced<APT_BX_ALL, APT_SRC_ALL>)},
 };
-static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures", APT_FUSED_FN(k_shade<APT_BX_ALL, APT_SRC_ALL, 1, 2>)};
+static const ShadeVariant kTexturedShade = {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL, 1>, "all models + image textures", APT_FUSED_FN(k_shade_traced<APT_BX_ALL, APT_SRC_ALL, 1>)};
 // Material classes for sorted shading: (class mask) x (emitter mask: point+area | all)
 // A kernel's register allocation is the maximum over the models it contains, so the classes are as fine as the models'
 // footprints differ: Lambertian alone runs at 4 waves per SIMD, together with Blinn-Phong (three double pows) at 2-3.
@@ -68,7 +70,7 @@ static const int kClassMask[APT_N_CLASS_DEFS] = {
     0x801,      // Blinn-Phong objects without a specular lobe (k_s = 0, finite k_g >= 0: shading.hpp mask bit 11): no double-precision pow
 };
 static const char* kClassName[APT_N_CLASS_DEFS] = {"lambertian", "blinn-phong", "oren-nayar", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans", "microfacet", "blinn-phong(no lobe)"};
-// Class kernels in groups (stages.hpp k_shade_group): one launch per GROUP and bounce instead of one per class.  Groups follow the register
+// Class kernels in groups (shade_stage.hpp k_shade_group): one launch per GROUP and bounce instead of one per class.  Groups follow the register
 // footprints - a kernel allocates for its largest member: 0 = up to 128 VGPRs (four waves per SIMD), 1 = up to 168 (three), 2 = beyond (two).
 typedef void (*group_fn)(DevScene, Params, Queues, Counters*, GroupIn, int, int);
 #define APT_N_GROUPS 3
@@ -709,8 +711,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     if (const char* force = getenv("APT_SORTED")) r->sorted = (atoi(force) != 0 && sc->n_classes >= 1 && sc->n_classes <= APT_MAX_CLASSES) ? 1 : 0;
     if (textured) r->sorted = 0;
     r->volumetric = c.volumetric ? 1 : 0;
-    // light samples traced by the shade kernel itself (stages.hpp k_shade FUSE): flat sweep, one sample per vertex, one shade kernel
-    // ... and, by default, its continuation ray too (FUSE = 2, "rays traced in place": no extend launch, no fix-up launch per bounce); APT_FUSED=0|1|2
+    // rays traced by the shade kernel itself (shade_stage.hpp k_shade_traced, "rays traced in place": no extend, shadow or fix-up launch per bounce):
+    // flat sweep, one light sample per vertex, one shade kernel; APT_FUSED=0 stages them
     // - unsorted or sorted by material class, any number of light samples per vertex
     {
         const bool can1 = r->trace_mode == 3 && !r->sorted && !c.volumetric && S == 1;
@@ -1132,15 +1134,12 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
         const int nq = r->nq;
 #if APT_FAST
         if (p.fused == 2) {
-            // rays traced in place (stages.hpp): generate and every bounce are ONE launch each; the rare rays that need the reference-order code
+            // rays traced in place (shade_stage.hpp): generate and every bounce are ONE launch each; the rare rays that need the reference-order code
             // are served by the next launch's prologue, the last bounce's deferred light samples by one fix-up launch at the end
             { LaunchTimer t(r, 0, st); hipLaunchKernelGGL(k_generate_trace, dim3(grid_for(total, r->grid_small, 1)), dim3(BLOCK), 0, st, sc, p, q, cnt); }
             int cur = 0;
             for (int b = 0; b < p.max_bounce; b++) {
-                {                                           // (the records are Queues::tr[cur]: one queue for the scene)
-                    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-                    LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->shade->traced, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, in, cur, b);
-                }
+                { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->shade->traced, dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, b); }      // (the records are Queues::tr[cur]: one queue for the scene)
                 cur ^= 1;
             }
             if (p.max_bounce > 0) { LaunchTimer t(r, 3, st, false); hipLaunchKernelGGL(kFixFlat[0], dim3(r->grid_fix), dim3(BLOCK), 0, st, sc, p, q, cnt, cur, (const uint32_t*)cnt->n_active[cur], lane_plan); }
@@ -1254,29 +1253,10 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
     out->n_samples = sum(ST_SAMPLES); out->n_extend = sum(ST_EXTEND); out->n_shade = sum(ST_SHADE);
     out->n_shadow = sum(ST_SHADOW); out->n_shadow_traced = sum(ST_SHADOW_TRACED); out->n_lit = sum(ST_LIT);
     out->n_draws = sum(ST_DRAWS); out->n_poisoned = sum(ST_POISON); out->n_track = sum(ST_TRACK);
-#if defined(APT_SHADE_PROF) || defined(APT_TILE_PROF) || defined(APT_WALK_STATS) || defined(APT_NEAR_STATS)
+#if defined(APT_WALK_STATS) || defined(APT_NEAR_STATS)
     const int64_t n_overflow = 0;                // profiling builds keep their counters in stats[8..15], which overlaps ST_OVERFLOW
 #else
     const int64_t n_overflow = sum(ST_OVERFLOW);
-#endif
-#ifdef APT_SHADE_PROF
-    {
-        std::vector<unsigned long long> dbg(2 * 16384);
-        (void)hipMemcpy(dbg.data(), (const char*)r->counters.p + offsetof(Counters, dbg), dbg.size() * 8, hipMemcpyDeviceToHost);
-        unsigned long long t0 = ~0ull, t1 = 0; int nw = 0;
-        for (int w = 0; w < 16384; w++) if (dbg[2 * w]) { t0 = std::min(t0, dbg[2 * w]); t1 = std::max(t1, dbg[2 * w + 1]); nw++; }
-        if (nw) {
-            int hist_s[10] = {0}, hist_e[10] = {0}; double span = (double)(t1 - t0) + 1;
-            for (int w = 0; w < 16384; w++) if (dbg[2 * w]) { hist_s[(int)(10 * (dbg[2 * w] - t0) / span)]++; hist_e[(int)(10 * (dbg[2 * w + 1] - t0) / span)]++; }
-            fprintf(stderr, "[shade waves] last launch: %d waves, span %.1f us; start deciles:", nw, span / 100.0);
-            for (int k = 0; k < 10; k++) fprintf(stderr, " %d", hist_s[k]);
-            fprintf(stderr, " ; end deciles:");
-            for (int k = 0; k < 10; k++) fprintf(stderr, " %d", hist_e[k]);
-            fprintf(stderr, "\n");
-        }
-    }
-    fprintf(stderr, "[shade prof] wave-cycles: load+hit %lld | mis/rr %lld | nee %lld | shadow append %lld | bsdf sample %lld | wave lifetime (100MHz ticks) %lld | wave lifetime (cycles) %lld | iterations %lld ; launches %lld kernel_ms %.3f\n",
-            (long long)sum(8), (long long)sum(9), (long long)sum(10), (long long)sum(11), (long long)sum(12), (long long)sum(13), (long long)sum(14), (long long)sum(15), (long long)r->launches[2], r->kernel_ms[2]);
 #endif
 #ifdef APT_NEAR_STATS
     fprintf(stderr, "[near stats] shaded vertices %lld, of which within 2e-3 of the vertex before them %lld\n", (long long)out->n_shade, (long long)sum(14));
@@ -1295,10 +1275,6 @@ APT_EXPORT int apt_get_stats(apt_renderer* r, apt_stats* out) {
     fprintf(stderr, "[walk stats] closest-hit rays %lld: %.2f node steps, %.2f primitive tests per ray | shadow rays %lld: %.2f node steps, %.2f primitive tests per ray\n",
             (long long)out->n_extend, (double)sum(10) / (double)std::max<int64_t>(1, out->n_extend), (double)sum(11) / (double)std::max<int64_t>(1, out->n_extend),
             (long long)out->n_shadow_traced, (double)sum(12) / (double)std::max<int64_t>(1, out->n_shadow_traced), (double)sum(13) / (double)std::max<int64_t>(1, out->n_shadow_traced));
-#endif
-#ifdef APT_TILE_PROF
-    fprintf(stderr, "[tile prof] wave-cycles: stage %lld | A %lld | wait %lld | B %lld | wait %lld | sweep total %lld | append %lld | tiles*waves %lld\n",
-            (long long)sum(8), (long long)sum(9), (long long)sum(10), (long long)sum(11), (long long)sum(12), (long long)sum(13), (long long)sum(14), (long long)sum(15));
 #endif
     for (int k = 0; k < APT_N_KERNELS; k++) { out->launches[k] = r->launches[k]; out->kernel_ms[k] = r->kernel_ms[k]; }
     out->render_ms = r->render_ms;

@@ -50,8 +50,8 @@ APT_HD uint32_t rng_u32(Philox& r) {
     const bool step = b != r.blk;
     if (step && b != r.nblk) { philox4x32_10(r.ctr0, b, 0u, 0u, r.key0, r.key1, r.n); r.nblk = b; }      // not opened ahead: generate here
     if (step) { r.c[0] = r.n[0]; r.c[1] = r.n[1]; r.c[2] = r.n[2]; r.c[3] = r.n[3]; r.blk = b; r.nblk = 0xffffffffu; }
-    const uint32_t w = d & 3u;     // select without dynamic register indexing
-    return (w == 0u) ? r.c[0] : ((w == 1u) ? r.c[1] : ((w == 2u) ? r.c[2] : r.c[3]));
+    const uint32_t w = d & 3u, c0 = r.c[0], c1 = r.c[1], c2 = r.c[2], c3 = r.c[3];     // select without dynamic register indexing (of VALUES: a conditional over the array's lvalues is a pointer phi, which can keep the block in scratch)
+    return (w == 0u) ? c0 : ((w == 1u) ? c1 : ((w == 2u) ? c2 : c3));
 }
 // For a stage that draws at most five numbers per path: both blocks those draws can touch, generated now, unconditionally.  A generation
 // computes every lane's own block in one pass, but left to the draw sites it runs at every site where ANY lane steps into a new block,

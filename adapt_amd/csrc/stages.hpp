@@ -99,8 +99,8 @@ struct Params {
     int volumetric_flat;      // 1: volumetric render (the flat shadow kernels never run: the fix-up launch has no shadow list)
     int nee_vm;               // 1: light samples are queued BY VERTEX (one slot per vertex and sub-queue, sample s in plane s of the sub-queue's region, unwanted samples marked tmax < 0), so that the flat shadow kernel adds a vertex's samples with ONE read-modify-write and the shade kernel moves the queue tail once per tile row (flat sweep, S > 1)
     int l_planes;             // radiance planes of L: light sample s of a vertex adds into plane s (2 <= S <= 4), so that no two entries of a shadow launch share a slot; 1 otherwise
-    int fused;                // 1: the shade kernel traces its own light samples (flat sweep, one sample per vertex, unsorted: stages.hpp "light samples traced in place"); no shadow queue, no shadow launch, radiance travels with the path (Queues::Lc)
-                              // 2: ... and its continuation ray too (k_generate its camera rays): no extend launch, no fix-up launch per bounce, rays that hit nothing never enter a queue (stages.hpp "rays traced in place")
+    int fused;                // 2: the shade kernel traces its own light sample and continuation ray, k_generate its camera rays (flat sweep, one sample per vertex, unsorted: shade_stage.hpp "rays traced in place"):
+                              //    no extend, shadow or fix-up launch per bounce, no shadow queue, radiance travels with the path's record, rays that hit nothing never enter a queue; 0: staged
     float w_min[3], w_max[3]; // world box = (objects U camera) +- 0.1 (path_tracer.py:130-138); volumetric tracer only
 };
 
@@ -160,11 +160,8 @@ struct Counters {
     uint32_t n_work[2][APT_MAX_NQ * CNT_PAD];     // BVH walk with dynamic fetch: next unclaimed queue position (0 extend, 1 shadow); zeroed with the batch's counters, then by the other walk kernel (surface renders with light samples) or by the host before the launch
     uint32_t n_tr[3][8 + 1][APT_MAX_NQ * CNT_PAD];   // rays traced in place: entries of the queues (material classes, then the staging queue) that bounce k of the batch reads, at [k % 3] (bounce k appends to [(k + 1) % 3] and zeroes [(k + 2) % 3], which bounce k - 1 read: no launch in between has to reset a counter)
     uint32_t fix_claim[APT_MAX_NQ * CNT_PAD];     // rays traced in place: which launch of the batch (1 + bounce) has had its fix-up lists claimed by a wave ...
-    uint32_t fix_done[APT_MAX_NQ * CNT_PAD];      // ... and served (stages.hpp fix_prologue)
+    uint32_t fix_done[APT_MAX_NQ * CNT_PAD];      // ... and served (shade_stage.hpp fix_prologue)
     unsigned long long stats[APT_MAX_NQ][16];    // [q][ST_*], 128 bytes per sub-queue
-#ifdef APT_SHADE_PROF
-    unsigned long long dbg[2 * 16384];           // per-wave (start, end) of the last k_shade launch, 100 MHz ticks
-#endif
 #ifdef APT_WALK_STATS
     unsigned long long wdbg[2][8];               // walk scheduling, [closest-hit | any-hit]: node iterations, lanes in them, primitive iterations, lanes in them, lanes holding a ray (summed over iterations), refills, lanes claimed, -
 #endif
@@ -366,21 +363,6 @@ APT_D SubLoop sub_loop(int nq, int nt = BLOCK) {
 #endif
 // occupancy targets (waves per SIMD the register allocator must allow): the stages are latency-bound on dependent
 // table lookups and LDS round trips, so more resident waves beat a few spilled registers (measured)
-#ifndef APT_LAMBERT_WAVES
-#define APT_LAMBERT_WAVES 1
-#endif
-#ifndef APT_SHADE_PREFETCH
-#define APT_SHADE_PREFETCH 1
-#endif
-#ifndef APT_SHADE_PREFETCH_PRIM
-#define APT_SHADE_PREFETCH_PRIM 1
-#endif
-#ifndef APT_SHADE_LATE_SHADOW
-#define APT_SHADE_LATE_SHADOW 0      // measured: the deferred shadow entry costs the kernel its fourth wave per SIMD (120 -> 130 VGPRs: C2 shade 10.6 -> 13.1 ms)
-#endif
-#ifndef APT_SHADE_WAVES
-#define APT_SHADE_WAVES 1
-#endif
 #ifndef APT_TILE_WAVES
 #define APT_TILE_WAVES 6
 #endif
@@ -502,29 +484,17 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
     }
     const float* ro = q.ray_o[cur]; const float* rd = q.ray_d[cur];
     const uint32_t qbase = (uint32_t)sl.q * p.subcap;
-#ifdef APT_TILE_PROF
-    unsigned long long tile_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
         const uint32_t pos = base + threadIdx.x;
         const bool valid = pos < n;
         const uint32_t idx = qbase + (valid ? pos : n - 1);            // idle lanes re-read the last ray (never written back)
-#ifdef APT_TILE_PROF
-        unsigned long long tile_t0 = __builtin_readcyclecounter();
-#endif
         const uint32_t io = idx << 2;
         const f3 o = ld3q(ro, p.cap, io);
         const f3 d = ld3q(rd, p.cap, io);
         HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = 0.f; rec.v = 0.f;
         if (MODE == 0) traverse<false>(sc.bvh, make_stack(plan), o, d, rec);
         else if (MODE == 1) sweep_wg<false, BLOCK>(sc.sweep, o, d, rec, valid, s_sweep);
-#ifdef APT_TILE_PROF
-        else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn), tile_prof);
-        unsigned long long tile_t1 = __builtin_readcyclecounter();
-        (void)tile_t0;
-#else
         else sweep_tile<false, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
-#endif
         if (!SORTED) {
             if (valid) { stq(q.hit_t, io, rec.t); stq(q.hit_prim, io, rec.prim); stq(q.hit_u, io, rec.u); stq(q.hit_v, io, rec.v); }
         } else {
@@ -545,13 +515,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
             const uint32_t cpos = (uint32_t)__shfl((int)tail, cls < 0 ? 0 : cls) + my_rank;
             if (cls >= 0) cq_store(q, (uint32_t)cls * p.cap + qbase + cpos, o, d, st_thr, st_id, st_meta, st_pdf, rec.t, rec.prim, rec.u, rec.v);
         }
-#ifdef APT_TILE_PROF
-        if (MODE == 2) { unsigned long long t2_ = __builtin_readcyclecounter(); tile_prof[5] += tile_t1 - tile_t0; tile_prof[6] += t2_ - tile_t1; tile_prof[7] += 1; }
-#endif
     }
-#ifdef APT_TILE_PROF
-    if (MODE == 2 && cnt && (threadIdx.x & 63) == 0) for (int k = 0; k < 8; k++) atomicAdd(&cnt->stats[sl.q][8 + k], tile_prof[k]);
-#endif
 }
 
 
@@ -700,638 +664,6 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
     flush_stat(ws.nodes, &cnt->stats[sq][10]); flush_stat(ws.prims, &cnt->stats[sq][11]);
     if (lane_id() == 0) for (int k = 0; k < 7; k++) atomicAdd(&cnt->wdbg[0][k], (unsigned long long)wd[k]);
 #endif
-}
-
-// ----------------------------------------------------------------- textures
-// Taichi's float `a % b` is a - b * floor(a / b) (python/taichi/lang/ops.py, mod)
-APT_D float ti_fmod(float a, float b) { float q = floorf(a / b); return a - b * q; }
-APT_D f3 mix3(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }          // taichi.math.mix: x * (1 - a) + y * a
-// Texture.query, bxdf/texture.py:111-139: bilinear lookup inside the texture's rectangle of the atlas
-APT_D f3 texture_query(const DevScene& sc, int map, int obj, float u, float v) {
-    const int* ti_ = sc.tex_i + 15 * obj + 5 * map; const float* tf = sc.tex_f + 6 * obj + 2 * map;
-    const float w = (float)ti_[3], h = (float)ti_[4];
-    const float scaled_u = ti_fmod((u * tf[0]) * w, w - 1.f), scaled_v = ti_fmod((v * tf[1]) * h, h - 1.f);
-    float floor_u = floorf(scaled_u), floor_v = floorf(scaled_v);
-    const float ratio_u = scaled_u - floor_u, ratio_v = scaled_v - floor_v;
-    floor_u = floor_u + (float)ti_[1]; floor_v = floor_v + (float)ti_[2];
-    const int fu = (int)floor_u, fv = (int)floor_v;
-    const float* img = sc.atlas[map]; const int W = sc.atlas_w[map];
-    const float* r0 = img + ((size_t)fv * W + fu) * 3; const float* r1 = r0 + (size_t)W * 3;
-    const f3 q_ff = mk3(r0[0], r0[1], r0[2]), q_cf = mk3(r0[3], r0[4], r0[5]), q_fc = mk3(r1[0], r1[1], r1[2]), q_cc = mk3(r1[3], r1[4], r1[5]);
-    return mix3(mix3(q_ff, q_cf, ratio_u), mix3(q_fc, q_cc, ratio_u), ratio_v);
-}
-// PathTracer.get_uv_item, path_tracer.py:276-289 (meshes only: textured spheres are refused at scene creation)
-APT_D bool get_uv_item(const DevScene& sc, int map, int obj, int prim, float bu, float bv, f3& out) {
-    if (sc.atlas[map] == nullptr || !(sc.tex_i[15 * obj + 5 * map] > -255)) return false;
-    const float* uv = sc.uvs + 6 * prim;
-    const float w0 = 1.f - bu - bv;
-    const float gu = (uv[2] * bu + uv[4] * bv) + uv[0] * w0, gv = (uv[3] * bu + uv[5] * bv) + uv[1] * w0;
-    out = texture_query(sc, map, obj, gu, gv);
-    return true;
-}
-
-// -------------------------------------------------------------------- shade
-APT_D void build_hit_rec(const DevScene& sc, float4 ra, float4 rb, int prim, float t, float u, float v, f3 o, f3 d, Hit& it, int& hit_light, f3& k_d, bool with_vn = true);
-APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3 o, f3 d, Hit& it, int& hit_light, f3& k_d) {
-    build_hit_rec(sc, sc.prim_shade[2 * prim], sc.prim_shade[2 * prim + 1], prim, t, u, v, o, d, it, hit_light, k_d);
-}
-APT_D void build_hit_rec(const DevScene& sc, float4 ra, float4 rb, int prim, float t, float u, float v, f3 o, f3 d, Hit& it, int& hit_light, f3& k_d, bool with_vn) {
-    const int code = __float_as_int(ra.w);
-    it.prim_id = prim; it.min_depth = t;
-    it.obj_id = (code < 0) ? ~code : code;
-    hit_light = __float_as_int(rb.x);
-    k_d = mk3(rb.y, rb.z, rb.w);
-    if (code < 0) {
-        // sphere: the record holds the centre; normal from the hit point (tracer_base.py:217-223)
-        it.n_g = normalize((o + d * t) - mk3(ra.x, ra.y, ra.z));
-        it.n_s = it.n_g;
-    } else {
-        it.n_g = mk3(ra.x, ra.y, ra.z);
-        if (with_vn && sc.has_vn) {
-            const float4 v0 = sc.vnormals[3 * prim], v1 = sc.vnormals[3 * prim + 1], v2 = sc.vnormals[3 * prim + 2];
-            // interpolated vertex normal, NOT re-normalised (tracer_base.py:228-230)
-            it.n_s = (mk3(v0.x, v0.y, v0.z) * (1.f - u - v) + mk3(v1.x, v1.y, v1.z) * u) + mk3(v2.x, v2.y, v2.z) * v;
-        } else it.n_s = it.n_g;
-    }
-}
-APT_D void build_hit(const DevScene& sc, int prim, float t, float u, float v, f3 o, f3 d, Hit& it) {
-    int light; f3 kd; build_hit(sc, prim, t, u, v, o, d, it, light, kd);
-}
-
-// BM / SM: material and emitter masks of the scene (shading.hpp); code for absent models is compiled out.
-// TEX: image-texture lookups.  Only the all-models kernel is instantiated with TEX = 1 (textured scenes run unsorted through
-// it): inlined into the specialised kernels the lookup costs e.g. the mod-Phong class kernel its fourth wave per SIMD
-// (126 -> 129 VGPRs) in every scene WITHOUT textures, and out of line it costs a call frame in scratch.
-// FUSE (product build, flat sweep, one light sample per vertex, unsorted: Params::fused) - LIGHT SAMPLES TRACED IN PLACE.  For a scene
-// of a few dozen records the any-hit sweep of a shadow ray costs fewer issue slots than the round trip of its 44-byte queue entry through
-// HBM plus the scattered read-modify-write of the path's radiance slot behind it: the row's light samples are swept right here (one ray
-// per lane against two records per packed instruction, traverse.hpp flat_any1), after the continuation has been sampled and the next
-// queue entry written, when little else is live.  The path's radiance then travels WITH the path (Queues::Lc, 12 bytes of the queue
-// record) and reaches its slot of L once, when the path ends.  The rare rays whose answer needs the reference-order sweep
-// (flat_needs_cull) still leave as shadow-queue entries, counted by n_fix_sh[cur], and are served by the next fix-up launch.
-#if APT_FAST
-// ---- rays traced in place (Params::fused == 2; product build, flat sweep, unsorted, one light sample per vertex)
-// The shade kernel sweeps its continuation ray against the scene's records itself (flat_closest1: one ray against two records per packed
-// instruction), as it already does with its light sample, and k_generate does the same for the camera rays: a bounce is ONE launch
-// instead of extend + fix-up + shade, the ray is never read back (24 + 8 bytes per segment), and a ray that hits nothing never enters a
-// queue - its path ends where it was sampled (18 % of C2's continuation rays: no record written, no idle lane in the next launch).
-// The rare rays that need the reference's own arithmetic (traverse.hpp flat_closest2: near-tied coplanar faces, directions for which
-// upstream's slab cull is part of the result) are queued with a provisional record and listed, as before - but the lists are served by
-// the NEXT launch itself instead of a fix-up launch per bounce (a launch boundary is a pipeline drain: ~20 us of a render lane each):
-// a wave that finds its sub-queue's lists non-empty claims them (one atomic), serves them - one entry per lane, the full reference-order
-// code - and publishes "done"; the sub-queue's other waves wait for that before they read a record.  The lists are empty in all but a few
-// launches per render, where the whole protocol is two scalar loads per wave; the serving code sits in front of the kernel's main loop,
-// where almost no register is live, so it costs the hot loop nothing (k_fix_flat alone allocates 84 VGPRs, the shade kernel 122).
-// Nothing depends on how workgroups are placed: whichever wave claims a list is running, hence the waiters cannot starve it.
-APT_D void fix_prologue(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, int cur, int sq, int bounce) {
-    const uint32_t epoch = (uint32_t)bounce + 1u;
-    const int ncls = q.tr_ncls;
-    uint32_t* n_def_p = &cnt->n_tr[bounce % 3][ncls][sq * CNT_PAD]; uint32_t* n_sh_p = &cnt->n_fix_sh[cur ^ 1][sq * CNT_PAD];
-    // Memory order.  The list lengths are read first (the claim word below is read AFTER them), then the claim word.  A wave that
-    // finds this bounce claimed - by a running or a finished server - waits for "done" with an acquire load whatever lengths it saw, so
-    // that everything the server appended or added (queue records, counters, radiance slots) happens-before this wave's reads; the
-    // server resets the light-sample list BEFORE it publishes "done", and only after its claim, so lengths of zero seen together with an
-    // unclaimed bounce are the lists' true lengths.
-    // (relaxed loads performed at L2 and a WORKGROUP-scope fence - a wait for the loads, no cache invalidate - give the load-load order;
-    // acquire loads at agent scope put a `buffer_inv` behind each of them in every wave of every launch: C1 4 709 -> 3 442 Msamples/s, C2's
-    // shade kernel 18.2 -> 20.0 ms per 256 spp, measured.  The acquire that matters is the one on "done" below.)
-    const uint32_t n_def = __hip_atomic_load(n_def_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), n_sh = min(__hip_atomic_load(n_sh_p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), q.sh_subcap);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    uint32_t old = __hip_atomic_load(&cnt->fix_claim[sq * CNT_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old < epoch) {
-        if ((n_def | n_sh) == 0u) return;                     // nothing listed, nobody serving
-        if (lane_id() == 0) old = atomicMax(&cnt->fix_claim[sq * CNT_PAD], epoch);
-        old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);
-    }
-    if (old >= epoch) {                                       // somebody else serves (or has served) the lists of this bounce
-        while (__hip_atomic_load(&cnt->fix_done[sq * CNT_PAD], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(16);
-        return;
-    }
-    const uint32_t qbase = (uint32_t)sq * p.subcap, sh_qbase = (uint32_t)sq * q.sh_subcap;
-    const bool need_uv = sc.has_vn || sc.tex_i != nullptr;
-    for (uint32_t base = 0; base < n_def; base += 64u) {      // staged rays: closest hit by the reference-order code, then the record joins its class queue (or the path ends)
-        const uint32_t li = base + lane_id(); const bool valid = li < n_def;
-        // (staging at the top of the sub-queue's own region: served from its LOWEST slot upwards - a resolved record is appended at or below the
-        // slot its ray was just read from, never onto a staged ray that is still to be served)
-        const uint32_t lj = valid ? li : n_def - 1u;
-        const uint32_t io = (q.tr_stage_top ? qbase + p.subcap - n_def + lj : (uint32_t)ncls * p.cap + qbase + lj) << 4;
-        const float4 ra = ldq(q.tr[cur][0], io), rb = ldq(q.tr[cur][1], io), rc = ldq(q.tr[cur][2], io), rd = ldq(q.tr[cur][3], io);
-        const f3 o = mk3(ra.x, ra.y, ra.z), d = mk3(rb.x, rb.y, rb.z);
-        HitRec r0, r1; r0.t = r1.t = 1e7f; r0.prim = r1.prim = -1; r0.u = r0.v = r1.u = r1.v = 0.f;
-        int c0, c1;
-        flat_closest2(sc.flat, sc.sweep, sc.prim_class, o, d, o, d, r0, r1, c0, c1);
-        if (valid && r0.prim >= 0) {
-            const int oc = ncls > 1 ? c0 : 0;
-            const uint32_t pos = atomicAdd(&cnt->n_tr[bounce % 3][oc][sq * CNT_PAD], 1u);      // (one atomic per entry: this path is a handful of rays per million)
-            const uint32_t slot = (uint32_t)oc * p.cap + qbase + pos, so = slot << 4;
-            stq(q.tr[cur][0], so, make_float4(ra.x, ra.y, ra.z, r0.t));
-            stq(q.tr[cur][1], so, make_float4(rb.x, rb.y, rb.z, __uint_as_float((__float_as_uint(rb.w) & ~0xffu) | (uint32_t)r0.prim)));
-            stq(q.tr[cur][2], so, rc); stq(q.tr[cur][3], so, rd);
-            if (need_uv) { float2 uv_; uv_.x = r0.u; uv_.y = r0.v; stq(q.tr_uv[cur], slot << 3, uv_); }
-        } else if (valid && !(rd.x == 0.f && rd.y == 0.f && rd.z == 0.f)) {      // nothing hit: the path ends, its radiance goes to its slot
-            const uint32_t id = __float_as_uint(rc.w), lp_ = id & ((1u << p.pix_bits) - 1u), s_ = id >> p.pix_bits;
-            add_radiance(q.L, p.cap, (s_ * (uint32_t)p.npix + lp_) << 2, mk3(rd.x, rd.y, rd.z), true);
-        }
-    }
-    uint32_t t_lit = 0;
-    for (uint32_t base = 0; base < n_sh; base += 64u) {       // light samples the previous bounce could not settle (shadow_flat_body<3>)
-        const uint32_t li = base + lane_id(); const bool valid = li < n_sh;
-        const uint32_t io = (sh_qbase + (valid ? li : n_sh - 1u)) << 2;
-        const f3 o = ld3q(q.sh_o, q.sh_cap, io), d = ld3q(q.sh_d, q.sh_cap, io), c = ld3q(q.sh_c, q.sh_cap, io);
-        const float dist = ldq(q.sh_tmax, io); const uint32_t slot = ldq(q.sh_id, io);
-        bool occ, occ_b;
-        const float lim = (dist > 0.0f) ? dist - 1e-4f : 1e7f;
-        flat_any2(sc.flat, sc.sweep, o, d, o, d, lim, lim, occ, occ_b);
-        // (several samples of one vertex may be listed - S > 1 - and share its slot: one entry at a time within the wave's 64)
-        const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
-        const bool add = valid && (!occ || weird);
-        for (unsigned long long m = __ballot(add); m != 0ull; m &= m - 1ull) {
-            if ((int)lane_id() == __ffsll((long long)m) - 1) add_radiance(q.L, p.cap, slot, occ ? c * 0.f : c, true);      // (k_shadow: an occluded non-finite sample enters upstream's sum as 0 * contribution)
-        }
-        t_lit += (valid && !occ) ? 1u : 0u;
-    }
-    flush_stat(t_lit, &cnt->stats[sq][ST_LIT]);
-    if (lane_id() == 0) __hip_atomic_store(n_sh_p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // consumed - before "done" is published (the bounce after this one appends to this list again; the staging queue's counter rotates with the others)
-    __threadfence();
-    if (lane_id() == 0) __hip_atomic_store(&cnt->fix_done[sq * CNT_PAD], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-#endif
-// The shade kernels' scalar operands.  Scene, parameters and queues arrive by value in the kernel-argument segment - ~1.8 KB, of which a
-// tile row touches ~165 dwords - and left alone the compiler loads every field it needs ONCE, in front of the row loop, where 102 scalar
-// registers cannot hold them: the rest lives in lanes of two spill VGPRs and comes back through v_readlane at every use (242 of the 2 200
-// VALU instructions of C2's row loop - on the unit this kernel is bound by).  So the arguments are read THROUGH THE SEGMENT POINTER, and
-// the pointer is made opaque at the head of every phase of a row (an empty asm: APT_ARGS_PHASE): a field's load can then not be hoisted
-// above the phase that uses it, it becomes an s_load (scalar memory, not a VALU issue slot; the segment stays in the scalar cache) next
-// to its use, and its register is free again after the phase.
-#ifndef APT_ARGS_RELOAD
-#define APT_ARGS_RELOAD 1
-#endif
-struct ShadeArgs3 { DevScene sc; Params p; Queues q; };          // the leading arguments of every shade kernel, laid out as the segment lays them out
-typedef const __attribute__((address_space(4))) ShadeArgs3* args3_ptr;
-APT_D args3_ptr kernel_args3() { return (args3_ptr)__builtin_amdgcn_kernarg_segment_ptr(); }
-APT_D const ShadeArgs3* args_fresh(args3_ptr a) {
-#if APT_ARGS_RELOAD
-    asm volatile("" : "+s"(a));
-#endif
-    return (const ShadeArgs3*)a;
-}
-#if APT_ARGS_RELOAD
-#define APT_ARGS_PHASE() (A_ = args_fresh(A0))
-#else
-#define APT_ARGS_PHASE() ((void)0)
-#endif
-template <int BM, int SM, int TEX = 0, int FUSE = 0>
-APT_D void shade_body(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur, int bounce) {
-    const ShadeArgs3* A_ = args_fresh(A0);                      // scene, parameters, queues: read through the kernel-argument segment, re-fetched per phase (APT_ARGS_PHASE)
-    constexpr bool CQ = FUSE == 4;                             // input: a packed class queue (Queues::cq); output: the staged pipeline's (as FUSE == 0)
-    constexpr int FZ = CQ ? 0 : FUSE;
-    const int nxt = cur ^ 1;
-    const SubLoop sl = sub_loop((A_->p).nq);
-    uint32_t n = (FZ >= 2) ? 0u : in.counts[sl.q * CNT_PAD];
-    const uint32_t qbase = (uint32_t)sl.q * (A_->p).subcap, sh_qbase = (uint32_t)sl.q * (A_->q).sh_subcap;
-    uint32_t* next_counter = (FZ >= 2) ? &cnt->n_tr[(bounce + 1) % 3][0][sl.q * CNT_PAD] : &cnt->n_active[nxt][sl.q * CNT_PAD];      // (FZ == 2: the first queue's tail)
-    if (FZ >= 2 && sl.first == 0 && threadIdx.x == 0) {      // (read by the previous bounce, appended to by the next one)
-        cnt->n_tr[(bounce + 2) % 3][in.cls][sl.q * CNT_PAD] = 0;
-        if (in.cls == 0) cnt->n_tr[(bounce + 2) % 3][(A_->q).tr_ncls][sl.q * CNT_PAD] = 0;
-    }
-    uint32_t* shadow_counter = &cnt->n_shadow[sl.q * CNT_PAD];
-    const EmitterGeom geom = {(A_->sc).precom, (A_->sc).normals, (A_->sc).obj_info};
-    uint32_t t_shade = 0, t_shadow = 0, t_poison = 0, t_traced = 0, t_lit = 0;        // wave-uniform tallies (SGPRs)
-#ifdef APT_NEAR_STATS
-    uint32_t t_near = 0;
-#endif
-    __shared__ uint32_t s_draws[BLOCK / 64];                  // RNG draws of this wave: a per-lane tally would hold a VGPR for the whole kernel
-    if (lane_id() == 0) s_draws[threadIdx.x >> 6] = 0;
-#ifdef APT_SHADE_PROF
-    unsigned long long sprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned long long life0_ = __builtin_readcyclecounter();
-    const unsigned long long wall0_ = wall_clock64();
-#define SH_TICK(k) do { unsigned long long now_ = __builtin_readcyclecounter(); sprof[k] += now_ - stick_; stick_ = now_; } while (0)
-#else
-#define SH_TICK(k) do { } while (0)
-#endif
-    // Software prefetch (the Lambertian / point-light kernel, which has the registers for it: C1 / C2).  A kernel that only streams
-    // k_shade's queues (13 SoA reads, 22 SoA writes per entry, same grid) moves 5.1 TB/s (tools/history/probes/stream_probe.hip), k_shade ~3:
-    // with 4 waves per SIMD each wave's loads are in flight only between its tile rows, and every row starts with two dependent round
-    // trips.  So the next row's record is requested at the top of this row - after this row's shading record, so that waiting for that
-    // one (vmcnt counts in order) does not wait for the prefetch - and lands while this row is shaded.
-    constexpr bool PF = ((APT_SHADE_PREFETCH != 0) && BM == 0x002 && SM == 0x1 && TEX == 0) || (APT_SHADE_PREFETCH == 2 && TEX == 0);
-    constexpr bool TRACE = FZ >= 2;                         // the continuation ray is traced in place too ("rays traced in place" above)
-    static_assert(APT_FLAT_MAX_PRIMS < (int)TR_NO_PRIM, "the packed record keeps the hit primitive in 8 bits");
-    constexpr bool PK = TRACE || CQ;                           // the input record is four 16-byte planes
-    const uint32_t in_base = PK ? (uint32_t)in.cls * (A_->p).cap + qbase : qbase;      // first slot of the queue this workgroup reads
-    const float4* trA = TRACE ? (A_->q).tr[cur][0] : (CQ ? (A_->q).cq[0] : nullptr); const float4* trB = TRACE ? (A_->q).tr[cur][1] : (CQ ? (A_->q).cq[1] : nullptr);
-    const float4* trC = TRACE ? (A_->q).tr[cur][2] : (CQ ? (A_->q).cq[2] : nullptr); const float4* trD = TRACE ? (A_->q).tr[cur][3] : (CQ ? (A_->q).cq[3] : nullptr);
-    int pf_prim = -1; float pf_t = 0.f; f3 pf_o = splat3(0.f), pf_d = splat3(0.f), pf_thr = splat3(0.f); uint32_t pf_id = 0, pf_meta = 0;      // (TRACE: pf_prim holds the packed word pm)
-    auto prefetch = [&](uint32_t b) {            // straight-line loads (lanes past the end re-read the last entry: never used), so that no wait lands at the end of a branch
-        const uint32_t ps = min(b + threadIdx.x, n - 1u);
-        if (TRACE) {
-            const uint32_t pio16 = (in_base + ps) << 4;
-            const float4 a = ldq(trA, pio16), b_ = ldq(trB, pio16), c = ldq(trC, pio16);
-            pf_o = mk3(a.x, a.y, a.z); pf_t = a.w; pf_d = mk3(b_.x, b_.y, b_.z); pf_prim = __float_as_int(b_.w); pf_thr = mk3(c.x, c.y, c.z); pf_id = __float_as_uint(c.w);
-            return;
-        }
-        const uint32_t pio = (qbase + ps) << 2;
-        pf_prim = ldq(in.prim, pio); pf_t = ldq(in.t, pio);
-        pf_o = ld3q(in.ray_o, (A_->p).cap, pio); pf_d = ld3q(in.ray_d, (A_->p).cap, pio); pf_thr = ld3q(in.thr, (A_->p).cap, pio);
-        pf_id = ldq(in.id, pio); pf_meta = ldq(in.meta, pio);
-    };
-    // the kernels without registers for that (material classes: 124-128 VGPRs) prefetch only the hit primitive - one register - so that a
-    // row's shading record can be requested together with its queue record instead of a round trip after it
-    constexpr bool PFP = !PF && (APT_SHADE_PREFETCH_PRIM != 0) && TEX == 0;
-    uint32_t t_extend = 0;
-#if APT_FAST
-    if (TRACE) {
-        fix_prologue((A_->sc), (A_->p), (A_->q), cnt, cur, sl.q, bounce);       // before the queue's length is read: the prologue may append to it
-        n = __hip_atomic_load(&cnt->n_tr[bounce % 3][in.cls][sl.q * CNT_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#endif
-    if (PF && n > 0) prefetch(sl.first);
-    auto prefetch_prim = [&](uint32_t b) {
-        const uint32_t ps = in_base + min(b + threadIdx.x, n - 1u);
-        pf_prim = PK ? ldq(reinterpret_cast<const int*>(trB), (ps << 4) + 12u) : ldq(in.prim, ps << 2);
-    };
-    if (PFP && n > 0) prefetch_prim(sl.first);
-    for (uint32_t base = sl.first; base < n; base += sl.stride) {
-#ifdef APT_SHADE_PROF
-        unsigned long long stick_ = __builtin_readcyclecounter();
-        sprof[7] += 1;
-#endif
-        APT_ARGS_PHASE();
-        const uint32_t pos = base + threadIdx.x;
-        const uint32_t idx = in_base + pos;
-        bool alive = pos < n;
-        int cu_prim = pf_prim; const float cu_t = pf_t; const f3 cu_o = pf_o, cu_d = pf_d, cu_thr = pf_thr; const uint32_t cu_id = pf_id; uint32_t cu_meta = pf_meta;
-        if (TRACE && (PF || PFP)) { cu_meta = tr_meta((uint32_t)pf_prim, (uint32_t)bounce); cu_prim = tr_prim((uint32_t)pf_prim); }
-        float4 cu_ra = make_float4(0.f, 0.f, 0.f, 0.f), cu_rb = cu_ra; uint32_t cu_key = 0;
-        if (PFP) {
-            const int rp = max(cu_prim, 0);
-            cu_ra = (A_->sc).prim_shade[2 * rp]; cu_rb = (A_->sc).prim_shade[2 * rp + 1];
-            prefetch_prim(base + sl.stride);
-        }
-        if (PF) {
-            const int rp = max(cu_prim, 0);
-            cu_ra = (A_->sc).prim_shade[2 * rp]; cu_rb = (A_->sc).prim_shade[2 * rp + 1];
-            cu_key = cu_id & ((1u << (A_->p).pix_bits) - 1u);
-            if ((A_->p).world != 1) cu_key = ldq((A_->p).pix_key, cu_key << 2);     // (multi-GPU: the pixel's global key; requested here for the same reason)
-            __builtin_amdgcn_sched_barrier(0);                 // the record first, then the prefetch: the wait for the record must not include the prefetch
-            prefetch(base + sl.stride);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        f3 o = splat3(0.f), d = mk3(0.f, 0.f, 1.f), thr = splat3(0.f), hit_point = splat3(0.f);
-        uint32_t id = 0, draw0 = 0, l_off = 0;                 // l_off: byte offset of this path's radiance slot
-        // FZ: the radiance the path has gathered so far (camera rays carry none: nothing is read at bounce 0) and, for entries that end
-        // here without being shaded (nothing hit, roulette), the path id that names the slot it goes to
-        f3 Lc = splat3(0.f);
-        const bool entry = alive;
-        float ray_pdf = 1.f;
-        if (TRACE) {
-            if (alive && bounce > 0) { const float4 dd = ldq(trD, idx << 4); Lc = mk3(dd.x, dd.y, dd.z); if (SM & 2) ray_pdf = dd.w; }
-            if (alive && bounce > 0) id = PF ? cu_id : __float_as_uint(ldq(reinterpret_cast<const float*>(trC), (idx << 4) + 12u));
-        } else {
-        }
-        bool was_spec = false;
-        Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
-        Hit it; it.obj_id = -1; it.prim_id = -1; it.n_s = it.n_g = mk3(1.f, 0.f, 0.f); it.min_depth = 0.f;
-        int hit_light = -1;
-        float emission_weight = 1.0f;
-        DevBxdf bx; bx.type = 1; bx.is_delta = 0; bx.is_bsdf = 0; bx.k_d = bx.k_s = bx.k_g = bx.mean = splat3(0.f); bx.ior = 1.f;
-        if (alive) {
-            const uint32_t io = idx << 2;
-            int prim = (PF || PFP) ? cu_prim : (TRACE ? tr_prim(__float_as_uint(ldq(reinterpret_cast<const float*>(trB), (idx << 4) + 12u))) : (CQ ? ldq(reinterpret_cast<const int*>(trB), (idx << 4) + 12u) : ldq(in.prim, io)));
-            if (prim < 0) alive = false;                         // nothing hit: path ends (vanilla_renderer.py:49)
-            else {
-                uint32_t meta; float tr_t_in = cu_t; float2 tr_uv_in; tr_uv_in.x = tr_uv_in.y = 0.f;
-                if (PF) { o = cu_o; d = cu_d; thr = cu_thr; id = cu_id; meta = cu_meta; }
-                else if (TRACE) {
-                    const float4 a = ldq(trA, idx << 4), b_ = ldq(trB, idx << 4), c = ldq(trC, idx << 4);
-                    o = mk3(a.x, a.y, a.z); tr_t_in = a.w; d = mk3(b_.x, b_.y, b_.z); thr = mk3(c.x, c.y, c.z); id = __float_as_uint(c.w);
-                    meta = tr_meta(__float_as_uint(b_.w), (uint32_t)bounce);
-                } else if (CQ) {
-                    const float4 a = ldq(trA, idx << 4), b_ = ldq(trB, idx << 4), c = ldq(trC, idx << 4), dd = ldq(trD, idx << 4);
-                    o = mk3(a.x, a.y, a.z); tr_t_in = a.w; d = mk3(b_.x, b_.y, b_.z); thr = mk3(c.x, c.y, c.z); id = __float_as_uint(c.w);
-                    meta = __float_as_uint(dd.x); if (SM & 2) ray_pdf = dd.y; tr_uv_in.x = dd.z; tr_uv_in.y = dd.w;
-                } else {
-                    o = ld3q(in.ray_o, (A_->p).cap, io);
-                    d = ld3q(in.ray_d, (A_->p).cap, io);
-                    thr = ld3q(in.thr, (A_->p).cap, io);
-                    id = ldq(in.id, io);
-                    meta = ldq(in.meta, io);
-                }
-                if ((SM & 2) && !PK) ray_pdf = ldq(in.pdf, io);          // (its only reader is the emission MIS weight: scenes without area lights never look at it)
-                was_spec = (meta >> 24) & 1u;
-                f3 rec_kd;
-                const bool need_uv = (A_->sc).has_vn || (TEX && (A_->sc).tex_i != nullptr);      // otherwise nobody reads the barycentrics (and the flat extend kernel does not write them)
-                if (TRACE && need_uv && !PF) tr_uv_in = ldq((A_->q).tr_uv[cur], idx << 3);
-                if (PF) {
-                    build_hit_rec((A_->sc), cu_ra, cu_rb, prim, cu_t, 0.f, 0.f, o, d, it, hit_light, rec_kd, false);
-                    if ((A_->sc).has_vn && __float_as_int(cu_ra.w) >= 0) {       // vertex normals: the barycentrics are fetched (and waited for) inside this branch only
-                        if (TRACE) tr_uv_in = ldq((A_->q).tr_uv[cur], idx << 3);
-                        const float4* vn = (A_->sc).vnormals + 3 * prim; const float bu = TRACE ? tr_uv_in.x : ldq(in.u, io), bv = TRACE ? tr_uv_in.y : ldq(in.v, io);
-                        const float4 v0 = vn[0], v1 = vn[1], v2 = vn[2];
-                        it.n_s = (mk3(v0.x, v0.y, v0.z) * (1.f - bu - bv) + mk3(v1.x, v1.y, v1.z) * bu) + mk3(v2.x, v2.y, v2.z) * bv;
-                    }
-                }
-                else if (PK && PFP) build_hit_rec((A_->sc), cu_ra, cu_rb, prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
-                else if (PK) build_hit((A_->sc), prim, tr_t_in, tr_uv_in.x, tr_uv_in.y, o, d, it, hit_light, rec_kd);
-                else if (PFP) build_hit_rec((A_->sc), cu_ra, cu_rb, prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
-                else build_hit((A_->sc), prim, ldq(in.t, io), need_uv ? ldq(in.u, io) : 0.f, need_uv ? ldq(in.v, io) : 0.f, o, d, it, hit_light, rec_kd);
-                if (BM == 0x002) bx.k_d = rec_kd;               // Lambertian-only scenes: type 1, not delta, not a BSDF (the defaults above), colour from the record
-                else bx = ld_bxdf_lane((A_->sc).bxdf + it.obj_id);
-                if (TEX && (A_->sc).tex_i != nullptr) {                // the scene declares image textures (TEX kernels only, see below)
-                    const float bu = PK ? tr_uv_in.x : ldq(in.u, io), bv = PK ? tr_uv_in.y : ldq(in.v, io);
-                    f3 tx;
-                    if (bounce == 0) {                           // PathTracer.process_ns, applied to the camera ray's hit only (vanilla_renderer.py:42)
-                        if (get_uv_item((A_->sc), 1, it.obj_id, prim, bu, bv, tx)) { m33 R; rotation_between(mk3(0.f, 1.f, 0.f), it.n_g, R); it.n_s = mul(R, tx); }
-                        if (get_uv_item((A_->sc), 2, it.obj_id, prim, bu, bv, tx)) it.n_s = delocalize(it.n_s, tx);
-                    }
-                    // it.tex (vanilla_renderer.py:66): every surface model reads its diffuse colour as select(tex invalid, k_d, tex)
-                    // and nothing else reads k_d on the device, so a valid lookup simply replaces this path's copy of k_d
-                    if (get_uv_item((A_->sc), 0, it.obj_id, prim, bu, bv, tx)) bx.k_d = tx;
-                }
-                SH_TICK(0);
-                const uint32_t lp = id & ((1u << (A_->p).pix_bits) - 1u), s = id >> (A_->p).pix_bits;
-                l_off = (s * (uint32_t)(A_->p).npix + lp) << 2;
-                draw0 = meta & 0xffffu;
-                rng_init(rng, PF ? cu_key : (((A_->p).world == 1) ? lp : ldq((A_->p).pix_key, lp << 2)), (A_->p).seed, (uint32_t)((A_->p).cnt_base + (int)s + 1), draw0);
-                // tail of the previous iteration: emission MIS weight for this hit (vanilla_renderer.py:111-117)
-                if (bounce > 0 && (A_->p).use_mis) {
-                    float e_pdf = 0.0f;
-                    if (hit_light >= 0 && bx.is_delta == 0 && !was_spec) e_pdf = emitter_solid_angle_pdf((A_->sc).src[hit_light], it, d);
-                    emission_weight = balance(ray_pdf, e_pdf);
-                }
-                if (!(SM & 2)) rng_open(rng);                   // no area lights: a shade with one light sample draws at most five numbers (rng.hpp)
-                // Russian roulette / cut-off (vanilla_renderer.py:50-57)
-                if ((A_->p).use_rr) {
-                    float mx = max3(thr);
-                    if (mx < (A_->p).rr_threshold && bounce >= (A_->p).rr_bounce_th) {
-                        if (rng_float(rng) > mx) alive = false;
-                        else thr = thr * (1.f / (mx + 1e-7f));
-                    }
-                } else if (max3(thr) < 1e-4f) alive = false;
-            }
-        }
-        t_shade += wave_count(alive);
-#ifdef APT_NEAR_STATS      // diagnostic build (tools/gpu_bias_probe.py --near): shaded vertices that sit within 2e-3 of the vertex before them - rays that re-hit the surface they left
-        t_near += wave_count(alive && bounce > 0 && it.min_depth < 2e-3f);
-#endif
-        if (alive) {
-            hit_point = d * it.min_depth + o;
-        }
-        // prefetching kernel: both queue-tail atomics of the row are sent early and awaited once, at the end of the row, so that the only
-        // full wait of a row comes after all of its arithmetic - by then the next row's record has long arrived
-        const bool cont_early = alive && (bounce + 1) < (A_->p).max_bounce;
-        Append next_app; next_app.m = 0ull; next_app.raw = 0u;
-        if (PF && !TRACE) next_app = append_issue(cont_early, next_counter);
-        SH_TICK(1);
-
-        APT_ARGS_PHASE();
-        // ---- next-event estimation: one shadow-queue entry per useful light sample
-        bool break_flag = false;
-        DevSrc src_only;                                      // the scene's only light, read once through the scalar path
-        if ((A_->sc).n_sources == 1) src_only = ld_src_uniform((A_->sc).src);
-        // light samples by vertex: ONE queue-tail atomic per tile row for all S samples of every vertex
-        uint32_t vbase = 0;
-        if (!FZ && (A_->p).nee_vm) vbase = wave_append(alive, shadow_counter);
-        bool f_want = false; f3 f_dir = mk3(0.f, 0.f, 1.f), f_c = splat3(0.f); float f_tmax = 0.f;
-        f3 f_sum = splat3(0.f); bool f_any = false;            // FZ: the vertex's unoccluded light samples, summed in sample order (as the by-vertex shadow kernel sums them), added to the path's radiance once
-#if APT_FAST
-        auto trace_light = [&](bool want, f3 dir, f3 c, float tmax) {
-            // a light sample swept in place; a ray that needs the reference-order sweep leaves as a shadow-queue entry for the next launch's prologue
-            const bool defer = want && flat_needs_cull((A_->sc).flat, dir);
-            bool occ = false;
-            if (__any(want && !defer)) occ = flat_any1((A_->sc).flat, hit_point, dir, (tmax > 0.0f) ? tmax - 1e-4f : 1e7f);
-            if (__any(defer)) {
-                const uint32_t spos = wave_append(defer, &cnt->n_fix_sh[cur][sl.q * CNT_PAD]);
-                if (defer && spos < (A_->q).sh_subcap) {
-                    const uint32_t so = (sh_qbase + spos) << 2, sc_ = (A_->q).sh_cap;
-                    st3q((A_->q).sh_o, sc_, so, hit_point); st3q((A_->q).sh_d, sc_, so, dir); stq((A_->q).sh_tmax, so, tmax); st3q((A_->q).sh_c, sc_, so, c); stq((A_->q).sh_id, so, l_off);
-                }
-            }
-            const bool traced = want && !defer;
-            if (traced) {
-                // (an occluded sample still enters upstream's sum as 0 * contribution: NaN for a non-finite one, see k_shadow)
-                const bool weird = !(isfinite(c.x) && isfinite(c.y) && isfinite(c.z));
-                if (!occ || weird) { const f3 a = occ ? c * 0.f : c; f_sum = f_any ? f_sum + a : a; f_any = true; }
-            }
-            t_traced += wave_count(want); t_lit += wave_count(traced && !occ);
-        };
-#endif
-        bool late_want = false; f3 late_dir = splat3(0.f), late_c = splat3(0.f); float late_tmax = 0.f; Append late_app; late_app.m = 0ull; late_app.raw = 0u;
-        for (int s = 0; s < (A_->p).S; s++) {
-            bool want = false, sampled = false, poisoned = false;
-            f3 light_dir = splat3(0.f), contrib = splat3(0.f);
-            float emitter_d = 0.f;
-            if (alive && !break_flag) {
-                // sample_light (path_tracer.py:537-554): one int is always drawn
-                const int ns = (A_->sc).n_sources;                    // wave-uniform: one light needs no modulo
-                int sidx = rng_int(rng);
-                sidx = (ns == 1) ? 0 : pymod(sidx, ns);
-                float emitter_pdf = (A_->p).inv_ns;
-                bool valid = true;
-                if (hit_light >= 0) {
-                    if (ns <= 1) valid = false;
-                    else {
-                        sidx = rng_int(rng);
-                        sidx = (ns == 2) ? 0 : pymod(sidx, ns - 1);
-                        if (sidx >= hit_light) sidx += 1;
-                        emitter_pdf = (A_->p).inv_ns1;
-                    }
-                }
-                if (!valid) break_flag = true;
-                else {
-                    const DevSrc src = (ns == 1) ? src_only : (CQ ? ld_src_lane((A_->sc).src + sidx) : (A_->sc).src[sidx]);      // (whole-record loads in the class kernels only: in C2's traced kernel their sixteen registers cost the fourth wave, 127 -> 132 VGPRs)
-                    f3 shadow_int; float direct_pdf;
-                    f3 emit_pos = emitter_sample_hit<SM>(src, geom, hit_point, rng, shadow_int, direct_pdf);
-                    f3 to_emitter = emit_pos - hit_point;
-                    emitter_d = norm(to_emitter);
-                    light_dir = to_emitter / emitter_d;
-                    sampled = true;
-                    f3 direct_spec = surface_eval<BM>(bx, it, d, light_dir, (A_->sc).world_ior, (A_->p).two_sides);
-                    float mis_w = 1.0f;
-                    if ((A_->p).use_mis && !(src.bool_bits & 0x01)) {
-                        float light_pdf = emitter_pdf * direct_pdf;
-                        float bsdf_pdf_v = surface_pdf<BM>(bx, it, light_dir, d, (A_->sc).world_ior, (A_->p).two_sides);
-                        mis_w = balance(light_pdf, bsdf_pdf_v);
-                    }
-                    if (isnan(mis_w)) {
-                        // Upstream the MIS weight multiplies the light sample even when the shadow ray is
-                        // occluded (0 * NaN), so a NaN weight poisons the whole pixel-sample, which is then
-                        // zeroed at the end (vanilla_renderer.py:87-95,119).  Reproduce that without tracing.
-                        if (FZ) Lc = splat3(mis_w); else stL((A_->q).L, (A_->p).cap, l_off, splat3(mis_w));
-                        poisoned = true;
-                    } else {
-                        f3 c = (direct_spec * shadow_int) * mis_w;
-                        if (ns != 1) c = c / emitter_pdf;               // one light: the pdf is exactly 1 and x / 1 == x (wave-uniform branch)
-                        contrib = (c * (A_->p).inv_S) * thr;
-                        want = !(contrib.x == 0.f && contrib.y == 0.f && contrib.z == 0.f);
-                    }
-                }
-            }
-            SH_TICK(2);
-            t_shadow += wave_count(sampled); t_poison += wave_count(poisoned);
-            if (!FZ && (A_->p).nee_vm) {
-                const uint32_t so = (sh_qbase + (uint32_t)s * (A_->p).subcap + vbase) << 2, sc_ = (A_->q).sh_cap;        // plane s of the sub-queue's region: consecutive lanes, consecutive entries
-                if (want) {
-                    st3q((A_->q).sh_o, sc_, so, hit_point);
-                    st3q((A_->q).sh_d, sc_, so, light_dir);
-                    stq((A_->q).sh_tmax, so, emitter_d);
-                    st3q((A_->q).sh_c, sc_, so, contrib);
-                } else if (alive) stq((A_->q).sh_tmax, so, -1.0f);                   // the vertex has no sample s worth tracing
-                if (alive && s == 0) stq((A_->q).sh_id, so, l_off);                   // one radiance slot per vertex, kept with its first entry
-            } else if (FZ) {
-                // traced at the end of the row, when little else is live: the vertex's one light sample waits in registers
-                f_want = want; f_dir = light_dir; f_c = contrib; f_tmax = emitter_d;
-            } else if (PF && APT_SHADE_LATE_SHADOW && s == (A_->p).S - 1) {
-                late_app = append_issue(want, shadow_counter);
-                late_want = want; late_dir = light_dir; late_c = contrib; late_tmax = emitter_d;
-            } else {
-                uint32_t spos = wave_append(want, shadow_counter);
-                if (want && spos < (A_->q).sh_subcap) {
-                    const uint32_t so = (sh_qbase + spos) << 2, sc_ = (A_->q).sh_cap;
-                    st3q((A_->q).sh_o, sc_, so, hit_point);
-                    st3q((A_->q).sh_d, sc_, so, light_dir);
-                    stq((A_->q).sh_tmax, so, emitter_d);
-                    st3q((A_->q).sh_c, sc_, so, contrib);
-                    stq((A_->q).sh_id, so, l_off | (((A_->p).l_planes > 1) ? (uint32_t)s : 0u));
-                }
-            }
-        }
-
-        SH_TICK(3);
-        APT_ARGS_PHASE();
-        // ---- emission of the surface we are on, then sample the continuation
-        bool cont = false;
-        f3 new_d = mk3(0.f, 1.f, 0.f);
-        float new_pdf = 1.f;
-        bool is_spec = false;
-        if (alive) {
-            // emission of the surface we are on (vanilla_renderer.py:99-104).  It has to stay AFTER the light sampling: with
-            // two-sided BRDFs the evaluation above flips it.n_s in place, upstream as here, and eval_le sees the flipped normal.
-            if ((SM & 2) && hit_light >= 0) {
-                f3 emit_int = emitter_eval_le((A_->sc).src[hit_light], hit_point - o, it.n_s);
-                if (!(emit_int.x == 0.f && emit_int.y == 0.f && emit_int.z == 0.f)) {
-                    f3 add = (emit_int * emission_weight) * thr;
-                    if (FZ) Lc = Lc + add;
-                    else add_radiance((A_->q).L, (A_->p).cap, l_off, add, true);      // (nothing else touches the path's slot while its shade kernel runs)
-                }
-            }
-            f3 spec;
-            // (pdf == 0 - a cosine-hemisphere draw of exactly 0, one in 2^24 - makes this spec / 0: +inf when the rounding residue of n_s . out is
-            // positive, NaN when it is not; upstream lets +inf through to the pixel and zeroes NaN.  The residue hangs on the last bits of the
-            // un-normalised interpolated vertex normal, i.e. of the barycentrics, which the product build's intersectors return to 1e-6 and not
-            // to the bit: DESIGN.md section 5 "non-finite pixels".  Re-sampling such a vertex here with the reference's own triangle test was
-            // measured: it costs the Lambertian kernel its fourth wave per SIMD, 122 -> 130 / 158 VGPRs inline / as a loop.)
-            new_d = surface_sample<BM>(bx, it, d, (A_->sc).world_ior, (A_->p).two_sides, rng, spec, new_pdf, is_spec);
-            thr = thr * (spec / new_pdf);
-            cont = (bounce + 1) < (A_->p).max_bounce;
-        }
-        if (rng.draw != draw0) atomicAdd(&s_draws[threadIdx.x >> 6], rng.draw - draw0);      // also paths that died in the roulette
-        SH_TICK(4);
-        if (PF && APT_SHADE_LATE_SHADOW && !(A_->p).nee_vm && (A_->p).S > 0) {
-            const uint32_t spos = append_pos(late_app);
-            if (late_want && spos < (A_->q).sh_subcap) {
-                const uint32_t so = (sh_qbase + spos) << 2, sc_ = (A_->q).sh_cap;
-                st3q((A_->q).sh_o, sc_, so, hit_point);
-                st3q((A_->q).sh_d, sc_, so, late_dir);
-                stq((A_->q).sh_tmax, so, late_tmax);
-                st3q((A_->q).sh_c, sc_, so, late_c);
-                stq((A_->q).sh_id, so, l_off | (((A_->p).l_planes > 1) ? (uint32_t)((A_->p).S - 1) : 0u));
-            }
-        }
-        APT_ARGS_PHASE();
-#if APT_FAST
-        // rays traced in place: the continuation ray meets the scene's records here.  Only rays that hit something (or whose answer is left
-        // to the reference-order code: listed, with a provisional record) enter the next queue; the tail atomic is on its way while the light
-        // sample is swept below.
-        float tr_t = 0.f; int tr_hit = -1; float tr_u = 0.f, tr_v = 0.f; int tr_q = -1;      // tr_q: the queue the record joins (-1: none)
-        TrAppend tr_app; tr_app.raw = 0u; tr_app.rank = 0u;
-        if (TRACE) {
-            int tr_idx = -1, tr_run = -1, hit_cls = 0;
-            if (__any(cont)) tr_idx = flat_closest1((A_->sc).flat, hit_point, new_d, 1e7f, tr_t, tr_run);
-            const bool tr_defer = cont && (tr_run >= 0 || flat_needs_cull((A_->sc).flat, new_d));
-            t_extend += wave_count(cont);
-            cont = cont && (tr_idx >= 0 || tr_defer);
-            if (cont && !tr_defer) { HitRec hr; flat_resolve((A_->sc).flat, tr_idx, tr_t, hit_point, new_d, hr, hit_cls); tr_hit = hr.prim; tr_u = hr.u; tr_v = hr.v; }
-            tr_q = !cont ? -1 : (tr_defer ? 1 : 0);            // (the queue, or the staging area at the top of its sub-queue's region)
-            { const Append a_ = append_issue(tr_q == 0, next_counter); tr_app.raw = a_.raw; tr_app.rank = rank_in(a_.m); }      // (one queue; a staged ray - rare - moves the staging queue's tail by itself, below)
-        }
-#endif
-        uint32_t npos = (PF && !TRACE) ? append_pos(next_app) : (TRACE ? 0u : wave_append(cont, next_counter));
-        if (cont && !TRACE) {
-            const uint32_t so = (qbase + npos) << 2;
-            st3q((A_->q).ray_o[nxt], (A_->p).cap, so, hit_point);
-            st3q((A_->q).ray_d[nxt], (A_->p).cap, so, new_d);
-            st3q((A_->q).thr[nxt], (A_->p).cap, so, thr);
-            stq((A_->q).id[nxt], so, id);
-            stq((A_->q).meta[nxt], so, pack_meta(rng.draw, (uint32_t)(bounce + 1), is_spec));
-            if (SM & 2) stq((A_->q).pdf[nxt], so, new_pdf);
-        }
-        APT_ARGS_PHASE();
-#if APT_FAST
-        if (FZ) {
-            trace_light(f_want, f_dir, f_c, f_tmax);               // the row's light samples
-            if (f_any) Lc = Lc + f_sum;
-            if (TRACE) {
-                npos = (uint32_t)__builtin_amdgcn_readlane((int)tr_app.raw, 0) + tr_app.rank;
-                if (__any(tr_q == 1)) { const uint32_t dpos = wave_append(tr_q == 1, next_counter + APT_MAX_NQ * CNT_PAD); if (tr_q == 1) npos = dpos; }
-                if (cont) {
-                    const uint32_t slot = (tr_q == 1) ? qbase + (A_->p).subcap - 1u - npos : (uint32_t)tr_q * (A_->p).cap + qbase + npos, so = slot << 4;      // (one queue: staged rays grow down from the top of the sub-queue's region)
-                    stq((A_->q).tr[nxt][0], so, make_float4(hit_point.x, hit_point.y, hit_point.z, tr_t));
-                    stq((A_->q).tr[nxt][1], so, make_float4(new_d.x, new_d.y, new_d.z, __uint_as_float(tr_pack(tr_hit, rng.draw, is_spec))));
-                    stq((A_->q).tr[nxt][2], so, make_float4(thr.x, thr.y, thr.z, __uint_as_float(id)));
-                    stq((A_->q).tr[nxt][3], so, make_float4(Lc.x, Lc.y, Lc.z, new_pdf));
-                    if ((A_->sc).has_vn || (A_->sc).tex_i != nullptr) { float2 uv_; uv_.x = tr_u; uv_.y = tr_v; stq((A_->q).tr_uv[nxt], slot << 3, uv_); }
-                }
-            }
-            if (!cont && entry && !(Lc.x == 0.f && Lc.y == 0.f && Lc.z == 0.f)) {
-                // the path ends here (nothing hit, roulette, last bounce): its radiance goes to its slot - added, not stored: a fix-up pass may have put a deferred sample's share there already
-                const uint32_t lp_ = id & ((1u << (A_->p).pix_bits) - 1u), s_ = id >> (A_->p).pix_bits;
-                add_radiance((A_->q).L, (A_->p).cap, (s_ * (uint32_t)(A_->p).npix + lp_) << 2, Lc, true);
-            }
-        }
-#endif
-        SH_TICK(5);
-    }
-    if (FZ) { flush_uniform(t_traced, &cnt->stats[sl.q][ST_SHADOW_TRACED]); flush_uniform(t_lit, &cnt->stats[sl.q][ST_LIT]); }
-    if (TRACE) flush_uniform(t_extend, &cnt->stats[sl.q][ST_EXTEND]);
-#ifdef APT_SHADE_PROF
-    sprof[6] = __builtin_readcyclecounter() - life0_;
-    sprof[5] = wall_clock64() - wall0_;          // 100 MHz constant clock: calibrates the cycle counter
-    if ((threadIdx.x & 63) == 0) { const uint32_t w_ = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64; if (w_ < 16384) { cnt->dbg[2 * w_] = wall0_; cnt->dbg[2 * w_ + 1] = wall_clock64(); } }
-    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; k++) atomicAdd(&cnt->stats[sl.q][8 + k], sprof[k]);
-#endif
-    flush_uniform(t_shade, &cnt->stats[sl.q][ST_SHADE]);
-    flush_uniform(t_shadow, &cnt->stats[sl.q][ST_SHADOW]);
-    if (lane_id() == 0 && s_draws[threadIdx.x >> 6]) atomicAdd(&cnt->stats[sl.q][ST_DRAWS], (unsigned long long)s_draws[threadIdx.x >> 6]);
-    flush_uniform(t_poison, &cnt->stats[sl.q][ST_POISON]);
-#ifdef APT_NEAR_STATS
-    flush_uniform(t_near, &cnt->stats[sl.q][14]);
-#endif
-}
-template <int BM, int SM, int TEX = 0, int FUSE = 0>
-__global__ void __launch_bounds__(BLOCK, (BM == 0x001 ? 3 : (BM == 0x002 ? APT_LAMBERT_WAVES : APT_SHADE_WAVES))) k_shade(DevScene sc, Params p, Queues q, Counters* cnt, ShadeIn in, int cur, int bounce) {
-    shade_body<BM, SM, TEX, FUSE>(kernel_args3(), cnt, in, cur, bounce);
-}
-
-// ---- class kernels in groups: ONE launch shades several material classes.
-// A class-sorted bounce was one launch per class (C5: 8 x 16 per batch), and a launch costs its lane 15-30 us however short its queue -
-// the pipeline drains, the next grid is dispatched, 1024 workgroups read their queue lengths: most of C5's shade time, a tenth of C3's.
-// The classes of a bounce are independent, so a group kernel walks the class queues of its members one after the other - every workgroup
-// its sub-queue of class A, then of class B, ... with no barrier in between: a workgroup that runs out of A entries starts on B while
-// others still shade A - and the launch boundary between them is gone.  A kernel's register allocation is the maximum over its members',
-// so the groups follow the footprints (api.hip kClassGroup): <= 128 VGPRs / four waves per SIMD (Lambertian, delta, lobe-free Blinn-Phong,
-// Lambertian transmission), <= 168 / three (Blinn-Phong, Oren-Nayar, thin coat, microfacet), beyond / two (modified Phong, Fresnel blend).
-// Members absent from the scene are skipped by a wave-uniform test (GroupIn::cls < 0).  Per vertex nothing changes: same class code, same
-// queues, same order inside a queue - images and statistics are those of the one-launch-per-class schedule bit for bit (GPU test).
-struct GroupIn { const uint32_t* counts[4]; int cls[4]; };     // per member: the class queue's per-sub-queue entry counts, its compact class id (-1: not in this scene)
-template <int SM, int WAVES, int B0, int B1, int B2, int B3>
-__global__ void __launch_bounds__(BLOCK, WAVES) k_shade_group(DevScene sc, Params p, Queues q, Counters* cnt, GroupIn g, int cur, int bounce) {
-    ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-    if constexpr (B0 != 0) if (g.cls[0] >= 0) { in.counts = g.counts[0]; in.cls = g.cls[0]; shade_body<B0, SM, 0, 4>(kernel_args3(), cnt, in, cur, bounce); }
-    if constexpr (B1 != 0) if (g.cls[1] >= 0) { in.counts = g.counts[1]; in.cls = g.cls[1]; shade_body<B1, SM, 0, 4>(kernel_args3(), cnt, in, cur, bounce); }
-    if constexpr (B2 != 0) if (g.cls[2] >= 0) { in.counts = g.counts[2]; in.cls = g.cls[2]; shade_body<B2, SM, 0, 4>(kernel_args3(), cnt, in, cur, bounce); }
-    if constexpr (B3 != 0) if (g.cls[3] >= 0) { in.counts = g.counts[3]; in.cls = g.cls[3]; shade_body<B3, SM, 0, 4>(kernel_args3(), cnt, in, cur, bounce); }
 }
 
 // ------------------------------------------------------------------- shadow
@@ -1713,90 +1045,4 @@ __global__ void __launch_bounds__(BLOCK) k_finalize(Params p, Queues q, float* a
 __global__ void k_divide(const float* accum, float* out, uint32_t n, float cnt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = accum[i] / cnt;        // pixels = color / cnt (vanilla_renderer.py:120)
-}
-
-// Shader clock under load: every wave of a full grid runs a dependent FMA chain for a fixed number of iterations and reports the
-// cycle counter (s_memtime-class counter, shader clock) against the constant 100 MHz wall clock.  out[2*w] = cycles, out[2*w+1] = ticks.
-__global__ void __launch_bounds__(BLOCK) k_clock_probe(int iters, float seed, unsigned long long* out, float* sink) {
-    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
-    float a = seed + (float)threadIdx.x, b = 1.000001f;
-    for (int i = 0; i < iters; i++) { a = __builtin_fmaf(a, b, 0.5f); b = __builtin_fmaf(b, 0.999999f, 1e-7f); }
-    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
-    if (a == 12345.678f) sink[0] = a + b;                  // keeps the chain alive
-    if ((threadIdx.x & 63) == 0) {
-        const uint32_t w = blockIdx.x * (BLOCK / 64) + threadIdx.x / 64;
-        out[2 * w] = c1 - c0; out[2 * w + 1] = w1 - w0;
-    }
-}
-
-// ------------------------------------------------------- unit entry kernels
-template <int MODE>
-__global__ void __launch_bounds__(TRACE_NT(MODE)) k_occluded(DevScene sc, uint32_t n, const float* o_, const float* d_, const float* tmax, int* occ, LdsPlan plan) {
-    for (uint32_t base = blockIdx.x * TRACE_NT(MODE); base < n; base += gridDim.x * TRACE_NT(MODE)) {
-        const uint32_t pos = base + threadIdx.x;
-        const bool valid = pos < n;
-        const uint32_t idx = valid ? pos : n - 1;
-        f3 o = mk3(o_[idx], o_[n + idx], o_[2 * n + idx]), d = mk3(d_[idx], d_[n + idx], d_[2 * n + idx]);
-        HitRec rec; rec.t = (tmax[idx] > 0.0f) ? tmax[idx] - 1e-4f : 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
-        const bool hit = (MODE == 0) ? traverse<true>(sc.bvh, make_stack(plan), o, d, rec)
-                       : (MODE == 1) ? sweep_any(sc.sweep, o, d, rec)
-                                     : sweep_tile<true, APT_TILE_NT>(sc.sweep, o, d, rec, valid, reinterpret_cast<float*>(s_dyn));
-        if (valid) occ[idx] = hit ? 1 : 0;
-    }
-}
-__global__ void k_rng_stream(uint32_t pixel, uint32_t seed, uint32_t sample, int n, uint32_t* out) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        Philox r; rng_init(r, pixel, seed, sample, 0u);
-        for (int k = 0; k < n; k++) out[k] = rng_u32(r);
-    }
-}
-// BxDF eval / pdf / sample on explicit inputs, RNG = Philox stream keyed by (test index, seed, 1)
-// in : per test 10 floats n_s n_g incid [+ out for eval]; bx: one DevBxdf per test
-__global__ void k_bxdf_eval(int n, const DevBxdf* bx, const float* in, float world_ior, float* out4) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const float* x = in + 12 * k;
-    Hit it; it.obj_id = 0; it.prim_id = 0; it.min_depth = 1.f; it.n_s = ld3(x); it.n_g = ld3(x + 3);
-    f3 wi = ld3(x + 6), wo = ld3(x + 9);
-    DevBxdf b = bx[k];
-    f3 e = surface_eval<APT_BX_ALL>(b, it, wi, wo, world_ior, 0);
-    float pdf = surface_pdf<APT_BX_ALL>(b, it, wo, wi, world_ior, 0);
-    out4[4 * k] = e.x; out4[4 * k + 1] = e.y; out4[4 * k + 2] = e.z; out4[4 * k + 3] = pdf;
-}
-__global__ void k_bxdf_sample(int n, const DevBxdf* bx, const float* in, float world_ior, uint32_t seed, float* out9) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const float* x = in + 12 * k;
-    Hit it; it.obj_id = 0; it.prim_id = 0; it.min_depth = 1.f; it.n_s = ld3(x); it.n_g = ld3(x + 3);
-    f3 wi = ld3(x + 6);
-    DevBxdf b = bx[k];
-    Philox r; rng_init(r, (uint32_t)k, seed, 1u, 0u);
-    f3 spec; float pdf; bool sp;
-    f3 dir = surface_sample<APT_BX_ALL>(b, it, wi, world_ior, 0, r, spec, pdf, sp);
-    float* o = out9 + 9 * k;
-    o[0] = dir.x; o[1] = dir.y; o[2] = dir.z; o[3] = spec.x; o[4] = spec.y; o[5] = spec.z; o[6] = pdf; o[7] = sp ? 1.f : 0.f; o[8] = (float)r.draw;
-}
-__global__ void k_texture_probe(DevScene sc, int n, const int* map_obj, const float* uv, float* out3) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    f3 r = texture_query(sc, map_obj[2 * k], map_obj[2 * k + 1], uv[2 * k], uv[2 * k + 1]);
-    out3[3 * k] = r.x; out3[3 * k + 1] = r.y; out3[3 * k + 2] = r.z;
-}
-// emitter sample_hit / eval_le / solid_angle_pdf on explicit inputs: in = src index, hit_pos, normal, ray_d, min_depth (11 floats)
-__global__ void k_emitter_probe(DevScene sc, int n, const float* in, uint32_t seed, float* out12) {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const float* x = in + 11 * k;
-    const DevSrc s = sc.src[(int)x[0]];
-    const EmitterGeom geom = {sc.precom, sc.normals, sc.obj_info};
-    Philox r; rng_init(r, (uint32_t)k, seed, 1u, 0u);
-    f3 inten; float pdf;
-    f3 pos = emitter_sample_hit<APT_SRC_ALL>(s, geom, ld3(x + 1), r, inten, pdf);
-    Hit it; it.obj_id = 0; it.prim_id = 0; it.n_s = it.n_g = ld3(x + 4); it.min_depth = x[10];
-    f3 rd = ld3(x + 7);
-    f3 le = emitter_eval_le(s, rd * x[10], ld3(x + 4));
-    float sap = emitter_solid_angle_pdf(s, it, rd);
-    float* o = out12 + 12 * k;
-    o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = inten.x; o[4] = inten.y; o[5] = inten.z; o[6] = pdf; o[7] = (float)r.draw;
-    o[8] = le.x; o[9] = le.y; o[10] = le.z; o[11] = sap;
 }

@@ -600,16 +600,8 @@ APT_D bool sweep_wg(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active, 
 // any-hit tiles need neither the (t, primitive) reduction slots nor (tn | u, v) per entry: 2-byte entries
 #define APT_TILE_LDS_BYTES_ANY(nt, n_obj) ((size_t)(nt) * 32 + (size_t)(n_obj) * ((size_t)(nt) * 2 + 4) + 16)
 struct TileEntry { uint32_t a; float b; };                 // (ray, tn) going in, (u, v) coming out
-#ifdef APT_TILE_PROF
-#define TILE_TICK(k) do { unsigned long long now_ = __builtin_readcyclecounter(); prof[k] += now_ - tick_; tick_ = now_; } while (0)
-#else
-#define TILE_TICK(k) do { } while (0)
-#endif
 template <bool ANY, int NT>
-APT_D bool sweep_tile(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active, float* lds, unsigned long long* prof = nullptr) {
-#ifdef APT_TILE_PROF
-    unsigned long long tick_ = __builtin_readcyclecounter();
-#endif
+APT_D bool sweep_tile(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active, float* lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_obj = sc.n_objects;
     float* s_ray = lds;                                                     // o.xyz d.xyz t0, SoA
     int* s_flag = reinterpret_cast<int*>(lds + 7 * NT);
@@ -626,7 +618,6 @@ APT_D bool sweep_tile(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active
     if (!ANY) s_best[tid] = ~0ull;
     if (tid < n_obj) s_cnt[tid] = 0;
     __syncthreads();
-    TILE_TICK(0);
     {   // phase A
         const f3 inv_d = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
         SweepRay sr; sr.set(o, d);
@@ -646,9 +637,7 @@ APT_D bool sweep_tile(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active
             }
         }
     }
-    TILE_TICK(1);
     __syncthreads();
-    TILE_TICK(2);
     {   // phase B: global chunk g of the concatenated lists -> (object, chunk)
         int g = wave;
         for (int ob = 0; ob < n_obj; ob++) {
@@ -684,9 +673,7 @@ APT_D bool sweep_tile(const SweepScene& sc, f3 o, f3 d, HitRec& rec, bool active
             g -= n_chunks;
         }
     }
-    TILE_TICK(3);
     __syncthreads();
-    TILE_TICK(4);
     if (ANY) return s_flag[tid] != 0;
     if (s_flag[tid]) { rec.t = t0; rec.prim = -1; rec.u = rec.v = 0.f; sweep<false>(sc, o, d, rec); return false; }
     const unsigned long long key = s_best[tid];

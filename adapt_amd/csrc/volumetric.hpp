@@ -8,7 +8,7 @@
 // multi-H-G and Rayleigh (bxdf/phase.py, sampler/phase_sampling.py), and one RGB grid volume (bxdf/volume.py: delta tracking for
 // free paths, ratio tracking for light samples).
 #pragma once
-#include "stages.hpp"
+#include "shade_stage.hpp"
 #ifndef APT_VSHADOW_WAVES
 #define APT_VSHADOW_WAVES 5
 #endif
