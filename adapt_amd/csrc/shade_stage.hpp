@@ -189,9 +189,9 @@ APT_D void vertex_reset(Vertex& vx) {
 }
 // Step 1, after the hit has been built (vx.it, vx.hit_light; rec_kd: the colour in the primitive's record): material and textures, the
 // path's radiance slot and random stream, the emission MIS weight of this hit (the tail of the previous iteration, vanilla_renderer.py:
-// 111-117) and the roulette (vanilla_renderer.py:50-57).  false: the path ends here.  key_known: `key` is the pixel's stream key already.
+// 111-117) and the roulette (vanilla_renderer.py:50-57).  false: the path ends here.
 template <int BM, int SM, int TEX>
-APT_D bool open_vertex(const ShadeArgs3* A_, Vertex& vx, Philox& rng, int prim, f3 rec_kd, uint32_t meta, float ray_pdf, float2 uv, int bounce, bool key_known, uint32_t key) {
+APT_D bool open_vertex(const ShadeArgs3* A_, Vertex& vx, Philox& rng, int prim, f3 rec_kd, uint32_t meta, float ray_pdf, float2 uv, int bounce) {
     const bool was_spec = (meta >> 24) & 1u;
     if (BM == 0x002) vx.bx.k_d = rec_kd;               // Lambertian-only scenes: type 1, not delta, not a BSDF (vertex_reset), colour from the record
     else vx.bx = ld_bxdf_lane((A_->sc).bxdf + vx.it.obj_id);
@@ -208,7 +208,7 @@ APT_D bool open_vertex(const ShadeArgs3* A_, Vertex& vx, Philox& rng, int prim, 
     const uint32_t lp = vx.id & ((1u << (A_->p).pix_bits) - 1u), s = vx.id >> (A_->p).pix_bits;
     vx.l_off = (s * (uint32_t)(A_->p).npix + lp) << 2;
     vx.draw0 = meta & 0xffffu;
-    rng_init(rng, key_known ? key : (((A_->p).world == 1) ? lp : ldq((A_->p).pix_key, lp << 2)), (A_->p).seed, (uint32_t)((A_->p).cnt_base + (int)s + 1), vx.draw0);
+    rng_init(rng, ((A_->p).world == 1) ? lp : ldq((A_->p).pix_key, lp << 2), (A_->p).seed, (uint32_t)((A_->p).cnt_base + (int)s + 1), vx.draw0);
     if (bounce > 0 && (A_->p).use_mis) {
         float e_pdf = 0.0f;
         if (vx.hit_light >= 0 && vx.bx.is_delta == 0 && !was_spec) e_pdf = emitter_solid_angle_pdf((A_->sc).src[vx.hit_light], vx.it, vx.d);
@@ -280,12 +280,6 @@ APT_D f3 emit_and_scatter(const ShadeArgs3* A_, Vertex& vx, Philox& rng, float& 
     vx.thr = vx.thr * (spec / new_pdf);
     return new_d;
 }
-// interpolated vertex normal, NOT re-normalised (tracer_base.py:228-230)
-APT_D f3 vertex_normal(const DevScene& sc, int prim, float bu, float bv) {
-    const float4* vn = sc.vnormals + 3 * prim;
-    const float4 v0 = vn[0], v1 = vn[1], v2 = vn[2];
-    return (mk3(v0.x, v0.y, v0.z) * (1.f - bu - bv) + mk3(v1.x, v1.y, v1.z) * bu) + mk3(v2.x, v2.y, v2.z) * bv;
-}
 // a shadow-queue entry (k_shadow / shadow_flat_body read these planes)
 APT_D void shadow_store(const Queues& q, uint32_t so, f3 o, f3 dir, float dist, f3 contrib) {
     st3q(q.sh_o, q.sh_cap, so, o); st3q(q.sh_d, q.sh_cap, so, dir); stq(q.sh_tmax, so, dist); st3q(q.sh_c, q.sh_cap, so, contrib);
@@ -324,76 +318,43 @@ APT_D void shade_traced(args3_ptr A0, Counters* cnt, int cur, int bounce) {
 #ifdef APT_NEAR_STATS
     uint32_t t_near = 0;
 #endif
-    // Software prefetch (the Lambertian / point-light kernel, which has the registers for it: C1 / C2).  With 4 waves per SIMD each wave's
-    // loads are in flight only between its tile rows, and every row starts with two dependent round trips.  So the next row's record is
-    // requested at the top of this row - after this row's shading record, so that waiting for that one (vmcnt counts in order) does not
-    // wait for the prefetch - and lands while this row is shaded.  The kernels without registers for that prefetch only the hit primitive
-    // (PFP: one register), so that a row's shading record can be requested together with its queue record instead of a round trip after it.
-    constexpr bool PF = BM == 0x002 && SM == 0x1 && TEX == 0, PFP = !PF && TEX == 0;
+    // The next row's hit primitive is requested one row ahead (PFP: one register), so that a row's shading record can be requested together
+    // with its queue record instead of a round trip after it.  (Rounds 2-4 prefetched the Lambertian kernel's whole record: thirteen
+    // registers.  Without them the kernel allocates 91 VGPRs - five waves per SIMD instead of four - and three render lanes gain 6 %:
+    // C2 4 310 -> 4 560 Msamples/s on the same box.)
+    constexpr bool PFP = TEX == 0;
     static_assert(APT_FLAT_MAX_PRIMS < (int)TR_NO_PRIM, "the packed record keeps the hit primitive in 8 bits");
     const float4* trA = (A_->q).tr[cur][0]; const float4* trB = (A_->q).tr[cur][1]; const float4* trC = (A_->q).tr[cur][2]; const float4* trD = (A_->q).tr[cur][3];
     fix_prologue((A_->sc), (A_->p), (A_->q), cnt, cur, sl.q, bounce);       // before the queue's length is read: the prologue may append to it
     const uint32_t n = __hip_atomic_load(&cnt->n_tr[bounce % 3][0][sl.q * CNT_PAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t pf_pm = 0; float pf_t = 0.f; f3 pf_o = splat3(0.f), pf_d = splat3(0.f), pf_thr = splat3(0.f); uint32_t pf_id = 0;      // (pf_pm: the packed word - primitive, draw index, specular flag)
-    auto prefetch = [&](uint32_t b) {            // straight-line loads (lanes past the end re-read the last entry: never used), so that no wait lands at the end of a branch
-        const uint32_t pio16 = (qbase + min(b + threadIdx.x, n - 1u)) << 4;
-        const float4 a = ldq(trA, pio16), b_ = ldq(trB, pio16), c = ldq(trC, pio16);
-        pf_o = mk3(a.x, a.y, a.z); pf_t = a.w; pf_d = mk3(b_.x, b_.y, b_.z); pf_pm = __float_as_uint(b_.w); pf_thr = mk3(c.x, c.y, c.z); pf_id = __float_as_uint(c.w);
-    };
-    auto prefetch_prim = [&](uint32_t b) { pf_pm = ldq(reinterpret_cast<const uint32_t*>(trB), ((qbase + min(b + threadIdx.x, n - 1u)) << 4) + 12u); };
-    if (PF && n > 0) prefetch(sl.first);
+    uint32_t pf_pm = 0;                                        // (the packed word: primitive, draw index, specular flag)
+    auto prefetch_prim = [&](uint32_t b) { pf_pm = ldq(reinterpret_cast<const uint32_t*>(trB), ((qbase + min(b + threadIdx.x, n - 1u)) << 4) + 12u); };      // (lanes past the end re-read the last entry: never used)
     if (PFP && n > 0) prefetch_prim(sl.first);
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
         APT_ARGS_PHASE();
         const uint32_t pos = base + threadIdx.x, idx = qbase + pos;                    // (unsorted renders: one queue for the scene)
         bool alive = pos < n;
-        const uint32_t cu_pm = pf_pm; const float cu_t = pf_t; const f3 cu_o = pf_o, cu_d = pf_d, cu_thr = pf_thr; const uint32_t cu_id = pf_id;
-        float4 cu_ra = make_float4(0.f, 0.f, 0.f, 0.f), cu_rb = cu_ra; uint32_t cu_key = 0;
-        if (PF || PFP) { const int rp = max(tr_prim(cu_pm), 0); cu_ra = (A_->sc).prim_shade[2 * rp]; cu_rb = (A_->sc).prim_shade[2 * rp + 1]; }
-        if (PFP) prefetch_prim(base + sl.stride);
-        if (PF) {
-            cu_key = cu_id & ((1u << (A_->p).pix_bits) - 1u);
-            if ((A_->p).world != 1) cu_key = ldq((A_->p).pix_key, cu_key << 2);     // (multi-GPU: the pixel's global key; requested here for the same reason)
-            __builtin_amdgcn_sched_barrier(0);                 // the record first, then the prefetch: the wait for the record must not include the prefetch
-            prefetch(base + sl.stride);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        const uint32_t cu_pm = pf_pm;
+        float4 cu_ra = make_float4(0.f, 0.f, 0.f, 0.f), cu_rb = cu_ra;
+        if (PFP) { const int rp = max(tr_prim(cu_pm), 0); cu_ra = (A_->sc).prim_shade[2 * rp]; cu_rb = (A_->sc).prim_shade[2 * rp + 1]; prefetch_prim(base + sl.stride); }
         Vertex vx; vertex_reset(vx);
         Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
-        // the radiance the path has gathered so far (camera rays carry none: nothing is read at bounce 0) and, for entries that end here
-        // without being shaded (roulette), the path id that names the slot it goes to
-        f3 Lc = splat3(0.f);
+        f3 Lc = splat3(0.f);                                   // the radiance the path has gathered so far (camera rays carry none: nothing is read at bounce 0)
         const bool entry = alive;
         float ray_pdf = 1.f;
-        if (alive && bounce > 0) {
-            const float4 dd = ldq(trD, idx << 4); Lc = mk3(dd.x, dd.y, dd.z); if (SM & 2) ray_pdf = dd.w;
-            vx.id = PF ? cu_id : __float_as_uint(ldq(reinterpret_cast<const float*>(trC), (idx << 4) + 12u));
-        }
+        if (alive && bounce > 0) { const float4 dd = ldq(trD, idx << 4); Lc = mk3(dd.x, dd.y, dd.z); if (SM & 2) ray_pdf = dd.w; }
         if (alive) {
-            uint32_t pm = cu_pm; float t_in = cu_t; float2 uv; uv.x = uv.y = 0.f;
-            if (PF) { vx.o = cu_o; vx.d = cu_d; vx.thr = cu_thr; vx.id = cu_id; }
-            else {
-                const float4 a = ldq(trA, idx << 4), b_ = ldq(trB, idx << 4), c = ldq(trC, idx << 4);
-                vx.o = mk3(a.x, a.y, a.z); t_in = a.w; vx.d = mk3(b_.x, b_.y, b_.z); vx.thr = mk3(c.x, c.y, c.z); vx.id = __float_as_uint(c.w);
-                if (!PFP) pm = __float_as_uint(b_.w);
-            }
+            const float4 a = ldq(trA, idx << 4), b_ = ldq(trB, idx << 4), c = ldq(trC, idx << 4);
+            vx.o = mk3(a.x, a.y, a.z); vx.d = mk3(b_.x, b_.y, b_.z); vx.thr = mk3(c.x, c.y, c.z); vx.id = __float_as_uint(c.w);
+            const uint32_t pm = PFP ? cu_pm : __float_as_uint(b_.w);
             const int prim = tr_prim(pm);
             if (prim < 0) alive = false;                         // nothing hit: path ends (vanilla_renderer.py:49)
             else {
-                f3 rec_kd;
-                const bool need_uv = (A_->sc).has_vn || (TEX && (A_->sc).tex_i != nullptr);      // otherwise nobody reads the barycentrics (and nobody wrote them)
-                if (PF) {
-                    build_hit_rec((A_->sc), cu_ra, cu_rb, prim, t_in, 0.f, 0.f, vx.o, vx.d, vx.it, vx.hit_light, rec_kd, false);
-                    if ((A_->sc).has_vn && __float_as_int(cu_ra.w) >= 0) {       // vertex normals: the barycentrics are fetched (and waited for) inside this branch only
-                        uv = ldq((A_->q).tr_uv[cur], idx << 3);
-                        vx.it.n_s = vertex_normal((A_->sc), prim, uv.x, uv.y);
-                    }
-                } else {
-                    if (need_uv) uv = ldq((A_->q).tr_uv[cur], idx << 3);
-                    if (PFP) build_hit_rec((A_->sc), cu_ra, cu_rb, prim, t_in, uv.x, uv.y, vx.o, vx.d, vx.it, vx.hit_light, rec_kd);
-                    else build_hit((A_->sc), prim, t_in, uv.x, uv.y, vx.o, vx.d, vx.it, vx.hit_light, rec_kd);
-                }
-                alive = open_vertex<BM, SM, TEX>(A_, vx, rng, prim, rec_kd, tr_meta(pm, (uint32_t)bounce), ray_pdf, uv, bounce, PF, cu_key);
+                f3 rec_kd; float2 uv; uv.x = uv.y = 0.f;
+                if ((A_->sc).has_vn || (TEX && (A_->sc).tex_i != nullptr)) uv = ldq((A_->q).tr_uv[cur], idx << 3);      // otherwise nobody reads the barycentrics (and nobody wrote them)
+                if (PFP) build_hit_rec((A_->sc), cu_ra, cu_rb, prim, a.w, uv.x, uv.y, vx.o, vx.d, vx.it, vx.hit_light, rec_kd);
+                else build_hit((A_->sc), prim, a.w, uv.x, uv.y, vx.o, vx.d, vx.it, vx.hit_light, rec_kd);
+                alive = open_vertex<BM, SM, TEX>(A_, vx, rng, prim, rec_kd, tr_meta(pm, (uint32_t)bounce), ray_pdf, uv, bounce);
             }
         }
         tl.shade += wave_count(alive);
@@ -499,70 +460,44 @@ APT_D void shade_staged(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur,
 #ifdef APT_NEAR_STATS
     uint32_t t_near = 0;
 #endif
-    // Software prefetch, as in shade_traced: the whole record for the Lambertian / point-light kernel (a kernel that only streams this
-    // stage's queues - 13 SoA reads, 22 SoA writes per entry, same grid - moves 5.1 TB/s, tools/history/probes/stream_probe.hip; the stage
-    // itself ~3), the hit primitive alone for the others.
-    constexpr bool PF = !CQ && BM == 0x002 && SM == 0x1 && TEX == 0, PFP = !PF && TEX == 0;
+    constexpr bool PFP = TEX == 0;                            // the next row's hit primitive is requested one row ahead, as in shade_traced
     const uint32_t in_base = CQ ? (uint32_t)in.cls * (A_->p).cap + qbase : qbase;      // first slot of the queue this workgroup reads
     const float4* cqA = CQ ? (A_->q).cq[0] : nullptr; const float4* cqB = CQ ? (A_->q).cq[1] : nullptr; const float4* cqC = CQ ? (A_->q).cq[2] : nullptr; const float4* cqD = CQ ? (A_->q).cq[3] : nullptr;
-    int pf_prim = -1; float pf_t = 0.f; f3 pf_o = splat3(0.f), pf_d = splat3(0.f), pf_thr = splat3(0.f); uint32_t pf_id = 0, pf_meta = 0;
-    auto prefetch = [&](uint32_t b) {            // straight-line loads (lanes past the end re-read the last entry: never used), so that no wait lands at the end of a branch
-        const uint32_t pio = (qbase + min(b + threadIdx.x, n - 1u)) << 2;
-        pf_prim = ldq(in.prim, pio); pf_t = ldq(in.t, pio);
-        pf_o = ld3q(in.ray_o, (A_->p).cap, pio); pf_d = ld3q(in.ray_d, (A_->p).cap, pio); pf_thr = ld3q(in.thr, (A_->p).cap, pio);
-        pf_id = ldq(in.id, pio); pf_meta = ldq(in.meta, pio);
-    };
+    int pf_prim = -1;
     auto prefetch_prim = [&](uint32_t b) {
         const uint32_t ps = in_base + min(b + threadIdx.x, n - 1u);
         pf_prim = CQ ? ldq(reinterpret_cast<const int*>(cqB), (ps << 4) + 12u) : ldq(in.prim, ps << 2);
     };
-    if (PF && n > 0) prefetch(sl.first);
     if (PFP && n > 0) prefetch_prim(sl.first);
     for (uint32_t base = sl.first; base < n; base += sl.stride) {
         APT_ARGS_PHASE();
         const uint32_t pos = base + threadIdx.x, idx = in_base + pos;
         bool alive = pos < n;
-        const int cu_prim = pf_prim; const float cu_t = pf_t; const f3 cu_o = pf_o, cu_d = pf_d, cu_thr = pf_thr; const uint32_t cu_id = pf_id, cu_meta = pf_meta;
-        float4 cu_ra = make_float4(0.f, 0.f, 0.f, 0.f), cu_rb = cu_ra; uint32_t cu_key = 0;
-        if (PF || PFP) { const int rp = max(cu_prim, 0); cu_ra = (A_->sc).prim_shade[2 * rp]; cu_rb = (A_->sc).prim_shade[2 * rp + 1]; }
-        if (PFP) prefetch_prim(base + sl.stride);
-        if (PF) {
-            cu_key = cu_id & ((1u << (A_->p).pix_bits) - 1u);
-            if ((A_->p).world != 1) cu_key = ldq((A_->p).pix_key, cu_key << 2);     // (multi-GPU: the pixel's global key; requested here for the same reason)
-            __builtin_amdgcn_sched_barrier(0);                 // the record first, then the prefetch: the wait for the record must not include the prefetch
-            prefetch(base + sl.stride);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        const int cu_prim = pf_prim;
+        float4 cu_ra = make_float4(0.f, 0.f, 0.f, 0.f), cu_rb = cu_ra;
+        if (PFP) { const int rp = max(cu_prim, 0); cu_ra = (A_->sc).prim_shade[2 * rp]; cu_rb = (A_->sc).prim_shade[2 * rp + 1]; prefetch_prim(base + sl.stride); }
         Vertex vx; vertex_reset(vx);
         Philox rng; rng_init(rng, 0u, 0u, 0u, 0u);
         if (alive) {
             const uint32_t io = idx << 2;
-            const int prim = (PF || PFP) ? cu_prim : (CQ ? ldq(reinterpret_cast<const int*>(cqB), (idx << 4) + 12u) : ldq(in.prim, io));
+            const int prim = PFP ? cu_prim : (CQ ? ldq(reinterpret_cast<const int*>(cqB), (idx << 4) + 12u) : ldq(in.prim, io));
             if (prim < 0) alive = false;                         // nothing hit: path ends (vanilla_renderer.py:49)
             else {
-                uint32_t meta; float t_in = cu_t, ray_pdf = 1.f; float2 uv; uv.x = uv.y = 0.f;
-                const bool need_uv = (A_->sc).has_vn || (TEX && (A_->sc).tex_i != nullptr);      // otherwise nobody reads the barycentrics (and the flat extend kernel does not write them)
-                if (PF) { vx.o = cu_o; vx.d = cu_d; vx.thr = cu_thr; vx.id = cu_id; meta = cu_meta; }
-                else if (CQ) {
+                uint32_t meta; float t_in, ray_pdf = 1.f; float2 uv; uv.x = uv.y = 0.f;
+                if (CQ) {
                     const float4 a = ldq(cqA, idx << 4), b_ = ldq(cqB, idx << 4), c = ldq(cqC, idx << 4), dd = ldq(cqD, idx << 4);
                     vx.o = mk3(a.x, a.y, a.z); t_in = a.w; vx.d = mk3(b_.x, b_.y, b_.z); vx.thr = mk3(c.x, c.y, c.z); vx.id = __float_as_uint(c.w);
                     meta = __float_as_uint(dd.x); if (SM & 2) ray_pdf = dd.y; uv.x = dd.z; uv.y = dd.w;
                 } else {
                     vx.o = ld3q(in.ray_o, (A_->p).cap, io); vx.d = ld3q(in.ray_d, (A_->p).cap, io); vx.thr = ld3q(in.thr, (A_->p).cap, io);
                     vx.id = ldq(in.id, io); meta = ldq(in.meta, io); t_in = ldq(in.t, io);
-                }
-                if (!CQ) {
                     if (SM & 2) ray_pdf = ldq(in.pdf, io);          // (its only reader is the emission MIS weight: scenes without area lights never look at it)
-                    if (need_uv && !PF) { uv.x = ldq(in.u, io); uv.y = ldq(in.v, io); }
+                    if ((A_->sc).has_vn || (TEX && (A_->sc).tex_i != nullptr)) { uv.x = ldq(in.u, io); uv.y = ldq(in.v, io); }      // otherwise nobody reads the barycentrics (and the flat extend kernel does not write them)
                 }
                 f3 rec_kd;
-                if (PF) {
-                    build_hit_rec((A_->sc), cu_ra, cu_rb, prim, t_in, 0.f, 0.f, vx.o, vx.d, vx.it, vx.hit_light, rec_kd, false);
-                    if ((A_->sc).has_vn && __float_as_int(cu_ra.w) >= 0) vx.it.n_s = vertex_normal((A_->sc), prim, ldq(in.u, io), ldq(in.v, io));      // the barycentrics are fetched (and waited for) inside this branch only
-                }
-                else if (PFP) build_hit_rec((A_->sc), cu_ra, cu_rb, prim, t_in, uv.x, uv.y, vx.o, vx.d, vx.it, vx.hit_light, rec_kd);
+                if (PFP) build_hit_rec((A_->sc), cu_ra, cu_rb, prim, t_in, uv.x, uv.y, vx.o, vx.d, vx.it, vx.hit_light, rec_kd);
                 else build_hit((A_->sc), prim, t_in, uv.x, uv.y, vx.o, vx.d, vx.it, vx.hit_light, rec_kd);
-                alive = open_vertex<BM, SM, TEX>(A_, vx, rng, prim, rec_kd, meta, ray_pdf, uv, bounce, PF, cu_key);
+                alive = open_vertex<BM, SM, TEX>(A_, vx, rng, prim, rec_kd, meta, ray_pdf, uv, bounce);
             }
         }
         tl.shade += wave_count(alive);
@@ -570,10 +505,6 @@ APT_D void shade_staged(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur,
         t_near += wave_count(alive && bounce > 0 && vx.it.min_depth < 2e-3f);
 #endif
         if (alive) vx.hit_point = vx.d * vx.it.min_depth + vx.o;
-        // prefetching kernel: the queue-tail atomic of the row is sent early and awaited at the end of the row, so that the only full wait
-        // of a row comes after all of its arithmetic - by then the next row's record has long arrived
-        Append next_app; next_app.m = 0ull; next_app.raw = 0u;
-        if (PF) next_app = append_issue(alive && (bounce + 1) < (A_->p).max_bounce, next_counter);
 
         APT_ARGS_PHASE();
         // ---- next-event estimation: one shadow-queue entry per useful light sample
@@ -612,7 +543,7 @@ APT_D void shade_staged(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur,
         }
         if (rng.draw != vx.draw0) atomicAdd(&s_draws[threadIdx.x >> 6], rng.draw - vx.draw0);      // also paths that died in the roulette
         APT_ARGS_PHASE();
-        const uint32_t npos = PF ? append_pos(next_app) : wave_append(cont, next_counter);
+        const uint32_t npos = wave_append(cont, next_counter);
         if (cont) {
             const uint32_t so = (qbase + npos) << 2;
             st3q((A_->q).ray_o[nxt], (A_->p).cap, so, vx.hit_point);
@@ -633,11 +564,8 @@ __global__ void __launch_bounds__(BLOCK) k_shade(DevScene sc, Params p, Queues q
     shade_staged<BM, SM, TEX, false>(kernel_args3(), cnt, in, cur, bounce);
 }
 #if APT_FAST
-#ifndef APT_TRACED_WAVES
-#define APT_TRACED_WAVES 1
-#endif
 template <int BM, int SM, int TEX = 0>
-__global__ void __launch_bounds__(BLOCK, (BM == 0x002 && SM == 0x01 ? APT_TRACED_WAVES : 1)) k_shade_traced(DevScene sc, Params p, Queues q, Counters* cnt, int cur, int bounce) {
+__global__ void __launch_bounds__(BLOCK) k_shade_traced(DevScene sc, Params p, Queues q, Counters* cnt, int cur, int bounce) {
     shade_traced<BM, SM, TEX>(kernel_args3(), cnt, cur, bounce);
 }
 #endif
