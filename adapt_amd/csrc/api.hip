@@ -648,7 +648,15 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     int B = c.spp_per_batch;
     r->n_lanes = (c.volumetric && sc->has_null_surface) ? 4 : 3;   // volumetric scenes with null surfaces: a fourth lane hides the host read-backs of their tails (V1 752 -> 782, V2 488 -> 517 Msamples/s); measured on C2: 1 lane 1 827, 2 lanes 2 196, 3 lanes 2 268, 4 lanes 2 178 Msamples/s (64 spp per lane-batch)
     if (const char* nl = getenv("APT_LANES")) r->n_lanes = std::min(4, std::max(1, atoi(nl)));
-    if (B <= 0) { B = (int)((16u << 20) / (uint32_t)r->npix); if (B < 1) B = 1; if (B > 1024) B = 1024; }   // ~16 Mi paths per lane (2.7 GB of queues each, of 288 GB) whatever the tile size: an 8-GPU rank owns 1/8 of the pixels and takes 8x the samples per batch
+    if (B <= 0) {
+        // ~32 Mi paths per lane-batch (5-17 GB of queues each, of 288 GB) whatever the tile size: an 8-GPU rank owns 1/8 of the pixels and takes
+        // 8x the samples per batch.  Measured 16 Mi -> 32 Mi on one box: C2 4 547 -> 4 685, C3 1 150 -> 1 177, C4 1 840 -> 1 922, C5 1 971 ->
+        // 2 078 Msamples/s (half the launches, each twice as long: a launch boundary drains and refills 256 CUs); 48-90 Mi is level or worse.
+        // Class-sorted and volumetric renders address (classes x capacity) 16-byte slots with 32-bit byte offsets: the batch stays below that.
+        B = (int)((32u << 20) / (uint32_t)r->npix); if (B < 1) B = 1; if (B > 1024) B = 1024;
+        const size_t n_cq = c.volumetric ? (size_t)sc->n_classes + 1 : ((sc->n_classes >= 2 && sc->n_classes <= APT_MAX_CLASSES) ? (size_t)sc->n_classes : 1);
+        while (B > 1 && n_cq * ((size_t)r->npix * (size_t)B + 64u * APT_MAX_NQ) >= ((size_t)1 << 28)) B--;
+    }
     r->spp_batch = B;
     const int S = c.num_shadow_ray;
     if (const char* e = getenv("APT_NQ")) r->nq = std::min(APT_MAX_NQ, std::max(1, atoi(e)));      // tuning knob: sub-queues per queue
@@ -1003,6 +1011,17 @@ static int resolve_events(apt_renderer* r) {
     return APT_OK;
 }
 
+// Samples per lane-batch of one render call.  A batch size the caller fixed is taken as it is; otherwise the call's samples are split into
+// EQUAL batches, a whole number of them per render lane (1024 spp at 128 per batch and three lanes: nine batches of 114, not eight of
+// 128 - the lane that would have run two of the eight idles a third of the step: C3 1 137 -> 1 177 Msamples/s).  The image does not depend
+// on the split: k_finalize adds a pixel's samples to the framebuffer one by one, in sample order, whatever batch they came in.
+static int lane_batch(const apt_renderer* r, int32_t n_spp) {
+    if (r->cfg.spp_per_batch > 0) return r->spp_batch;
+    int n_batches = (n_spp + r->spp_batch - 1) / r->spp_batch;
+    n_batches = ((n_batches + r->n_lanes - 1) / r->n_lanes) * r->n_lanes;
+    return std::max(1, std::min(r->spp_batch, (n_spp + n_batches - 1) / n_batches));
+}
+
 // Volumetric render (VolumeRenderer.render x n_spp).  Batches go round-robin over the render lanes like the surface tracer's, in
 // rounds: first every lane of the round gets its generate + max_bounce iterations (asynchronous), then, lane by lane, the
 // null-surface tail (live count read back, two more iterations while paths remain) and the ordered finalize.  While the host
@@ -1012,7 +1031,7 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
     const int nq = r->nq;
     int done = 0;
     hipEvent_t prev_fin = nullptr;
-    const int batch_cap = (r->cfg.spp_per_batch <= 0 && n_spp < r->n_lanes * r->spp_batch) ? std::max(1, (n_spp + r->n_lanes - 1) / r->n_lanes) : r->spp_batch;
+    const int batch_cap = lane_batch(r, n_spp);
     struct Issued { int li, cur; Params p; size_t total; };
     while (done < n_spp) {
         std::vector<Issued> round;
@@ -1119,7 +1138,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
     hipEvent_t prev_fin = nullptr;
     const int si = r->sorted ? 1 : 0;            // (sorted: extend appends every hit path's record to the packed queue of its material class, Queues::cq)
     // a call smaller than one full round of lane-batches is split evenly so that every lane has work
-    const int batch_cap = (r->cfg.spp_per_batch <= 0 && n_spp < r->n_lanes * r->spp_batch) ? std::max(1, (n_spp + r->n_lanes - 1) / r->n_lanes) : r->spp_batch;
+    const int batch_cap = lane_batch(r, n_spp);
     while (done < n_spp) {
         const int B = (n_spp - done < batch_cap) ? (n_spp - done) : batch_cap;
         const int li = batch % r->n_lanes;

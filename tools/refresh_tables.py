@@ -4,7 +4,7 @@ import json, re, sys
 rnd = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 P = f"profiles/r{rnd:02d}"
 rows = [("c1", "C1 cbox 256x256, 64 spp, 4 b", "2 851", "2 770", "3 528", "4 883"), ("c2", "C2 cbox 512x512, 1024 spp, 8 b", "2 341", "2 372", "3 597", "4 161"), ("c3", "C3 csphere 512x512, 1024 spp, 16 b, S=4", "615", "614", "973", "1 086"),
-        ("c4", "C4 three-bunnies* 800x800, 8 b, S=2 (156 spp/step)", "816", "1 329", "1 346", "1 824"), ("c5", "C5 bunny-field* 1280x720, 16 b, S=1 (162 spp/step)", "731", "1 213", "1 321", "1 867"),
+        ("c4", "C4 three-bunnies* 800x800, 8 b, S=2 (156 spp/step)", "816", "1 329", "1 346", "1 824"), ("c5", "C5 bunny-field* 1280x720, 16 b, S=1 (216 spp/step)", "731", "1 213", "1 321", "1 867"),
         ("v1", "V1 fog Cornell box, 512x512, 256 spp, 16 b, **volumetric tracer**", "804-816", "807", "918", "951"), ("v2", "V2 media_a, 512x512, 256 spp, 8 b, S=2, **volumetric tracer**", "528-531", "522", "531", "545"),
         ("v3", "V3 volgrid_a (RGB grid volume), 512x512, 128 spp, 8 b, S=2, **volumetric tracer**", "543", "533", "515", "519")]
 out = []

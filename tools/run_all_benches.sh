@@ -5,7 +5,7 @@ python bench.py --config c2 --steps 3 --warmup 1 > gpurun_out/bench/c2.json 2> g
 python bench.py --config c1 --steps 10 --warmup 2 --cpu-seconds 8 > gpurun_out/bench/c1.json 2> gpurun_out/bench/c1.err
 python bench.py --config c3 --steps 2 --warmup 1 --cpu-seconds 10 > gpurun_out/bench/c3.json 2> gpurun_out/bench/c3.err
 python bench.py --config c4 --steps 1 --warmup 1 --spp 156 --cpu-seconds 10 > gpurun_out/bench/c4.json 2> gpurun_out/bench/c4.err
-python bench.py --config c5 --steps 1 --warmup 1 --spp 162 --cpu-seconds 10 > gpurun_out/bench/c5.json 2> gpurun_out/bench/c5.err
+python bench.py --config c5 --steps 1 --warmup 1 --spp 216 --cpu-seconds 10 > gpurun_out/bench/c5.json 2> gpurun_out/bench/c5.err
 python bench.py --config v1 --steps 2 --warmup 1 --cpu-seconds 10 > gpurun_out/bench/v1.json 2> gpurun_out/bench/v1.err
 python bench.py --config v3 --steps 2 --warmup 1 --cpu-seconds 10 > gpurun_out/bench/v3.json 2> gpurun_out/bench/v3.err
 python bench.py --config v2 --steps 2 --warmup 1 --cpu-seconds 10 > gpurun_out/bench/v2.json 2> gpurun_out/bench/v2.err
