@@ -646,7 +646,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     r->npix = r->n_cols * c.height;
     if (r->npix <= 0) { return fail(APT_E_INVALID, "apt_renderer_create: this rank owns no pixels"); }
     int B = c.spp_per_batch;
-    r->n_lanes = (c.volumetric && sc->has_null_surface) ? 4 : 3;   // volumetric scenes with null surfaces: a fourth lane hides the host read-backs of their tails (V1 752 -> 782, V2 488 -> 517 Msamples/s); measured on C2: 1 lane 1 827, 2 lanes 2 196, 3 lanes 2 268, 4 lanes 2 178 Msamples/s (64 spp per lane-batch)
+    r->n_lanes = 3;   // measured on C2: 1 lane 1 827, 2 lanes 2 196, 3 lanes 2 268, 4 lanes 2 178 Msamples/s (round 2, 64 spp per lane-batch); round 5, 32 Mi paths per lane-batch: C2 4 559 / 4 590 / 4 287 with 2 / 3 / 4, C5 1 844 / 2 028 / 2 129 with 1 / 2 / 3; volumetric scenes with null surfaces ran four lanes in rounds 3-4 (the fourth hid the host read-backs of their tails): at this batch size V1 1 374 with three, 1 299 with four
     if (const char* nl = getenv("APT_LANES")) r->n_lanes = std::min(4, std::max(1, atoi(nl)));
     if (B <= 0) {
         // ~32 Mi paths per lane-batch (5-17 GB of queues each, of 288 GB) whatever the tile size: an 8-GPU rank owns 1/8 of the pixels and takes

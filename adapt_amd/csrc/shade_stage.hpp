@@ -520,9 +520,9 @@ APT_D void shade_staged(args3_ptr A0, Counters* cnt, const ShadeIn& in, int cur,
             tl.shadow += wave_count(ls.sampled); tl.poison += wave_count(ls.poisoned);
             if ((A_->p).nee_vm) {
                 const uint32_t so = (sh_qbase + (uint32_t)s * (A_->p).subcap + vbase) << 2;        // plane s of the sub-queue's region: consecutive lanes, consecutive entries
-                if (ls.want) shadow_store((A_->q), so, vx.hit_point, ls.dir, ls.dist, ls.contrib);
+                if (ls.want) { st3q((A_->q).sh_d, (A_->q).sh_cap, so, ls.dir); stq((A_->q).sh_tmax, so, ls.dist); st3q((A_->q).sh_c, (A_->q).sh_cap, so, ls.contrib); }
                 else if (alive) stq((A_->q).sh_tmax, so, -1.0f);                   // the vertex has no sample s worth tracing
-                if (alive && s == 0) stq((A_->q).sh_id, so, vx.l_off);                   // one radiance slot per vertex, kept with its first entry
+                if (alive && s == 0) { stq((A_->q).sh_id, so, vx.l_off); st3q((A_->q).sh_o, (A_->q).sh_cap, so, vx.hit_point); }      // one radiance slot and ONE origin per vertex, kept with its first entry (the S samples leave from the same point: 12 bytes written and read once instead of S times)
             } else {
                 const uint32_t spos = wave_append(ls.want, shadow_counter);
                 if (ls.want && spos < (A_->q).sh_subcap) {

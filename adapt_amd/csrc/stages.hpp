@@ -911,6 +911,7 @@ APT_D void shadow_flat_body(const DevScene& sc, const Params& p, const Queues& q
             const uint32_t pos = (VAR == 2) ? ldq(q.fix_sh, (qbase + (valid ? li : n - 1u)) << 2) : (valid ? li : n - 1u);
             const uint32_t io = (qbase + pos) << 2;
             const uint32_t slot = ldq(q.sh_id, io);
+            const f3 o = ld3q(q.sh_o, q.sh_cap, io);                              // (one origin per vertex, with its first entry)
             f3 sum = splat3(0.f); bool any = false, defer = false;
             uint32_t v_traced = 0, v_lit = 0;
             for (int smp = 0; smp < p.S; smp += 2) {
@@ -918,7 +919,6 @@ APT_D void shadow_flat_body(const DevScene& sc, const Params& p, const Queues& q
                 const uint32_t ia = io + ((uint32_t)smp * p.subcap << 2), ib = io + ((uint32_t)(two ? smp + 1 : smp) * p.subcap << 2);
                 const float ta = ldq(q.sh_tmax, ia), tb = ldq(q.sh_tmax, ib);
                 const bool la = valid && !(ta < 0.0f), lb = valid && two && !(tb < 0.0f);
-                const f3 o = ld3q(q.sh_o, q.sh_cap, la ? ia : ib);                 // (the origin is written with every wanted sample)
                 const f3 da = ld3q(q.sh_d, q.sh_cap, ia), db = ld3q(q.sh_d, q.sh_cap, ib);
                 bool oa, ob, spa, spb;
                 flat_any2<VAR == 1>(sc.flat, sc.sweep, o, da, o, db, la ? ((ta > 0.0f) ? ta - 1e-4f : 1e7f) : -1.0f, lb ? ((tb > 0.0f) ? tb - 1e-4f : 1e7f) : -1.0f, oa, ob, spa, spb);

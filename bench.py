@@ -228,8 +228,6 @@ def main():
     rdr = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world,
                    band_width=BAND_WIDTH, profile=False, spp_per_batch=args.spp_per_batch)      # the timed region carries no per-launch events (below)
     info = rdr.info()
-    if args.lanes <= 0 and "APT_LANES" not in os.environ and volumetric and bool(((rdr.flat.bxdf_i[:, 2] != 0) & (rdr.flat.bxdf_i[:, 0] < 0)).any()):
-        lanes = 4                            # library default for volumetric scenes with null surfaces (api.hip)
 
     gathered = [None]
     gather_ms = []

@@ -287,6 +287,10 @@ def test_cbox_is_bit_reproducible_and_batch_invariant(renderer):
     c.render(n_spp=24)
     assert np.array_equal(img, c.color.to_numpy())
     assert a.stats()["n_shade"] == b.stats()["n_shade"] == c.stats()["n_shade"]
+    # the library's own split (no batch size given: equal lane-batches, a whole number per render lane - api.hip lane_batch)
+    d = renderer("cbox", width=128, height=128)
+    d.render(n_spp=24)
+    assert np.array_equal(img, d.color.to_numpy()) and d.stats()["n_shade"] == a.stats()["n_shade"]
 
 
 @pytest.mark.parametrize("tag", ["cbox", "features_b"])          # one shadow ray per hit: no two float atomics ever meet on a radiance slot
