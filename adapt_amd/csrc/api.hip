@@ -103,19 +103,20 @@ static const extend_fn kFixFlat[2] = {APT_FLAT_FN(k_fix_flat<0>), APT_FLAT_FN(k_
 static const extend_fn kExtendDyn[2] = {k_extend_dyn<0>, k_extend_dyn<1>};      // BVH walk with dynamic ray fetch [sorted]
 static const shadow_fn kShadow[4] = {k_shadow<0>, k_shadow<1>, k_shadow<2>, APT_FLAT_FN(k_shadow_flat<1>)};      // (flat: the hot variant; its list is served by the next kFixFlat launch)
 static const occluded_fn kOccluded[4] = {k_occluded<0>, k_occluded<1>, k_occluded<2>, APT_FLAT_FN(k_occluded_flat)};
-// Volumetric shading sorted by EVENT (volumetric.hpp k_vevent / k_vshade_ev): rows = the surface classes (kClassMask order; the volumetric
-// tracer does not split Blinn-Phong by lobe), then the all-models surface kernel (textured scenes, or more classes than queues: ONE surface
-// queue), then the medium kernel; [emitter set: point + area | all][without / with a grid volume]
+// Volumetric shading sorted by EVENT (volumetric.hpp k_vevent / k_vshade_ev): one queue per surface class (kClassMask order; the volumetric
+// tracer does not split Blinn-Phong by lobe) and one for the medium, shaded by the group kernels below; textured scenes, or scenes with
+// more classes than queues, keep ONE surface queue, shaded by the all-models kernel: [emitter set: point + area | all][without / with a grid volume]
 typedef void (*vevent_fn)(DevScene, Params, Queues, Counters*, int, int);
 typedef void (*vev_shade_fn)(DevScene, Params, Queues, Counters*, int, int);
 static const vevent_fn kVEvent[2] = {k_vevent<0>, k_vevent<1>};
-#define APT_VEV_ROW(BM, MI) {{k_vshade_ev<BM, 0x03, 0, MI>, k_vshade_ev<BM, 0x03, 1, MI>}, {k_vshade_ev<BM, APT_SRC_ALL, 0, MI>, k_vshade_ev<BM, APT_SRC_ALL, 1, MI>}}
-#define APT_VEV_ALL (APT_N_CLASS_DEFS)
-#define APT_VEV_MEDIUM (APT_N_CLASS_DEFS + 1)
-static const vev_shade_fn kVEventShade[APT_N_CLASS_DEFS + 2][2][2] = {
-    APT_VEV_ROW(0x002, 0), APT_VEV_ROW(0x001, 0), APT_VEV_ROW(0x040, 0), APT_VEV_ROW(0x504, 0), APT_VEV_ROW(0x010, 0), APT_VEV_ROW(0x020, 0), APT_VEV_ROW(0x080, 0),
-    APT_VEV_ROW(0x200, 0), APT_VEV_ROW(0x008, 0), APT_VEV_ROW(0x001, 0), APT_VEV_ROW(APT_BX_ALL, 0), APT_VEV_ROW(0x000, 1),
-};
+static const vev_shade_fn kVEventAll[2][2] = {{k_vshade_ev<APT_BX_ALL, 0x03, 0, 0>, k_vshade_ev<APT_BX_ALL, 0x03, 1, 0>}, {k_vshade_ev<APT_BX_ALL, APT_SRC_ALL, 0, 0>, k_vshade_ev<APT_BX_ALL, APT_SRC_ALL, 1, 0>}};
+// ... launched in register-footprint groups (volumetric.hpp k_vshade_ev_group): class definition -> (group, member slot); the medium is member 0 of group 1
+typedef void (*vev_group_fn)(DevScene, Params, Queues, Counters*, VGroupIn, int);
+#define APT_N_VGROUPS 3
+static const int kVClassGroup[APT_N_CLASS_DEFS] = {0, 2, 0, 0, 2, 2, 1, 0, 1, 2};
+static const int kVClassSlot[APT_N_CLASS_DEFS] = {0, 0, 1, 2, 1, 2, 1, 3, 2, 3};
+#define APT_VGROUP_ROW(SM, VOL) {k_vshade_ev_group<SM, VOL, 4, 0x002, 0x040, 0x504, 0x200>, k_vshade_ev_group<SM, VOL, 3, APT_VEV_MEDIUM_CODE, 0x080, 0x008, 0>, k_vshade_ev_group<SM, VOL, 1, 0x001, 0x010, 0x020, 0x001>}
+static const vev_group_fn kVGroup[2][2][APT_N_VGROUPS] = {{APT_VGROUP_ROW(0x03, 0), APT_VGROUP_ROW(0x03, 1)}, {APT_VGROUP_ROW(APT_SRC_ALL, 0), APT_VGROUP_ROW(APT_SRC_ALL, 1)}};      // [emitter set][grid volume][group]
 typedef void (*vshadow_fn)(DevScene, Params, Queues, Counters*, LdsPlan, int);
 static const vshadow_fn kVShadow[5] = {k_vshadow<0>, k_vshadow<1>, k_vshadow<2>, nullptr, APT_FLAT_FN(k_vshadow_flat)};     // volumetric: transmittance walk (one closest-hit query per pass; [4]: the flat sweep, two samples per lane, every segment in one launch)
 #define APT_SWEEP_MAX_PRIMS 96   // up to here the uniform sweep beats the BVH walk (no divergence, scalar loads)
@@ -188,8 +189,10 @@ struct apt_renderer {
     int v_ncls = 0;               // class queues in use (surface classes + the miss class when misses matter)
     int vevent = 0;               // volumetric shading sorted by event: k_vevent decides what every path does, one kernel per event queue (v_ncls of them: surface classes, the medium last)
     int vev_single = 0;           // ... with ONE surface queue served by the all-models kernel (textured scenes, more classes than queues)
-    vev_shade_fn vev_fn[APT_MAX_CLASSES] = {};
+    vev_shade_fn vev_all = nullptr;
     bool vev_live[APT_MAX_CLASSES] = {};      // an event queue that can receive entries at all (a class of null surfaces only is never shaded)
+    vev_group_fn vgroup_fn[APT_N_VGROUPS] = {};           // ... the event kernels in groups
+    int vgroup_cls[APT_N_VGROUPS][4] = {};                // ... event queue of each member slot (-1: none)
     group_fn group_fn_[APT_N_GROUPS] = {};                // ... the group kernels for this scene's emitter set
     int group_cls[APT_N_GROUPS][4] = {};                  // ... compact class id of each member slot (-1: the scene has no such class)
     std::string shade_name;
@@ -656,6 +659,13 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         B = (int)((32u << 20) / (uint32_t)r->npix); if (B < 1) B = 1; if (B > 1024) B = 1024;
         const size_t n_cq = c.volumetric ? (size_t)sc->n_classes + 1 : ((sc->n_classes >= 2 && sc->n_classes <= APT_MAX_CLASSES) ? (size_t)sc->n_classes : 1);
         while (B > 1 && n_cq * ((size_t)r->npix * (size_t)B + 64u * APT_MAX_NQ) >= ((size_t)1 << 28)) B--;
+        // ... and the lanes' queue pools within a third of the memory that is free now (a second renderer beside this one, a device shared by
+        // several ranks, a smaller part): ~0.4-0.8 KB per path (upper estimate: SoA queues, packed records, one 64-byte record per class queue)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t per_path = 4u * (64u + 16u * n_cq + 11u * (size_t)std::max(1, c.num_shadow_ray));
+            while (B > 1 && (size_t)r->npix * (size_t)B * (size_t)r->n_lanes * per_path > free_b / 3) B = (B + 1) / 2;
+        }
     }
     r->spp_batch = B;
     const int S = c.num_shadow_ray;
@@ -739,14 +749,14 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         const int n_surf = r->vev_single ? 1 : sc->n_classes;
         r->v_ncls = n_surf + 1;
         const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : 1, vi = sc->has_volume ? 1 : 0;
-        for (int c = 0; c < n_surf; c++) {
-            r->vev_fn[c] = kVEventShade[r->vev_single ? APT_VEV_ALL : sc->class_def[c]][smi][vi];
-            r->vev_live[c] = false;
-        }
+        r->vev_all = kVEventAll[smi][vi];
+        for (int c = 0; c <= n_surf; c++) r->vev_live[c] = false;
         for (size_t o = 0; o < sc->obj_class.size(); o++)           // which surface queues can receive a hit at all
             if (!sc->obj_null[o]) r->vev_live[r->vev_single ? 0 : sc->obj_class[o]] = true;
-        r->vev_fn[n_surf] = kVEventShade[APT_VEV_MEDIUM][smi][vi];
         r->vev_live[n_surf] = true;
+        for (int g = 0; g < APT_N_VGROUPS; g++) { r->vgroup_fn[g] = kVGroup[smi][vi][g]; for (int k = 0; k < 4; k++) r->vgroup_cls[g][k] = -1; }
+        if (!r->vev_single) for (int c = 0; c < n_surf; c++) if (r->vev_live[c]) r->vgroup_cls[kVClassGroup[sc->class_def[c]]][kVClassSlot[sc->class_def[c]]] = c;
+        r->vgroup_cls[1][0] = n_surf;                         // the medium's queue is the last one
         for (int a = 0; a < 3; a++) {                         // path_tracer.py:136-138
             p.w_min[a] = std::min(c.cam_t[a], sc->box_min[a]) - 0.1f; p.w_max[a] = std::max(c.cam_t[a], sc->box_max[a]) + 0.1f;
         }
@@ -1058,9 +1068,12 @@ static int render_volumetric(apt_renderer* r, int32_t n_spp) {
                 {
                     // what every path does this iteration (roulette, hit or world box, free path), then one kernel per event queue
                     { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(kVEvent[r->scene->has_volume ? 1 : 0], dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, is.cur, r->vev_single); }
-                    for (int c = 0; c < r->v_ncls; c++) {
-                        if (!r->vev_live[c]) continue;
-                        LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vev_fn[c], dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, c, is.cur);
+                    if (r->vev_single && r->vev_live[0]) { LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vev_all, dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, 0, is.cur); }      // (one surface queue, the all-models kernel)
+                    for (int g = 0; g < APT_N_VGROUPS; g++) {      // one launch per register-footprint group of event queues
+                        VGroupIn gi; bool any = false;
+                        for (int k = 0; k < 4; k++) { gi.cls[k] = r->vgroup_cls[g][k]; any = any || gi.cls[k] >= 0; }
+                        if (!any) continue;
+                        LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->vgroup_fn[g], dim3(grid_for(is.total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, is.p, q, cnt, gi, is.cur);
                     }
                     if (is.p.S <= 0) { unchain(r, st); HIP_TRY(hipMemsetAsync(cnt->n_cls, 0, sizeof(cnt->n_cls), st)); }     // normally k_vshadow's first pass recycles these
                 }

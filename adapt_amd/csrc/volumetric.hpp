@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(BLOCK) k_vevent(DevScene sc, Params p, Queues 
 }
 
 template <int BM, int SM, int VOL, int MI>
-__global__ void __launch_bounds__(BLOCK) k_vshade_ev(DevScene sc, Params p, Queues q, Counters* cnt, int cls, int cur) {
+APT_D void vshade_ev_body(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, int cls, int cur) {
     constexpr bool TEX = (BM == APT_BX_ALL);
     const int nxt = cur ^ 1;
     const SubLoop sl = sub_loop(p.nq);
@@ -467,6 +467,34 @@ __global__ void __launch_bounds__(BLOCK) k_vshade_ev(DevScene sc, Params p, Queu
     flush_uniform(t_shadow, &cnt->stats[sl.q][ST_SHADOW]);
     if (lane_id() == 0 && s_draws[threadIdx.x >> 6]) atomicAdd(&cnt->stats[sl.q][ST_DRAWS], (unsigned long long)s_draws[threadIdx.x >> 6]);
     flush_uniform(t_poison, &cnt->stats[sl.q][ST_POISON]);
+}
+template <int BM, int SM, int VOL, int MI>
+__global__ void __launch_bounds__(BLOCK) k_vshade_ev(DevScene sc, Params p, Queues q, Counters* cnt, int cls, int cur) {
+    vshade_ev_body<BM, SM, VOL, MI>(sc, p, q, cnt, cls, cur);
+}
+// ---- event kernels in groups: ONE launch shades several event queues, as k_shade_group does for the surface tracer's class queues (the
+// launch boundary between two short kernels costs more than either: V2 ran five event kernels of 24-57 us per iteration).  A kernel
+// allocates for its largest member, so the groups follow the footprints (api.hip kVGroup): four waves per SIMD (Lambertian, Oren-Nayar,
+// delta, Lambertian transmission: 103-124 VGPRs), three (the MEDIUM kernel, thin coat, microfacet: 120-156), two (Blinn-Phong, modified
+// Phong, Fresnel blend: 169-210).  A member code is a material mask, or APT_VEV_MEDIUM_CODE for the medium kernel; queues absent from
+// the scene are skipped by a wave-uniform test.  Same code per event, same order inside a queue: images and statistics are those of one
+// launch per queue.
+#define APT_VEV_MEDIUM_CODE 0x10000
+struct VGroupIn { int cls[4]; };          // per member: its event queue (-1: not in this scene)
+template <int B, int SM, int VOL>
+APT_D void vshade_ev_member(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, int cls, int cur) {
+    if constexpr (B == APT_VEV_MEDIUM_CODE) vshade_ev_body<0x000, SM, VOL, 1>(sc, p, q, cnt, cls, cur);
+    else vshade_ev_body<B, SM, VOL, 0>(sc, p, q, cnt, cls, cur);
+}
+template <int SM, int VOL, int WAVES, int B0, int B1, int B2, int B3>
+__global__ void __launch_bounds__(BLOCK, WAVES) k_vshade_ev_group(DevScene sc, Params p, Queues q, Counters* cnt, VGroupIn g, int cur) {
+    // (scene, parameters and queues are read through the kernel-argument segment, the pointer made opaque per member: left to itself the
+    // compiler loads the fields of all four members up front - 240 scalar registers spilled, some of them to scratch; shade_stage.hpp)
+    const args3_ptr A0 = kernel_args3();
+    if constexpr (B0 != 0) if (g.cls[0] >= 0) { const ShadeArgs3* A = args_fresh(A0); vshade_ev_member<B0, SM, VOL>(A->sc, A->p, A->q, cnt, g.cls[0], cur); }
+    if constexpr (B1 != 0) if (g.cls[1] >= 0) { const ShadeArgs3* A = args_fresh(A0); vshade_ev_member<B1, SM, VOL>(A->sc, A->p, A->q, cnt, g.cls[1], cur); }
+    if constexpr (B2 != 0) if (g.cls[2] >= 0) { const ShadeArgs3* A = args_fresh(A0); vshade_ev_member<B2, SM, VOL>(A->sc, A->p, A->q, cnt, g.cls[2], cur); }
+    if constexpr (B3 != 0) if (g.cls[3] >= 0) { const ShadeArgs3* A = args_fresh(A0); vshade_ev_member<B3, SM, VOL>(A->sc, A->p, A->q, cnt, g.cls[3], cur); }
 }
 
 // ------------------------------------------------------------------ vshadow
