@@ -93,13 +93,13 @@ def kernel_bytes(st):
         "finalize": 12 * n_s,                # read L (framebuffer RMW is 24 B per pixel per batch: negligible)
     }
     if st.get("launches", {}).get("shadow", 1) == 0 and n_sh > 0:
-        # light samples traced in place (stages.hpp k_shade FUSE): the shade kernel does the shadow stage's work as well, so the UNIT of work
+        # rays traced in place (shade_stage.hpp k_shade_traced): the shade kernel does the shadow stage's work as well, so the UNIT of work
         # it is credited with is SURVEY 8(d)'s for both stages - 88 B per shadow ray + 24 B per unoccluded one on top of its own - although
         # the entries never travel through HBM (what it really moves is the `traffic` figure: 64 + 12 B read, 48 + 12 B written per entry)
         kb["shade"] += kb["shadow"]
         kb["shadow"] = 0
     if st.get("launches", {}).get("extend", 1) == 0 and n_e > 0:
-        # rays traced in place (stages.hpp "rays traced in place"): k_generate sweeps the camera rays and the shade kernel its continuation ray,
+        # rays traced in place (shade_stage.hpp "rays traced in place"): k_generate sweeps the camera rays and the shade kernel its continuation ray,
         # there is no extend launch - by the same rule the two kernels are credited with the extend stage's 40 B per ray they trace
         kb["generate"] += 40 * n_s
         kb["shade"] += 40 * n_cont

@@ -125,7 +125,7 @@ def test_fix_up_lists_carry_every_ray_when_asked_to(tag, kw, renderer, monkeypat
 
 @pytest.mark.parametrize("tag,kw", [("cbox", {}), ("cbox", {"max_bounce": 1}), ("glass_box", {"num_shadow_ray": 1}), ("balls_mono", {"num_shadow_ray": 1}), ("textured", {"num_shadow_ray": 1})])
 def test_rays_traced_in_place_render_the_staged_pipeline_s_image(tag, kw, renderer, monkeypatch):
-    """Unsorted flat-sweep renders with one light sample per vertex run ONE launch per bounce (stages.hpp "rays traced in place",
+    """Unsorted flat-sweep renders with one light sample per vertex run ONE launch per bounce (shade_stage.hpp "rays traced in place",
     APT_FUSED=2, the default): the shade kernel sweeps its light sample and its continuation ray itself, k_generate the camera rays, and
     the rays that need the reference-order code are served by the next launch's prologue.  Against the staged pipeline - APT_FUSED=0
     (extend + fix-up + shade + shadow) - the ray, the records and the arithmetic per (ray, record) are the same, so

@@ -16,8 +16,8 @@ _DEM = {}
 
 
 def short(name):
-    """Demangled kernel name without its argument list (template arguments say which variant ran: k_shade<material mask, emitter mask,
-    textures, FUSE>, k_shade_group<emitter mask, waves, member masks...>, k_vshade_ev<material mask, emitter mask, grid volume, medium>,
+    """Demangled kernel name without its argument list (template arguments say which variant ran: k_shade / k_shade_traced<material mask,
+    emitter mask, textures>, k_shade_group<emitter mask, waves, member masks...>, k_vshade_ev_group<emitter mask, grid volume, waves, member masks...>,
     k_extend / k_shadow / k_vshadow<traversal mode: 0 tree, 1 sweep, 2 tile>, k_extend_dyn / k_extend_flat<sorted, ...>)."""
     if name not in _DEM:
         import re
