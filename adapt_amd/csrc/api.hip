@@ -1021,12 +1021,11 @@ static int resolve_events(apt_renderer* r) {
     return APT_OK;
 }
 
-// Samples per lane-batch of one render call.  A batch size the caller fixed is taken as it is; otherwise the call's samples are split into
-// EQUAL batches, a whole number of them per render lane (1024 spp at 128 per batch and three lanes: nine batches of 114, not eight of
-// 128 - the lane that would have run two of the eight idles a third of the step: C3 1 137 -> 1 177 Msamples/s).  The image does not depend
-// on the split: k_finalize adds a pixel's samples to the framebuffer one by one, in sample order, whatever batch they came in.
+// Samples per lane-batch of one render call: the call's samples are split into EQUAL batches of at most the renderer's batch size, a whole
+// number of them per render lane (1024 spp at 128 per batch and three lanes: nine batches of 114, not eight of 128 - the lane that would
+// have run two of the eight idles a third of the step: C3 1 137 -> 1 177 Msamples/s).  The image does not depend on the split: k_finalize
+// adds a pixel's samples to the framebuffer one by one, in sample order, whatever batch they came in.
 static int lane_batch(const apt_renderer* r, int32_t n_spp) {
-    if (r->cfg.spp_per_batch > 0) return r->spp_batch;
     int n_batches = (n_spp + r->spp_batch - 1) / r->spp_batch;
     n_batches = ((n_batches + r->n_lanes - 1) / r->n_lanes) * r->n_lanes;
     return std::max(1, std::min(r->spp_batch, (n_spp + n_batches - 1) / n_batches));

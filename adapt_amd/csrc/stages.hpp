@@ -142,7 +142,7 @@ struct ShadeIn {
     const float* ray_o; const float* ray_d; const float* thr; const uint32_t* id; const uint32_t* meta; const float* pdf;
     const float* t; const int* prim; const float* u; const float* v;
     const uint32_t* counts;                      // per-sub-queue entry counts (stride CNT_PAD)
-    int cls;                                     // rays traced in place: which of Queues::tr's queues this launch reads
+    int cls;                                     // class-sorted renders: which of the packed class queues (Queues::cq) this launch reads
 };
 
 #ifndef APT_MAX_NQ
@@ -888,7 +888,7 @@ template <int VAR>
 APT_D void shadow_flat_body(const DevScene& sc, const Params& p, const Queues& q, Counters* cnt, int par) {
     // VAR 1 / 2: hot variant and the fix-up pass (see k_extend_flat); an entry whose ray needs the reference-order sweep is listed by
     // VAR 1 - untouched: no radiance, no statistics - and done in full by VAR 2.
-    // VAR 3: the fix-up pass of a render whose shade kernel traces its light samples itself (k_shade FUSE): the shadow queue then holds
+    // VAR 3: the fix-up pass of a render whose shade kernel traces its rays itself (shade_stage.hpp k_shade_traced): the shadow queue then holds
     // nothing but the deferred entries, n_fix_sh[par] of them, and every one is done in full, one per lane, like VAR 2's.
     const SubLoop sl = sub_loop(p.nq, VAR >= 2 ? BLOCK : FLAT_NT);
     const uint32_t n = (VAR == 2) ? cnt->n_fix_sh[par][sl.q * CNT_PAD] : ((VAR == 3) ? min(cnt->n_fix_sh[par][sl.q * CNT_PAD], q.sh_subcap) : min(cnt->n_shadow[sl.q * CNT_PAD], q.sh_subcap));

@@ -950,8 +950,8 @@ APT_D void flat_any2(const FlatScene& fl, const SweepScene& sw, f3 o0, f3 d0, f3
     bool a, b; flat_any2<false>(fl, sw, o0, d0, o1, d1, lim0, lim1, occ0, occ1, a, b);
 }
 // Occlusion of ONE ray per lane below `lim`: the lane's ray against two records per packed instruction (FlatScene::pairs) - the mirror
-// image of flat_loop<true>, for kernels that hold one path per lane (the shade kernels that trace their own light samples: stages.hpp
-// "light samples traced in place").  Same arithmetic per (ray, record) as flat_loop: the two answers are the same bit for bit.
+// image of flat_loop<true>, for kernels that hold one path per lane (the shade kernel that traces its own rays: shade_stage.hpp
+// "rays traced in place").  Same arithmetic per (ray, record) as flat_loop: the two answers are the same bit for bit.
 APT_D bool flat_any1(const FlatScene& fl, f3 o, f3 d, float lim) {
     cf_ptr at = (cf_ptr)fl.pairs;
     const v2f ox = sp2(o.x), oy = sp2(o.y), oz = sp2(o.z), dx = sp2(d.x), dy = sp2(d.y), dz = sp2(d.z);
@@ -999,7 +999,7 @@ APT_D bool flat_any1(const FlatScene& fl, f3 o, f3 d, float lim) {
     return occ;
 }
 // Closest hit of ONE ray per lane below `lim`, two records per packed instruction (FlatScene::pairs): flat_loop<false> for kernels that hold
-// one path per lane (the shade kernels that trace their continuation ray in place, k_generate's camera rays: stages.hpp "rays traced in
+// one path per lane (the shade kernels that trace their continuation ray in place, k_generate's camera rays: shade_stage.hpp "rays traced in
 // place").  Records are visited in flat_loop's order with flat_loop's arithmetic per (ray, record), so distance and winner are the same
 // bit for bit.  A pair that straddles the border between a plain section and its coplanar-group section is treated as a group pair: its
 // plain record may then be remembered as a runner-up, which only sends the ray to the reference-order arithmetic a little more often.

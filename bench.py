@@ -328,7 +328,7 @@ def main():
     timed, overlap, prof = region_roofline(st, counters, n_simd, sclk), None, None
     if not args.no_profile:
         rp = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world, band_width=BAND_WIDTH, profile=True,
-                      spp_per_batch=args.spp_per_batch)
+                      spp_per_batch=info["spp_per_batch"])      # (the batch size the timed renderer chose: its own choice could differ, made with less free memory)
         rp.render(n_spp=1); rp.synchronize()
         rp.render(n_spp=spp_step); rp.synchronize(); rp.clear()
         tp = time.perf_counter()
@@ -349,7 +349,7 @@ def main():
     if lanes > 1 and not args.no_exclusive_pass and not args.no_profile:
         os.environ["APT_LANES"] = "1"
         r1 = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world, band_width=BAND_WIDTH, profile=True,
-                      spp_per_batch=args.spp_per_batch)
+                      spp_per_batch=info["spp_per_batch"])
         os.environ["APT_LANES"] = str(lanes)
         n1 = max(1, min(spp_step, 256))
         r1.render(n_spp=n1); r1.synchronize(); r1.clear()
