@@ -325,10 +325,18 @@ def main():
     # per material class and bounce).  So the TIMED region runs without them (`value` is the rate of the render as a user runs it), and the
     # same K steps are repeated with the events on (`roofline.timed_region`: per-kernel sums with the lanes overlapping, and what the
     # events cost: `event_overhead`).
+    def second_renderer():
+        """A renderer with per-launch events beside the timed one, at the batch size the timed one chose (its own choice is made with less free
+        memory and could differ); when that does not fit - several ranks sharing one device - at the size the library then picks."""
+        kw = dict(width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world, band_width=BAND_WIDTH, profile=True)
+        try:
+            return Renderer(*parsed, spp_per_batch=info["spp_per_batch"], **kw)
+        except _lib.AptError:
+            return Renderer(*parsed, spp_per_batch=args.spp_per_batch, **kw)
+
     timed, overlap, prof = region_roofline(st, counters, n_simd, sclk), None, None
     if not args.no_profile:
-        rp = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world, band_width=BAND_WIDTH, profile=True,
-                      spp_per_batch=info["spp_per_batch"])      # (the batch size the timed renderer chose: its own choice could differ, made with less free memory)
+        rp = second_renderer()
         rp.render(n_spp=1); rp.synchronize()
         rp.render(n_spp=spp_step); rp.synchronize(); rp.clear()
         tp = time.perf_counter()
@@ -348,8 +356,7 @@ def main():
     alone, source, one_lane_rate = timed, "repeat of the timed region with per-launch events (one render lane: kernels do not overlap)", None
     if lanes > 1 and not args.no_exclusive_pass and not args.no_profile:
         os.environ["APT_LANES"] = "1"
-        r1 = Renderer(*parsed, width=W, height=H, max_bounce=bounces, device=local_rank, rank=rank, world_size=world, band_width=BAND_WIDTH, profile=True,
-                      spp_per_batch=info["spp_per_batch"])
+        r1 = second_renderer()
         os.environ["APT_LANES"] = str(lanes)
         n1 = max(1, min(spp_step, 256))
         r1.render(n_spp=n1); r1.synchronize(); r1.clear()

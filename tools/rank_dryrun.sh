@@ -9,7 +9,7 @@ python bench.py --gpus 1 --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --
 for n in $RANKS; do
   for mode in strong weak; do
     python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29500 + n)) bench.py --gpus $n --config $CFG --steps 1 --warmup 0 \
-        --no-cpu-baseline --no-exclusive-pass --single-device --backend gloo --scaling $mode --dump-image gpurun_out/rank${n}_$mode.npy > gpurun_out/rank${n}_$mode.json 2> gpurun_out/rank${n}_$mode.err
+        --no-cpu-baseline --no-exclusive-pass --no-profile --single-device --backend gloo --scaling $mode --dump-image gpurun_out/rank${n}_$mode.npy > gpurun_out/rank${n}_$mode.json 2> gpurun_out/rank${n}_$mode.err
     python - <<PY
 import json, numpy as np
 try:
