@@ -93,7 +93,10 @@ typedef struct apt_render_cfg {
     uint32_t seed;                                /* Philox key word 1 (key word 0 = global pixel index x*H+y) */
     /* tile ownership: columns x with (x / band_width) % world_size == rank belong to this renderer */
     int32_t band_width, rank, world_size;
-    int32_t spp_per_batch;                        /* samples per pixel in flight per wavefront batch (0 = auto) */
+    int32_t spp_per_batch;                        /* samples per pixel in flight per wavefront batch; 0 = auto: ~32 Mi paths per render lane,
+                                                     fitted under the class queues' 32-bit slot addressing and a third of the free device memory.
+                                                     A render call splits its samples into equal batches of at most this size, a whole number
+                                                     per lane; the image does not depend on the split */
     int32_t device;                               /* HIP device ordinal */
     int32_t profile;                              /* 1 = time every kernel launch with HIP events */
     int32_t volumetric;                           /* 0 = Renderer.render (renderer/vanilla_renderer.py:32-120); 1 = VolumeRenderer.render
