@@ -22,7 +22,7 @@ for c in ("c1", "c2", "c3", "c4", "c5"):
         if k not in st: continue
         v = st[k]; kn = cj[k]["kernels"][0]
         name = ("k_extend_flat" if "extend_flat" in kn else "k_extend_dyn" if "extend_dyn" in kn else "k_shadow_flat" if "shadow_flat" in kn else "k_shadow_dyn" if "shadow_dyn" in kn
-                else "k_shade_group (classes)" if "shade_group" in kn else "k_shade")
+                else "k_shade_group (classes)" if "shade_group" in kn else "k_shade_traced" if "shade_traced" in kn else "k_shade")
         t.append(f"| {c.upper()} | {name} | {v['GB/s']:.0f} ({100 * v['frac']:.1f} %) | {v['traffic_over_algorithmic']:.2f} | {100 * v['valu']['busy_frac']:.0f} % | {100 * cj[k]['valu_lane_utilisation']:.0f} % | {cj[k]['valu_insts_per_unit']:.1f} |")
 s = open("DESIGN.md").read().split("\n")
 first = [i for i, l in enumerate(s) if re.match(r"\| C[1-5] \| k_", l)]
