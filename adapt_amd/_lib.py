@@ -69,6 +69,7 @@ SYMBOLS = {
     "apt_bvh_wide_counts": (C.c_int, [C.c_void_p, i32p, i32p]),
     "apt_flat_records": (C.c_int, [f32p, C.c_int32, i32p, C.c_int32, i32p, f32p, C.c_int32, f32p, C.c_int32, i32p, i32p]),
     "apt_bvh_wide_export": (C.c_int, [C.c_void_p, u32p, i32p]),
+    "apt_bvh_wide_frame": (C.c_int, [C.c_void_p, f32p, f32p]),
     "apt_bvh_free": (None, [C.c_void_p]),
     "apt_bvh_build_linear": (C.c_int, [f32p, C.c_int32, i32p, i32p, C.c_int32, f32p, f32p, C.POINTER(C.c_void_p)]),
     "apt_linear_bvh_counts": (C.c_int, [C.c_void_p, i32p, i32p]),

@@ -37,7 +37,7 @@ def get_options(argv=None):
     p.add_argument("--output_path", default="./outputs/", type=str)
     p.add_argument("--chkpt_path", default="./checkpoint/", type=str)
     p.add_argument("--img_name", default="pbr", type=str)
-    p.add_argument("--img_ext", default="png", choices=["png", "bmp", "npy"])
+    p.add_argument("--img_ext", default="png", choices=["png", "jpg", "bmp", "npy"])      # parsers/opts.py:25 (jpg through Pillow)
     p.add_argument("--scene", default="cbox", type=str)
     p.add_argument("--name", default="c2_cbox.xml", type=str)
     p.add_argument("--arch", default="hip", choices=["hip", "cpu", "gpu", "vulkan", "cuda"], help="kept for CLI compatibility; rendering always uses HIP")
@@ -88,6 +88,10 @@ def write_image(img: np.ndarray, path: str):
         return
     px = to_display(img)
     h, w, _ = px.shape
+    if ext in ("jpg", "jpeg"):
+        from .parsers.image_io import write_jpeg
+        write_jpeg(path, px)
+        return
     if ext == "png":
         def chunk(tag, data):
             return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)

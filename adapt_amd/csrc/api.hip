@@ -281,6 +281,11 @@ APT_EXPORT int apt_bvh_wide_export(const apt_bvh* b, uint32_t* nodes, int32_t* p
     memcpy(prim_order, b->wide.prim_order.data(), b->wide.prim_order.size() * sizeof(int32_t));
     return APT_OK;
 }
+APT_EXPORT int apt_bvh_wide_frame(const apt_bvh* b, float gmin[3], float gstep[3]) {
+    if (!b || !gmin || !gstep) return fail(APT_E_INVALID, "apt_bvh_wide_frame: bad argument");
+    for (int a = 0; a < 3; a++) { gmin[a] = b->wide.frame.gmin[a]; gstep[a] = b->wide.frame.gstep[a]; }
+    return APT_OK;
+}
 APT_EXPORT void apt_bvh_free(apt_bvh* b) { delete b; }
 
 // ---- `bvh_cpp.bvh_build`-compatible export (host only): the reference-layout tree for AdaPT's own traversal kernels
@@ -326,8 +331,8 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     apt_scene* s = new apt_scene();
     s->device = device;
     const int N = d->n_prims, O = d->n_objects, S = d->n_sources;
-    // the walk addresses primitive (48 B) and node (80 B, at most one per primitive) records with 32-bit byte offsets (traverse.hpp)
-    if (N >= (1 << 26) || (uint64_t)N * (uint64_t)APT_NODE_BYTES >= (1ull << 32)) { delete s; return fail(APT_E_INVALID, "apt_scene_create: more than 53 687 091 primitives (32-bit record offsets)"); }
+    // the 64-byte nodes of the walk hold child and primitive indices in 24 bits (bvh_wide.cpp); records are addressed with 32-bit byte offsets
+    if (N >= (1 << 24)) { delete s; return fail(APT_E_INVALID, "apt_scene_create: more than 16 777 215 primitives (24-bit indices in the 64-byte tree nodes)"); }
     s->n_prims = N; s->n_objects = O; s->n_sources = S;
     const bool timing = getenv("APT_SCENE_TIMING") != nullptr;      // stderr: where apt_scene_create spends its time
     auto t_prev = std::chrono::steady_clock::now();
@@ -337,8 +342,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
         fprintf(stderr, "[scene timing] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
-    int max_leaf = 1;                     // primitives per leaf of the binary tree (the 8-wide node encodes at most 3 per leaf child); measured 1 / 2 / 3: C4 1274 / 1236 / 1228, C5 1117 / 1073 / 1043 Msamples/s - a primitive test costs ~75 instructions whatever the fraction of the wave that needs it, a child box 19
-    if (const char* ml = getenv("APT_BVH_LEAF")) max_leaf = std::min(3, std::max(1, atoi(ml)));
+    const int max_leaf = 1;               // primitives per leaf of the binary tree: the 64-byte node's leaf child IS one primitive (measured 1 / 2 / 3 per leaf on the 80-byte node, rounds 2 and 5: C4 1274 / 1236 / 1228, C5 1117 / 1073 / 1043 Msamples/s; C4 extend 34.1 / 33.5 / 33.5 ms, C5's any-hit walk 25.7 / 27.9 / 28.9)
     // builder: binned SAH on the host (best tree) below a million primitives, PLOC on the device above (scene-load time); APT_BVH_BUILDER=sah|ploc|lbvh overrides.
     // Measured on one MI355X (Msamples/s, C4 95 k / C5 285 k triangles): SAH 1303 / 1216, PLOC 1287 / 1157, LBVH 1186 / 1048; apt_scene_create at 1.14 M
     // primitives: SAH ~800 ms, PLOC or LBVH ~500 ms (what is left is the 8-wide collapse and the table uploads, shared by all three)
@@ -532,6 +536,7 @@ APT_EXPORT int apt_scene_create(const apt_scene_desc* d, int32_t device, apt_sce
     UP(obj_info, oi); UP(emitter_id, ei); UP(bxdf, bx); UP(src, sr); UP(sweep_recs, sw); UP(sweep_tab, sw_tab); UP(obj_aabb, aabb);
     DevScene& ds = s->dev;
     ds.bvh.nodes = s->nodes.as<uint4>(); ds.bvh.prims = s->prims.as<float4>(); ds.bvh.slot_prim = s->slot_prim.as<int>(); ds.bvh.n_nodes = s->wide.n_nodes(); ds.bvh.n_prims = N;
+    for (int a = 0; a < 3; a++) { ds.bvh.gmin[a] = s->wide.frame.gmin[a]; ds.bvh.gstep[a] = s->wide.frame.gstep[a]; ds.bvh.ginv[a] = 1.0f / s->wide.frame.gstep[a]; }
     ds.sweep.stream = s->sweep_recs.as<float>(); ds.sweep.obj_tab = s->sweep_tab.as<int>(); ds.sweep.prim_obj = s->prim_obj.as<int>(); ds.sweep.n_objects = O;
     s->has_aabb = d->obj_aabb != nullptr;
     ds.normals = s->normals.as<float>(); ds.vnormals = s->vnormals.as<float4>(); ds.precom = s->precom.as<float>();
@@ -658,7 +663,10 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         // Class-sorted and volumetric renders address (classes x capacity) 16-byte slots with 32-bit byte offsets: the batch stays below that.
         B = (int)((32u << 20) / (uint32_t)r->npix); if (B < 1) B = 1; if (B > 1024) B = 1024;
         const size_t n_cq = c.volumetric ? (size_t)sc->n_classes + 1 : ((sc->n_classes >= 2 && sc->n_classes <= APT_MAX_CLASSES) ? (size_t)sc->n_classes : 1);
-        while (B > 1 && n_cq * ((size_t)r->npix * (size_t)B + 64u * APT_MAX_NQ) >= ((size_t)1 << 28)) B--;
+        // (the capacity a batch of B really gets, as computed below: whole waves, dealt over the sub-queues)
+        int nq_fit = r->nq; if (const char* e = getenv("APT_NQ")) nq_fit = std::min(APT_MAX_NQ, std::max(1, atoi(e)));
+        auto cap_of = [&](int b) { const size_t nw = ((size_t)r->npix * (size_t)b + 63) / 64; return ((nw + (size_t)nq_fit - 1) / (size_t)nq_fit) * 64 * (size_t)nq_fit; };
+        while (B > 1 && n_cq * cap_of(B) >= ((size_t)1 << 28)) B--;
         // ... and the lanes' queue pools within a third of the memory that is free now (a second renderer beside this one, a device shared by
         // several ranks, a smaller part): ~0.4-0.8 KB per path (upper estimate: SoA queues, packed records, one 64-byte record per class queue)
         size_t free_b = 0, total_b = 0;
@@ -736,7 +744,11 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         const bool can1 = r->trace_mode == 3 && !r->sorted && !c.volumetric && S == 1;
         bool can2 = can1 && r->shade->traced != nullptr;
         p.fused = can2 ? 2 : 0;
-        if (const char* f = getenv("APT_FUSED")) { const int want = atoi(f); p.fused = (want >= 2 && can2) ? 2 : 0; }
+        if (const char* f = getenv("APT_FUSED")) {
+            const int want = atoi(f);
+            if (want == 1) fprintf(stderr, "adapt_mi: APT_FUSED=1 (light samples only traced in place) was retired in round 5; running the staged pipeline (APT_FUSED=0). Use 2 for rays traced in place.\n");
+            p.fused = (want >= 2 && can2) ? 2 : 0;
+        }
         if (p.fused == 2) { p.nee_vm = 0; p.l_planes = 1; }      // no shadow queue: a vertex's light samples are summed in registers
     }
     if (r->volumetric) {
@@ -851,7 +863,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         if (const char* sd = getenv("APT_BVH_LDS_LEVELS")) lds_levels = std::max(2, atoi(sd));
         pl.stack_depth = std::min(full_depth, lds_levels);   // deeper levels spill to per-lane global columns (traverse.hpp TravStack)
         r->ovf_levels = full_depth - pl.stack_depth;
-        pl.ovf = nullptr; pl.ovf_stride = 0; pl.lds_nodes = 0; pl.lds_prims = 0;
+        pl.ovf = nullptr; pl.ovf_stride = 0;
         const size_t stack_b = (size_t)pl.stack_depth * BLOCK * 8;
         r->plan = pl;
         r->lds_bytes = stack_b + (size_t)6 * BLOCK * 4;      // (+ k_extend_dyn's parked path state: six floats per thread)
@@ -1026,6 +1038,7 @@ static int resolve_events(apt_renderer* r) {
 // have run two of the eight idles a third of the step: C3 1 137 -> 1 177 Msamples/s).  The image does not depend on the split: k_finalize
 // adds a pixel's samples to the framebuffer one by one, in sample order, whatever batch they came in.
 static int lane_batch(const apt_renderer* r, int32_t n_spp) {
+    if (n_spp <= 0) return 1;                       // nothing to split (apt_render(r, 0) is a no-op, not a division by zero)
     int n_batches = (n_spp + r->spp_batch - 1) / r->spp_batch;
     n_batches = ((n_batches + r->n_lanes - 1) / r->n_lanes) * r->n_lanes;
     return std::max(1, std::min(r->spp_batch, (n_spp + n_batches - 1) / n_batches));

@@ -7,7 +7,7 @@
 #include <vector>
 
 #ifndef APT_NODE_BYTES
-#define APT_NODE_BYTES 80u
+#define APT_NODE_BYTES 64u
 #endif
 #define APT_NODE_DWORDS (APT_NODE_BYTES / 4u)
 namespace apt {
@@ -40,7 +40,7 @@ struct BvhData {
     int n_nodes() const { return (int)(nodes.size() / 16); }
 };
 // prims: n_prims*9 (triangle v0 v1 v2 | sphere centre, r r r, -); obj_info: n_objects*3 (first, count, is_sphere)
-// max_leaf: primitives per leaf (1..4; the 8-wide tree below wants 3)
+// max_leaf: primitives per leaf (1..4; the 8-wide tree below wants 1)
 int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, BvhData& out, int max_leaf = 4);
 
 // bvh_gpu.hip: the same binary tree (single-primitive leaves) built on the device.  algo 0: LBVH (Morton sort + Karras' radix tree +
@@ -48,8 +48,10 @@ int build_bvh(const float* prims, int n_prims, const int32_t* obj_info, int n_ob
 int build_bvh_gpu(const float* prims, int n_prims, const int32_t* obj_info, int n_objects, int device, BvhData& out, int algo = 0);
 
 // 8-wide tree with quantised child boxes, what the traversal kernels walk (bvh_wide.cpp; layout in traverse.hpp).
+struct WideFrame { float gmin[3], gstep[3]; };      // the global grid the node corners live on: world = gmin + gstep * grid (power-of-two steps)
 struct WideBvhData {
-    std::vector<uint32_t> nodes;       // APT_NODE_DWORDS (20 = 80 bytes; the first 20 carry the node) per node, node 0 = root, breadth-first
+    WideFrame frame;
+    std::vector<uint32_t> nodes;       // APT_NODE_DWORDS (16 = 64 bytes) per node, node 0 = root, breadth-first
     std::vector<int32_t> prim_order;   // leaf-order slot -> original primitive index
     int max_depth = 0;                 // levels of 8-wide nodes
     int n_nodes() const { return (int)(nodes.size() / APT_NODE_DWORDS); }

@@ -183,7 +183,7 @@ APT_D uint32_t tr_meta(uint32_t pm, uint32_t bounce) { return pack_meta(pm >> 8,
 #endif
 
 // LDS of the BVH-walk stages (dynamic, sized per scene by the host): the traversal stack, stack_depth * BLOCK 8-byte groups laid out [level][lane]
-struct LdsPlan { int lds_nodes, lds_prims, stack_depth; uint2* ovf; int ovf_stride; };     // stack_depth: levels kept in LDS; ovf: global spill columns (one per thread of the largest grid); lds_nodes / lds_prims: unused (nothing is staged)
+struct LdsPlan { int stack_depth; uint2* ovf; int ovf_stride; };     // stack_depth: levels kept in LDS; ovf: global spill columns (one per thread of the largest grid)
 extern __shared__ float4 s_dyn[];
 typedef __attribute__((address_space(3))) float lds_f;
 APT_D TravStack make_stack(const LdsPlan& plan) {
@@ -580,7 +580,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
     // per-lane ray state
     int state = 0;                              // 0 no ray, 1 walking, 2 finished (result not yet handed in)
     uint32_t io = 0;
-    WalkRay r = make_walk_ray(splat3(0.f), mk3(0.f, 0.f, 1.f));
+    WalkRay r = make_walk_ray(sc.bvh, splat3(0.f), mk3(0.f, 0.f, 1.f));
     HitRec rec; rec.t = 1e7f; rec.prim = -1; rec.u = rec.v = 0.f;
     WalkStats ws; ws.nodes = ws.prims = 0;
     int sp = 0;
@@ -631,7 +631,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc,
             const uint32_t pos = base + rank_in(m);
             if (need && pos < n) {
                 io = (qbase + pos) << 2;
-                r = make_walk_ray(ld3q(ro, p.cap, io), ld3q(rd, p.cap, io));
+                r = make_walk_ray(sc.bvh, ld3q(ro, p.cap, io), ld3q(rd, p.cap, io));
                 if (SORTED) {
                     const f3 t_ = ld3q(q.thr[cur_q], p.cap, io);
                     park[0] = t_.x; park[BLOCK] = t_.y; park[2 * BLOCK] = t_.z;
@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
     int state = 0;                              // 0 no ray, 1 walking, 2 finished
     bool occluded = false;
     uint32_t io = 0;
-    WalkRay r = make_walk_ray(splat3(0.f), mk3(0.f, 0.f, 1.f));
+    WalkRay r = make_walk_ray(sc.bvh, splat3(0.f), mk3(0.f, 0.f, 1.f));
     HitRec rec; rec.t = 0.f; rec.prim = -1; rec.u = rec.v = 0.f;      // rec.t = the search limit (distance to the light - 1e-4)
     WalkStats ws; ws.nodes = ws.prims = 0;
     int sp = 0;
@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc,
             const uint32_t pos = base + rank_in(m);
             if (need && pos < n) {
                 io = (qbase + pos) << 2;
-                r = make_walk_ray(ld3q(q.sh_o, sc_, io), ld3q(q.sh_d, sc_, io));
+                r = make_walk_ray(sc.bvh, ld3q(q.sh_o, sc_, io), ld3q(q.sh_d, sc_, io));
                 const float dist = ldq(q.sh_tmax, io);
                 { const f3 c_ = ld3q(q.sh_c, sc_, io); park[0] = c_.x; park[BLOCK] = c_.y; park[2 * BLOCK] = c_.z; park[3 * BLOCK] = __uint_as_float(ldq(q.sh_id, io)); }
                 rec.t = (dist > 0.0f) ? dist - 1e-4f : 1e7f;

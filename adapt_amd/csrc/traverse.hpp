@@ -6,11 +6,14 @@
 // The per-primitive tests are the reference's, operation for operation (triangle: solve
 // [e1 e2 -d] (u v t)^T = o - p0 with the adjugate inverse; sphere: tracer_base.py:184-199),
 // so the closest hit is the same hit; the tree around them is ours (bvh_build.cpp -> bvh_wide.cpp):
-//   * an 8-wide tree with child boxes quantised to 8 bits per plane: one 80-byte node fetch decides up to eight subtrees.  The
-//     walk is bound by the latency of its DEPENDENT fetches (measured: with the binary tree, 15 fetches per ray, 74 % of the wave
-//     cycles waiting on memory), so the wide node cuts the round trips to a third and the node bytes to a fifth;
+//   * an 8-wide tree with child boxes quantised to 8 bits per plane: one 64-byte node fetch (four 16-byte pieces, layout in
+//     bvh_wide.cpp) decides up to eight subtrees.  A closest-hit ray of the 95 k-triangle scene makes ~5 node steps where the binary
+//     tree made ~15; what a step costs the CU is its scattered 16-byte accesses (one lane-access per cycle through the vector-memory
+//     pipe, whatever the bytes: tools/probe_gather.hip), hence the node's size;
+//   * node corners live on a global 16-bit grid and the ray is moved into grid units once (make_walk_ray), so a plane of any node is
+//     the exact small integer `corner + q * 2^e` and the slab test is one FMA per plane: t = q * (2^e / d') + (corner - o') / d';
 //   * front-to-back order without sorting: child slots are assigned by octant at build time, a ray visits the hit slots in the
-//     order `slot XOR ray octant`; the hits of a node travel as one bit mask ("node group"), its leaf primitives as another
+//     order `slot XOR ray octant`; the hits of a node travel as one bit mask ("node group"), its hit leaf primitives as another
 //     ("triangle group"), and the per-lane stack holds 8-byte groups, in LDS laid out [level][lane] (bank-conflict free), deep
 //     levels spilling to a per-lane global column;
 //   * box tests are conservative, not exact: decoded boxes contain the builder's boxes, which are padded by 1e-4 + 1e-5 |x| —
@@ -20,10 +23,11 @@
 #include "vec.hpp"
 
 struct DevBvh {
-    const uint4* nodes;      // 5 uint4 (80 bytes) per node, layout in bvh_wide.cpp
+    const uint4* nodes;      // 4 uint4 (64 bytes) per node, layout in bvh_wide.cpp
     const float4* prims;     // 3 float4 per primitive, leaf order
     const int* slot_prim;    // leaf-order slot -> primitive index (product build: its records carry no id, the walk reports the slot and the winner is looked up once per ray)
     int n_nodes, n_prims;
+    float gmin[3], ginv[3], gstep[3];      // the global grid of the node corners: grid = (world - gmin) * ginv, gstep = 1 / ginv (powers of two)
 };
 // primitive record, exact build:   triangle q0=(p0, e1.x) q1=(e1.yz, e2.xy) q2=(e2.z, prim_id, 0, -)
 //                                  sphere   q0=(centre, r)                  q2=(-, prim_id, 1, -)
@@ -32,10 +36,6 @@ struct DevBvh {
 #ifndef APT_FAST_LEAVES
 #define APT_FAST_LEAVES APT_FAST     // product build: precomputed-transform leaf records (0: the exact build's records and test in the product build, measurement only)
 #endif
-#ifndef APT_NODE_BYTES
-#define APT_NODE_BYTES 80u     // node stride (bvh_wide.cpp emits APT_NODE_BYTES / 4 dwords per node; 128: one node per cache line, measurement only)
-#endif
-
 struct HitRec { float t; int prim; float u, v; };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -52,10 +52,15 @@ APT_D float walk_rcp(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e30f, d)
 // three orders of magnitude above it; the exact per-primitive tests divide for themselves
 APT_D float walk_rcp(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e30f, d) : __builtin_amdgcn_rcpf(d); }
 #endif
-APT_D WalkRay make_walk_ray(f3 o, f3 d) {
+APT_D WalkRay make_walk_ray(const DevBvh& b, f3 o, f3 d) {
     WalkRay r; r.o = o; r.d = d;
-    r.inv = mk3(walk_rcp(d.x), walk_rcp(d.y), walk_rcp(d.z));
-    r.noo = mk3(-(o.x * r.inv.x), -(o.y * r.inv.y), -(o.z * r.inv.z));
+    // inv and noo are the ray in GRID units (a plane X of the tree is world gmin + gstep * X): t = (X - o') * (gstep / d), o' = (o - gmin) / gstep
+    r.inv = mk3(walk_rcp(d.x) * b.gstep[0], walk_rcp(d.y) * b.gstep[1], walk_rcp(d.z) * b.gstep[2]);
+    const f3 og = mk3((o.x - b.gmin[0]) * b.ginv[0], (o.y - b.gmin[1]) * b.ginv[1], (o.z - b.gmin[2]) * b.ginv[2]);
+    r.noo = mk3(-(og.x * r.inv.x), -(og.y * r.inv.y), -(og.z * r.inv.z));
+    // a ray with a NaN or infinite component hits nothing (as under the compare-based test of rounds 2-5, where NaN slabs failed every `tn <= tf`;
+    // the sign-bit test below would let v_max / v_min drop the NaNs and walk the whole tree): every entry distance huge
+    if (!(fabsf((r.noo.x + r.noo.y + r.noo.z) + (r.inv.x + r.inv.y + r.inv.z)) < 3e38f)) { r.inv = splat3(0.f); r.noo = splat3(3e38f); }
     const uint32_t oct = (r.inv.x < 0.f ? 4u : 0u) | (r.inv.y < 0.f ? 2u : 0u) | (r.inv.z < 0.f ? 1u : 0u);
     r.octinv4 = (7u - oct) * 0x01010101u;
     return r;
@@ -118,47 +123,56 @@ APT_D grp_t tpop(const TravStack& s, int& sp) {
 struct WalkStats { uint32_t nodes, prims; };
 
 // record strides as shift-adds: v_mul_lo_u32 issues at quarter rate and sits at the head of every dependent fetch of the walk
-APT_D uint32_t mul80(uint32_t i) { return (i << 6) + (i << 4); }
 APT_D uint32_t mul48(uint32_t i) { return (i << 5) + (i << 4); }
 APT_D float ubyte_f(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu); }       // v_cvt_f32_ubyte<b>
 
 // Fetch node `idx` and test its eight child boxes against the ray segment [0, tmax].
-// Out: hit mask - bits 31..24 the INNER children that are hit, at position 24 + (slot ^ (7 - ray octant)) so that "highest bit
-// first" is front to back; bits 23..0 the primitives of the hit leaf children, by offset from tri_base.
-APT_D uint32_t node8_test(const DevBvh& b, uint32_t idx, const WalkRay& r, float tmax, uint32_t& child_base, uint32_t& tri_base, uint32_t& imask) {
-    const char* base = reinterpret_cast<const char*>(b.nodes) + ((APT_NODE_BYTES == 80u) ? mul80(idx) : idx * APT_NODE_BYTES);          // wave-uniform base + 32-bit offset
+// Out: ng = node group of the node's INNER children (x = index of the first one; y = the hit ones in bits 31..24, at position
+// 24 + (slot ^ (7 - ray octant)) so that "highest bit first" is front to back, and the node's inner-slot mask in bits 7..0);
+// tg = triangle group of its LEAF children (x = index of the first one's primitive | the node's leaf-slot mask << 24; y = the hit ones,
+// bit = slot).  Child k of either kind is `first + popcount(mask & ((1 << slot) - 1))`.
+APT_D void node8_test(const DevBvh& b, uint32_t idx, const WalkRay& r, float tmax, grp_t& ng, grp_t& tg) {
+    const char* base = reinterpret_cast<const char*>(b.nodes) + (idx << 6);          // wave-uniform base + 32-bit offset
     const uint4 n0 = *reinterpret_cast<const uint4*>(base), n1 = *reinterpret_cast<const uint4*>(base + 16), n2 = *reinterpret_cast<const uint4*>(base + 32),
-                n3 = *reinterpret_cast<const uint4*>(base + 48), n4 = *reinterpret_cast<const uint4*>(base + 64);
-    child_base = n1.x; tri_base = n1.y; imask = n0.w >> 24;
-    // slab arithmetic in the node's quantised frame: t = q * (2^e / d) + (p - o) / d
-    const float sx = ldexpf(r.inv.x, (int)(n0.w << 24) >> 24), sy = ldexpf(r.inv.y, (int)(n0.w << 16) >> 24), sz = ldexpf(r.inv.z, (int)(n0.w << 8) >> 24);
-    const float cx = __builtin_fmaf(__uint_as_float(n0.x), r.inv.x, r.noo.x), cy = __builtin_fmaf(__uint_as_float(n0.y), r.inv.y, r.noo.y),
-                cz = __builtin_fmaf(__uint_as_float(n0.z), r.inv.z, r.noo.z);
+                n3 = *reinterpret_cast<const uint4*>(base + 48);
+    const uint32_t lmask = (n0.y >> 16) & 0xffu, imask = n0.y >> 24;
+    // slab arithmetic in the node's frame (grid units): t = q * (2^e * inv) + (corner * inv + noo)
+    const float sx = ldexpf(r.inv.x, (int)((n0.z >> 24) & 15u)), sy = ldexpf(r.inv.y, (int)(n0.z >> 28)), sz = ldexpf(r.inv.z, (int)((n0.w >> 24) & 15u));
+    const float cx = __builtin_fmaf((float)(n0.x & 0xffffu), r.inv.x, r.noo.x), cy = __builtin_fmaf((float)(n0.x >> 16), r.inv.y, r.noo.y),
+                cz = __builtin_fmaf((float)(n0.y & 0xffffu), r.inv.z, r.noo.z);
     // near / far planes by the sign of the direction, four children per dword
     const bool nx = r.inv.x < 0.f, ny = r.inv.y < 0.f, nz = r.inv.z < 0.f;
-    const uint32_t nearx[2] = {nx ? n3.z : n2.x, nx ? n3.w : n2.y}, farx[2] = {nx ? n2.x : n3.z, nx ? n2.y : n3.w};
-    const uint32_t neary[2] = {ny ? n4.x : n2.z, ny ? n4.y : n2.w}, fary[2] = {ny ? n2.z : n4.x, ny ? n2.w : n4.y};
-    const uint32_t nearz[2] = {nz ? n4.z : n3.x, nz ? n4.w : n3.y}, farz[2] = {nz ? n3.x : n4.z, nz ? n3.y : n4.w};
-    const uint32_t meta[2] = {n1.z, n1.w};
-    uint32_t hitmask = 0;
+    const uint32_t nearx[2] = {nx ? n2.z : n1.x, nx ? n2.w : n1.y}, farx[2] = {nx ? n1.x : n2.z, nx ? n1.y : n2.w};
+    const uint32_t neary[2] = {ny ? n3.x : n1.z, ny ? n3.y : n1.w}, fary[2] = {ny ? n1.z : n3.x, ny ? n1.w : n3.y};
+    const uint32_t nearz[2] = {nz ? n3.z : n2.x, nz ? n3.w : n2.y}, farz[2] = {nz ? n2.x : n3.z, nz ? n2.y : n3.w};
+    // one bit per child, child 7 first: the sign of (exit - entry) is shifted in from the right, so that child c ends up in bit c
+    // (two instructions per child where compare + select + shift + or were six)
+    uint32_t miss = 0;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const uint32_t m4 = meta[h];
-        const uint32_t inner4 = ((m4 & (m4 << 1)) & 0x10101010u) >> 4;                 // 1 per byte whose low five bits are >= 24
-        const uint32_t shift4 = (m4 ^ (r.octinv4 & (inner4 * 0xffu))) & 0x1f1f1f1fu;    // bit position of the child's first bit
-        const uint32_t bits4 = (m4 >> 5) & 0x07070707u;                                 // 1 (inner) or unary primitive count
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const v2f tx = __builtin_elementwise_fma(mk2(ubyte_f(nearx[h], c), ubyte_f(farx[h], c)), sp2(sx), sp2(cx));
-            const v2f ty = __builtin_elementwise_fma(mk2(ubyte_f(neary[h], c), ubyte_f(fary[h], c)), sp2(sy), sp2(cy));
-            const v2f tz = __builtin_elementwise_fma(mk2(ubyte_f(nearz[h], c), ubyte_f(farz[h], c)), sp2(sz), sp2(cz));
-            const float tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);
-            const float tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), tmax);
-            const uint32_t bits = ((bits4 >> (8 * c)) & 0xffu) << ((shift4 >> (8 * c)) & 0xffu);
-            hitmask |= (tn <= tf) ? bits : 0u;
-        }
+    for (int k = 7; k >= 0; k--) {
+        const int h = k >> 2, c = k & 3;
+        const v2f tx = __builtin_elementwise_fma(mk2(ubyte_f(nearx[h], c), ubyte_f(farx[h], c)), sp2(sx), sp2(cx));
+        const v2f ty = __builtin_elementwise_fma(mk2(ubyte_f(neary[h], c), ubyte_f(fary[h], c)), sp2(sy), sp2(cy));
+        const v2f tz = __builtin_elementwise_fma(mk2(ubyte_f(nearz[h], c), ubyte_f(farz[h], c)), sp2(sz), sp2(cz));
+        const float tn = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.f);
+        const float tf = fminf(fminf(fminf(tx.y, ty.y), tz.y), tmax);
+        miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(tf - tn), 31u);
     }
-    return hitmask;
+    const uint32_t hit_l = ~miss & lmask;
+    uint32_t x = ~miss & imask;
+    // inner hits to their priority positions: bit `slot` -> bit `slot ^ (7 - octant)` (three conditional swaps of bit groups)
+    const uint32_t oi = r.octinv4;
+    x = (oi & 4u) ? (((x << 4) | (x >> 4)) & 0xffu) : x;
+    x = (oi & 2u) ? (((x & 0x33u) << 2) | ((x >> 2) & 0x33u)) : x;
+    x = (oi & 1u) ? (((x & 0x55u) << 1) | ((x >> 1) & 0x55u)) : x;
+    ng.x = n0.z & 0x00ffffffu; ng.y = (x << 24) | imask;
+    tg.x = (n0.w & 0x00ffffffu) | (lmask << 24); tg.y = hit_l;
+}
+// the primitive a triangle group's bit `slot` stands for (leaf order), and the bit taken out of the group
+APT_D uint32_t tri_take(grp_t& tg) {
+    const uint32_t k = 31u - (uint32_t)__clz((int)tg.y);
+    tg.y &= ~(1u << k);
+    return (tg.x & 0x00ffffffu) + (uint32_t)__popc((tg.x >> 24) & ((1u << k) - 1u));
 }
 
 #if APT_FAST
@@ -188,52 +202,14 @@ APT_D float walk_scalar_test(float4 q0, float4 q1, float4 q2, f3 o, f3 d, float&
 }
 template <bool ANY>
 APT_D bool tri_one(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
-    const uint32_t k = 31u - (uint32_t)__clz((int)tg.y);
-    tg.y &= ~(1u << k);
-    const char* base = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k);
+    const uint32_t slot = tri_take(tg);
+    const char* base = reinterpret_cast<const char*>(b.prims) + mul48(slot);
     const float4 p0 = *reinterpret_cast<const float4*>(base), p1 = *reinterpret_cast<const float4*>(base + 16), p2 = *reinterpret_cast<const float4*>(base + 32);
     float u, v;
     const float t = walk_scalar_test(p0, p1, p2, r.o, r.d, u, v);
     WALK_COUNT(ws.prims);
     if (ANY) return t > 1e-4f && t < rec.t;
-    if (t > 1e-4f && t < rec.t) { rec.t = t; rec.prim = (int)(tg.x + k); rec.u = u; rec.v = v; }
-    return false;
-}
-template <bool ANY>
-APT_D bool tri_two(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
-    const uint32_t k0 = 31u - (uint32_t)__clz((int)tg.y);
-    const uint32_t rest = tg.y & ~(1u << k0);
-    const bool two = rest != 0u;
-    const uint32_t k1 = two ? 31u - (uint32_t)__clz((int)rest) : k0;
-    tg.y = two ? (rest & ~(1u << k1)) : 0u;
-    const char* ba = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k0);
-    const char* bb = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k1);
-    const float4 a0 = *reinterpret_cast<const float4*>(ba), a1 = *reinterpret_cast<const float4*>(ba + 16), a2 = *reinterpret_cast<const float4*>(ba + 32);
-    const float4 b0 = *reinterpret_cast<const float4*>(bb), b1 = *reinterpret_cast<const float4*>(bb + 16), b2 = *reinterpret_cast<const float4*>(bb + 32);
-    WALK_COUNT(ws.prims); if (two) WALK_COUNT(ws.prims);
-    v2f t, u, v;
-    if (a0.w != a0.w || b0.w != b0.w) {                                          // a sphere among the two (NaN marker): scalar tests
-        float uu, vv;
-        t.x = walk_scalar_test(a0, a1, a2, r.o, r.d, uu, vv); u.x = uu; v.x = vv;
-        t.y = walk_scalar_test(b0, b1, b2, r.o, r.d, uu, vv); u.y = uu; v.y = vv;
-    } else {
-        const v2f sx = sp2(r.o.x) - mk2(a0.x, b0.x), sy = sp2(r.o.y) - mk2(a0.y, b0.y), sz = sp2(r.o.z) - mk2(a0.z, b0.z);
-        const v2f dx = sp2(r.d.x), dy = sp2(r.d.y), dz = sp2(r.d.z);
-        const v2f tx = mk2(a2.y, b2.y), ty = mk2(a2.z, b2.z), tz = mk2(a2.w, b2.w);
-        const v2f t_o = fma2(tx, sx, fma2(ty, sy, tz * sz));
-        const v2f t_d = fma2(tx, dx, fma2(ty, dy, tz * dz));
-        v2f inv; inv.x = __builtin_amdgcn_rcpf(t_d.x); inv.y = __builtin_amdgcn_rcpf(t_d.y);
-        t = -t_o * inv;
-        const v2f px = fma2(t, dx, sx), py = fma2(t, dy, sy), pz = fma2(t, dz, sz);
-        u = fma2(mk2(a0.w, b0.w), px, fma2(mk2(a1.x, b1.x), py, mk2(a1.y, b1.y) * pz));
-        v = fma2(mk2(a1.z, b1.z), px, fma2(mk2(a1.w, b1.w), py, mk2(a2.x, b2.x) * pz));
-        const v2f w = (sp2(1.0f) - u) - v;
-        t.x = (fminf(fminf(u.x, v.x), w.x) >= 0.f) ? t.x : -1.f;
-        t.y = (fminf(fminf(u.y, v.y), w.y) >= 0.f) ? t.y : -1.f;
-    }
-    if (ANY) return (t.x > 1e-4f && t.x < rec.t) || (t.y > 1e-4f && t.y < rec.t);
-    if (t.x > 1e-4f && t.x < rec.t) { rec.t = t.x; rec.prim = (int)(tg.x + k0); rec.u = u.x; rec.v = v.x; }
-    if (t.y > 1e-4f && t.y < rec.t) { rec.t = t.y; rec.prim = (int)(tg.x + k1); rec.u = u.y; rec.v = v.y; }
+    if (t > 1e-4f && t < rec.t) { rec.t = t; rec.prim = (int)slot; rec.u = u; rec.v = v; }
     return false;
 }
 // leaf slot -> primitive index (low 28 bits) and material class (bits 28..30) of a finished closest-hit walk: ONE lookup at the hand-in,
@@ -247,9 +223,7 @@ APT_D int walk_prim(const DevBvh& b, int slot) { return slot >= 0 ? (b.slot_prim
 // Any hit: true at a primitive with 1e-4 < t < rec.t.
 template <bool ANY>
 APT_D bool tri_one(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
-    const uint32_t k = 31u - (uint32_t)__clz((int)tg.y);
-    tg.y &= ~(1u << k);
-    const char* base = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k);
+    const char* base = reinterpret_cast<const char*>(b.prims) + mul48(tri_take(tg));
     const float4 p0 = *reinterpret_cast<const float4*>(base), p1 = *reinterpret_cast<const float4*>(base + 16), p2 = *reinterpret_cast<const float4*>(base + 32);
     float u, v;
     const float t = prim_test(p0, p1, p2, r.o, r.d, u, v);
@@ -259,63 +233,14 @@ APT_D bool tri_one(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, Wa
     if (t > 1e-4f && (t < rec.t || (t == rec.t && kid < rec.prim))) { rec.t = t; rec.prim = kid; rec.u = u; rec.v = v; }
     return false;
 }
-// Two primitives of a triangle group per call, in the two halves of packed f32 instructions (v_pk_mul_f32 / v_pk_add_f32 round
-// each half exactly like the scalar instruction, and -ffp-contract=off forbids a packed FMA): the same arithmetic as prim_test(),
-// ~95 instructions for two triangles instead of 2 x 75.  A lane with a single pending primitive tests it in both halves; spheres
-// (rare in scenes large enough for the tree) take the scalar path.
-template <bool ANY>
-APT_D bool tri_two(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
-    const uint32_t k0 = 31u - (uint32_t)__clz((int)tg.y);
-    const uint32_t rest = tg.y & ~(1u << k0);
-    const bool two = rest != 0u;
-    const uint32_t k1 = two ? 31u - (uint32_t)__clz((int)rest) : k0;
-    tg.y = two ? (rest & ~(1u << k1)) : 0u;
-    const char* ba = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k0);
-    const char* bb = reinterpret_cast<const char*>(b.prims) + mul48(tg.x + k1);
-    const float4 a0 = *reinterpret_cast<const float4*>(ba), a1 = *reinterpret_cast<const float4*>(ba + 16), a2 = *reinterpret_cast<const float4*>(ba + 32);
-    const float4 b0 = *reinterpret_cast<const float4*>(bb), b1 = *reinterpret_cast<const float4*>(bb + 16), b2 = *reinterpret_cast<const float4*>(bb + 32);
-    WALK_COUNT(ws.prims); if (two) WALK_COUNT(ws.prims);
-    v2f t, u, v;
-    if (__float_as_int(a2.z) != 0 || __float_as_int(b2.z) != 0) {              // a sphere among the two: scalar tests
-        float uu, vv;
-        t.x = prim_test(a0, a1, a2, r.o, r.d, uu, vv); u.x = uu; v.x = vv;
-        t.y = prim_test(b0, b1, b2, r.o, r.d, uu, vv); u.y = uu; v.y = vv;
-    } else {
-        // columns (e1, e2, -d); inverse = adjugate * (1/det), Taichi's 3x3 formula - prim_test() on two triangles at once
-        const v2f a00 = mk2(a0.w, b0.w), a10 = mk2(a1.x, b1.x), a20 = mk2(a1.y, b1.y);      // e1
-        const v2f a01 = mk2(a1.z, b1.z), a11 = mk2(a1.w, b1.w), a21 = mk2(a2.x, b2.x);      // e2
-        const v2f a02 = sp2(-r.d.x), a12 = sp2(-r.d.y), a22 = sp2(-r.d.z);
-        const v2f c00 = a11 * a22 - a21 * a12, c01 = a21 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
-        const v2f det = (a00 * c00 + a10 * c01) + a20 * c02;
-        v2f inv_det; inv_det.x = 1.0f / det.x; inv_det.y = 1.0f / det.y;
-        const v2f sx = sp2(r.o.x) - mk2(a0.x, b0.x), sy = sp2(r.o.y) - mk2(a0.y, b0.y), sz = sp2(r.o.z) - mk2(a0.z, b0.z);
-        const v2f c10 = a12 * a20 - a22 * a10, c11 = a22 * a00 - a02 * a20, c12 = a02 * a10 - a12 * a00;
-        const v2f c20 = a10 * a21 - a20 * a11, c21 = a20 * a01 - a00 * a21, c22 = a00 * a11 - a10 * a01;
-        u = ((inv_det * c00) * sx + (inv_det * c01) * sy) + (inv_det * c02) * sz;
-        v = ((inv_det * c10) * sx + (inv_det * c11) * sy) + (inv_det * c12) * sz;
-        t = ((inv_det * c20) * sx + (inv_det * c21) * sy) + (inv_det * c22) * sz;
-        const v2f uv = u + v;
-        t.x = (u.x >= 0.f && v.x >= 0.f && uv.x <= 1.0f) ? t.x : -1.f;
-        t.y = (u.y >= 0.f && v.y >= 0.f && uv.y <= 1.0f) ? t.y : -1.f;
-    }
-    if (ANY) return (t.x > 1e-4f && t.x < rec.t) || (t.y > 1e-4f && t.y < rec.t);
-    const int ka = __float_as_int(a2.y), kb = __float_as_int(b2.y);
-    if (t.x > 1e-4f && (t.x < rec.t || (t.x == rec.t && ka < rec.prim))) { rec.t = t.x; rec.prim = ka; rec.u = u.x; rec.v = v.x; }
-    if (t.y > 1e-4f && (t.y < rec.t || (t.y == rec.t && kb < rec.prim))) { rec.t = t.y; rec.prim = kb; rec.u = u.y; rec.v = v.y; }
-    return false;
-}
 APT_D int walk_prim(const DevBvh&, int prim) { return prim; }      // exact build: the records carry the primitive index
 #endif
-#if APT_FAST_LEAVES && !defined(APT_TRI_PAIR)
-#define APT_TRI_SINGLE 1     // with the cheap leaf test the walk is bound by its divergent 16-byte loads, not by arithmetic: the pair test fetches six per iteration whether or not the lane has a second primitive pending (measured: C4 extend 22.2 -> 21.1 ms per 64 spp, C5 14.05 -> 13.7 per 32)
-#endif
+// (One primitive per call.  Rounds 2-3 tested two of a lane's pending primitives in the halves of packed instructions; with the product
+// build's cheap leaf test the walk answers to its scattered 16-byte loads, not to arithmetic, and the pair test fetched six whether or
+// not the lane had a second primitive pending: C4 extend 22.2 -> 21.1 ms per 64 spp, C5 14.05 -> 13.7 per 32 for the single test, round 4.)
 template <bool ANY>
 APT_D bool tri_group(const DevBvh& b, grp_t& tg, const WalkRay& r, HitRec& rec, WalkStats& ws) {
-#ifdef APT_TRI_SINGLE
     while (tg.y != 0u) if (tri_one<ANY>(b, tg, r, rec, ws)) return true;
-#else
-    while (tg.y != 0u) if (tri_two<ANY>(b, tg, r, rec, ws)) return true;
-#endif
     return false;
 }
 
@@ -331,11 +256,8 @@ APT_D void group_step(const DevBvh& b, const TravStack& ts, int& sp, grp_t& ng, 
         if (APT_GROUP_HAS_NODES(ng)) tpush(ts, sp, ng);
         const uint32_t slot = (bit - 24u) ^ (r.octinv4 & 7u);
         const uint32_t idx = ng.x + (uint32_t)__popc(pim & ((1u << slot) - 1u));
-        uint32_t cb, tb, im;
-        const uint32_t hm = node8_test(b, idx, r, tmax, cb, tb, im);
+        node8_test(b, idx, r, tmax, ng, tg);
         WALK_COUNT(ws.nodes);
-        ng.x = cb; ng.y = (hm & 0xff000000u) | im;
-        tg.x = tb; tg.y = hm & 0x00ffffffu;
     } else { tg = ng; ng.x = 0u; ng.y = 0u; }
 }
 #define APT_ROOT_GROUP mk_grp(0u, 0x80000000u)           // "child in priority position 7 of a parent with no inner-child mask" = node 0
@@ -344,7 +266,7 @@ APT_D void group_step(const DevBvh& b, const TravStack& ts, int& sp, grp_t& ng, 
 // ANY = true : returns true on the first hit with 1e-4 < t < rec.t.
 template <bool ANY>
 APT_D bool traverse(const DevBvh& bvh, const TravStack& ts, f3 o, f3 d, HitRec& rec) {
-    const WalkRay r = make_walk_ray(o, d);
+    const WalkRay r = make_walk_ray(bvh, o, d);
     WalkStats ws; ws.nodes = ws.prims = 0;
     int sp = 0;
     grp_t ng = APT_ROOT_GROUP, tg = mk_grp(0u, 0u);

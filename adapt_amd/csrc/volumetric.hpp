@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(BLOCK) k_vevent(DevScene sc, Params p, Queues 
             }
         }
         if (rng.draw != draw0) atomicAdd(&s_draws[threadIdx.x >> 6], rng.draw - draw0);
-        if (alive && rng.draw > 0x7fffffu) atomicAdd(&cnt->stats[sl.q][ST_OVERFLOW], 1ull);
+        if (pass && rng.draw > 0x7fffffu) atomicAdd(&cnt->stats[sl.q][ST_OVERFLOW], 1ull);      // counted where a next-ray record is written with the truncated index: here for pass-throughs, in the event kernels for continuations (once per record, not once per kernel the path crosses)
         // the pass-throughs go straight back into the ray queue, the events into their queues (all queue tails with one atomic instruction)
         const uint32_t npos = wave_append(pass, next_counter);
         if (pass) {

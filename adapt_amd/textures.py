@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from .parsers.general_parser import get
-from .parsers.image_io import imread_rgb
+from .parsers.image_io import imread_rgb, resize_bilinear_u8
 
 __all__ = ["Texture_np", "image_packer", "parse_texture", "TEX_TAGS", "TEX_INVALID"]
 
@@ -43,8 +43,9 @@ class Texture_np:
         self.texture_path = path
         img = imread_rgb(path)
         self.h, self.w = int(img.shape[0]), int(img.shape[1])
-        if self.h > max_size or self.w > max_size:
-            raise NotImplementedError(f"texture larger than {max_size} px (the reference resizes with OpenCV; not reproduced)")
+        if self.h > max_size or self.w > max_size:              # texture.py:65-68: each side clamped on its own (aspect not kept), cv.resize defaults
+            self.w, self.h = min(self.w, max_size), min(self.h, max_size)
+            img = resize_bilinear_u8(img, self.w, self.h)
         self.texture_img = img.astype(np.float32) / 255.
         if self.tag == "bump":                                   # up axis z -> y (texture.py:69-71)
             self.texture_img[..., [1, 2]] = self.texture_img[..., [2, 1]]

@@ -22,7 +22,7 @@ __all__ = ["TilePlan", "gather_tiles", "gather_tiles_device", "gather_image", "a
 
 
 class TilePlan:
-    """Pure index arithmetic; mirrored on the device side by `local_to_global` in csrc/kernels.hip."""
+    """Pure index arithmetic; mirrored on the device side by `local_to_global` in csrc/stages.hpp."""
 
     def __init__(self, width: int, height: int, band_width: int, world_size: int):
         if width <= 0 or height <= 0 or band_width <= 0 or world_size <= 0:

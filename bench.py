@@ -158,6 +158,47 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def host_cpu_report(omp_threads):
+    """What the CPU leg can run on: OpenMP's idea of the machine, the affinity mask of this process, the cgroup CPU quota and the CPU model.
+    (Round 5's line said "128 threads" where the 8-thread and the all-thread rates were equal: the box's container is granted a fraction
+    of the host, which omp_get_max_threads() does not see.)  threads_used = min of the three, at least 1."""
+    rep = {"omp_max_threads": int(omp_threads), "os_cpu_count": os.cpu_count()}
+    try:
+        rep["sched_affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        rep["sched_affinity"] = None
+    quota = None
+    try:                                            # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        rep["cgroup_cpu_max"] = f"{q} {per}"
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                        # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            rep["cgroup_cpu_max"] = f"{q} {per}"
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            rep["cgroup_cpu_max"] = None
+    rep["cgroup_quota_cpus"] = None if quota is None else round(quota, 2)
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    rep["cpu_model"] = model
+    try:
+        rep["loadavg_1min"] = round(os.getloadavg()[0], 2)
+    except OSError:
+        rep["loadavg_1min"] = None
+    limits = [int(omp_threads)] + ([rep["sched_affinity"]] if rep["sched_affinity"] else []) + ([max(1, int(quota + 0.5))] if quota else [])
+    rep["threads_used"] = max(1, min(limits))
+    return rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -421,8 +462,11 @@ def main():
         # triangles (tests/golden/bvhref_bunnies3.npz: its own two intersectors disagree there), so parity is judged against the
         # oracle's BRUTE-FORCE intersector and the CPU rate is taken with the reference-layout BVH (what the reference would run)
         osc = ob.OracleScene(pack_scene(*parsed), rc.cam_t, build_bvh=rc.use_bvh)
-        cores = ob.num_threads()
+        host = host_cpu_report(ob.num_threads())
+        cores = host["threads_used"]                   # min(OpenMP's count, the affinity mask, the cgroup quota): what the leg can really run on
         t = time.perf_counter(); osc.render(rc, 1, threads=cores); one = time.perf_counter() - t
+        t = time.perf_counter(); osc.render(rc, 1, threads=1); one_1t = time.perf_counter() - t
+        host["parallel_speedup_measured"] = {"threads": cores, "speedup_over_1_thread": round(one_1t / max(one, 1e-9), 2), "note": "1 spp of the workload on 1 thread vs on threads_used: what the host really delivers"}
         n_cpu = int(max(1, min(512, round(args.cpu_seconds / max(one, 1e-3)))))
         t = time.perf_counter(); ref, cnt, ost = osc.render(rc, n_cpu, threads=cores); cpu_dt = time.perf_counter() - t
         # AdaPT itself runs this kernel on 8 CPU threads (ti.loop_config(parallelize=8), vanilla_renderer.py:35): time that too, on a
@@ -430,7 +474,8 @@ def main():
         n8 = max(1, min(n_cpu, int(round(n_cpu * min(cores, 8) / cores / 2)) or 1))
         t = time.perf_counter(); osc.render(rc, n8, threads=min(cores, 8)); dt8 = time.perf_counter() - t
         out["cpu_baseline"] = {"value": round(W * H * n_cpu / cpu_dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                               "at_8_threads": {"value": round(W * H * n8 / dt8 / 1e6, 4), "spp": n8, "seconds": round(dt8, 1)},
+                               "at_8_threads": {"value": round(W * H * n8 / dt8 / 1e6, 4), "spp": n8, "seconds": round(dt8, 1), "threads": min(cores, 8)},
+                               "host": host,
                                "sample": f"{W}x{H} x {n_cpu} spp of the same workload (same scene, bounces, seed), {cpu_dt:.1f} s on {cores} OpenMP threads; "
                                          "oracle/pt_oracle.c = C restatement of the reference path (real AdaPT needs taichi, absent here)"
                                          + ("; reference-layout BVH" if rc.use_bvh else "")}
@@ -473,7 +518,7 @@ def main():
                          "non_finite_pixels": int((~fin).sum()), "non_finite_pixels_coincide": nonfin_same}
         if nonfin_note is not None:
             out["parity"]["non_finite_mismatch"] = nonfin_note
-        out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        out["speedup_vs_cpu"] = {"value": round(value / out["cpu_baseline"]["value"], 1), "against": f"the C port on {cores} host threads (cpu_baseline.host says what the box offers)"}
         chk.close()
     if rank == 0:
         print(json.dumps(out))

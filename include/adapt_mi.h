@@ -127,10 +127,12 @@ int apt_bvh_counts(const apt_bvh*, int32_t* n_nodes, int32_t* n_leaf_prims, int3
 /* nodes: n_nodes*16 floats (two child boxes + two child links); prim_order: n_prims ints (BVH order -> original prim) */
 int apt_bvh_export(const apt_bvh*, float* nodes, int32_t* prim_order);
 /* The tree the traversal kernels walk: the binary tree (rebuilt with single-primitive leaves) collapsed to 8-wide nodes with
- * 8-bit quantised child boxes, 80 bytes = 20 dwords per node, breadth-first, node 0 = root (layout: csrc/bvh_wide.cpp);
- * prim_order: leaf-order slot -> original primitive.  n_levels = depth in 8-wide nodes. */
+ * 8-bit quantised child boxes, 64 bytes = 16 dwords per node, breadth-first, node 0 = root (layout: csrc/bvh_wide.cpp);
+ * prim_order: leaf-order slot -> original primitive.  n_levels = depth in 8-wide nodes.  apt_bvh_wide_frame: the global grid the
+ * 16-bit node corners live on (world = gmin + gstep * grid, power-of-two steps). */
 int apt_bvh_wide_counts(const apt_bvh*, int32_t* n_nodes, int32_t* n_levels);
-int apt_bvh_wide_export(const apt_bvh*, uint32_t* nodes /* n_nodes*20 */, int32_t* prim_order /* n_prims */);
+int apt_bvh_wide_export(const apt_bvh*, uint32_t* nodes /* n_nodes*16 */, int32_t* prim_order /* n_prims */);
+int apt_bvh_wide_frame(const apt_bvh*, float gmin[3], float gstep[3]);
 void apt_bvh_free(apt_bvh*);
 
 /* ---- records of the flat sweep (host; csrc/flat_build.cpp).  What the product build's small-scene intersector reads instead of the

@@ -1697,7 +1697,7 @@ static v3 render_sample(const ctx_t* c, int i, int j, int cnt, rng_t* rng, orc_s
 /* ===================================================================== volumetric path tracer
  * VolumeRenderer.render (renderer/vpt.py:145-258) with homogeneous media: the world medium and media attached to BSDF objects
  * (bxdf/medium.py:71-125), their phase functions (bxdf/phase.py, sampler/phase_sampling.py), null surfaces (bsdf.py:214-216) and
- * the transmittance walk track_ray (vpt.py:99-138).  Grid volumes (bxdf/volume.py) are not restated. */
+ * the transmittance walk track_ray (vpt.py:99-138).  Grid volumes (bxdf/volume.py) follow further down ("grid volume" section). */
 static float random_rgb(rng_t* r, v3 v) {                          /* general_sampling.py:17-27 */
     int idx = pymod(rng_int(r), 3);
     float res = (idx == 0) ? v.x : ((idx == 1) ? v.y : v.z);

@@ -285,64 +285,67 @@ def build_wide(fs):
     _lib.check(lib.apt_bvh_build(prims.ctypes.data_as(_lib.f32p), fs.n_prims, info.ctypes.data_as(_lib.i32p), fs.n_objects, C.byref(h)))
     nn, lv = C.c_int32(), C.c_int32()
     _lib.check(lib.apt_bvh_wide_counts(h, C.byref(nn), C.byref(lv)))
-    nodes, order = np.zeros((nn.value, 20), np.uint32), np.zeros(fs.n_prims, np.int32)
+    nodes, order = np.zeros((nn.value, 16), np.uint32), np.zeros(fs.n_prims, np.int32)
     _lib.check(lib.apt_bvh_wide_export(h, nodes.ctypes.data_as(_lib.u32p), order.ctypes.data_as(_lib.i32p)))
+    gmin, gstep = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    _lib.check(lib.apt_bvh_wide_frame(h, gmin.ctypes.data_as(_lib.f32p), gstep.ctypes.data_as(_lib.f32p)))
     lib.apt_bvh_free(h)
-    return nodes, order, lv.value
+    return nodes, order, lv.value, (gmin, gstep)
 
 
 def decode_wide(nodes):
-    """-> per node: p (3,), scale (3,) = 2^e, imask, child_base, tri_base, meta (8,), qlo (3, 8), qhi (3, 8)"""
-    p = nodes[:, 0:3].copy().view(np.float32)
-    e = nodes[:, 3]
-    ex = np.stack([(e >> (8 * a)) & 0xff for a in range(3)], 1).astype(np.uint8).view(np.int8).astype(np.int32)
-    by = np.ascontiguousarray(nodes[:, 6:20]).view(np.uint8).reshape(-1, 7, 8)
-    return p, np.ldexp(np.float32(1), ex).astype(np.float32), (e >> 24).astype(np.int32), nodes[:, 4].astype(np.int64), nodes[:, 5].astype(np.int64), by[:, 0], by[:, 1:4], by[:, 4:7]
+    """64-byte nodes (csrc/bvh_wide.cpp) -> per node: corner (3,) in grid units, scale (3,) = 2^e in grid units, leaf mask, inner mask,
+    child_base, tri_base, qlo (3, 8), qhi (3, 8)"""
+    w = nodes.astype(np.int64)
+    corner = np.stack([w[:, 0] & 0xffff, w[:, 0] >> 16, w[:, 1] & 0xffff], 1)
+    lmask, imask = (w[:, 1] >> 16) & 0xff, w[:, 1] >> 24
+    ex = np.stack([(w[:, 2] >> 24) & 15, w[:, 2] >> 28, (w[:, 3] >> 24) & 15], 1)
+    assert ((w[:, 3] >> 28) == 0).all()
+    by = np.ascontiguousarray(nodes[:, 4:16]).view(np.uint8).reshape(-1, 6, 8)
+    return corner, np.ldexp(1.0, ex), lmask, imask, w[:, 2] & 0xffffff, w[:, 3] & 0xffffff, by[:, 0:3], by[:, 3:6]
 
 
 @pytest.mark.parametrize("scene", ["cbox", "balls_mono", "bunnies1"])
 def test_wide_bvh_invariants(scene, flat):
-    """Every primitive sits in exactly one leaf (<= 3 per leaf, <= 24 per node); inner children are consecutive and counted by the
-    inner-child mask; every decoded child box contains the boxes of all primitives below it (the quantisation rounds outwards)."""
+    """Every primitive sits in exactly one leaf child (one primitive per leaf, at most eight per node); inner children are consecutive and
+    counted by the inner-slot mask, leaf primitives by the leaf-slot mask; every decoded child box contains the boxes of all primitives
+    below it (the quantisation rounds outwards, the 16-bit corner lies at or below the node's box)."""
     if scene == "bunnies1":
         from adapt_amd.scene_pack import pack_scene
         from adapt_amd.synth import three_bunnies
         fs = pack_scene(*three_bunnies(1))
     else:
         fs = flat(scene)
-    nodes, order, levels = build_wide(fs)
+    nodes, order, levels, (gmin, gstep) = build_wide(fs)
     assert sorted(order.tolist()) == list(range(fs.n_prims))
-    p, sc, imask, cbase, tbase, meta, qlo, qhi = decode_wide(nodes)
+    assert np.all(np.log2(gstep.astype(np.float64)) % 1 == 0)                           # power-of-two steps: the grid transform is exact
+    corner, sc, lmask, imask, cbase, tbase, qlo, qhi = decode_wide(nodes)
+    assert (corner >= 0).all() and (corner <= 65535).all() and (lmask & imask == 0).all()
     sphere = np.repeat(fs.obj_info[:, 2], fs.obj_info[:, 1]).astype(bool)
     seen_nodes, seen_slots, depth_seen = set(), [], [0]
+    g0, gs = gmin.astype(np.float64), gstep.astype(np.float64)
 
     def walk(n, d):
         assert n not in seen_nodes and d <= levels
         seen_nodes.add(n); depth_seen[0] = max(depth_seen[0], d)
-        lo_all, hi_all = np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
+        lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
         rank, tri_next = 0, 0
         for s in range(8):
-            m = int(meta[n, s])
-            inner = (m & 0x1f) >= 24
-            assert bool((imask[n] >> s) & 1) == (m != 0 and inner)
-            if m == 0:
+            leaf, inner = bool((lmask[n] >> s) & 1), bool((imask[n] >> s) & 1)
+            if not (leaf or inner):
                 assert (qlo[n, :, s] == 255).all() and (qhi[n, :, s] == 0).all()          # inverted box: never hit
                 continue
-            blo = p[n] + qlo[n, :, s].astype(np.float32) * sc[n]
-            bhi = p[n] + qhi[n, :, s].astype(np.float32) * sc[n]
+            blo = g0 + gs * (corner[n] + qlo[n, :, s].astype(np.float64) * sc[n])            # world = gmin + gstep * (corner + q * 2^e), exact in double
+            bhi = g0 + gs * (corner[n] + qhi[n, :, s].astype(np.float64) * sc[n])
             if inner:
-                assert (m & 0x1f) == 24 + s and (m >> 5) == 1
                 clo, chi = walk(int(cbase[n]) + rank, d + 1)
                 rank += 1
             else:
-                cnt = {1: 1, 3: 2, 7: 3}[m >> 5]
-                assert (m & 0x1f) == tri_next and tri_next + cnt <= 24
-                clo, chi = np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
-                for slot in range(int(tbase[n]) + tri_next, int(tbase[n]) + tri_next + cnt):
-                    a, b = prim_bounds(fs, order[slot], sphere[order[slot]])
-                    clo, chi = np.minimum(clo, a), np.maximum(chi, b)
-                    seen_slots.append(slot)
-                tri_next += cnt
+                slot = int(tbase[n]) + tri_next
+                a, b = prim_bounds(fs, order[slot], sphere[order[slot]])
+                clo, chi = a.astype(np.float64), b.astype(np.float64)
+                seen_slots.append(slot)
+                tri_next += 1
             assert np.all(blo <= clo) and np.all(bhi >= chi), (n, s)
             lo_all, hi_all = np.minimum(lo_all, clo), np.maximum(hi_all, chi)
         return lo_all, hi_all
@@ -350,7 +353,7 @@ def test_wide_bvh_invariants(scene, flat):
     walk(0, 1)
     assert sorted(seen_slots) == list(range(fs.n_prims)) and len(seen_nodes) == nodes.shape[0] and depth_seen[0] == levels
     if fs.n_prims > 1000:
-        assert nodes.shape[0] < fs.n_prims / 2.5 and levels <= 12         # 80-byte nodes over single-primitive leaves
+        assert nodes.shape[0] < fs.n_prims / 2.5 and levels <= 12         # 64-byte nodes over single-primitive leaves
 
 
 def test_wide_bvh_walk_finds_every_brute_force_hit():
@@ -360,8 +363,9 @@ def test_wide_bvh_walk_finds_every_brute_force_hit():
     from adapt_amd.scene_pack import pack_scene
     from adapt_amd.synth import three_bunnies
     fs = pack_scene(*three_bunnies(1))
-    nodes, order, levels = build_wide(fs)
-    p, sc, imask, cbase, tbase, meta, qlo, qhi = decode_wide(nodes)
+    nodes, order, levels, (gmin, gstep) = build_wide(fs)
+    corner, sc, lmask, imask, cbase, tbase, qlo, qhi = decode_wide(nodes)
+    ginv = (np.float32(1) / gstep).astype(np.float32)
     rs = np.random.RandomState(9)
     n = 300
     O = rs.uniform([0.3, 0.2, 0.3], [5.2, 5.2, 5.2], size=(n, 3)).astype(np.float32)
@@ -384,11 +388,11 @@ def test_wide_bvh_walk_finds_every_brute_force_hit():
     for o, d in zip(O, D):
         k_true, t_true = brute(o.astype(np.float64), d.astype(np.float64))
         with np.errstate(all="ignore"):
-            inv = np.where(np.abs(d) < 1e-30, np.copysign(f32(1e30), d), f32(1) / d).astype(np.float32)
-        noo = (-(o * inv)).astype(np.float32)
+            inv = (np.where(np.abs(d) < 1e-30, np.copysign(f32(1e30), d), f32(1) / d).astype(np.float32) * gstep).astype(np.float32)      # the ray in grid units (traverse.hpp make_walk_ray)
+        og = ((o - gmin).astype(np.float32) * ginv).astype(np.float32)
+        noo = (-(og * inv)).astype(np.float32)
         octinv = 7 - ((4 if inv[0] < 0 else 0) | (2 if inv[1] < 0 else 0) | (1 if inv[2] < 0 else 0))
         reached, stack, tmax = set(), [(0, 0x80000000)], f32(1e7)
-        order_ok = True
         while stack:
             base, bits = stack.pop()
             if bits <= 0x00ffffff:
@@ -400,22 +404,24 @@ def test_wide_bvh_walk_finds_every_brute_force_hit():
                 stack.append((base, bits))
             slot = (bit - 24) ^ octinv
             nidx = base + bin(pim & ((1 << slot) - 1)).count("1")
-            s_ = (inv * sc[nidx]).astype(np.float32); c_ = (p[nidx] * inv + noo).astype(np.float32)       # (numpy: separate roundings; the margin is the builder's padding)
-            hm = 0
+            s_ = (inv * sc[nidx].astype(np.float32)).astype(np.float32); c_ = (corner[nidx].astype(np.float32) * inv + noo).astype(np.float32)       # (numpy: separate roundings; the margin is the builder's padding)
+            hit8 = 0
             for sl in range(8):
-                m = int(meta[nidx, sl])
-                if m == 0:
+                if not ((int(lmask[nidx]) | int(imask[nidx])) >> sl) & 1:
                     continue
                 qn = np.where(inv < 0, qhi[nidx, :, sl], qlo[nidx, :, sl]).astype(np.float32); qf = np.where(inv < 0, qlo[nidx, :, sl], qhi[nidx, :, sl]).astype(np.float32)
                 tn = max(float((qn * s_ + c_).max()), 0.0); tf = min(float((qf * s_ + c_).min()), float(tmax))
-                if tn <= tf:
-                    inner = (m & 0x1f) >= 24
-                    hm |= (m >> 5) << (((m & 0x1f) ^ octinv) if inner else (m & 0x1f))
-            for k in range(24):
-                if (hm >> k) & 1:
-                    reached.add(int(order[int(tbase[nidx]) + k]))
-            if hm & 0xff000000:
-                stack.append((int(cbase[nidx]), (hm & 0xff000000) | int(imask[nidx])))
+                if not np.signbit(np.float32(tf) - np.float32(tn)):                    # the device's test: sign bit of (exit - entry)
+                    hit8 |= 1 << sl
+            for sl in range(8):
+                if ((hit8 & int(lmask[nidx])) >> sl) & 1:
+                    reached.add(int(order[int(tbase[nidx]) + bin(int(lmask[nidx]) & ((1 << sl) - 1)).count("1")]))
+            hi_ = 0
+            for sl in range(8):
+                if ((hit8 & int(imask[nidx])) >> sl) & 1:
+                    hi_ |= 1 << (sl ^ octinv)
+            if hi_:
+                stack.append((int(cbase[nidx]), (hi_ << 24) | int(imask[nidx])))
         assert k_true < 0 or k_true in reached, (o, d, k_true, t_true)
 
 
@@ -433,4 +439,5 @@ def test_host_threads_build_the_same_tree(monkeypatch):
         out[threads] = build_wide(fs)
     for threads in ("2", "7", "32"):
         assert np.array_equal(out["1"][0], out[threads][0]) and np.array_equal(out["1"][1], out[threads][1]) and out["1"][2] == out[threads][2], threads
+        assert np.array_equal(out["1"][3][0], out[threads][3][0]) and np.array_equal(out["1"][3][1], out[threads][3][1])
     assert sorted(out["1"][1].tolist()) == list(range(fs.n_prims))

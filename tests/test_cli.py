@@ -42,5 +42,9 @@ def test_image_orientation_and_png(tmp_path):
     assert len(raw) == 3 * (1 + 4 * 3) and raw[1:4] == b"\xff\x00\x00"
     write_image(img, str(tmp_path / "a.bmp"))
     assert (tmp_path / "a.bmp").read_bytes()[:2] == b"BM"
+    pil = pytest.importorskip("PIL.Image")                     # --img_ext jpg (parsers/opts.py:25)
+    write_image(img, str(tmp_path / "a.jpg"))
+    with pil.open(tmp_path / "a.jpg") as im:
+        assert im.format == "JPEG" and im.size == (4, 3)
     write_image(img, str(tmp_path / "a.npy"))
     assert np.array_equal(np.load(tmp_path / "a.npy"), img, equal_nan=True)

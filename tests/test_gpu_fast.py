@@ -208,6 +208,30 @@ def test_c2_full_frame_every_pixel_128_spp_product_build(renderer, parsed, oracl
         assert ok, findings
 
 
+def test_c3_full_frame_every_pixel_64_spp_product_build(renderer, parsed, oracle_scene):
+    """BASELINE configs[2] (csphere: glass, mirror, Fresnel blend, four light samples per vertex, 16 bounces) at its full film size, 64 of its
+    1024 spp, product build against the oracle on the same Philox stream, EVERY pixel of the 512 x 512 film, un-gated (round 5 had a 128 x 96
+    crop and 8 x 8 tile means; ~10 s of the box's host threads).  Held to SURVEY 8(d) as it is worded: >= 99 % of the pixels within
+    1e-3 (1 + x), relMSE <= 1e-4 (run of record at 1024 spp, profiles/r05_full_size_parity.log: 99.970 %, 3.5e-8)."""
+    from oracle import binding as ob
+    tag, spp = "balls_mono", 64
+    r = renderer(tag)
+    assert (r.w, r.h) == (512, 512) and r.info()["arithmetic"] == "fast" and r.info()["traversal"] == "flat"
+    r.render(n_spp=spp)
+    acc, st = r.color.to_numpy(), r.stats()
+    rc = make_config(parsed(tag)[3])
+    ref, cnt, ost = oracle_scene(tag).render(rc, spp, threads=ob.num_threads())
+    fin = np.isfinite(acc).all(axis=2) & np.isfinite(ref).all(axis=2)
+    m = image_metrics(np.where(fin[..., None], acc, 0) / spp, np.where(fin[..., None], ref, 0) / spp)
+    record_metric("c3 full frame 64 spp product build", dict(m, n_shade=st["n_shade"], n_shade_oracle=ost["n_shade"], non_finite=int((~fin).sum())))
+    assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-4, m                        # SURVEY 8(d), verbatim
+    for k in ("n_shade", "n_shadow", "n_draws"):
+        assert abs(st[k] - ost[k]) <= 5e-5 * ost[k], (k, st[k], ost[k])
+    if not np.array_equal(np.isfinite(acc), np.isfinite(ref)):
+        ok, findings = oracle_scene(tag).explain_non_finite(rc, acc, ref, spp)
+        assert ok, findings
+
+
 def test_the_one_non_finite_pixel_of_c2_is_a_zero_pdf_knife_edge(renderer, parsed, oracle_scene):
     """BENCH_r03's parity leg: pixel (215, 277) of C2 is inf in the oracle's 512-spp render and finite in the product build's.  Sample 508
     of that pixel draws a cosine-hemisphere variate of exactly 0 at its first vertex (Philox word 0x000000a9 >> 8): pdf = 0, throughput =
@@ -420,12 +444,34 @@ def test_rays_with_a_zero_direction_component_get_the_reference_answer(renderer,
 
 
 # tag, width, height, spp, overrides, min fraction of pixels within 1e-3 (1 + |x|), max relMSE.
-# C1 (the config the tolerance is stated on) and the other diffuse Cornell renders hold SURVEY 8(d)'s per-pixel criterion with room to spare;
-# scenes with glass, mirrors or glossy lobes are chaotic in the hit point (an ulp in a hit is amplified by every bounce and re-draws the
-# path).  Every bound is the value MEASURED on MI355X (round 5, profiles/r05_parity_metrics.log; the GPU path is bit-reproducible, so
-# the measurement is a property of the build) with a margin of two on the failing fraction and on relMSE:
-#   measured: cbox 256 99.945 % / 2.9e-7, cbox 96 99.946 % / 5.2e-7, balls_mono 99.71 % / 3.8e-7, glass_box 96.8 % / 2.6e-5, features_a
-#   91.2 % / 7.3e-5, features_b 93.2 % / 3.7e-4, features_c 92.2 % / 8.7e-5, textured 98.0 % / 1.4e-4, microfacet 99.67 % / 5.5e-6
+#
+# SURVEY 8(d) states its tolerance ON C1: ">= 99 % of pixels within 1e-3 (1 + |x|) per channel at 64 spp (C1), image relMSE <= 1e-4".  The
+# product build meets it on C1 and on every BASELINE config (C2 / C3 at full film size: the two *_full_frame_every_pixel_* tests above;
+# C4 / C5: the crop tests below) and on the diffuse Cornell renders.  On the FEATURE scenes of this repo (glass, mirrors, glossy lobes in
+# a closed box at 96 x 96) the SAME-STREAM per-pixel criterion is not met, and the bounds below are NOT 8(d)'s: they are regression guards,
+# the value measured on MI355X (the GPU path is bit-reproducible, so the measurement is a property of the build; profiles/
+# r05_parity_metrics.log, re-recorded every round by record_metric) with a margin of two on the failing fraction and on relMSE.
+# Side by side, so that the relaxation is visible:
+#
+#   scene            8(d) asks (same stream)     product build, measured     exact build (asserted)     bound asserted here
+#   cbox 256 (C1)    >= 99 %, relMSE <= 1e-4     99.945 %, 2.9e-7            >= 99.5 %, <= 1e-4         99.89 %, 6e-7      (inside 8(d))
+#   cbox 96          >= 99 %, relMSE <= 1e-4     99.946 %, 5.2e-7            >= 99.5 %, <= 1e-4         99.89 %, 1.1e-6    (inside 8(d))
+#   balls_mono (C3)  >= 99 %, relMSE <= 1e-4     99.71 %, 3.8e-7             >= 99.5 %, <= 1e-4         99.4 %, 8e-7       (inside 8(d))
+#   microfacet       >= 99 %, relMSE <= 1e-4     99.67 %, 5.5e-6             >= 99.5 %, <= 1e-4         99.3 %, 1.2e-5     (inside 8(d))
+#   textured         >= 99 %, relMSE <= 1e-4     98.0 %, 1.4e-4              >= 99.5 %, <= 1e-4         96 %, 3e-4         (OUTSIDE: per-pixel and relMSE)
+#   glass_box        >= 99 %, relMSE <= 1e-4     96.8 %, 2.6e-5              >= 99.5 %, <= 1e-4         93.6 %, 5.5e-5     (OUTSIDE: per-pixel)
+#   features_a       >= 99 %, relMSE <= 1e-4     91.2 %, 7.3e-5              >= 99.5 %, <= 1e-4         82.4 %, 1.5e-4     (OUTSIDE: per-pixel)
+#   features_b       >= 99 %, relMSE <= 1e-4     93.2 %, 3.7e-4              >= 99.5 %, <= 1e-4         86.3 %, 7.5e-4     (OUTSIDE: per-pixel and relMSE)
+#   features_c       >= 99 %, relMSE <= 1e-4     92.2 %, 8.7e-5              >= 99.5 %, <= 1e-4         84.3 %, 1.8e-4     (OUTSIDE: per-pixel)
+#
+# Why outside, and what stands in for the per-pixel criterion there: a specular or glossy path is chaotic in its hit point - an ulp of
+# difference in one hit (the flat sweep's precomputed-transform test against the reference's adjugate solve, both within 1e-5 t) is amplified
+# by every bounce until a branch flips and the REST of the path is re-drawn; the pixel then carries another, equally valid sample.  That is
+# a property of comparing two float32 intersectors on one random stream, not an error of the estimator, and 8(d) provides the check that
+# separates the two: "relMSE(HIP, CPU-other-seed) within 1.5x of relMSE(CPU-seedA, CPU-seedB)".  test_statistical_cross_check_other_seed
+# asserts exactly that for EVERY scene of this table (round 6: features_a / b / c, glass_box, microfacet added), and
+# test_no_systematic_difference_between_the_builds holds the product build's vertex counts, energy and image to the exact build's on every
+# one of them at 1 024 - 2 048 spp.  The exact build (tests/test_gpu_parity.py) holds 8(d) verbatim on all of these scenes.
 IMAGE_CASES = [
     ("cbox", 256, 256, 64, {"max_bounce": 4}, 0.9989, 6e-7),
     ("cbox", 96, 96, 64, {}, 0.9989, 1.1e-6),
@@ -470,14 +516,21 @@ def test_image_matches_reference_run(tag, renderer):
     assert abs(r.stats()["n_draws"] - int(g["draws"].sum())) <= max(2e-3 * int(g["draws"].sum()), 250)       # (a re-drawn glass path of features_c is ~80 draws; two or three of them differ in a render this small, in either direction)
 
 
-@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "textured"])
+# same-seed relMSE bound at 48 x 48 x 64 spp as a fraction of the seed-to-seed noise floor (measured x 2, recorded by record_metric): the scenes
+# that hold 8(d)'s 1e-4 outright carry None
+_SAME_SEED_FRACTION_OF_NOISE = {"cbox": None, "balls_mono": None, "microfacet": None, "textured": 1e-2, "glass_box": 5e-2, "features_a": 5e-2, "features_b": 5e-2, "features_c": 5e-2}
+
+
+@pytest.mark.parametrize("tag", ["cbox", "balls_mono", "textured", "glass_box", "features_a", "features_b", "features_c", "microfacet"])
 def test_statistical_cross_check_other_seed(tag, renderer, parsed, oracle_scene):
-    """the product build is the same ESTIMATOR, not merely the same stream - against a CPU render with ANOTHER seed its relMSE
-    stays within 1.5x of the relMSE between two CPU renders with different seeds (the same seeds as the exact build's test)."""
+    """SURVEY 8(d), as it is worded: "relMSE(HIP, CPU-other-seed) within 1.5x of relMSE(CPU-seedA, CPU-seedB)" - the product build is the same
+    ESTIMATOR, not merely the same stream.  Every scene of IMAGE_CASES (round 6: the five feature scenes added - the ones whose same-stream
+    per-pixel agreement is below 8(d)'s 99 %, for which this is the check that says the difference is re-drawn paths and not a bias)."""
     w, h, spp = 48, 48, 64
 
     def rel(a, b):
-        return float(np.mean((a - b) ** 2 / (b ** 2 + 1e-2)))
+        fin = np.isfinite(a).all(axis=2) & np.isfinite(b).all(axis=2)
+        return float(np.mean((a[fin] - b[fin]) ** 2 / (b[fin] ** 2 + 1e-2)))
     cpu = {}
     for seed in (0, 1, 2):
         rc = make_config(parsed(tag)[3], width=w, height=h, seed=seed)
@@ -486,11 +539,14 @@ def test_statistical_cross_check_other_seed(tag, renderer, parsed, oracle_scene)
     r.render(n_spp=spp)
     hip = r.pixels.to_numpy().astype(np.float64)
     noise = rel(cpu[1], cpu[2])
+    same = rel(hip, cpu[0])
+    record_metric(f"other-seed cross-check {tag}", {"noise_cpu1_cpu2": noise, "hip_vs_cpu1": rel(hip, cpu[1]), "hip_vs_cpu2": rel(hip, cpu[2]), "hip_vs_cpu0_same_seed": same})
     assert noise > 0 and rel(hip, cpu[1]) <= 1.5 * noise and rel(hip, cpu[2]) <= 1.5 * noise, (rel(hip, cpu[1]), rel(hip, cpu[2]), noise)
-    assert rel(hip, cpu[0]) <= (1e-4 if tag != "textured" else 1e-2 * noise) < noise              # and on the SAME seed it is the same image, far below the noise floor
+    frac = _SAME_SEED_FRACTION_OF_NOISE[tag]
+    assert same <= (1e-4 if frac is None else frac * noise) < noise, (same, noise)      # and on the SAME seed it is the same image, far below the noise floor
 
 
-@pytest.mark.parametrize("tag,spp", [("textured", 1024), ("features_a", 2048), ("cbox", 2048), ("glass_box", 1024)])
+@pytest.mark.parametrize("tag,spp", [("textured", 1024), ("features_a", 2048), ("cbox", 2048), ("glass_box", 1024), ("balls_mono", 1024), ("features_b", 1024), ("features_c", 1024), ("microfacet", 1024)])
 def test_no_systematic_difference_between_the_builds(tag, spp, renderer):
     """The bias probe of round 3 (tools/gpu_bias_probe.py, profiles/r03_bias_probe.log) as a test: at a sample count where the per-pixel
     chaos of ulp-level hit differences averages out, the product build shades the same number of vertices as the exact build on the same

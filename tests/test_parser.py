@@ -178,6 +178,60 @@ def test_textured_scene_parse(parsed, flat):
     assert np.array_equal(fs.tex_f[o, 2], np.float32([1.0, 2.0]))
 
 
+def test_jpeg_albedo_map_loads_and_matches_the_ppm_of_the_same_image(tmp_path):
+    """Every textured scene the reference ships names .jpg files (scenes/cbox/bunny.xml:176-186; texture.py:61 reads them with cv.imread).
+    scenes/test/textured.xml with its albedo maps re-encoded as JPEG (quality 100, no chroma subsampling) parses to the same records and
+    to atlases within JPEG's loss of the PPM-fed ones."""
+    Image = pytest.importorskip("PIL.Image")
+    from adapt_amd.parsers import scene_parsing
+    from adapt_amd.parsers.image_io import imread_rgb
+    from adapt_amd.scene_pack import pack_scene
+    src = os.path.join(ROOT, "scenes", "test")
+    xml = open(os.path.join(src, "textured.xml")).read()
+    assert "scenes/test/tex/wood.ppm" in xml and "scenes/test/tex/tiles.ppm" in xml
+    os.makedirs(tmp_path / "tex")
+    for name in os.listdir(os.path.join(src, "tex")):
+        rgb = imread_rgb(os.path.join(src, "tex", name))
+        if name in ("wood.ppm", "tiles.ppm"):
+            Image.fromarray(rgb, "RGB").save(tmp_path / "tex" / name.replace(".ppm", ".jpg"), format="JPEG", quality=100, subsampling=0)
+        else:
+            Image.fromarray(rgb, "RGB").save(tmp_path / "tex" / name.replace(".ppm", ".png"), format="PNG")      # (and the PNG reader on the way)
+    xml = xml.replace("wood.ppm", "wood.jpg").replace("tiles.ppm", "tiles.jpg").replace("_bump.ppm", "_bump.png").replace("_normal.ppm", "_normal.png")
+    xml = xml.replace("scenes/test/tex/", str(tmp_path / "tex") + "/")
+    xml = xml.replace('value="../meshes/', 'value="' + os.path.join(ROOT, "scenes", "meshes") + "/").replace('value="meshes/', 'value="' + os.path.join(src, "meshes") + "/")
+    (tmp_path / "textured_jpg.xml").write_text(xml)
+    a = pack_scene(*scene_parsing(str(tmp_path), "textured_jpg.xml"))
+    b = pack_scene(*scene_parsing(src, "textured.xml"))
+    assert np.array_equal(a.tex_i, b.tex_i) and np.array_equal(a.tex_f, b.tex_f) and np.array_equal(a.uvs, b.uvs)
+    assert np.array_equal(a.atlas[1], b.atlas[1]) and np.array_equal(a.atlas[2], b.atlas[2])            # PNG: lossless
+    d = np.abs(a.atlas[0] - b.atlas[0]) * 255.0
+    assert d.max() <= 4.01 and d.mean() <= 0.6, (d.max(), d.mean())                                     # JPEG at quality 100: a level or two (measured: max 3, mean 0.21)
+    jpg = imread_rgb(str(tmp_path / "tex" / "wood.jpg"))
+    assert jpg.dtype == np.uint8 and jpg.shape == (32, 48, 3)
+
+
+def test_oversized_textures_are_resized_like_cv_resize(tmp_path):
+    """texture.py:65-68: a side above max_size is clamped to it (each side on its own) and the image goes through cv.resize's default
+    (bilinear, pixel centres, 11-bit fixed point).  Known answers of the restatement, and the Texture_np path through it."""
+    import xml.etree.ElementTree as xet
+    from adapt_amd.parsers.image_io import resize_bilinear_u8, write_ppm
+    from adapt_amd.textures import Texture_np
+    rs = np.random.RandomState(3)
+    img = rs.randint(0, 256, size=(6, 8, 3)).astype(np.uint8)
+    assert np.array_equal(resize_bilinear_u8(img, 8, 6), img)
+    assert np.array_equal(resize_bilinear_u8(np.full((9, 7, 3), 77, np.uint8), 3, 4), np.full((4, 3, 3), 77, np.uint8))
+    # 4 -> 2 along x: sample positions 0.5 and 2.5 - the mean of pixels (0, 1) and (2, 3), rounded half up by the +2 >> 2
+    row = np.uint8([[[10, 0, 255], [20, 0, 255], [30, 1, 0], [41, 2, 0]]])
+    assert resize_bilinear_u8(row, 2, 1).tolist() == [[[15, 0, 255], [36, 2, 0]]]
+    # upscaling clamps at the borders: the first and last samples sit outside the pixel centres
+    up = resize_bilinear_u8(np.uint8([[[0], [100]]]), 4, 1)[0, :, 0]
+    assert up.tolist() == [0, 25, 75, 100]
+    write_ppm(str(tmp_path / "big.ppm"), rs.randint(0, 256, size=(5, 40, 3)).astype(np.uint8))
+    el = xet.fromstring(f'<texture type="image" id="big" tag="albedo"><string name="filename" value="{tmp_path / "big.ppm"}"/></texture>')
+    t = Texture_np(el, max_size=16)
+    assert (t.w, t.h) == (16, 5) and t.texture_img.shape == (5, 16, 3) and t.texture_img.dtype == np.float32
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/scenes"), reason="reference tree only exists in the authoring container")
 def test_textured_scene_matches_reference_parser(flat):
     """The reference's own parser (OpenCV / rectpack replaced by the generator's stand-ins) on scenes/test/textured.xml: same
