@@ -15,11 +15,11 @@ rm -rf $OUT; mkdir -p $OUT $ROOT/gpurun_out/profiles
 export TMPDIR=/tmp
 cd /tmp
 CMD="python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --spp $SPP --lanes 1 --no-cpu-baseline --no-profile"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/pmc_sq -o sq -- $CMD > $OUT/pmc_sq.log 2>&1
-rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM --kernel-trace -d $OUT/pmc_sq2 -o sq2 -- $CMD > $OUT/pmc_sq2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- $CMD > $OUT/pmc_write.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $CMD > $OUT/stats.log 2>&1
+timeout 420 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/pmc_sq -o sq -- $CMD > $OUT/pmc_sq.log 2>&1
+timeout 420 rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM --kernel-trace -d $OUT/pmc_sq2 -o sq2 -- $CMD > $OUT/pmc_sq2.log 2>&1
+timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- $CMD > $OUT/pmc_fetch.log 2>&1
+timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- $CMD > $OUT/pmc_write.log 2>&1
 cd $ROOT
 TXT=$ROOT/gpurun_out/profiles/$(printf "r%02d" $RND)_${CFG}_rocprofv3.txt
 { echo "# rocprofv3 passes of: bench.py --config $CFG --steps 1 --warmup 1 --spp $SPP --lanes 1 --no-cpu-baseline --no-profile"; echo "# (1 + $SPP + $SPP spp rendered per pass: kernel-load render, warm-up step, timed step; tools/pmc_round.sh)"; python $ROOT/tools/summarize_prof.py $OUT; } > $TXT 2>&1
