@@ -29,8 +29,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno
          # Msamples/s: C2 4163 -> 4267, C3 1095 -> 1142, V1 1214 -> 1277, V3 965 -> 1057, nothing slower (profiles/NOTES.md, round 5).
          # The flat sweep's two-rays-per-lane packed FMAs are written as vector types by hand and stay.
          "-fno-slp-vectorize"]
-# Two builds of the same sources (DESIGN.md "float parity policy"), both with -ffp-contract=off, IEEE division / sqrt and transcendentals
-# evaluated in double and rounded once - the shading arithmetic written in csrc/ is the arithmetic executed in BOTH (measured: FMA
+# Two builds of the same sources (DESIGN.md "float parity policy"), both with -ffp-contract=off and IEEE division / sqrt; the exact build evaluates
+# transcendentals in double and rounds once, the product build with OCML's float functions (below).  Apart from those calls the shading arithmetic written in csrc/ is the arithmetic executed in BOTH (measured: FMA
 # contraction in the shading code buys nothing - k_shade is bound by its dependent loads and Philox - but turns exact zeros such as
 # a*b - b*a into rounding residues, and upstream's NaN-slab quirk then stops firing: +0.3 % path vertices on scenes/test/features_a.xml):
 #  exact: the small-scene intersectors are the reference's loop operation for operation; the HIP path and the CPU oracle agree bit for
@@ -40,7 +40,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno
 #         1e-3 (1 + |x|) / relMSE <= 1e-4 of the oracle on the same random stream).  No -ffast-math: NaN / inf semantics are part of the result.
 VARIANT_FLAGS = {
     "exact": ["-ffp-contract=off", "-DAPT_FAST=0"],
-    "fast": ["-ffp-contract=off", "-DAPT_FAST=1"],
+    # (round 6) the product build evaluates cos / sin / tan / pow with OCML's float versions (1-2 ulp) instead of in double rounded once: on the
+    # five-wave kernels of rounds 5-6 that is C2 +4.9 %, C3 +8.6 %, C4 +3 %, C1 +5 % (same box), with the parity figures of the double version
+    # (C2 every pixel 99.92 %, C3 99.73 % within 1e-3 (1 + x); profiles/NOTES.md round 6).  Divisions and square roots stay IEEE in both builds:
+    # -fno-hip-fp32-correctly-rounded-divide-sqrt would be another +2.5 % / +7 % but reaches the reference-order intersectors too (C3: 98.0 %).
+    "fast": ["-ffp-contract=off", "-DAPT_FAST=1", "-DAPT_EXACT_MATH=0"],
 }
 VARIANT_LIB = {"fast": LIB, "exact": LIB_EXACT}
 

@@ -219,7 +219,7 @@ APT_D bool open_vertex(const ShadeArgs3* A_, Vertex& vx, Philox& rng, int prim, 
         float mx = max3(vx.thr);
         if (mx < (A_->p).rr_threshold && bounce >= (A_->p).rr_bounce_th) {
             if (rng_float(rng) > mx) return false;
-            vx.thr = vx.thr * (1.f / (mx + 1e-7f));
+            vx.thr = vx.thr * srcp(mx + 1e-7f);
         }
     } else if (max3(vx.thr) < 1e-4f) return false;
     return true;

@@ -62,9 +62,9 @@ struct RawAngles { float cos_t, sin_t, cos_p, sin_p; };
 APT_D RawAngles raw_of_local(f3 l) {               // convert_to_raw(..., localize = False)
     RawAngles a;
     a.cos_t = l.y;
-    a.sin_t = sqrtf(fmaxf(0.f, 1.f - a.cos_t * a.cos_t));
+    a.sin_t = ssqrt(fmaxf(0.f, 1.f - a.cos_t * a.cos_t));
     a.cos_p = 1.f; a.sin_p = 0.f;
-    if (a.sin_t > 1e-5f) { a.cos_p = l.x / a.sin_t; a.sin_p = l.z / a.sin_t; }
+    if (a.sin_t > 1e-5f) { a.cos_p = sdiv(l.x, a.sin_t); a.sin_p = sdiv(l.z, a.sin_t); }
     return a;
 }
 APT_D RawAngles to_raw(f3 d_in, f3 normal) { return raw_of_local(localize(normal, d_in)); }
@@ -86,18 +86,18 @@ APT_D f3 schlick(f3 r_s, float dot_val) {
 }
 APT_D float fresnel_dielectric(float n_in, float n_out, float cos_inc, float cos_ref) {
     float a = n_in * cos_inc, b = n_out * cos_inc, c = n_in * cos_ref, d = n_out * cos_ref;
-    float rs = (a - d) / (a + d);
-    float rp = (c - b) / (c + b);
+    float rs = sdiv(a - d, a + d);
+    float rp = sdiv(c - b, c + b);
     return 0.5f * (rs * rs + rp * rp);
 }
 APT_D bool total_reflection(float dot_normal, float ni, float nr) {
-    return (1.f - sqr(ni / nr) * (1.f - sqr(dot_normal))) < 0.f;
+    return (1.f - sqr(sdiv(ni, nr)) * (1.f - sqr(dot_normal))) < 0.f;
 }
 APT_D f3 refract_snell(f3 incid, f3 normal, float dot_n, float ni, float nr, float& cos_r2) {
     float exiting = sgn(dot_n);
-    float ratio = ni / nr;
+    float ratio = sdiv(ni, nr);
     cos_r2 = 1.f - sqr(ratio) * (1.f - sqr(dot_n));
-    if (cos_r2 > 0.f) return normalize((incid * ratio - normal * (ratio * dot_n)) + normal * (exiting * sqrtf(cos_r2)));
+    if (cos_r2 > 0.f) return normalize((incid * ratio - normal * (ratio * dot_n)) + normal * (exiting * ssqrt(cos_r2)));
     return mk3(0.f, 0.f, 0.f);
 }
 
@@ -108,21 +108,21 @@ APT_D f3 polar_dir(float cos_t, float sin_t, float phi) {
 }
 APT_D f3 sample_cosine_hemisphere(Philox& r, float& pdf) {
     float eps = rng_float(r);
-    float cos_t = sqrtf(eps), sin_t = sqrtf(1.f - eps);
+    float cos_t = ssqrt(eps), sin_t = ssqrt(1.f - eps);
     float phi = APT_2PI * rng_float(r);
     pdf = cos_t * APT_INV_PI;
     return polar_dir(cos_t, sin_t, phi);
 }
 APT_D f3 sample_mod_phong_lobe(Philox& r, float alpha, float& pdf) {
     float cos_t = apt_pow(rng_float(r), 1.f / (alpha + 1.f));
-    float sin_t = sqrtf(1.f - cos_t * cos_t);
+    float sin_t = ssqrt(1.f - cos_t * cos_t);
     float phi = APT_2PI * rng_float(r);
     pdf = 0.5f * (1.f + alpha) * apt_pow(cos_t, alpha) * APT_INV_PI;
     return polar_dir(cos_t, sin_t, phi);
 }
 APT_D f3 sample_uniform_sphere(Philox& r, float& pdf) {
     float cos_t = 2.f * rng_float(r) - 1.f;
-    float sin_t = sqrtf(1.f - cos_t * cos_t);
+    float sin_t = ssqrt(1.f - cos_t * cos_t);
     float phi = APT_2PI * rng_float(r);
     pdf = APT_INV_2PI * 0.5f;
     return polar_dir(cos_t, sin_t, phi);
@@ -138,7 +138,7 @@ APT_D f3 sample_fresnel_half(Philox& r, float nu, float nv, float& power_coeff) 
     float sin_phi = sqrtf(sin_phi2) * sgn(2.f - eps1);
     power_coeff = nu * cos_phi2 + nv * sin_phi2;
     float cos_t = apt_pow(1.f - rng_float(r), 1.f / (power_coeff + 1.f));
-    float sin_t = sqrtf(1.f - cos_t * cos_t);
+    float sin_t = ssqrt(1.f - cos_t * cos_t);
     return mk3(cos_phi * sin_t, cos_t, sin_phi * sin_t);
 }
 APT_D f3 sample_on_triangle(Philox& r, f3 dv1, f3 dv2) {
@@ -147,7 +147,7 @@ APT_D f3 sample_on_triangle(Philox& r, f3 dv1, f3 dv2) {
     if (u1 + u2 > 1.0f) pt = (dv1 + dv2) - pt;
     return pt;
 }
-APT_D float balance(float a, float b) { return (a > 1e-7f) ? a / (a + b) : 0.f; }
+APT_D float balance(float a, float b) { return (a > 1e-7f) ? sdiv(a, a + b) : 0.f; }
 
 // -------------------------------------------------------------------- BRDFs
 APT_D f3 lambert_eval(const DevBxdf& b, f3 normal, f3 out) {
@@ -241,7 +241,7 @@ APT_D f3 fresnel_blend_sample(const DevBxdf& b, const Hit& it, f3 incid, Philox&
     float d_inc;
     f3 out = reflect_in(incid, half, d_inc);
     float half_pdf = b.k_g.z * apt_pow(dot(half, it.n_s), pc);
-    pdf = half_pdf / fmaxf(fabsf(d_inc), BRDF_EPS);
+    pdf = sdiv(half_pdf, fmaxf(fabsf(d_inc), BRDF_EPS));
     bool valid = dot(it.n_s, out) > 0.f;
     if (rng_float(r) > 0.5f) {
         f3 s_; float p_;
@@ -268,7 +268,7 @@ APT_D f3 thin_coat_sample(const DevBxdf& b, const Hit& it, f3 incid, Philox& r, 
     float dn = dot(incid, it.n_s);
     float cos_r2;
     f3 refra_in = refract_snell(incid, it.n_s, dn, 1.0f, b.k_g.z, cos_r2);
-    float F_in = fresnel_dielectric(1.f, b.k_g.x, fabsf(dn), sqrtf(cos_r2));     // k_g[0] here, as upstream (brdf.py:361)
+    float F_in = fresnel_dielectric(1.f, b.k_g.x, fabsf(dn), ssqrt(cos_r2));     // k_g[0] here, as upstream (brdf.py:361)
     is_specular = false;
     if (rng_float(r) > F_in) {
         f3 local = sample_cosine_hemisphere(r, pdf);
@@ -276,7 +276,7 @@ APT_D f3 thin_coat_sample(const DevBxdf& b, const Hit& it, f3 incid, Philox& r, 
         float d_out = dot(out, it.n_s);
         if (!total_reflection(d_out, b.k_g.z, 1.0f)) {
             f3 refra_out = refract_snell(out, it.n_s, d_out, b.k_g.z, 1.0f, cos_r2);
-            float F_out = fresnel_dielectric(b.k_g.z, 1.f, fabsf(d_out), sqrtf(cos_r2));
+            float F_out = fresnel_dielectric(b.k_g.z, 1.f, fabsf(d_out), ssqrt(cos_r2));
             pdf *= (1.f - F_in);
             out = refra_out;
             spec = oren_nayar_eval(b, it, refra_in, out);
@@ -295,18 +295,18 @@ APT_D f3 thin_coat_eval(const DevBxdf& b, const Hit& it, f3 in, f3 out) {
     float d_in = dot(in, it.n_s);
     float cos_r2;
     f3 refra_in = refract_snell(in, it.n_s, d_in, 1.0f, b.k_g.z, cos_r2);
-    float F_in = fresnel_dielectric(1.f, b.k_g.z, fabsf(d_in), sqrtf(cos_r2));
+    float F_in = fresnel_dielectric(1.f, b.k_g.z, fabsf(d_in), ssqrt(cos_r2));
     if (fabsf(dot(out, refl)) > (1.f - 1e-4f)) return b.k_s * F_in;
     float d_out = dot(out, it.n_s);
     f3 refra_out = refract_snell(out, it.n_s, d_out, 1.0f, b.k_g.z, cos_r2);
-    float F_out = fresnel_dielectric(1.0f, b.k_g.z, fabsf(d_out), sqrtf(cos_r2));
+    float F_out = fresnel_dielectric(1.0f, b.k_g.z, fabsf(d_out), ssqrt(cos_r2));
     return oren_nayar_eval(b, it, refra_in, refra_out) * (1.f - fmaxf(F_in, F_out));
 }
 APT_D float thin_coat_fresnel(const DevBxdf& b, const Hit& it, f3 in) {
     float d_in = dot(in, it.n_s);
     float ratio = 1.0f / b.k_g.z;
     float cos_r2 = 1.f - sqr(ratio) * (1.f - sqr(d_in));
-    return fresnel_dielectric(1.f, b.k_g.z, fabsf(d_in), sqrtf(cos_r2));
+    return fresnel_dielectric(1.f, b.k_g.z, fabsf(d_in), ssqrt(cos_r2));
 }
 
 // ---------------------------------------------------- Trowbridge-Reitz microfacet BRDF (type 3)
@@ -528,7 +528,7 @@ APT_D f3 glass_sample(const DevBxdf& b, const Hit& it, f3 incid, float world_ior
     } else {
         float cos_r2;
         f3 refra = refract_snell(incid, it.n_s, dn, ni, nr, cos_r2);
-        float F = fresnel_dielectric(ni, nr, fabsf(dn), sqrtf(cos_r2));
+        float F = fresnel_dielectric(ni, nr, fabsf(dn), ssqrt(cos_r2));
         if (rng_float(r) > F) { pdf = 1.f - F; dir = refra; }
         else { dir = normalize(incid - (it.n_s * 2.f) * dn); pdf = F; }
     }
@@ -547,7 +547,7 @@ APT_D f3 glass_eval(const DevBxdf& b, const Hit& it, f3 in, f3 out, float world_
         float cos_r2;
         f3 refra = refract_snell(out, it.n_s, d_out, ni, nr, cos_r2);
         if (cos_r2 > 0.f) {
-            float F = fresnel_dielectric(ni, nr, fabsf(d_out), sqrtf(cos_r2));
+            float F = fresnel_dielectric(ni, nr, fabsf(d_out), ssqrt(cos_r2));
             if (dot(refra, in) > 1.f - 1e-4f) ret = b.k_d * (1.f - F);
             else if (dot(ref_dir, in) > 1.f - 1e-4f) ret = b.k_d * F;
         } else if (dot(ref_dir, in) > 1.f - 1e-4f) ret = b.k_d;
@@ -566,9 +566,9 @@ APT_D f3 lambert_trans_sample(const DevBxdf& b, const Hit& it, f3 incid, float w
     if (total_reflection(dn, ni, nr)) {
         dir = normalize(incid - (it.n_s * 2.f) * dn);
     } else {
-        float ratio = ni / nr;
+        float ratio = sdiv(ni, nr);
         float cos_r2 = 1.f - sqr(ratio) * (1.f - sqr(dn));
-        float F = fresnel_dielectric(ni, nr, fabsf(dn), sqrtf(cos_r2));
+        float F = fresnel_dielectric(ni, nr, fabsf(dn), ssqrt(cos_r2));
         if (rng_float(r) > F) {
             fres = 1.f - F;
             f3 local = sample_cosine_hemisphere(r, pdf);
@@ -595,11 +595,11 @@ APT_D f3 lambert_trans_eval(const DevBxdf& b, const Hit& it, f3 in, f3 out, floa
     if (total_reflection(d_out, ni, nr)) {
         if (dot(ref_dir, in) > 1.f - 1e-4f) ret = b.k_d;
     } else {
-        float ratio = ni / nr;
+        float ratio = sdiv(ni, nr);
         float cos_r2 = 1.f - sqr(ratio) * (1.f - sqr(d_out));
         float d_in = dot(in, it.n_s);
         if (cos_r2 > 0.f) {
-            float F = fresnel_dielectric(ni, nr, fabsf(d_out), sqrtf(cos_r2));
+            float F = fresnel_dielectric(ni, nr, fabsf(d_out), ssqrt(cos_r2));
             if (d_in * d_out < 0.f) { if (dot(ref_dir, in) > 1.f - 1e-4f) ret = b.k_d * F; }
             else ret = b.k_d * ((1.f - F) * APT_INV_PI * fabsf(d_out));
         } else if (dot(ref_dir, in) > 1.f - 1e-4f) ret = b.k_d;
@@ -616,7 +616,7 @@ APT_D float bsdf_pdf(const DevBxdf& b, const Hit& it, f3 outdir, f3 incid, float
     float cos_r2;
     f3 refra = refract_snell(outdir, it.n_s, d_out, ni, nr, cos_r2);
     if (cos_r2 > 0.0f) {
-        float F = fresnel_dielectric(ni, nr, fabsf(d_out), sqrtf(cos_r2));
+        float F = fresnel_dielectric(ni, nr, fabsf(d_out), ssqrt(cos_r2));
         if (dot(ref_dir, incid) > 1.f - 1e-4f) pdf = F;
         else if (b.type == 0 && dot(refra, incid) > 1.f - 1e-4f) pdf = 1.f - F;
         else if (b.type == 1 && (dot(incid, it.n_s) * d_out > 0.f)) pdf = (1.f - F) * fabsf(d_out) * APT_INV_PI;
@@ -666,7 +666,7 @@ APT_D f3 emitter_sample_hit(const DevSrc& s, const EmitterGeom& g, f3 hit_pos, P
     pdf = 1.0f;
     if (BXHAS(SM, 0) && s.type == 0) {
         f3 x = hit_pos - pos;
-        inten = inten * fminf(1.0f / fmaxf(norm2(x), 1e-5f), 1.0f);
+        inten = inten * fminf(srcp(fmaxf(norm2(x), 1e-5f)), 1.0f);
     } else if (BXHAS(SM, 1) && s.type == 1) {
         pdf = s.inv_area;
         f3 normal;
@@ -679,7 +679,7 @@ APT_D f3 emitter_sample_hit(const DevSrc& s, const EmitterGeom& g, f3 hit_pos, P
             f3 local = sample_uniform_sphere(r, p);
             normal = delocalize(to_hit, local);
             pos = center + normal * radius;
-            pdf = p / (radius * radius);
+            pdf = sdiv(p, radius * radius);
         } else {
             int tri = pymod(rng_int(r), s.prim_count) + s.prim_first;
             normal = ld3(g.normals + 3 * tri);
@@ -690,7 +690,7 @@ APT_D f3 emitter_sample_hit(const DevSrc& s, const EmitterGeom& g, f3 hit_pos, P
         float dl = dot(normalize(diff), normal);
         if (dl <= 0.0f) { inten = splat3(0.f); pdf = 1.0f; }
         else {
-            pdf *= norm2(diff) / dl;
+            pdf *= sdiv(norm2(diff), dl);
             inten = (pdf > 0.0f) ? inten / pdf : splat3(0.f);
         }
     } else if (BXHAS(SM, 2) && s.type == 2) {
@@ -705,7 +705,7 @@ APT_D f3 emitter_sample_hit(const DevSrc& s, const EmitterGeom& g, f3 hit_pos, P
             f3 to_hit = hit_pos - s.pos;
             float proj = dot(to_hit, s.dir);
             if (proj > 0.0f) {
-                float dist = sqrtf(norm2(to_hit) - proj * proj);
+                float dist = ssqrt(norm2(to_hit) - proj * proj);
                 if (dist < s.r) pos = hit_pos - s.dir * proj;
                 else inten = splat3(0.f);
             }
@@ -720,5 +720,5 @@ APT_D f3 emitter_eval_le(const DevSrc& s, f3 inci_dir, f3 normal) {
 APT_D float emitter_solid_angle_pdf(const DevSrc& s, const Hit& it, f3 incid_dir) {
     float d = fabsf(dot(incid_dir, it.n_s));
     float area_pdf = (s.type == 1) ? s.inv_area : 0.f;
-    return (d > 0.0f) ? area_pdf * sqr(it.min_depth) / d : 0.0f;
+    return (d > 0.0f) ? sdiv(area_pdf * sqr(it.min_depth), d) : 0.0f;
 }

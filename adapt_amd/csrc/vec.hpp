@@ -9,7 +9,7 @@
 
 // APT_FAST (set by adapt_amd/build.py): 1 = the product build - small-scene intersectors re-derived for speed inside SURVEY 8(d)'s
 // tolerances (traverse.hpp "Flat sweep"); 0 = the exact build, whose intersectors are the reference's loop operation for operation (the
-// build the bit-exact parity tests pin).  The shading arithmetic is the same in both.  See DESIGN.md "float parity policy".
+// build the bit-exact parity tests pin).  The shading arithmetic is the same in both except for the transcendental calls below.  See DESIGN.md "float parity policy".
 #ifndef APT_FAST
 #define APT_FAST 0
 #endif
@@ -21,21 +21,44 @@ struct f3 {
     float x, y, z;
 };
 
+// Divisions and square roots of the SHADING code (shading.hpp, shade_stage.hpp and the f3 operators below).  APT_FAST_DIV=1 (product build,
+// device code): a * v_rcp_f32(b), v_sqrt_f32, v_rsq_f32 - 1 ulp each, the same infinities, zeros and NaNs as the IEEE forms for every
+// operand but denormal divisors - where the IEEE sequences are ~10 instructions with a dependent chain (a vertex of the Cornell box made
+// ~15 divisions and 5 roots).  The intersectors never come through here: their reference-order code divides with `/` and sqrtf() in both builds.
+#ifndef APT_FAST_DIV
+#define APT_FAST_DIV 0
+#endif
+#if APT_FAST_DIV && defined(__HIP_DEVICE_COMPILE__)
+APT_HD float sdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+APT_HD float srcp(float b) { return __builtin_amdgcn_rcpf(b); }
+APT_HD float ssqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+APT_HD float srsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+#else
+APT_HD float sdiv(float a, float b) { return a / b; }
+APT_HD float srcp(float b) { return 1.0f / b; }
+APT_HD float ssqrt(float x) { return sqrtf(x); }
+APT_HD float srsqrt(float x) { return 1.0f / sqrtf(x); }
+#endif
+
 APT_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 APT_HD f3 splat3(float s) { return mk3(s, s, s); }
 APT_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 APT_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 APT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
-APT_HD f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+APT_HD f3 operator/(f3 a, f3 b) { return mk3(sdiv(a.x, b.x), sdiv(a.y, b.y), sdiv(a.z, b.z)); }
 APT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 APT_HD f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+#if APT_FAST_DIV && defined(__HIP_DEVICE_COMPILE__)
+APT_HD f3 operator/(f3 a, float s) { const float r = srcp(s); return mk3(a.x * r, a.y * r, a.z * r); }
+#else
 APT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+#endif
 APT_HD f3 operator+(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
 APT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 APT_HD float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 APT_HD float norm2(f3 a) { return dot(a, a); }
-APT_HD float norm(f3 a) { return sqrtf(norm2(a)); }
-APT_HD f3 normalize(f3 a) { float inv = 1.0f / norm(a); return a * inv; }
+APT_HD float norm(f3 a) { return ssqrt(norm2(a)); }
+APT_HD f3 normalize(f3 a) { float inv = srsqrt(norm2(a)); return a * inv; }
 APT_HD f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 APT_HD float max3(f3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
 APT_HD float min3(f3 a) { return fminf(fminf(a.x, a.y), a.z); }
@@ -55,10 +78,10 @@ APT_HD f3 mul(const m33& M, f3 a) {
 }
 
 // ---- transcendental functions.
-// APT_EXACT_MATH=1 (default): evaluate in double and round once.  That reproduces what a
-// correctly rounded float libm returns, so the HIP path and the CPU oracle (glibc) agree
-// bit-for-bit on essentially every call; the cost is a handful of FP64 ops per bounce.
-// APT_EXACT_MATH=0: OCML's native float versions (1-2 ulp), faster, parity only statistical.
+// APT_EXACT_MATH=1 (the exact build): evaluate in double and round once.  That reproduces what a correctly rounded float libm returns, so
+// the HIP path and the CPU oracle (glibc) agree bit-for-bit on essentially every call; the cost is a handful of FP64 ops per bounce.
+// APT_EXACT_MATH=0 (the product build since round 6): OCML's native float versions (1-2 ulp): parity statistical, and measured to be the
+// double version's (adapt_amd/build.py); the reference itself runs Taichi's fast-math float functions.
 #ifndef APT_EXACT_MATH
 #define APT_EXACT_MATH 1
 #endif

@@ -116,11 +116,16 @@ def test_fix_up_lists_carry_every_ray_when_asked_to(tag, kw, renderer, monkeypat
     f = renderer(tag, width=w, height=h, **kw)
     assert f.info()["traversal"] == "flat" and f.info()["arithmetic"] == "fast"
     f.render(n_spp=spp); img = f.color.to_numpy(); st = f.stats()
-    for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"):
-        assert st[k] == est[k], (k, st[k], est[k])
-    if f.num_shadow_ray == 1: assert np.array_equal(img, ref, equal_nan=True)
-    else:                                     # several light samples per vertex: the product build adds a vertex's samples first, then the vertex to the slot
-        assert np.allclose(img, ref, rtol=1e-6, atol=1e-6 * float(np.nanmax(np.abs(ref))), equal_nan=True)     # (the exact build keeps one radiance plane per sample): the last bit of a sum
+    # Rounds 3-5 asserted equality to the last count and bit here: the product build then shaded with the exact build's arithmetic.  Since round 6
+    # it evaluates cos / sin / pow in float (adapt_amd/build.py), so a sampled direction differs in its last bit now and then and a handful of the
+    # ~10^4 paths of this render take another branch: counts agree to 1.5e-3 (measured with every ray deferred: 7e-5 .. 4.8e-4), pixels as far as a
+    # re-drawn path among six samples lets them.  What "every ray through the lists" must still deliver to the last count is the SAMPLES.
+    assert st["n_samples"] == est["n_samples"]
+    for k in ("n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"):
+        assert abs(st[k] - est[k]) <= max(1.5e-3 * est[k], 8), (k, st[k], est[k])
+    m = image_metrics(img / spp, ref / spp)
+    record_metric(f"fix-up lists carry every ray {tag} {kw}", m)
+    assert m["frac_within"] >= 0.95 and abs(np.nanmean(img) - np.nanmean(ref)) <= 0.02 * np.nanmean(ref), m
 
 
 @pytest.mark.parametrize("tag,kw", [("cbox", {}), ("cbox", {"max_bounce": 1}), ("glass_box", {"num_shadow_ray": 1}), ("balls_mono", {"num_shadow_ray": 1}), ("textured", {"num_shadow_ray": 1})])
@@ -450,19 +455,19 @@ def test_rays_with_a_zero_direction_component_get_the_reference_answer(renderer,
 # C4 / C5: the crop tests below) and on the diffuse Cornell renders.  On the FEATURE scenes of this repo (glass, mirrors, glossy lobes in
 # a closed box at 96 x 96) the SAME-STREAM per-pixel criterion is not met, and the bounds below are NOT 8(d)'s: they are regression guards,
 # the value measured on MI355X (the GPU path is bit-reproducible, so the measurement is a property of the build; profiles/
-# r05_parity_metrics.log, re-recorded every round by record_metric) with a margin of two on the failing fraction and on relMSE.
+# r06_parity_metrics.log - round 6's product build, float transcendentals - re-recorded every round by record_metric) with a margin of two on the failing fraction and on relMSE.
 # Side by side, so that the relaxation is visible:
 #
 #   scene            8(d) asks (same stream)     product build, measured     exact build (asserted)     bound asserted here
 #   cbox 256 (C1)    >= 99 %, relMSE <= 1e-4     99.945 %, 2.9e-7            >= 99.5 %, <= 1e-4         99.89 %, 6e-7      (inside 8(d))
 #   cbox 96          >= 99 %, relMSE <= 1e-4     99.946 %, 5.2e-7            >= 99.5 %, <= 1e-4         99.89 %, 1.1e-6    (inside 8(d))
 #   balls_mono (C3)  >= 99 %, relMSE <= 1e-4     99.71 %, 3.8e-7             >= 99.5 %, <= 1e-4         99.4 %, 8e-7       (inside 8(d))
-#   microfacet       >= 99 %, relMSE <= 1e-4     99.67 %, 5.5e-6             >= 99.5 %, <= 1e-4         99.3 %, 1.2e-5     (inside 8(d))
+#   microfacet       >= 99 %, relMSE <= 1e-4     99.59 %, 6.6e-6             >= 99.5 %, <= 1e-4         99.2 %, 1.4e-5     (inside 8(d))
 #   textured         >= 99 %, relMSE <= 1e-4     98.0 %, 1.4e-4              >= 99.5 %, <= 1e-4         96 %, 3e-4         (OUTSIDE: per-pixel and relMSE)
-#   glass_box        >= 99 %, relMSE <= 1e-4     96.8 %, 2.6e-5              >= 99.5 %, <= 1e-4         93.6 %, 5.5e-5     (OUTSIDE: per-pixel)
-#   features_a       >= 99 %, relMSE <= 1e-4     91.2 %, 7.3e-5              >= 99.5 %, <= 1e-4         82.4 %, 1.5e-4     (OUTSIDE: per-pixel)
-#   features_b       >= 99 %, relMSE <= 1e-4     93.2 %, 3.7e-4              >= 99.5 %, <= 1e-4         86.3 %, 7.5e-4     (OUTSIDE: per-pixel and relMSE)
-#   features_c       >= 99 %, relMSE <= 1e-4     92.2 %, 8.7e-5              >= 99.5 %, <= 1e-4         84.3 %, 1.8e-4     (OUTSIDE: per-pixel)
+#   glass_box        >= 99 %, relMSE <= 1e-4     96.3 %, 3.4e-5              >= 99.5 %, <= 1e-4         92.6 %, 6.8e-5     (OUTSIDE: per-pixel)
+#   features_a       >= 99 %, relMSE <= 1e-4     89.5 %, 1.75e-4             >= 99.5 %, <= 1e-4         79 %, 3.5e-4       (OUTSIDE: per-pixel and relMSE)
+#   features_b       >= 99 %, relMSE <= 1e-4     92.3 %, 4.7e-4              >= 99.5 %, <= 1e-4         84.6 %, 9.4e-4     (OUTSIDE: per-pixel and relMSE)
+#   features_c       >= 99 %, relMSE <= 1e-4     90.1 %, 1.33e-4             >= 99.5 %, <= 1e-4         80 %, 2.7e-4       (OUTSIDE: per-pixel and relMSE)
 #
 # Why outside, and what stands in for the per-pixel criterion there: a specular or glossy path is chaotic in its hit point - an ulp of
 # difference in one hit (the flat sweep's precomputed-transform test against the reference's adjugate solve, both within 1e-5 t) is amplified
@@ -476,12 +481,12 @@ IMAGE_CASES = [
     ("cbox", 256, 256, 64, {"max_bounce": 4}, 0.9989, 6e-7),
     ("cbox", 96, 96, 64, {}, 0.9989, 1.1e-6),
     ("balls_mono", 96, 96, 64, {}, 0.994, 8e-7),
-    ("glass_box", 96, 96, 64, {}, 0.936, 5.5e-5),
-    ("features_a", 96, 96, 64, {}, 0.824, 1.5e-4),
-    ("features_b", 96, 96, 64, {}, 0.863, 7.5e-4),
-    ("features_c", 96, 96, 64, {}, 0.843, 1.8e-4),
+    ("glass_box", 96, 96, 64, {}, 0.926, 6.8e-5),
+    ("features_a", 96, 96, 64, {}, 0.79, 3.5e-4),
+    ("features_b", 96, 96, 64, {}, 0.846, 9.4e-4),
+    ("features_c", 96, 96, 64, {}, 0.80, 2.7e-4),
     ("textured", 64, 48, 16, {}, 0.96, 3e-4),           # (its normal-mapped wall sends out rays that are not of unit length: traverse.hpp flat_needs_cull)
-    ("microfacet", 64, 48, 16, {}, 0.993, 1.2e-5),
+    ("microfacet", 64, 48, 16, {}, 0.992, 1.4e-5),
 ]
 
 
@@ -513,7 +518,7 @@ def test_image_matches_reference_run(tag, renderer):
     r.render(n_spp=spp)
     m = image_metrics(r.pixels.to_numpy(), g["pixels"])
     assert m["frac_within"] >= 0.93 and m["relMSE"] <= 1e-2, m
-    assert abs(r.stats()["n_draws"] - int(g["draws"].sum())) <= max(2e-3 * int(g["draws"].sum()), 250)       # (a re-drawn glass path of features_c is ~80 draws; two or three of them differ in a render this small, in either direction)
+    assert abs(r.stats()["n_draws"] - int(g["draws"].sum())) <= max(2e-3 * int(g["draws"].sum()), 400)       # (a re-drawn glass path of features_c is ~80 draws; two or three of them differ in a render this small, in either direction)
 
 
 # same-seed relMSE bound at 48 x 48 x 64 spp as a fraction of the seed-to-seed noise floor (measured x 2, recorded by record_metric): the scenes
@@ -744,9 +749,12 @@ def test_full_size_c5_crop_product_build_vs_brute_force_oracle(cx, cy):
 @pytest.mark.parametrize("tag,mode", [("cbox", "tile"), ("balls_mono", "sweep"), ("features_b", "tile"), ("glass_box", "sweep"), ("features_a", "sweep")])
 def test_shipped_library_is_bit_checked_where_it_runs_the_reference_arithmetic(tag, mode, renderer, monkeypatch):
     """the bit-exact parity tests run on libadapt_mi_exact.so, the library that ships is libadapt_mi.so.  With APT_TRAVERSAL forced
-    to one of the exact build's small-scene intersectors (its tree walk tests leaves with its own records) the shipped library executes the same arithmetic in every stage - queues, class sorting, shading,
-    radiance slots, finalize - so its image and path statistics must be the exact build's bit for bit (one light sample per vertex or
-    radiance planes; more than four samples would be float atomics)."""
+    to one of the exact build's small-scene intersectors the shipped library executes the exact build's code in every stage - queues, class
+    sorting, radiance slots, finalize - and, through round 5, the same shading arithmetic: images and statistics were equal bit for bit.  Since
+    round 6 its cos / sin / tan / pow are OCML's float functions (adapt_amd/build.py), so what is left to assert is that NOTHING ELSE differs:
+    sample counts equal, every other count within 1.5e-3 (a few of ~10^4 paths re-drawn after a last-bit difference in a direction), the image
+    within a re-drawn path's reach.  Cornell box, one bounce (Lambertian + point light: its only transcendental is the azimuth of the
+    cosine-hemisphere sample, AFTER the last shaded vertex) stays bit-identical, which pins the rest of the pipeline to the bit."""
     w, h, spp = 64, 48, 5
     monkeypatch.setenv("APT_TRAVERSAL", mode)
     e = renderer(tag, width=w, height=h, exact=True)
@@ -754,9 +762,18 @@ def test_shipped_library_is_bit_checked_where_it_runs_the_reference_arithmetic(t
     assert f.info()["arithmetic"] == "fast" and f.info()["traversal"] == mode == e.info()["traversal"], (f.info(), e.info())
     e.render(n_spp=spp); f.render(n_spp=spp)
     se, sf = e.stats(), f.stats()
-    for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"):
-        assert sf[k] == se[k], (k, sf[k], se[k])
-    assert np.array_equal(f.color.to_numpy(), e.color.to_numpy(), equal_nan=True)
+    assert sf["n_samples"] == se["n_samples"]
+    for k in ("n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"):
+        assert abs(sf[k] - se[k]) <= max(1.5e-3 * se[k], 8), (k, sf[k], se[k])
+    m = image_metrics(f.color.to_numpy() / spp, e.color.to_numpy() / spp)
+    record_metric(f"shipped library on the exact build's intersector {tag} {mode}", m)
+    assert m["frac_within"] >= 0.95, m
+    if tag == "cbox":
+        e1 = renderer(tag, width=w, height=h, exact=True, max_bounce=1)
+        f1 = renderer(tag, width=w, height=h, max_bounce=1)
+        e1.render(n_spp=spp); f1.render(n_spp=spp)
+        assert all(e1.stats()[k] == f1.stats()[k] for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"))
+        assert np.array_equal(f1.color.to_numpy(), e1.color.to_numpy(), equal_nan=True)
 
 
 @pytest.mark.parametrize("which", ["bunnies1", "bunnies2", "balls_mono", "features_c"])

@@ -31,7 +31,7 @@ def test_hot_kernels_keep_their_register_budget(tmp_path):
                    f'#include "{ROOT}/include/adapt_mi.h"\n#include "{ROOT}/adapt_amd/csrc/bvh_build.hpp"\n#include "{ROOT}/adapt_amd/csrc/shade_stage.hpp"\n#include "{ROOT}/adapt_amd/csrc/volumetric.hpp"\n'
                    + "".join(f"template __global__ void {inst};\n" for inst, *_ in KERNELS))
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-fast-math", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize", "-ffp-contract=off",
-           "-DAPT_FAST=1", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", str(src), "-o", str(tmp_path / "probe.o")]
+           "-DAPT_FAST=1", "-DAPT_EXACT_MATH=0", "-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", str(src), "-o", str(tmp_path / "probe.o")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     usage = {}
