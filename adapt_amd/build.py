@@ -44,7 +44,10 @@ VARIANT_FLAGS = {
     # five-wave kernels of rounds 5-6 that is C2 +4.9 %, C3 +8.6 %, C4 +3 %, C1 +5 % (same box), with the parity figures of the double version
     # (C2 every pixel 99.92 %, C3 99.73 % within 1e-3 (1 + x); profiles/NOTES.md round 6).  Divisions and square roots stay IEEE in both builds:
     # -fno-hip-fp32-correctly-rounded-divide-sqrt would be another +2.5 % / +7 % but reaches the reference-order intersectors too (C3: 98.0 %).
-    "fast": ["-ffp-contract=off", "-DAPT_FAST=1", "-DAPT_EXACT_MATH=0"],
+    # -DAPT_FAST_DIV=1 (round 6): the divisions and square roots of the NON-DELTA shading code - light sampling, MIS weights, lobe sampling, throughput,
+    # roulette - as v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 (vec.hpp sdiv ...); mirrors, glass and every intersector keep IEEE.  Same box, on top of
+    # the float transcendentals: C2 4 873 -> 5 001, C3 1 257 -> 1 336, C4 1 975 -> 2 016; C2 every pixel 99.92 %, C3 99.62 % (with the delta code fast too: 97.8 %).
+    "fast": ["-ffp-contract=off", "-DAPT_FAST=1", "-DAPT_EXACT_MATH=0", "-DAPT_FAST_DIV=1"],
 }
 VARIANT_LIB = {"fast": LIB, "exact": LIB_EXACT}
 

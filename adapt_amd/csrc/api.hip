@@ -71,13 +71,16 @@ static const int kClassMask[APT_N_CLASS_DEFS] = {
 };
 static const char* kClassName[APT_N_CLASS_DEFS] = {"lambertian", "blinn-phong", "oren-nayar", "delta", "mod-phong", "fresnel-blend", "thin-coat", "lambert-trans", "microfacet", "blinn-phong(no lobe)"};
 // Class kernels in groups (shade_stage.hpp k_shade_group): one launch per GROUP and bounce instead of one per class.  Groups follow the register
-// footprints - a kernel allocates for its largest member: 0 = up to 128 VGPRs (four waves per SIMD), 1 = up to 168 (three), 2 = beyond (two).
+// footprints - a kernel allocates for its largest member: 0 = the lean classes, up to 96 VGPRs (five waves per SIMD), 1 = the rest, up to 128 (four).
 typedef void (*group_fn)(DevScene, Params, Queues, Counters*, GroupIn, int, int);
-#define APT_N_GROUPS 3
-static const int kClassGroup[APT_N_CLASS_DEFS] = {0, 1, 1, 0, 2, 2, 1, 0, 1, 0};      // class definition -> group
-static const int kClassSlot[APT_N_CLASS_DEFS] = {0, 0, 1, 1, 0, 1, 2, 2, 3, 3};       // ... and its member slot there (the B0..B3 order below)
-#define APT_GROUP_ROW(SM) {k_shade_group<SM, 4, 0x002, 0x504, 0x200, 0x801>, k_shade_group<SM, 3, 0x001, 0x040, 0x080, 0x008>, k_shade_group<SM, 1, 0x010, 0x020, 0, 0>}
-// (group 0 is held to four waves per SIMD: its members allocate 120-126 VGPRs alone, 129 together - the allocator then parks one 8-byte constant in scratch)
+#define APT_N_GROUPS 2
+static const int kClassGroup[APT_N_CLASS_DEFS] = {0, 1, 1, 0, 1, 1, 1, 0, 1, 0};      // class definition -> group
+static const int kClassSlot[APT_N_CLASS_DEFS] = {0, 0, 1, 1, 4, 5, 2, 2, 3, 3};       // ... and its member slot there (the B0..B5 order below)
+#ifndef APT_GROUP0_WAVES
+#define APT_GROUP0_WAVES 5
+#endif
+#define APT_GROUP_ROW(SM) {k_shade_group<SM, APT_GROUP0_WAVES, 0x002, 0x504, 0x200, 0x801>, k_shade_group<SM, 4, 0x001, 0x040, 0x080, 0x008, 0x010, 0x020>}
+// (group 0 at five waves: 93 VGPRs with point + spot lights, 96 and one 8-byte scratch slot with area lights; at four it took 99)
 static const group_fn kGroupShade[3][APT_N_GROUPS] = {APT_GROUP_ROW(0x03), APT_GROUP_ROW(APT_SRC_ALL), APT_GROUP_ROW(0x05)};      // [emitter set: point + area | all | point + spot (no area light: no emission code, no pdf in the record, both Philox blocks up front)][group]
 #define APT_CLASS_PHONG 1
 #define APT_CLASS_PHONG_NO_LOBE 9
@@ -194,7 +197,7 @@ struct apt_renderer {
     vev_group_fn vgroup_fn[APT_N_VGROUPS] = {};           // ... the event kernels in groups
     int vgroup_cls[APT_N_VGROUPS][4] = {};                // ... event queue of each member slot (-1: none)
     group_fn group_fn_[APT_N_GROUPS] = {};                // ... the group kernels for this scene's emitter set
-    int group_cls[APT_N_GROUPS][4] = {};                  // ... compact class id of each member slot (-1: the scene has no such class)
+    int group_cls[APT_N_GROUPS][APT_GROUP_SLOTS] = {};    // ... compact class id of each member slot (-1: the scene has no such class)
     std::string shade_name;
     LdsPlan plan{};
     size_t lds_bytes = 0, lds_bytes_any = 0;     // dynamic LDS of the closest-hit / any-hit trace kernels
@@ -783,7 +786,7 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     } else if (r->sorted) {
         const int smi = ((sc->src_mask & ~0x03) == 0) ? 0 : (((sc->src_mask & ~0x05) == 0) ? 2 : 1);
         r->shade_name = "sorted:";
-        for (int g = 0; g < APT_N_GROUPS; g++) { r->group_fn_[g] = kGroupShade[smi][g]; for (int k = 0; k < 4; k++) r->group_cls[g][k] = -1; }
+        for (int g = 0; g < APT_N_GROUPS; g++) { r->group_fn_[g] = kGroupShade[smi][g]; for (int k = 0; k < APT_GROUP_SLOTS; k++) r->group_cls[g][k] = -1; }
         r->shade_name = "sorted, launched in register-footprint groups:";
         for (int c = 0; c < ncls; c++) {
             r->group_cls[kClassGroup[sc->class_def[c]]][kClassSlot[sc->class_def[c]]] = c;
@@ -1204,7 +1207,7 @@ static int render_impl(apt_renderer* r, int32_t n_spp) {
             } else {
                 for (int g = 0; g < APT_N_GROUPS; g++) {       // one launch per register-footprint group: its workgroups walk the member classes' queues one after the other
                     GroupIn gi; bool any = false;
-                    for (int k = 0; k < 4; k++) { const int c = r->group_cls[g][k]; gi.cls[k] = c; gi.counts[k] = c >= 0 ? (const uint32_t*)cnt->n_cls[c] : nullptr; any = any || c >= 0; }
+                    for (int k = 0; k < APT_GROUP_SLOTS; k++) { const int c = r->group_cls[g][k]; gi.cls[k] = c; gi.counts[k] = c >= 0 ? (const uint32_t*)cnt->n_cls[c] : nullptr; any = any || c >= 0; }
                     if (!any) continue;
                     LaunchTimer t(r, 2, st); hipLaunchKernelGGL(r->group_fn_[g], dim3(grid_for(total, r->grid_small, nq)), dim3(BLOCK), 0, st, sc, p, q, cnt, gi, cur, b);
                 }

@@ -249,14 +249,14 @@ APT_D LightSample sample_light(const ShadeArgs3* A_, Vertex& vx, Philox& rng, co
     if (ns != 1) src = LANE_SRC ? ld_src_lane((A_->sc).src + sidx) : (A_->sc).src[sidx];
     f3 shadow_int; float direct_pdf;
     const f3 to_emitter = emitter_sample_hit<SM>(src, geom, vx.hit_point, rng, shadow_int, direct_pdf) - vx.hit_point;
-    ls.dist = norm(to_emitter);
-    ls.dir = to_emitter / ls.dist;
+    ls.dist = fnorm(to_emitter);
+    ls.dir = fdiv3(to_emitter, ls.dist);
     ls.sampled = true;
     const f3 direct_spec = surface_eval<BM>(vx.bx, vx.it, vx.d, ls.dir, (A_->sc).world_ior, (A_->p).two_sides);
     if ((A_->p).use_mis && !(src.bool_bits & 0x01)) ls.mis_w = balance(emitter_pdf * direct_pdf, surface_pdf<BM>(vx.bx, vx.it, ls.dir, vx.d, (A_->sc).world_ior, (A_->p).two_sides));
     if (isnan(ls.mis_w)) { ls.poisoned = true; return ls; }
     f3 c = (direct_spec * shadow_int) * ls.mis_w;
-    if (ns != 1) c = c / emitter_pdf;               // one light: the pdf is exactly 1 and x / 1 == x (wave-uniform branch)
+    if (ns != 1) c = fdiv3(c, emitter_pdf);               // one light: the pdf is exactly 1 and x / 1 == x (wave-uniform branch)
     ls.contrib = (c * (A_->p).inv_S) * vx.thr;
     ls.want = !(ls.contrib.x == 0.f && ls.contrib.y == 0.f && ls.contrib.z == 0.f);
     return ls;
@@ -277,7 +277,7 @@ APT_D f3 emit_and_scatter(const ShadeArgs3* A_, Vertex& vx, Philox& rng, float& 
     }
     f3 spec;
     const f3 new_d = surface_sample<BM>(vx.bx, vx.it, vx.d, (A_->sc).world_ior, (A_->p).two_sides, rng, spec, new_pdf, is_spec);
-    vx.thr = vx.thr * (spec / new_pdf);
+    vx.thr = vx.thr * fdiv3(spec, new_pdf);
     return new_d;
 }
 // a shadow-queue entry (k_shadow / shadow_flat_body read these planes)
@@ -576,16 +576,22 @@ __global__ void __launch_bounds__(BLOCK) k_shade_traced(DevScene sc, Params p, Q
 // The classes of a bounce are independent, so a group kernel walks the class queues of its members one after the other - every workgroup
 // its sub-queue of class A, then of class B, ... with no barrier in between: a workgroup that runs out of A entries starts on B while
 // others still shade A - and the launch boundary between them is gone.  A kernel's register allocation is the maximum over its members',
-// so the groups follow the footprints (api.hip kClassGroup): <= 128 VGPRs / four waves per SIMD (Lambertian, delta, lobe-free Blinn-Phong,
-// Lambertian transmission), <= 168 / three (Blinn-Phong, Oren-Nayar, thin coat, microfacet), beyond / two (modified Phong, Fresnel blend).
+// so the groups follow the footprints (api.hip kClassGroup).  Round 5 had three - up to 128 VGPRs / four waves per SIMD, up to 168 / three,
+// beyond / two (modified Phong and Fresnel blend with their double-precision pow: 201-217).  With the product build's float transcendentals
+// and 1-ulp divisions (round 6) no class kernel allocates more than 125, so there are TWO: the lean classes - Lambertian, delta, lobe-free
+// Blinn-Phong, Lambertian transmission: 93-96 VGPRs, held to FIVE waves per SIMD - and everything else (Blinn-Phong, Oren-Nayar, thin coat,
+// microfacet, modified Phong, Fresnel blend: 111-125, four waves).
 // Members absent from the scene are skipped by a wave-uniform test (GroupIn::cls < 0).  Per vertex nothing changes: same class code, same
 // queues, same order inside a queue - images and statistics are those of the one-launch-per-class schedule bit for bit (GPU test).
-struct GroupIn { const uint32_t* counts[4]; int cls[4]; };     // per member: the class queue's per-sub-queue entry counts, its compact class id (-1: not in this scene)
-template <int SM, int WAVES, int B0, int B1, int B2, int B3>
+#define APT_GROUP_SLOTS 6
+struct GroupIn { const uint32_t* counts[APT_GROUP_SLOTS]; int cls[APT_GROUP_SLOTS]; };     // per member: the class queue's per-sub-queue entry counts, its compact class id (-1: not in this scene)
+template <int SM, int WAVES, int B0, int B1, int B2, int B3, int B4 = 0, int B5 = 0>
 __global__ void __launch_bounds__(BLOCK, WAVES) k_shade_group(DevScene sc, Params p, Queues q, Counters* cnt, GroupIn g, int cur, int bounce) {
     ShadeIn in = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if constexpr (B0 != 0) if (g.cls[0] >= 0) { in.counts = g.counts[0]; in.cls = g.cls[0]; shade_staged<B0, SM, 0, true>(kernel_args3(), cnt, in, cur, bounce); }
     if constexpr (B1 != 0) if (g.cls[1] >= 0) { in.counts = g.counts[1]; in.cls = g.cls[1]; shade_staged<B1, SM, 0, true>(kernel_args3(), cnt, in, cur, bounce); }
     if constexpr (B2 != 0) if (g.cls[2] >= 0) { in.counts = g.counts[2]; in.cls = g.cls[2]; shade_staged<B2, SM, 0, true>(kernel_args3(), cnt, in, cur, bounce); }
+    if constexpr (B4 != 0) if (g.cls[4] >= 0) { in.counts = g.counts[4]; in.cls = g.cls[4]; shade_staged<B4, SM, 0, true>(kernel_args3(), cnt, in, cur, bounce); }
+    if constexpr (B5 != 0) if (g.cls[5] >= 0) { in.counts = g.counts[5]; in.cls = g.cls[5]; shade_staged<B5, SM, 0, true>(kernel_args3(), cnt, in, cur, bounce); }
     if constexpr (B3 != 0) if (g.cls[3] >= 0) { in.counts = g.counts[3]; in.cls = g.cls[3]; shade_staged<B3, SM, 0, true>(kernel_args3(), cnt, in, cur, bounce); }
 }

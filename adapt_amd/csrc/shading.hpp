@@ -40,7 +40,7 @@ APT_D void rotation_between(f3 fixed, f3 target, m33& R) {
     f3 axis = cross(fixed, target);
     float c = dot(fixed, target);
     if (fabsf(c) < 1.0f - 1e-5f) {
-        f3 n = normalize(axis);
+        f3 n = fnormalize(axis);
         float k = 1.0f - c;
         float kx = k * n.x, ky = k * n.y, kz = k * n.z;
         R.m[0][0] = (c + kx * n.x) + 0.0f;     R.m[0][1] = (0.0f + kx * n.y) + (-axis.z); R.m[0][2] = (0.0f + kx * n.z) + axis.y;
@@ -86,18 +86,18 @@ APT_D f3 schlick(f3 r_s, float dot_val) {
 }
 APT_D float fresnel_dielectric(float n_in, float n_out, float cos_inc, float cos_ref) {
     float a = n_in * cos_inc, b = n_out * cos_inc, c = n_in * cos_ref, d = n_out * cos_ref;
-    float rs = sdiv(a - d, a + d);
-    float rp = sdiv(c - b, c + b);
+    float rs = (a - d) / (a + d);
+    float rp = (c - b) / (c + b);
     return 0.5f * (rs * rs + rp * rp);
 }
 APT_D bool total_reflection(float dot_normal, float ni, float nr) {
-    return (1.f - sqr(sdiv(ni, nr)) * (1.f - sqr(dot_normal))) < 0.f;
+    return (1.f - sqr(ni / nr) * (1.f - sqr(dot_normal))) < 0.f;
 }
 APT_D f3 refract_snell(f3 incid, f3 normal, float dot_n, float ni, float nr, float& cos_r2) {
     float exiting = sgn(dot_n);
-    float ratio = sdiv(ni, nr);
+    float ratio = ni / nr;
     cos_r2 = 1.f - sqr(ratio) * (1.f - sqr(dot_n));
-    if (cos_r2 > 0.f) return normalize((incid * ratio - normal * (ratio * dot_n)) + normal * (exiting * ssqrt(cos_r2)));
+    if (cos_r2 > 0.f) return normalize((incid * ratio - normal * (ratio * dot_n)) + normal * (exiting * sqrtf(cos_r2)));
     return mk3(0.f, 0.f, 0.f);
 }
 
@@ -268,7 +268,7 @@ APT_D f3 thin_coat_sample(const DevBxdf& b, const Hit& it, f3 incid, Philox& r, 
     float dn = dot(incid, it.n_s);
     float cos_r2;
     f3 refra_in = refract_snell(incid, it.n_s, dn, 1.0f, b.k_g.z, cos_r2);
-    float F_in = fresnel_dielectric(1.f, b.k_g.x, fabsf(dn), ssqrt(cos_r2));     // k_g[0] here, as upstream (brdf.py:361)
+    float F_in = fresnel_dielectric(1.f, b.k_g.x, fabsf(dn), sqrtf(cos_r2));     // k_g[0] here, as upstream (brdf.py:361)
     is_specular = false;
     if (rng_float(r) > F_in) {
         f3 local = sample_cosine_hemisphere(r, pdf);
@@ -276,7 +276,7 @@ APT_D f3 thin_coat_sample(const DevBxdf& b, const Hit& it, f3 incid, Philox& r, 
         float d_out = dot(out, it.n_s);
         if (!total_reflection(d_out, b.k_g.z, 1.0f)) {
             f3 refra_out = refract_snell(out, it.n_s, d_out, b.k_g.z, 1.0f, cos_r2);
-            float F_out = fresnel_dielectric(b.k_g.z, 1.f, fabsf(d_out), ssqrt(cos_r2));
+            float F_out = fresnel_dielectric(b.k_g.z, 1.f, fabsf(d_out), sqrtf(cos_r2));
             pdf *= (1.f - F_in);
             out = refra_out;
             spec = oren_nayar_eval(b, it, refra_in, out);
@@ -295,18 +295,18 @@ APT_D f3 thin_coat_eval(const DevBxdf& b, const Hit& it, f3 in, f3 out) {
     float d_in = dot(in, it.n_s);
     float cos_r2;
     f3 refra_in = refract_snell(in, it.n_s, d_in, 1.0f, b.k_g.z, cos_r2);
-    float F_in = fresnel_dielectric(1.f, b.k_g.z, fabsf(d_in), ssqrt(cos_r2));
+    float F_in = fresnel_dielectric(1.f, b.k_g.z, fabsf(d_in), sqrtf(cos_r2));
     if (fabsf(dot(out, refl)) > (1.f - 1e-4f)) return b.k_s * F_in;
     float d_out = dot(out, it.n_s);
     f3 refra_out = refract_snell(out, it.n_s, d_out, 1.0f, b.k_g.z, cos_r2);
-    float F_out = fresnel_dielectric(1.0f, b.k_g.z, fabsf(d_out), ssqrt(cos_r2));
+    float F_out = fresnel_dielectric(1.0f, b.k_g.z, fabsf(d_out), sqrtf(cos_r2));
     return oren_nayar_eval(b, it, refra_in, refra_out) * (1.f - fmaxf(F_in, F_out));
 }
 APT_D float thin_coat_fresnel(const DevBxdf& b, const Hit& it, f3 in) {
     float d_in = dot(in, it.n_s);
     float ratio = 1.0f / b.k_g.z;
     float cos_r2 = 1.f - sqr(ratio) * (1.f - sqr(d_in));
-    return fresnel_dielectric(1.f, b.k_g.z, fabsf(d_in), ssqrt(cos_r2));
+    return fresnel_dielectric(1.f, b.k_g.z, fabsf(d_in), sqrtf(cos_r2));
 }
 
 // ---------------------------------------------------- Trowbridge-Reitz microfacet BRDF (type 3)
@@ -528,7 +528,7 @@ APT_D f3 glass_sample(const DevBxdf& b, const Hit& it, f3 incid, float world_ior
     } else {
         float cos_r2;
         f3 refra = refract_snell(incid, it.n_s, dn, ni, nr, cos_r2);
-        float F = fresnel_dielectric(ni, nr, fabsf(dn), ssqrt(cos_r2));
+        float F = fresnel_dielectric(ni, nr, fabsf(dn), sqrtf(cos_r2));
         if (rng_float(r) > F) { pdf = 1.f - F; dir = refra; }
         else { dir = normalize(incid - (it.n_s * 2.f) * dn); pdf = F; }
     }
@@ -547,7 +547,7 @@ APT_D f3 glass_eval(const DevBxdf& b, const Hit& it, f3 in, f3 out, float world_
         float cos_r2;
         f3 refra = refract_snell(out, it.n_s, d_out, ni, nr, cos_r2);
         if (cos_r2 > 0.f) {
-            float F = fresnel_dielectric(ni, nr, fabsf(d_out), ssqrt(cos_r2));
+            float F = fresnel_dielectric(ni, nr, fabsf(d_out), sqrtf(cos_r2));
             if (dot(refra, in) > 1.f - 1e-4f) ret = b.k_d * (1.f - F);
             else if (dot(ref_dir, in) > 1.f - 1e-4f) ret = b.k_d * F;
         } else if (dot(ref_dir, in) > 1.f - 1e-4f) ret = b.k_d;
@@ -566,9 +566,9 @@ APT_D f3 lambert_trans_sample(const DevBxdf& b, const Hit& it, f3 incid, float w
     if (total_reflection(dn, ni, nr)) {
         dir = normalize(incid - (it.n_s * 2.f) * dn);
     } else {
-        float ratio = sdiv(ni, nr);
+        float ratio = ni / nr;
         float cos_r2 = 1.f - sqr(ratio) * (1.f - sqr(dn));
-        float F = fresnel_dielectric(ni, nr, fabsf(dn), ssqrt(cos_r2));
+        float F = fresnel_dielectric(ni, nr, fabsf(dn), sqrtf(cos_r2));
         if (rng_float(r) > F) {
             fres = 1.f - F;
             f3 local = sample_cosine_hemisphere(r, pdf);
@@ -595,11 +595,11 @@ APT_D f3 lambert_trans_eval(const DevBxdf& b, const Hit& it, f3 in, f3 out, floa
     if (total_reflection(d_out, ni, nr)) {
         if (dot(ref_dir, in) > 1.f - 1e-4f) ret = b.k_d;
     } else {
-        float ratio = sdiv(ni, nr);
+        float ratio = ni / nr;
         float cos_r2 = 1.f - sqr(ratio) * (1.f - sqr(d_out));
         float d_in = dot(in, it.n_s);
         if (cos_r2 > 0.f) {
-            float F = fresnel_dielectric(ni, nr, fabsf(d_out), ssqrt(cos_r2));
+            float F = fresnel_dielectric(ni, nr, fabsf(d_out), sqrtf(cos_r2));
             if (d_in * d_out < 0.f) { if (dot(ref_dir, in) > 1.f - 1e-4f) ret = b.k_d * F; }
             else ret = b.k_d * ((1.f - F) * APT_INV_PI * fabsf(d_out));
         } else if (dot(ref_dir, in) > 1.f - 1e-4f) ret = b.k_d;
@@ -616,7 +616,7 @@ APT_D float bsdf_pdf(const DevBxdf& b, const Hit& it, f3 outdir, f3 incid, float
     float cos_r2;
     f3 refra = refract_snell(outdir, it.n_s, d_out, ni, nr, cos_r2);
     if (cos_r2 > 0.0f) {
-        float F = fresnel_dielectric(ni, nr, fabsf(d_out), ssqrt(cos_r2));
+        float F = fresnel_dielectric(ni, nr, fabsf(d_out), sqrtf(cos_r2));
         if (dot(ref_dir, incid) > 1.f - 1e-4f) pdf = F;
         else if (b.type == 0 && dot(refra, incid) > 1.f - 1e-4f) pdf = 1.f - F;
         else if (b.type == 1 && (dot(incid, it.n_s) * d_out > 0.f)) pdf = (1.f - F) * fabsf(d_out) * APT_INV_PI;
@@ -687,17 +687,17 @@ APT_D f3 emitter_sample_hit(const DevSrc& s, const EmitterGeom& g, f3 hit_pos, P
             pos = sample_on_triangle(r, ld3(pc), ld3(pc + 3)) + ld3(pc + 6);
         }
         f3 diff = hit_pos - pos;
-        float dl = dot(normalize(diff), normal);
+        float dl = dot(fnormalize(diff), normal);
         if (dl <= 0.0f) { inten = splat3(0.f); pdf = 1.0f; }
         else {
             pdf *= sdiv(norm2(diff), dl);
-            inten = (pdf > 0.0f) ? inten / pdf : splat3(0.f);
+            inten = (pdf > 0.0f) ? fdiv3(inten, pdf) : splat3(0.f);
         }
     } else if (BXHAS(SM, 2) && s.type == 2) {
         f3 to_hit = hit_pos - pos;
-        float depth = fmaxf(norm(to_hit), 1e-5f);
-        to_hit = to_hit / depth;
-        if (dot(to_hit, s.dir) > s.r) inten = inten / (depth * depth);
+        float depth = fmaxf(fnorm(to_hit), 1e-5f);
+        to_hit = fdiv3(to_hit, depth);
+        if (dot(to_hit, s.dir) > s.r) inten = fdiv3(inten, depth * depth);
         else inten = splat3(0.f);
     } else if (BXHAS(SM, 4) && s.type == 4) {
         pdf = 0.f;

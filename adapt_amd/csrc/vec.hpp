@@ -9,7 +9,7 @@
 
 // APT_FAST (set by adapt_amd/build.py): 1 = the product build - small-scene intersectors re-derived for speed inside SURVEY 8(d)'s
 // tolerances (traverse.hpp "Flat sweep"); 0 = the exact build, whose intersectors are the reference's loop operation for operation (the
-// build the bit-exact parity tests pin).  The shading arithmetic is the same in both except for the transcendental calls below.  See DESIGN.md "float parity policy".
+// build the bit-exact parity tests pin).  The shading arithmetic is the same in both except for the transcendental calls and the sdiv / ssqrt helpers below (product build: float functions, 1-ulp division and roots outside delta interactions).  See DESIGN.md "float parity policy".
 #ifndef APT_FAST
 #define APT_FAST 0
 #endif
@@ -21,9 +21,9 @@ struct f3 {
     float x, y, z;
 };
 
-// Divisions and square roots of the SHADING code (shading.hpp, shade_stage.hpp and the f3 operators below).  APT_FAST_DIV=1 (product build,
-// device code): a * v_rcp_f32(b), v_sqrt_f32, v_rsq_f32 - 1 ulp each, the same infinities, zeros and NaNs as the IEEE forms for every
-// operand but denormal divisors - where the IEEE sequences are ~10 instructions with a dependent chain (a vertex of the Cornell box made
+// Divisions and square roots of the non-delta SHADING code (light sampling, MIS weights, lobe sampling and evaluation, throughput, roulette).
+// APT_FAST_DIV=1 (device code): a * v_rcp_f32(b), v_sqrt_f32, v_rsq_f32 - 1 ulp each, the same infinities, zeros and NaNs as the IEEE forms for
+// every operand but denormal divisors - where the IEEE sequences are ~10 instructions with a dependent chain (a vertex of the Cornell box makes
 // ~15 divisions and 5 roots).  The intersectors never come through here: their reference-order code divides with `/` and sqrtf() in both builds.
 #ifndef APT_FAST_DIV
 #define APT_FAST_DIV 0
@@ -45,20 +45,26 @@ APT_HD f3 splat3(float s) { return mk3(s, s, s); }
 APT_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 APT_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 APT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
-APT_HD f3 operator/(f3 a, f3 b) { return mk3(sdiv(a.x, b.x), sdiv(a.y, b.y), sdiv(a.z, b.z)); }
+APT_HD f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
 APT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 APT_HD f3 operator*(float s, f3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
-#if APT_FAST_DIV && defined(__HIP_DEVICE_COMPILE__)
-APT_HD f3 operator/(f3 a, float s) { const float r = srcp(s); return mk3(a.x * r, a.y * r, a.z * r); }
-#else
 APT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
-#endif
 APT_HD f3 operator+(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
 APT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 APT_HD float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 APT_HD float norm2(f3 a) { return dot(a, a); }
-APT_HD float norm(f3 a) { return ssqrt(norm2(a)); }
-APT_HD f3 normalize(f3 a) { float inv = srsqrt(norm2(a)); return a * inv; }
+APT_HD float norm(f3 a) { return sqrtf(norm2(a)); }
+APT_HD f3 normalize(f3 a) { float inv = 1.0f / norm(a); return a * inv; }
+// the shading code's flavours (sdiv / ssqrt above): light sampling, MIS, lobe sampling, throughput.  NOT used by delta interactions (mirror,
+// glass: shading.hpp keeps `/`, sqrtf and normalize() there) - a perturbation at EVERY vertex of a specular chain compounds (measured: C3 every
+// pixel 99.7 % -> 97.8 % with them fast as well), one that enters a chain from a diffuse vertex does not (the float sin / cos of the lobe samples)
+#if APT_FAST_DIV && defined(__HIP_DEVICE_COMPILE__)
+APT_HD f3 fdiv3(f3 a, float s) { const float r = srcp(s); return a * r; }
+#else
+APT_HD f3 fdiv3(f3 a, float s) { return a / s; }                 // (the reference divides every component: three IEEE divisions, not one reciprocal)
+#endif
+APT_HD float fnorm(f3 a) { return ssqrt(norm2(a)); }
+APT_HD f3 fnormalize(f3 a) { return a * srsqrt(norm2(a)); }
 APT_HD f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 APT_HD float max3(f3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
 APT_HD float min3(f3 a) { return fminf(fminf(a.x, a.y), a.z); }

@@ -117,12 +117,12 @@ def test_fix_up_lists_carry_every_ray_when_asked_to(tag, kw, renderer, monkeypat
     assert f.info()["traversal"] == "flat" and f.info()["arithmetic"] == "fast"
     f.render(n_spp=spp); img = f.color.to_numpy(); st = f.stats()
     # Rounds 3-5 asserted equality to the last count and bit here: the product build then shaded with the exact build's arithmetic.  Since round 6
-    # it evaluates cos / sin / pow in float (adapt_amd/build.py), so a sampled direction differs in its last bit now and then and a handful of the
-    # ~10^4 paths of this render take another branch: counts agree to 1.5e-3 (measured with every ray deferred: 7e-5 .. 4.8e-4), pixels as far as a
+    # it evaluates cos / sin / pow in float and the non-delta shading code's divisions and roots with the 1-ulp instructions (adapt_amd/build.py), so a sampled direction differs in its last bit now and then and a handful of the
+    # ~10^4 paths of this render take another branch: counts agree to 2.5e-3 (measured with every ray deferred: 7e-5 .. 1.7e-3 on renders of ~10^4 vertices), pixels as far as a
     # re-drawn path among six samples lets them.  What "every ray through the lists" must still deliver to the last count is the SAMPLES.
     assert st["n_samples"] == est["n_samples"]
     for k in ("n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"):
-        assert abs(st[k] - est[k]) <= max(1.5e-3 * est[k], 8), (k, st[k], est[k])
+        assert abs(st[k] - est[k]) <= max(2.5e-3 * est[k], 8), (k, st[k], est[k])
     m = image_metrics(img / spp, ref / spp)
     record_metric(f"fix-up lists carry every ray {tag} {kw}", m)
     assert m["frac_within"] >= 0.95 and abs(np.nanmean(img) - np.nanmean(ref)) <= 0.02 * np.nanmean(ref), m
@@ -455,19 +455,19 @@ def test_rays_with_a_zero_direction_component_get_the_reference_answer(renderer,
 # C4 / C5: the crop tests below) and on the diffuse Cornell renders.  On the FEATURE scenes of this repo (glass, mirrors, glossy lobes in
 # a closed box at 96 x 96) the SAME-STREAM per-pixel criterion is not met, and the bounds below are NOT 8(d)'s: they are regression guards,
 # the value measured on MI355X (the GPU path is bit-reproducible, so the measurement is a property of the build; profiles/
-# r06_parity_metrics.log - round 6's product build, float transcendentals - re-recorded every round by record_metric) with a margin of two on the failing fraction and on relMSE.
+# r06_parity_metrics.log - round 6's product build: float transcendentals, 1-ulp divisions in the non-delta shading code - re-recorded every round by record_metric) with a margin of two on the failing fraction and on relMSE.
 # Side by side, so that the relaxation is visible:
 #
 #   scene            8(d) asks (same stream)     product build, measured     exact build (asserted)     bound asserted here
 #   cbox 256 (C1)    >= 99 %, relMSE <= 1e-4     99.945 %, 2.9e-7            >= 99.5 %, <= 1e-4         99.89 %, 6e-7      (inside 8(d))
 #   cbox 96          >= 99 %, relMSE <= 1e-4     99.946 %, 5.2e-7            >= 99.5 %, <= 1e-4         99.89 %, 1.1e-6    (inside 8(d))
-#   balls_mono (C3)  >= 99 %, relMSE <= 1e-4     99.71 %, 3.8e-7             >= 99.5 %, <= 1e-4         99.4 %, 8e-7       (inside 8(d))
-#   microfacet       >= 99 %, relMSE <= 1e-4     99.59 %, 6.6e-6             >= 99.5 %, <= 1e-4         99.2 %, 1.4e-5     (inside 8(d))
+#   balls_mono (C3)  >= 99 %, relMSE <= 1e-4     99.60 %, 4.8e-7             >= 99.5 %, <= 1e-4         99.2 %, 1e-6       (inside 8(d))
+#   microfacet       >= 99 %, relMSE <= 1e-4     99.45 %, 3.9e-5             >= 99.5 %, <= 1e-4         98.9 %, 8e-5       (inside 8(d))
 #   textured         >= 99 %, relMSE <= 1e-4     98.0 %, 1.4e-4              >= 99.5 %, <= 1e-4         96 %, 3e-4         (OUTSIDE: per-pixel and relMSE)
-#   glass_box        >= 99 %, relMSE <= 1e-4     96.3 %, 3.4e-5              >= 99.5 %, <= 1e-4         92.6 %, 6.8e-5     (OUTSIDE: per-pixel)
-#   features_a       >= 99 %, relMSE <= 1e-4     89.5 %, 1.75e-4             >= 99.5 %, <= 1e-4         79 %, 3.5e-4       (OUTSIDE: per-pixel and relMSE)
-#   features_b       >= 99 %, relMSE <= 1e-4     92.3 %, 4.7e-4              >= 99.5 %, <= 1e-4         84.6 %, 9.4e-4     (OUTSIDE: per-pixel and relMSE)
-#   features_c       >= 99 %, relMSE <= 1e-4     90.1 %, 1.33e-4             >= 99.5 %, <= 1e-4         80 %, 2.7e-4       (OUTSIDE: per-pixel and relMSE)
+#   glass_box        >= 99 %, relMSE <= 1e-4     95.8 %, 4.1e-5              >= 99.5 %, <= 1e-4         91.6 %, 8.2e-5     (OUTSIDE: per-pixel)
+#   features_a       >= 99 %, relMSE <= 1e-4     88.2 %, 1.74e-4             >= 99.5 %, <= 1e-4         76.4 %, 3.5e-4     (OUTSIDE: per-pixel and relMSE)
+#   features_b       >= 99 %, relMSE <= 1e-4     91.3 %, 6.0e-4              >= 99.5 %, <= 1e-4         82.6 %, 1.2e-3     (OUTSIDE: per-pixel and relMSE)
+#   features_c       >= 99 %, relMSE <= 1e-4     88.4 %, 1.66e-4             >= 99.5 %, <= 1e-4         76.8 %, 3.4e-4     (OUTSIDE: per-pixel and relMSE)
 #
 # Why outside, and what stands in for the per-pixel criterion there: a specular or glossy path is chaotic in its hit point - an ulp of
 # difference in one hit (the flat sweep's precomputed-transform test against the reference's adjugate solve, both within 1e-5 t) is amplified
@@ -480,13 +480,13 @@ def test_rays_with_a_zero_direction_component_get_the_reference_answer(renderer,
 IMAGE_CASES = [
     ("cbox", 256, 256, 64, {"max_bounce": 4}, 0.9989, 6e-7),
     ("cbox", 96, 96, 64, {}, 0.9989, 1.1e-6),
-    ("balls_mono", 96, 96, 64, {}, 0.994, 8e-7),
-    ("glass_box", 96, 96, 64, {}, 0.926, 6.8e-5),
-    ("features_a", 96, 96, 64, {}, 0.79, 3.5e-4),
-    ("features_b", 96, 96, 64, {}, 0.846, 9.4e-4),
-    ("features_c", 96, 96, 64, {}, 0.80, 2.7e-4),
+    ("balls_mono", 96, 96, 64, {}, 0.992, 1e-6),
+    ("glass_box", 96, 96, 64, {}, 0.916, 8.2e-5),
+    ("features_a", 96, 96, 64, {}, 0.764, 3.5e-4),
+    ("features_b", 96, 96, 64, {}, 0.826, 1.2e-3),
+    ("features_c", 96, 96, 64, {}, 0.768, 3.4e-4),
     ("textured", 64, 48, 16, {}, 0.96, 3e-4),           # (its normal-mapped wall sends out rays that are not of unit length: traverse.hpp flat_needs_cull)
-    ("microfacet", 64, 48, 16, {}, 0.992, 1.4e-5),
+    ("microfacet", 64, 48, 16, {}, 0.989, 8e-5),
 ]
 
 
@@ -751,10 +751,11 @@ def test_shipped_library_is_bit_checked_where_it_runs_the_reference_arithmetic(t
     """the bit-exact parity tests run on libadapt_mi_exact.so, the library that ships is libadapt_mi.so.  With APT_TRAVERSAL forced
     to one of the exact build's small-scene intersectors the shipped library executes the exact build's code in every stage - queues, class
     sorting, radiance slots, finalize - and, through round 5, the same shading arithmetic: images and statistics were equal bit for bit.  Since
-    round 6 its cos / sin / tan / pow are OCML's float functions (adapt_amd/build.py), so what is left to assert is that NOTHING ELSE differs:
-    sample counts equal, every other count within 1.5e-3 (a few of ~10^4 paths re-drawn after a last-bit difference in a direction), the image
-    within a re-drawn path's reach.  Cornell box, one bounce (Lambertian + point light: its only transcendental is the azimuth of the
-    cosine-hemisphere sample, AFTER the last shaded vertex) stays bit-identical, which pins the rest of the pipeline to the bit."""
+    round 6 its cos / sin / tan / pow are OCML's float functions and its non-delta shading divides with v_rcp_f32 (adapt_amd/build.py), so what is left
+    to assert is that NOTHING ELSE differs: sample counts equal, every other count within 2.5e-3 (a few of ~10^4 paths re-drawn after a last-bit difference in a direction), the image
+    within a re-drawn path's reach.  Cornell box, one bounce (Lambertian + point light: no path can take another branch - the light sample's
+    1 / d^2 and the direction to the light are its only rounded-differently operations) has the same counts and the same image to 1e-6,
+    which pins the rest of the pipeline."""
     w, h, spp = 64, 48, 5
     monkeypatch.setenv("APT_TRAVERSAL", mode)
     e = renderer(tag, width=w, height=h, exact=True)
@@ -764,7 +765,7 @@ def test_shipped_library_is_bit_checked_where_it_runs_the_reference_arithmetic(t
     se, sf = e.stats(), f.stats()
     assert sf["n_samples"] == se["n_samples"]
     for k in ("n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"):
-        assert abs(sf[k] - se[k]) <= max(1.5e-3 * se[k], 8), (k, sf[k], se[k])
+        assert abs(sf[k] - se[k]) <= max(2.5e-3 * se[k], 8), (k, sf[k], se[k])
     m = image_metrics(f.color.to_numpy() / spp, e.color.to_numpy() / spp)
     record_metric(f"shipped library on the exact build's intersector {tag} {mode}", m)
     assert m["frac_within"] >= 0.95, m
@@ -773,7 +774,7 @@ def test_shipped_library_is_bit_checked_where_it_runs_the_reference_arithmetic(t
         f1 = renderer(tag, width=w, height=h, max_bounce=1)
         e1.render(n_spp=spp); f1.render(n_spp=spp)
         assert all(e1.stats()[k] == f1.stats()[k] for k in ("n_samples", "n_extend", "n_shade", "n_shadow", "n_shadow_traced", "n_lit", "n_draws"))
-        assert np.array_equal(f1.color.to_numpy(), e1.color.to_numpy(), equal_nan=True)
+        assert np.allclose(f1.color.to_numpy(), e1.color.to_numpy(), rtol=2e-6, atol=0, equal_nan=True)
 
 
 @pytest.mark.parametrize("which", ["bunnies1", "bunnies2", "balls_mono", "features_c"])

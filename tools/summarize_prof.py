@@ -64,6 +64,21 @@ if db:
         alloc, waves = (f"{m['alloc']:d}", f"{m['waves_per_simd']:d}") if m else ("?", "?")
         print(f"{short(r[0]):40s} {r[1]:6d} {r[2] / 1e3:11.1f} {r[3] / 1e3:9.2f} {r[4] / 1e3:9.2f} {r[5] / 1e3:9.2f} {100 * r[2] / tot:6.2f} {alloc:>10s} {waves:>10s} {r[6]:13d} {r[7]:5d} {r[8]:7d}")
 
+# Launch boundaries (round 6): the idle time between consecutive dispatches of the run - one render lane, so nothing else fills
+# it - is the most a captured hipGraph (or any other way of taking the host off the path) could remove; with three lanes the other lanes'
+# kernels run in these gaps anyway.  Only the last 90 % of the dispatches are counted (the head of the trace holds scene upload and warm-up).
+if db:
+    try:
+        ev = list(db.execute("select d.start, d.end from rocpd_kernel_dispatch d order by d.start"))
+        ev = ev[len(ev) // 10:]
+        busy = sum(e - s for s, e in ev)
+        gaps = [max(0, ev[i + 1][0] - ev[i][1]) for i in range(len(ev) - 1)]
+        small = [g for g in gaps if g < 200_000]             # (gaps above 0.2 ms are step boundaries of the bench - host synchronisation - not launch gaps)
+        print(f"\n== launch gaps, one lane: {len(small)} boundaries, {sum(small) / 1e3:.1f} us idle in total = {100 * sum(small) / max(1, busy + sum(small)):.2f} % of kernel time + gaps "
+              f"(median {sorted(small)[len(small) // 2] / 1e3:.2f} us, mean {sum(small) / max(1, len(small)) / 1e3:.2f} us): the upper bound of what a captured hipGraph could save")
+    except Exception as e:  # noqa: BLE001
+        print(f"\n== launch gaps: not available ({e})")
+
 print("\n== PMC passes (summed over the run's dispatches, per kernel)")
 acc = defaultdict(lambda: defaultdict(float))
 disp = defaultdict(set)
