@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 # edges), 1.032 with 16, 1.016 with 4; the per-rank rate itself does not depend on the band width.
 BAND_WIDTH = 4
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-ROUND = 5                       # profiles/r0<ROUND>_<config>_counters.json: PMC figures of THIS round's kernels
+ROUND = 6                       # profiles/r0<ROUND>_<config>_counters.json: PMC figures of THIS round's kernels
 STAGES = ("extend", "shade", "shadow")
 
 CONFIGS = {
