@@ -862,14 +862,14 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
     {
         LdsPlan pl;
         const int full_depth = sc->wide.max_depth + 2;
-        int lds_levels = 8;                                  // 16 KiB per 256-thread workgroup (measured: 6, 10 and 14 levels run alike - the 8-wide tree is at most 8-9 levels deep)
+        int lds_levels = 7;                                  // 14 KiB per 256-thread workgroup (measured: 6, 10 and 14 levels run alike - the 8-wide tree is at most 8-9 levels deep; 8 through round 5: the eighth level's 2 KiB hold the walk's permutation table now, seven workgroups per CU as before)
         if (const char* sd = getenv("APT_BVH_LDS_LEVELS")) lds_levels = std::max(2, atoi(sd));
         pl.stack_depth = std::min(full_depth, lds_levels);   // deeper levels spill to per-lane global columns (traverse.hpp TravStack)
         r->ovf_levels = full_depth - pl.stack_depth;
         pl.ovf = nullptr; pl.ovf_stride = 0;
         const size_t stack_b = (size_t)pl.stack_depth * BLOCK * 8;
         r->plan = pl;
-        r->lds_bytes = stack_b + (size_t)6 * BLOCK * 4;      // (+ k_extend_dyn's parked path state: six floats per thread)
+        r->lds_bytes = stack_b + (size_t)6 * BLOCK * 4 + 2048;      // (+ k_extend_dyn's parked path state: six floats per thread, + the walk kernels' 8 x 256-byte priority-permutation table: stages.hpp make_walk_stack)
         if (r->lds_bytes > 160 * 1024) { return fail(APT_E_INVALID, "apt_renderer_create: BVH too deep for the LDS traversal stack"); }
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / r->lds_bytes));
         r->grid_trace = cus * per_cu;
@@ -918,7 +918,8 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)k_shadow_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
     }
-    r->grid_small = cus * (r->volumetric ? 8 : (p.fused == 2 ? 5 : 4));       // (rays traced in place: the kernel holds FIVE workgroups per CU since round 5 - one lane 3 440 -> 3 630 Msamples/s on C2 with 5 per CU, three lanes level)  streaming stages, persistent grid in 256-thread workgroups per CU.  Measured (tools/grid_sweep.sh, 2 / 3 / 4 / 5 / 8 per CU): C2 3 385 / 3 350 / 3 378 / 3 312 / 3 279 Msamples/s (a shade kernel holds 4 workgroups per CU; a second round of workgroups only adds a tail), C1 / C3 / C4 / C5 within 1 %, V1 823 / 838 / 842 / 840 / 858
+    r->grid_small = cus * (r->volumetric ? 8 : ((p.fused == 2 || r->sorted) ? 5 : 4));       // (round 6: class-sorted renders too - their lean group holds five workgroups per CU now: C5 2 243 -> 2 261, C3 one lane 1 035 -> 1 103, three lanes level)
+    //       // (rays traced in place: the kernel holds FIVE workgroups per CU since round 5 - one lane 3 440 -> 3 630 Msamples/s on C2 with 5 per CU, three lanes level)  streaming stages, persistent grid in 256-thread workgroups per CU.  Measured (tools/grid_sweep.sh, 2 / 3 / 4 / 5 / 8 per CU): C2 3 385 / 3 350 / 3 378 / 3 312 / 3 279 Msamples/s (a shade kernel holds 4 workgroups per CU; a second round of workgroups only adds a tail), C1 / C3 / C4 / C5 within 1 %, V1 823 / 838 / 842 / 840 / 858
     if (const char* g = getenv("APT_GRID_SMALL")) r->grid_small = cus * std::max(1, atoi(g));       // tuning knobs: workgroups per CU
     if (const char* g = getenv("APT_GRID_TRACE")) r->grid_trace = cus * std::max(1, atoi(g));
     if (r->trace_mode != 2) { r->lds_bytes_any = r->lds_bytes; r->grid_shadow = r->grid_trace; }

@@ -191,6 +191,15 @@ APT_D TravStack make_stack(const LdsPlan& plan) {
     ts.lds = (lds_u2*)(reinterpret_cast<grp_t*>(s_dyn)) + threadIdx.x;
     ts.stride = BLOCK; ts.k = plan.stack_depth; ts.ovf_stride = plan.ovf_stride;
     ts.ovf = plan.ovf ? (glb_u2*)(reinterpret_cast<grp_t*>(plan.ovf) + (blockIdx.x * blockDim.x + threadIdx.x)) : (glb_u2*)nullptr;
+    ts.lut = (lds_u8*)nullptr;
+    return ts;
+}
+// the walk kernels' stack: + the priority-permutation table behind the stack and the parked path state (api.hip sizes the LDS: stack, 6 floats per thread, 2 KiB)
+APT_D TravStack make_walk_stack(const LdsPlan& plan) {
+    TravStack ts = make_stack(plan);
+    ts.lut = (lds_u8*)(reinterpret_cast<float*>(s_dyn) + (size_t)plan.stack_depth * BLOCK * 2 + 6 * BLOCK);
+    fill_permute_lut(ts.lut);
+    __syncthreads();
     return ts;
 }
 
@@ -564,7 +573,7 @@ APT_D void walk_settle(const TravStack& ts, int& sp, grp_t& ng, const grp_t& tg,
 #endif
 template <int SORTED>
 __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_extend_dyn(DevScene sc, Params p, Queues q, Counters* cnt, int cur_q, const uint32_t* n_src, LdsPlan plan) {
-    const TravStack ts = make_stack(plan);
+    const TravStack ts = make_walk_stack(plan);
     const int sq = (int)(blockIdx.x % (uint32_t)p.nq);
     const uint32_t n = n_src[sq * CNT_PAD];
     if (blockIdx.x / (uint32_t)p.nq == 0 && threadIdx.x == 0) {
@@ -710,7 +719,7 @@ __global__ void __launch_bounds__(TRACE_NT(MODE), (MODE == 2 ? APT_TILE_WAVES : 
 // Any-hit twin of k_extend_dyn: a lane leaves the walk at its first occluder or when its stack runs empty, adds its contribution if
 // unoccluded, and claims the next shadow ray as soon as the wave runs low on walking lanes.
 __global__ void __launch_bounds__(BLOCK) APT_WALK_ATTR k_shadow_dyn(DevScene sc, Params p, Queues q, Counters* cnt, LdsPlan plan) {
-    const TravStack ts = make_stack(plan);
+    const TravStack ts = make_walk_stack(plan);
     const int sq = (int)(blockIdx.x % (uint32_t)p.nq);
     const uint32_t n = min(cnt->n_shadow[sq * CNT_PAD], q.sh_subcap);
     if (blockIdx.x / (uint32_t)p.nq == 0 && threadIdx.x == 0) {

@@ -104,7 +104,17 @@ typedef unsigned int grp_t __attribute__((ext_vector_type(2)));      // (x, y) g
 APT_D grp_t mk_grp(uint32_t x, uint32_t y) { grp_t g; g.x = x; g.y = y; return g; }
 typedef __attribute__((address_space(3))) grp_t lds_u2;
 typedef __attribute__((address_space(1))) grp_t glb_u2;
-struct TravStack { lds_u2* lds; int stride; glb_u2* ovf; int ovf_stride; int k; };
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+// lut: 8 x 256 bytes in LDS, lut[oi * 256 + x] = the bits of x moved from position s to s ^ oi (node8_test's priority order), or null
+struct TravStack { lds_u2* lds; int stride; glb_u2* ovf; int ovf_stride; int k; lds_u8* lut; };
+APT_D uint32_t xor_permute8(uint32_t x, uint32_t oi) {            // bit `slot` -> bit `slot ^ oi`: three conditional swaps of bit groups
+    x = (oi & 4u) ? (((x << 4) | (x >> 4)) & 0xffu) : x;
+    x = (oi & 2u) ? (((x & 0x33u) << 2) | ((x >> 2) & 0x33u)) : x;
+    x = (oi & 1u) ? (((x & 0x55u) << 1) | ((x >> 1) & 0x55u)) : x;
+    return x;
+}
+// every thread of a 256-thread workgroup fills its column of the table (callers synchronise before the first walk)
+APT_D void fill_permute_lut(lds_u8* lut) { for (uint32_t oi = 0; oi < 8u; oi++) lut[oi * 256u + threadIdx.x] = (unsigned char)xor_permute8(threadIdx.x & 0xffu, oi); }
 APT_D void tpush(const TravStack& s, int& sp, grp_t v) {
     if (sp < s.k) s.lds[sp * s.stride] = v; else s.ovf[(sp - s.k) * s.ovf_stride] = v;
     sp++;
@@ -131,7 +141,7 @@ APT_D float ubyte_f(uint32_t w, int b) { return (float)((w >> (8 * b)) & 0xffu);
 // 24 + (slot ^ (7 - ray octant)) so that "highest bit first" is front to back, and the node's inner-slot mask in bits 7..0);
 // tg = triangle group of its LEAF children (x = index of the first one's primitive | the node's leaf-slot mask << 24; y = the hit ones,
 // bit = slot).  Child k of either kind is `first + popcount(mask & ((1 << slot) - 1))`.
-APT_D void node8_test(const DevBvh& b, uint32_t idx, const WalkRay& r, float tmax, grp_t& ng, grp_t& tg) {
+APT_D void node8_test(const DevBvh& b, const TravStack& ts, uint32_t idx, const WalkRay& r, float tmax, grp_t& ng, grp_t& tg) {
     const char* base = reinterpret_cast<const char*>(b.nodes) + (idx << 6);          // wave-uniform base + 32-bit offset
     const uint4 n0 = *reinterpret_cast<const uint4*>(base), n1 = *reinterpret_cast<const uint4*>(base + 16), n2 = *reinterpret_cast<const uint4*>(base + 32),
                 n3 = *reinterpret_cast<const uint4*>(base + 48);
@@ -160,11 +170,10 @@ APT_D void node8_test(const DevBvh& b, uint32_t idx, const WalkRay& r, float tma
     }
     const uint32_t hit_l = ~miss & lmask;
     uint32_t x = ~miss & imask;
-    // inner hits to their priority positions: bit `slot` -> bit `slot ^ (7 - octant)` (three conditional swaps of bit groups)
-    const uint32_t oi = r.octinv4;
-    x = (oi & 4u) ? (((x << 4) | (x >> 4)) & 0xffu) : x;
-    x = (oi & 2u) ? (((x & 0x33u) << 2) | ((x >> 2) & 0x33u)) : x;
-    x = (oi & 1u) ? (((x & 0x55u) << 1) | ((x >> 1) & 0x55u)) : x;
+    // inner hits to their priority positions: bit `slot` -> bit `slot ^ (7 - octant)` - one byte from a 2 KiB table in LDS where the kernel keeps one
+    // (the walk kernels: 3 instructions for 15; the walk is bound by the issue of its node steps), three conditional bit-group swaps elsewhere
+    if (ts.lut) x = ts.lut[(r.octinv4 & 0x700u) | x];
+    else x = xor_permute8(x, r.octinv4 & 7u);
     ng.x = n0.z & 0x00ffffffu; ng.y = (x << 24) | imask;
     tg.x = (n0.w & 0x00ffffffu) | (lmask << 24); tg.y = hit_l;
 }
@@ -256,7 +265,7 @@ APT_D void group_step(const DevBvh& b, const TravStack& ts, int& sp, grp_t& ng, 
         if (APT_GROUP_HAS_NODES(ng)) tpush(ts, sp, ng);
         const uint32_t slot = (bit - 24u) ^ (r.octinv4 & 7u);
         const uint32_t idx = ng.x + (uint32_t)__popc(pim & ((1u << slot) - 1u));
-        node8_test(b, idx, r, tmax, ng, tg);
+        node8_test(b, ts, idx, r, tmax, ng, tg);
         WALK_COUNT(ws.nodes);
     } else { tg = ng; ng.x = 0u; ng.y = 0u; }
 }

@@ -746,6 +746,58 @@ def test_full_size_c5_crop_product_build_vs_brute_force_oracle(cx, cy):
     assert c5_crop_vs_brute_force_oracle(cx, cy, within=0.999, rel=3e-6)["arithmetic"] == "fast"          # (measured, worst of the three windows: 99.967 %, 1.2e-6)
 
 
+def test_rendering_zero_samples_is_a_no_op(renderer):
+    """apt_render(r, 0) divided by zero in the batch split (Renderer.render(n_spp=0) passes 0 straight through).  Surface and
+    volumetric path: nothing rendered, counter untouched, and the renderer still works afterwards."""
+    from adapt_amd.renderer import VolumeRenderer
+    from adapt_amd.parsers import scene_parsing
+    import os
+    r = renderer("cbox", width=32, height=24)
+    r.render(n_spp=0)
+    assert r.cnt[None] == 0 and r.stats()["n_samples"] == 0 and not np.any(r.color.to_numpy())
+    r.render(n_spp=2); r.render(n_spp=0)
+    assert r.cnt[None] == 2 and r.stats()["n_samples"] == 32 * 24 * 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    v = VolumeRenderer(*scene_parsing(os.path.join(root, "scenes", "vpt"), "cbox_fog.xml"), width=32, height=24)
+    try:
+        v.render(n_spp=0)
+        assert v.cnt[None] == 0
+        v.render(n_spp=1)
+        assert v.cnt[None] == 1 and np.isfinite(v.pixels.to_numpy()).all()
+    finally:
+        v.close()
+
+
+def test_non_finite_rays_hit_nothing_in_the_tree_walk(monkeypatch):
+    """The 64-byte node test reads a child's hit from the SIGN of (exit - entry), and v_max / v_min drop NaN operands: a ray with a NaN or
+    infinite component would walk the whole tree.  make_walk_ray turns such rays into rays that enter nothing (traverse.hpp) - as under the
+    compare-based test of rounds 2-5, where every `tn <= tf` on NaN slabs was false.  Both builds; finite rays next to them are unaffected."""
+    from adapt_amd.renderer import Renderer
+    from adapt_amd.synth import three_bunnies
+    monkeypatch.setenv("APT_TRAVERSAL", "bvh")
+    tup = three_bunnies(1)
+    rs = np.random.RandomState(11)
+    n = 2048
+    o = rs.uniform([0.5, 0.5, 0.5], [5.0, 5.0, 5.0], size=(n, 3)).astype(np.float32)
+    d = rs.normal(size=(n, 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    bad = np.arange(0, n, 7)
+    o2, d2 = o.copy(), d.copy()
+    d2[bad[0::3], 0] = np.nan; d2[bad[1::3], 1] = np.inf; o2[bad[2::3], 2] = np.nan
+    for exact in (False, True):
+        r = Renderer(*tup, width=32, height=32, exact=exact)
+        try:
+            assert r.info()["traversal"] == "bvh"
+            p_ref, t_ref, _ = r.intersect(o, d)
+            p, t, _ = r.intersect(o2, d2)
+            good = np.ones(n, bool); good[bad] = False
+            assert (p[bad] == -1).all(), (exact, p[bad][:8])
+            assert np.array_equal(p[good], p_ref[good]) and np.array_equal(t[good], t_ref[good]) and (p_ref[good] >= 0).sum() > n // 4
+            occ = r.occluded(o2, d2, np.full(n, 3.0, np.float32))
+            assert not occ[bad].any()
+        finally:
+            r.close()
+
+
 @pytest.mark.parametrize("tag,mode", [("cbox", "tile"), ("balls_mono", "sweep"), ("features_b", "tile"), ("glass_box", "sweep"), ("features_a", "sweep")])
 def test_shipped_library_is_bit_checked_where_it_runs_the_reference_arithmetic(tag, mode, renderer, monkeypatch):
     """the bit-exact parity tests run on libadapt_mi_exact.so, the library that ships is libadapt_mi.so.  With APT_TRAVERSAL forced
