@@ -47,7 +47,7 @@ typedef void (*shade_fn)(DevScene, Params, Queues, Counters*, ShadeIn, int, int)
 typedef void (*shade_traced_fn)(DevScene, Params, Queues, Counters*, int, int);
 struct ShadeVariant { int bm, sm; shade_fn fn; const char* name; shade_traced_fn traced; };      // traced: the kernel that traces its light sample and its continuation ray itself (shade_stage.hpp k_shade_traced: flat sweep, one light sample per vertex)
 static const ShadeVariant kShadeVariants[] = {
-    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade_traced<0x002, 0x01>)},
+    {0x002, 0x01, k_shade<0x002, 0x01>, "lambertian/point", APT_FUSED_FN(k_shade_traced_lean<0x002, 0x01>)},
     {0x003, 0x03, k_shade<0x003, 0x03>, "phong+lambertian/point+area", APT_FUSED_FN(k_shade_traced<0x003, 0x03>)},
     {0x107, 0x03, k_shade<0x107, 0x03>, "phong+lambertian+mirror+glass/point+area", APT_FUSED_FN(k_shade_traced<0x107, 0x03>)},
     {APT_BX_ALL, APT_SRC_ALL, k_shade<APT_BX_ALL, APT_SRC_ALL>, "all models", APT_FUSED_FN(k_shade_traced<APT_BX_ALL, APT_SRC_ALL>)},

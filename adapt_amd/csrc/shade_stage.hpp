@@ -568,6 +568,15 @@ template <int BM, int SM, int TEX = 0>
 __global__ void __launch_bounds__(BLOCK) k_shade_traced(DevScene sc, Params p, Queues q, Counters* cnt, int cur, int bounce) {
     shade_traced<BM, SM, TEX>(kernel_args3(), cnt, cur, bounce);
 }
+// The Lambertian / point-light specialisation (C1 / C2) under a register bound: with round 6's float transcendentals it allocates 77 VGPRs
+// (six waves per SIMD); asked for seven the allocator finds 72 without a spill (eight: 64 and 24 bytes of scratch).
+#ifndef APT_TRACED_WAVES
+#define APT_TRACED_WAVES 7
+#endif
+template <int BM, int SM>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(APT_TRACED_WAVES, APT_TRACED_WAVES))) k_shade_traced_lean(DevScene sc, Params p, Queues q, Counters* cnt, int cur, int bounce) {
+    shade_traced<BM, SM, 0>(kernel_args3(), cnt, cur, bounce);
+}
 #endif
 
 // ---- class kernels in groups: ONE launch shades several material classes.

@@ -15,7 +15,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # (explicit instantiation, mangled-name prefix, VGPR budget, why)
 KERNELS = [
-    ("k_shade_traced<0x002, 0x01, 0>(DevScene, Params, Queues, Counters*, int, int)", "_Z14k_shade_tracedILi2ELi1ELi0EE", 96, "C1 / C2: rays traced in place, five waves per SIMD"),
+    ("k_shade_traced_lean<0x002, 0x01>(DevScene, Params, Queues, Counters*, int, int)", "_Z19k_shade_traced_leanILi2ELi1EE", 72, "C1 / C2: rays traced in place, seven waves per SIMD"),
     ("k_shade_group<0x05, 5, 0x002, 0x504, 0x200, 0x801, 0, 0>(DevScene, Params, Queues, Counters*, GroupIn, int, int)", "_Z13k_shade_groupILi5ELi5ELi2ELi1284ELi512ELi2049ELi0ELi0EE", 96, "C4: the lean group of class kernels, five waves per SIMD, spot lights"),
     ("k_extend_dyn<1>(DevScene, Params, Queues, Counters*, int, const uint32_t*, LdsPlan)", "_Z12k_extend_dynILi1EE", 72, "C4 / C5: closest-hit walk, seven waves per SIMD"),
     ("k_shade_group<0x03, 5, 0x002, 0x504, 0x200, 0x801, 0, 0>(DevScene, Params, Queues, Counters*, GroupIn, int, int)", "_Z13k_shade_groupILi3ELi5ELi2ELi1284ELi512ELi2049ELi0ELi0EE", 96, "C3 / C5: the lean group of class kernels, five waves per SIMD (one 8-byte scratch slot)"),
