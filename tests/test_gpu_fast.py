@@ -1014,3 +1014,27 @@ def test_flat_transmittance_walk_against_the_tiled_walk(tag, monkeypatch):
         assert abs(a[1][k] - b[1][k]) <= max(1e-3 * b[1][k], 20), (k, a[1][k], b[1][k])
     m = image_metrics(a[0], b[0])
     assert m["frac_within"] >= 0.99 and m["relMSE"] <= 1e-4, m
+
+
+def test_cli_end_to_end_writes_a_jpeg_and_resumes_from_its_checkpoint(tmp_path, capsys):
+    """render.py's flow through adapt_amd.cli.main on the GPU: AdaPT's flags (--no_gui renders iter_num + 1 samples, render.py:80-81), the
+    output name `<img_name>-<scene file>-<type>.<ext>`, --img_ext jpg (parsers/opts.py:25), and a --save_iter checkpoint that a second run
+    loads (render.py:96-100,119-121): the counter continues where the first run saved."""
+    import os
+    from adapt_amd.cli import main
+    pil = pytest.importorskip("PIL.Image")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--input_path", os.path.join(root, "scenes"), "--scene", "cbox", "--name", "c2_cbox.xml", "--type", "pt", "--no_gui",
+              "--output_path", str(tmp_path / "out"), "--chkpt_path", str(tmp_path / "chk"), "--img_name", "t", "--img_ext", "jpg", "--width", "64", "--height", "48"]
+    assert main(common + ["--iter_num", "7", "--save_iter", "4"]) == 0
+    out = tmp_path / "out" / "t-c2_cbox-pt.jpg"
+    with pil.open(out) as im:
+        assert im.format == "JPEG" and im.size == (64, 48)
+        a = np.asarray(im.convert("RGB"), np.float32)
+    assert a.mean() > 5.0                                            # a lit Cornell box, not a black frame
+    assert (tmp_path / "chk" / "t-c2_cbox-pt.pkl").exists()
+    text = capsys.readouterr().out
+    assert "8 samples" in text                                       # iter_num + 1
+    assert main(common + ["--iter_num", "3", "--load"]) == 0
+    text = capsys.readouterr().out
+    assert "recovered from check-point, elapsed counter: 4" in text  # saved before iteration 4 (the last multiple of save_iter below 8)
