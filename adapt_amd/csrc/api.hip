@@ -918,8 +918,9 @@ APT_EXPORT int apt_renderer_create(const apt_scene* sc, const apt_render_cfg* cf
         HIP_TRY(hipFuncSetAttribute((const void*)kExtendDyn[1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)k_shadow_dyn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)r->lds_bytes));
     }
-    r->grid_small = cus * (r->volumetric ? 8 : ((p.fused == 2 || r->sorted) ? 5 : 4));       // (round 6: class-sorted renders too - their lean group holds five workgroups per CU now: C5 2 243 -> 2 261, C3 one lane 1 035 -> 1 103, three lanes level)
-    //       // (rays traced in place: the kernel holds FIVE workgroups per CU since round 5 - one lane 3 440 -> 3 630 Msamples/s on C2 with 5 per CU, three lanes level)  streaming stages, persistent grid in 256-thread workgroups per CU.  Measured (tools/grid_sweep.sh, 2 / 3 / 4 / 5 / 8 per CU): C2 3 385 / 3 350 / 3 378 / 3 312 / 3 279 Msamples/s (a shade kernel holds 4 workgroups per CU; a second round of workgroups only adds a tail), C1 / C3 / C4 / C5 within 1 %, V1 823 / 838 / 842 / 840 / 858
+    // streaming stages: persistent grid in 256-thread workgroups per CU.  (rays traced in place: the kernel holds FIVE workgroups per CU since round 5 - one lane 3 440 -> 3 630 Msamples/s on C2 with 5 per CU, three lanes level)  streaming stages, persistent grid in 256-thread workgroups per CU.  Measured (tools/grid_sweep.sh, 2 / 3 / 4 / 5 / 8 per CU): C2 3 385 / 3 350 / 3 378 / 3 312 / 3 279 Msamples/s (a shade kernel holds 4 workgroups per CU; a second round of workgroups only adds a tail), C1 / C3 / C4 / C5 within 1 %, V1 823 / 838 / 842 / 840 / 858
+    // (round 6: class-sorted renders too - their lean group holds five workgroups per CU now: C5 2 243 -> 2 261, C3 one lane 1 035 -> 1 103, three lanes level)
+    r->grid_small = cus * (r->volumetric ? 8 : ((p.fused == 2 || r->sorted) ? 5 : 4));
     if (const char* g = getenv("APT_GRID_SMALL")) r->grid_small = cus * std::max(1, atoi(g));       // tuning knobs: workgroups per CU
     if (const char* g = getenv("APT_GRID_TRACE")) r->grid_trace = cus * std::max(1, atoi(g));
     if (r->trace_mode != 2) { r->lds_bytes_any = r->lds_bytes; r->grid_shadow = r->grid_trace; }

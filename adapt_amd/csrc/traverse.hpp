@@ -188,8 +188,8 @@ APT_D uint32_t tri_take(grp_t& tg) {
 APT_D v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 #endif
 #if APT_FAST_LEAVES
-// Product build: the leaf test of the flat sweep (planar_solve below) on the tree's primitives, two of a lane's pending primitives in the
-// halves of packed f32 instructions.  Record = corner p0 and the rows U, V, T of [e1 e2 n]^-1 (Baldwin & Weber, JCGT 2016; computed in
+// Product build: the leaf test of the flat sweep (planar_solve below) on the tree's primitives, one pending primitive of a lane per call
+// (tri_group below).  Record = corner p0 and the rows U, V, T of [e1 e2 n]^-1 (Baldwin & Weber, JCGT 2016; computed in
 // double on the host): s = o - p0 (the reference's own first operation, tracer_base.py:206: a ray that STARTS on the primitive keeps its
 // height T . s a sum of small products), t = -T.s / T.d with ONE reciprocal, then (u, v) = (U.P, V.P) at the hit point P = s + t d -
 // ~40 instructions per pair where the adjugate solve with its IEEE division takes ~95.  Inside SURVEY 8(d): t within 1e-5 relative of the
